@@ -1,0 +1,257 @@
+"""oracle — CPU checkers for the sort-and-rasterize hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product (``gaussiansplats3d_amd``) never does.
+
+* :func:`sort_indexes` / :func:`integer_centers` — ``sort_oracle.c``, restating
+  ``/root/reference/src/worker/sorter.cpp:17-168`` and ``src/splatmesh/SplatMesh.js:1912-1926``.
+* :func:`sort_indexes_numpy` — independent numpy restatement of the static integer path
+  (SURVEY.md Appendix A.1), used to cross-check the C oracle.
+* :func:`ref_sort_indexes` — the REFERENCE's own ``sorter_no_simd.cpp`` compiled into
+  ``oracle/_ref/libsorter_ref.so`` by ``oracle/Makefile`` (present only after ``make -C oracle``
+  where ``/root/reference`` exists; the prebuilt file travels to the GPU box).
+* :func:`project` / :func:`render` — ``raster_oracle.c``, restating the GLSL in
+  ``src/splatmesh/SplatMaterial.js`` + ``SplatMaterial3D.js`` (parity UNPINNED by the reference, see
+  the file header).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/libsorter_ref.so when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("sort_oracle.c", "raster_oracle.c")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libsorter_ref.so")
+    if (force or not os.path.exists(ref_so)) and os.path.exists("/root/reference/src/worker/sorter_no_simd.cpp"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        _LIB = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        _LIB.gso_sort_indexes.restype = C.c_int
+        _LIB.gro_render.restype = C.c_uint64
+    return _LIB
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libsorter_ref.so"))
+
+
+def _ref():
+    global _REF
+    if _REF is None:
+        build()
+        _REF = C.CDLL(os.path.join(_HERE, "_ref", "libsorter_ref.so"))
+        _REF.sortIndexes.restype = None
+    return _REF
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+# --------------------------------------------------------------------------- sort
+def integer_centers(centers3):
+    """SplatMesh.getIntegerCenters(padFour=True): fp32[n,3] -> int32[n,4]."""
+    c = np.ascontiguousarray(centers3, dtype=np.float32).reshape(-1, 3)
+    out = np.empty((c.shape[0], 4), dtype=np.int32)
+    _lib().gso_integer_centers(_p(c, _f32p), C.c_uint32(c.shape[0]), _p(out, _i32p))
+    return out
+
+
+def _sort_args(indexes, centers4, mvp, sort_count, render_count, precomputed, scene_indexes, transforms, use_int):
+    indexes = np.ascontiguousarray(indexes, dtype=np.uint32)
+    centers4 = np.ascontiguousarray(centers4, dtype=np.int32 if use_int else np.float32)
+    mvp = np.ascontiguousarray(np.asarray(mvp, dtype=np.float64).astype(np.float32).reshape(16))
+    if render_count is None:
+        render_count = indexes.shape[0]
+    if sort_count is None:
+        sort_count = render_count
+    if precomputed is not None:
+        precomputed = np.ascontiguousarray(precomputed, dtype=np.int32 if use_int else np.float32)
+    if scene_indexes is not None:
+        scene_indexes = np.ascontiguousarray(scene_indexes, dtype=np.uint32)
+    if transforms is not None:
+        transforms = np.ascontiguousarray(transforms, dtype=np.float32)
+    return indexes, centers4, mvp, int(sort_count), int(render_count), precomputed, scene_indexes, transforms
+
+
+def sort_indexes(indexes, centers4, mvp, sort_count=None, render_count=None, precision=16,
+                 use_int=True, dynamic=False, precomputed=None, scene_indexes=None, transforms=None,
+                 return_intermediates=False):
+    """C oracle for sortIndexes.  centers4: int32[n,4] (or fp32[n,4]); mvp: 16 column-major values.
+
+    Returns uint32[render_count]; with return_intermediates also (keys, buckets, (lo, hi), status).
+    """
+    (indexes, centers4, mvp, sort_count, render_count, precomputed, scene_indexes,
+     transforms) = _sort_args(indexes, centers4, mvp, sort_count, render_count, precomputed, scene_indexes,
+                              transforms, use_int)
+    out = np.zeros(render_count, dtype=np.uint32)
+    keys = np.zeros(render_count, dtype=np.int32)
+    buckets = np.zeros(render_count, dtype=np.int32)
+    lohi = np.zeros(2, dtype=np.int32)
+    st = _lib().gso_sort_indexes(
+        _p(indexes, _u32p), centers4.ctypes.data_as(C.c_void_p),
+        precomputed.ctypes.data_as(C.c_void_p) if precomputed is not None else None,
+        _p(mvp, _f32p), _p(out, _u32p), _p(scene_indexes, _u32p), _p(transforms, _f32p),
+        C.c_uint32(1 << precision), C.c_uint32(sort_count), C.c_uint32(render_count),
+        C.c_int(precomputed is not None), C.c_int(bool(use_int)), C.c_int(bool(dynamic)),
+        _p(keys, _i32p), _p(buckets, _i32p), _p(lohi, _i32p))
+    if st < 0:
+        raise MemoryError("sort oracle")
+    if return_intermediates:
+        return out, keys, buckets, (int(lohi[0]), int(lohi[1])), st
+    return out
+
+
+def ref_sort_indexes(indexes, centers4, mvp, sort_count=None, render_count=None, precision=16,
+                     use_int=True, dynamic=False, precomputed=None, scene_indexes=None, transforms=None):
+    """The reference's own compiled sorter (oracle/_ref).  Guards the hi==lo case, where the native
+    build of the reference source dereferences a wild pointer: callers must not pass
+    inputs whose keys are all equal."""
+    (indexes, centers4, mvp, sort_count, render_count, precomputed, scene_indexes,
+     transforms) = _sort_args(indexes, centers4, mvp, sort_count, render_count, precomputed, scene_indexes,
+                              transforms, use_int)
+    n = centers4.shape[0]
+    rng = 1 << precision
+    out = np.zeros(max(render_count, 1), dtype=np.uint32)
+    mapped = np.zeros(max(render_count, 1), dtype=np.int32)
+    freq = np.zeros(2 * rng, dtype=np.uint32)          # SortWorker.js:137-138 allocates 2*range, zeroed :53-55
+    dummy_u = np.zeros(1, dtype=np.uint32)
+    dummy_f = np.zeros(16, dtype=np.float32)
+    _ref().sortIndexes(
+        _p(indexes, _u32p), centers4.ctypes.data_as(C.c_void_p),
+        (precomputed if precomputed is not None else mapped).ctypes.data_as(C.c_void_p),
+        _p(mapped, _i32p), _p(freq, _u32p), _p(mvp, _f32p), _p(out, _u32p),
+        _p(scene_indexes if scene_indexes is not None else dummy_u, _u32p),
+        _p(transforms if transforms is not None else dummy_f, _f32p),
+        C.c_uint32(rng), C.c_uint32(sort_count), C.c_uint32(render_count), C.c_uint32(n),
+        C.c_bool(precomputed is not None), C.c_bool(bool(use_int)), C.c_bool(bool(dynamic)))
+    return out[:render_count]
+
+
+def sort_indexes_numpy(indexes, int_centers4, mvp, sort_count=None, render_count=None, precision=16):
+    """numpy restatement of the static integer path: independent of the C oracle."""
+    idx = np.ascontiguousarray(indexes, dtype=np.uint32)
+    ci = np.ascontiguousarray(int_centers4, dtype=np.int32)
+    R = idx.shape[0] if render_count is None else int(render_count)
+    Rs = R if sort_count is None else int(sort_count)
+    s0 = R - Rs
+    m32 = np.asarray(mvp, dtype=np.float64).astype(np.float32).reshape(16)
+    m = np.trunc(m32[[2, 6, 10]].astype(np.float64) * 1000.0).astype(np.int64)
+    tail = idx[s0:R]
+    c = ci[tail].astype(np.int64)
+    # int32 wrap-around of every product and sum == arithmetic mod 2^32
+    d = (c[:, 0] * m[0] + c[:, 1] * m[1] + c[:, 2] * m[2]) & 0xFFFFFFFF
+    d = d.astype(np.uint32).view(np.int32)
+    out = idx[:R].copy()
+    if Rs == 0:
+        return out
+    lo, hi = int(d.min()), int(d.max())
+    rng = 1 << precision
+    if hi == lo:
+        b = np.zeros(Rs, dtype=np.int64)
+    else:
+        range_map = np.float32(rng - 1) / (np.float32(hi) - np.float32(lo))
+        diff = ((d.astype(np.int64) - lo) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        b = np.trunc(diff.astype(np.float32) * range_map).astype(np.int64)
+        b = np.clip(b, 0, rng - 1)
+    order = np.argsort(b, kind="stable")            # ascending bucket, ties in input order
+    out[s0:R] = tail[order][::-1]                   # reversed: descending bucket, ties reversed
+    return out
+
+
+# --------------------------------------------------------------------------- raster
+class Camera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_pos", C.c_float * 3),
+                ("focal", C.c_float * 2), ("viewport", C.c_float * 2), ("splat_scale", C.c_float),
+                ("kernel2d", C.c_float), ("max_splat_px", C.c_float), ("inv_focal_adj", C.c_float),
+                ("sh_degree", C.c_int32), ("sh_stored", C.c_int32), ("antialiased", C.c_int32),
+                ("point_cloud", C.c_int32)]
+
+
+SPLAT2D = np.dtype([("visible", np.int32), ("cx", np.float32), ("cy", np.float32), ("b1x", np.float32),
+                    ("b1y", np.float32), ("b2x", np.float32), ("b2y", np.float32), ("r", np.float32),
+                    ("g", np.float32), ("b", np.float32), ("a", np.float32), ("ndcz", np.float32)])
+
+
+def make_camera(view, proj, cam_pos, width, height, sh_degree=0, sh_stored=0, splat_scale=1.0,
+                kernel2d=0.3, max_splat_px=1024.0, focal_adjustment=1.0, antialiased=False,
+                point_cloud=False):
+    """Uniforms as Viewer.updateSplatMesh / SplatMesh.updateUniforms derive them (dpr = 1)."""
+    cam = Camera()
+    v32 = np.asarray(view, dtype=np.float64).astype(np.float32).reshape(16)
+    p32 = np.asarray(proj, dtype=np.float64).astype(np.float32).reshape(16)
+    cam.view[:] = v32.tolist()
+    cam.proj[:] = p32.tolist()
+    cam.cam_pos[:] = np.asarray(cam_pos, dtype=np.float32).tolist()
+    p64 = np.asarray(proj, dtype=np.float64).reshape(16)
+    cam.focal[0] = p64[0] * 0.5 * width * focal_adjustment      # Viewer.js:662-665,673
+    cam.focal[1] = p64[5] * 0.5 * height * focal_adjustment
+    cam.viewport[0] = float(width)
+    cam.viewport[1] = float(height)
+    cam.splat_scale = splat_scale
+    cam.kernel2d = kernel2d
+    cam.max_splat_px = max_splat_px
+    cam.inv_focal_adj = 1.0 / focal_adjustment
+    cam.sh_degree = sh_degree
+    cam.sh_stored = sh_stored
+    cam.antialiased = int(antialiased)
+    cam.point_cloud = int(point_cloud)
+    return cam
+
+
+def _scene_args(centers, cov, rgba, sh):
+    centers = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, 3)
+    cov = np.ascontiguousarray(cov, dtype=np.float32).reshape(-1, 6)
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+    if sh is not None:
+        sh = np.ascontiguousarray(sh, dtype=np.float32).reshape(centers.shape[0], -1)
+    return centers, cov, rgba, sh
+
+
+def project(cam, centers, cov, rgba, sh=None, order=None):
+    centers, cov, rgba, sh = _scene_args(centers, cov, rgba, sh)
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+    count = centers.shape[0] if order is None else order.shape[0]
+    out = np.zeros(count, dtype=SPLAT2D)
+    _lib().gro_project(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p), _p(sh, _f32p),
+                       _p(order, _u32p), C.c_uint32(count), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-3):
+    """Returns (fb float32[H,W,4] row0=bottom, rgba8 uint8[H,W,4], ambig uint8[H,W], fragments)."""
+    centers, cov, rgba, sh = _scene_args(centers, cov, rgba, sh)
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+    count = centers.shape[0] if order is None else order.shape[0]
+    W, H = int(cam.viewport[0]), int(cam.viewport[1])
+    fb = np.zeros((H, W, 4), dtype=np.float32)
+    amb = np.zeros((H, W), dtype=np.uint8)
+    frags = _lib().gro_render(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p),
+                              _p(sh, _f32p), _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)),
+                              C.c_float(amb_eps), _p(fb, _f32p), _p(amb, _u8p))
+    q = np.empty((H, W, 4), dtype=np.uint8)
+    _lib().gro_quantize(_p(fb, _f32p), C.c_uint64(fb.size), _p(q, _u8p))
+    return fb, q, amb, int(frags)

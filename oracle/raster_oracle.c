@@ -1,0 +1,234 @@
+/*
+ * oracle/raster_oracle.c — TEST INFRASTRUCTURE ONLY (never linked into or called by the product path).
+ *
+ * fp32 CPU restatement of the reference's splat rasterisation = GLSL vertex + fragment shader + GL blend:
+ *   vertex, common half   /root/reference/src/splatmesh/SplatMaterial.js:112-341
+ *   vertex, 3D half       /root/reference/src/splatmesh/SplatMaterial3D.js:81-217
+ *   fragment              /root/reference/src/splatmesh/SplatMaterial3D.js:235-251
+ *   blend / target        /root/reference/src/splatmesh/SplatMaterial3D.js:65-75, src/Viewer.js:358-359
+ *   uniforms              /root/reference/src/splatmesh/SplatMesh.js:1248-1280, src/Viewer.js:651-677
+ *   quad                  /root/reference/src/splatmesh/SplatGeometry.js:14-23
+ *
+ * Parity status: UNPINNED by the reference — the reference has no tests, goldens or CPU rasteriser, and
+ * WebGL cannot run here.  This file is a line-by-line arithmetic restatement of the
+ * shader source in IEEE fp32 (compiled with -ffp-contract=off); goldens under tests/golden/raster_*.npz
+ * are produced by THIS code and exist to catch regressions, not to pin it to the reference.
+ *
+ * Conventions: matrices are column-major float[16] like three.js / GLSL; framebuffer row 0 is the
+ * BOTTOM row (GL window coordinates); pixel (x,y) is sampled at its centre (x+0.5, y+0.5).
+ * Splats are composited in the order given (index 0 drawn first = farthest), NormalBlending:
+ *   rgb = a*src + (1-a)*rgb ; alpha = a + (1-a)*alpha      (three r160 blendFuncSeparate)
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef struct {
+    float view[16];        /* modelViewMatrix = view * meshWorld                         */
+    float proj[16];        /* projectionMatrix                                          */
+    float cam_pos[3];      /* cameraPosition (world)                                    */
+    float focal[2];        /* SplatMesh.updateUniforms: proj[0]*0.5*W , proj[5]*0.5*H   */
+    float viewport[2];     /* W, H in pixels                                            */
+    float splat_scale;     /* 1                                                         */
+    float kernel2d;        /* 0.3                                                       */
+    float max_splat_px;    /* 1024                                                      */
+    float inv_focal_adj;   /* 1                                                         */
+    int32_t sh_degree;     /* degree evaluated (0..2), <= degree stored                 */
+    int32_t sh_stored;     /* degree stored: 0,1,2 -> 0,9,24 floats per splat           */
+    int32_t antialiased;   /* 0                                                         */
+    int32_t point_cloud;   /* 0                                                         */
+} gro_camera;
+
+/* Per-splat result of the vertex stage. */
+typedef struct {
+    int32_t visible;       /* 0 = rejected (clip / eigen / NaN)                          */
+    float cx, cy;          /* centre in pixels, GL window coords                         */
+    float b1x, b1y;        /* basisVector1 in pixels (quad half-axis)                    */
+    float b2x, b2y;        /* basisVector2 in pixels                                     */
+    float r, g, b, a;      /* vColor                                                    */
+    float ndcz;
+} gro_splat2d;
+
+static float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+/* Vertex stage for one splat.  Every line cites the shader line it restates. */
+static void project_one(const gro_camera* cam, const float* c, const float* cov, const uint8_t* rgba,
+                        const float* sh, gro_splat2d* o) {
+    const float* MV = cam->view;
+    const float* P = cam->proj;
+    memset(o, 0, sizeof(*o));
+
+    /* SplatMaterial.js:156  viewCenter = MV * vec4(c,1) */
+    float v[4], q[4];
+    for (int r = 0; r < 4; r++) v[r] = MV[r] * c[0] + MV[4 + r] * c[1] + MV[8 + r] * c[2] + MV[12 + r];
+    /* :158 clipCenter = P * viewCenter */
+    for (int r = 0; r < 4; r++) q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
+    /* :160-164 1.2x frustum reject */
+    const float clip = 1.2f * q[3];
+    if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) return;
+    /* :166 */
+    const float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];
+    /* quad z == centre z (SplatMaterial3D.js:209) -> GL clips the whole quad on ndc z */
+    if (!(ndcz >= -1.0f && ndcz <= 1.0f)) return;
+
+    /* :169 vColor = rgba/255 */
+    float col[3] = {(float)rgba[0] * (1.0f / 255.0f), (float)rgba[1] * (1.0f / 255.0f),
+                    (float)rgba[2] * (1.0f / 255.0f)};
+    float alpha = (float)rgba[3] * (1.0f / 255.0f);
+
+    if (cam->sh_stored >= 1 && cam->sh_degree >= 1) {
+        /* :185 worldViewDir = normalize(splatCenter - cameraPosition) */
+        float d[3] = {c[0] - cam->cam_pos[0], c[1] - cam->cam_pos[1], c[2] - cam->cam_pos[2]};
+        const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+        const float SH_C1 = 0.4886025119029199f;
+        /* :273  sh1..sh3 are RGB triples, coefficient-major */
+        for (int ch = 0; ch < 3; ch++)
+            col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
+        if (cam->sh_stored >= 2 && cam->sh_degree >= 2) {
+            /* :308-330 */
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float C0 = 1.0925484f, C1 = -1.0925484f, C2 = 0.3153916f, C3 = -1.0925484f, C4 = 0.5462742f;
+            for (int ch = 0; ch < 3; ch++)
+                col[ch] += (C0 * xy) * sh[9 + ch] + (C1 * yz) * sh[12 + ch] +
+                           (C2 * (2.0f * zz - xx - yy)) * sh[15 + ch] + (C3 * xz) * sh[18 + ch] +
+                           (C4 * (xx - yy)) * sh[21 + ch];
+        }
+        /* :337 */
+        for (int ch = 0; ch < 3; ch++) col[ch] = clamp01(col[ch]);
+    }
+
+    /* SplatMaterial3D.js:105-109  Vrk (symmetric) */
+    const float V00 = cov[0], V01 = cov[1], V02 = cov[2], V11 = cov[3], V12 = cov[4], V22 = cov[5];
+    /* :120-126  J (GLSL column-major constructor) as math matrix Jm[row][col]:
+     *   col0 = (fx/z, 0, -(fx*x)*s), col1 = (0, fy/z, -(fy*y)*s), col2 = 0 */
+    const float s = 1.0f / (v[2] * v[2]);
+    const float j00 = cam->focal[0] / v[2], j20 = -(cam->focal[0] * v[0]) * s;
+    const float j11 = cam->focal[1] / v[2], j21 = -(cam->focal[1] * v[1]) * s;
+    /* :130 W = transpose(mat3(MV)) -> Wm[r][c] = MV3[c][r] = MV[4*r + c]  (MV[4*col+row]) */
+    /* :131 T = W * J : T[r][c] = sum_k Wm[r][k] * Jm[k][c]; only columns 0 and 1 are non-zero */
+    float T0[3], T1[3];
+    for (int r = 0; r < 3; r++) {
+        const float w0 = MV[4 * r + 0], w1 = MV[4 * r + 1], w2 = MV[4 * r + 2];
+        T0[r] = w0 * j00 + w2 * j20;
+        T1[r] = w1 * j11 + w2 * j21;
+    }
+    /* :134 cov2Dm = transpose(T) * Vrk * T  -> 2x2 upper-left */
+    const float VT0[3] = {V00 * T0[0] + V01 * T0[1] + V02 * T0[2], V01 * T0[0] + V11 * T0[1] + V12 * T0[2],
+                          V02 * T0[0] + V12 * T0[1] + V22 * T0[2]};
+    const float VT1[3] = {V00 * T1[0] + V01 * T1[1] + V02 * T1[2], V01 * T1[0] + V11 * T1[1] + V12 * T1[2],
+                          V02 * T1[0] + V12 * T1[1] + V22 * T1[2]};
+    float a = T0[0] * VT0[0] + T0[1] * VT0[1] + T0[2] * VT0[2];
+    const float bb = T0[0] * VT1[0] + T0[1] * VT1[1] + T0[2] * VT1[2];
+    float d = T1[0] * VT1[0] + T1[1] * VT1[1] + T1[2] * VT1[2];
+
+    if (cam->antialiased) {                                    /* :137-144 */
+        const float det0 = a * d - bb * bb;
+        a += cam->kernel2d; d += cam->kernel2d;
+        const float det1 = a * d - bb * bb;
+        const float ratio = det0 / det1;
+        alpha *= sqrtf(ratio > 0.0f ? ratio : 0.0f);
+        if (alpha < (1.0f / 255.0f)) return;
+    } else {                                                   /* :147-150 */
+        a += cam->kernel2d; d += cam->kernel2d;
+    }
+    /* :174-182 */
+    const float D = a * d - bb * bb;
+    const float half_tr = 0.5f * (a + d);
+    const float disc = half_tr * half_tr - D;
+    const float term2 = sqrtf(disc > 0.1f ? disc : 0.1f);
+    float l1 = half_tr + term2, l2 = half_tr - term2;
+    if (cam->point_cloud) l1 = l2 = 0.2f;                      /* :184-186 */
+    if (l2 <= 0.0f) return;                                    /* :188 */
+    /* :190-192  normalize(vec2(b, l1 - a)); (0,0) -> NaN -> nothing is rasterised */
+    const float ex = bb, ey = l1 - a;
+    const float elen = sqrtf(ex * ex + ey * ey);
+    const float e1x = ex / elen, e1y = ey / elen;
+    if (!(e1x == e1x) || !(e1y == e1y)) return;
+    const float e2x = e1y, e2y = -e1x;
+    /* :195-196 */
+    const float sqrt8 = sqrtf(8.0f);
+    float h1 = sqrt8 * sqrtf(l1); if (h1 > cam->max_splat_px) h1 = cam->max_splat_px;
+    float h2 = sqrt8 * sqrtf(l2); if (h2 > cam->max_splat_px) h2 = cam->max_splat_px;
+    /* ndcOffset = (q.x*b1 + q.y*b2) * (1/viewport) * 2 * invFocalAdj  (:206-207)  => pixel offset =
+     * ndcOffset * viewport/2 = (q.x*b1 + q.y*b2) * invFocalAdj */
+    const float k = cam->splat_scale * cam->inv_focal_adj;
+    o->b1x = e1x * k * h1; o->b1y = e1y * k * h1;
+    o->b2x = e2x * k * h2; o->b2y = e2y * k * h2;
+    o->cx = (ndcx * 0.5f + 0.5f) * cam->viewport[0];
+    o->cy = (ndcy * 0.5f + 0.5f) * cam->viewport[1];
+    o->r = col[0]; o->g = col[1]; o->b = col[2]; o->a = alpha;
+    o->ndcz = ndcz;
+    o->visible = 1;
+}
+
+/* Vertex stage for splats order[0..count) (order==NULL -> identity). */
+void gro_project(const gro_camera* cam, const float* centers, const float* cov, const uint8_t* rgba,
+                 const float* sh, const uint32_t* order, uint32_t count, gro_splat2d* out) {
+    const int shn = cam->sh_stored == 0 ? 0 : (cam->sh_stored == 1 ? 9 : 24);
+    for (uint32_t i = 0; i < count; i++) {
+        const size_t g = order ? order[i] : i;
+        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL, out + i);
+    }
+}
+
+/*
+ * Full frame.  fb = float RGBA [H][W][4], row 0 = bottom, must be zeroed by the caller (clear colour
+ * (0,0,0,0), Viewer.js:358-359).  rop8 != 0 emulates the RGBA8 render target by rounding dst to unorm8
+ * after every splat (what the reference's ROP really does); rop8 == 0 keeps fp32 (the parity target).
+ * ambig (nullable, [H][W] bytes): set to 1 where some splat's A fell within 8 +- amb_eps, i.e. where
+ * the discontinuous `A > 8 -> discard` may legitimately flip under different fp32 evaluation orders.
+ * Returns the number of (pixel, splat) fragments that survived the discard.
+ */
+uint64_t gro_render(const gro_camera* cam, const float* centers, const float* cov, const uint8_t* rgba,
+                    const float* sh, const uint32_t* order, uint32_t count, int rop8, float amb_eps,
+                    float* fb, uint8_t* ambig) {
+    const int W = (int)cam->viewport[0], H = (int)cam->viewport[1];
+    const int shn = cam->sh_stored == 0 ? 0 : (cam->sh_stored == 1 ? 9 : 24);
+    uint64_t frags = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const size_t g = order ? order[i] : i;
+        gro_splat2d s;
+        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL, &s);
+        if (!s.visible) continue;
+        /* bounding box of the quad centre +- b1 +- b2 */
+        const float ext_x = fabsf(s.b1x) + fabsf(s.b2x), ext_y = fabsf(s.b1y) + fabsf(s.b2y);
+        float fx0 = floorf(s.cx - ext_x - 1.0f), fx1 = ceilf(s.cx + ext_x + 1.0f);
+        float fy0 = floorf(s.cy - ext_y - 1.0f), fy1 = ceilf(s.cy + ext_y + 1.0f);
+        if (fx0 < 0.0f) fx0 = 0.0f;
+        if (fy0 < 0.0f) fy0 = 0.0f;
+        if (fx1 > (float)(W - 1)) fx1 = (float)(W - 1);
+        if (fy1 > (float)(H - 1)) fy1 = (float)(H - 1);
+        if (!(fx0 <= fx1) || !(fy0 <= fy1)) continue;
+        const float n1 = s.b1x * s.b1x + s.b1y * s.b1y, n2 = s.b2x * s.b2x + s.b2y * s.b2y;
+        for (int py = (int)fy0; py <= (int)fy1; py++) {
+            for (int px = (int)fx0; px <= (int)fx1; px++) {
+                const float dx = ((float)px + 0.5f) - s.cx, dy = ((float)py + 0.5f) - s.cy;
+                /* quad-local coordinates q in [-1,1]^2 (b1 is orthogonal to b2) */
+                const float qx = (dx * s.b1x + dy * s.b1y) / n1;
+                const float qy = (dx * s.b2x + dy * s.b2y) / n2;
+                /* vPosition = q*sqrt8 (SplatMaterial3D.js:213); A = dot(vPosition,vPosition) (:237) */
+                const float A = 8.0f * (qx * qx + qy * qy);
+                if (ambig && fabsf(A - 8.0f) <= amb_eps) ambig[(size_t)py * W + px] = 1;
+                if (!(A <= 8.0f)) continue;                    /* :242 `if (A > 8.0) discard` */
+                const float al = expf(-0.5f * A) * s.a;        /* :249 */
+                float* dst = fb + 4 * ((size_t)py * W + px);
+                const float om = 1.0f - al;
+                dst[0] = al * s.r + om * dst[0];
+                dst[1] = al * s.g + om * dst[1];
+                dst[2] = al * s.b + om * dst[2];
+                dst[3] = al + om * dst[3];
+                if (rop8)
+                    for (int ch = 0; ch < 4; ch++) dst[ch] = floorf(clamp01(dst[ch]) * 255.0f + 0.5f) * (1.0f / 255.0f);
+                frags++;
+            }
+        }
+    }
+    return frags;
+}
+
+/* unorm8 conversion of a float framebuffer, round-to-nearest like GL. */
+void gro_quantize(const float* fb, uint64_t count, uint8_t* out) {
+    for (uint64_t i = 0; i < count; i++) out[i] = (uint8_t)floorf(clamp01(fb[i]) * 255.0f + 0.5f);
+}

@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: Msplats/s sorted + rasterized (BASELINE.json metric).
+
+One "step" = one frame of the hot path on the garden.ply stand-in (configs[2]: 5.8 M splats, SH-2, 1920x1080):
+depth-key + device-wide stable radix sort of ALL splats (cull off, R = N, the reference's own no-tree path,
+src/Viewer.js:2061-2073), then project -> tile-bin -> tile-sort -> blend into an RGBA8 framebuffer.  Inputs are
+resident in HBM before the timed region.  With --gpus N every rank sorts + projects the replicated scene and
+rasterises a strip of tile rows; strips are gathered to rank 0 over RCCL inside the timed region (strong scaling).
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SH_BYTES = {0: 0, 1: 18, 2: 48}
+
+
+def algorithmic_bytes(R, Rs, D, P, sh_degree, cov_half, precision=16):
+    """B = 56*Rs + (84+S)*R + 40*D + 4*P (72+S instead of 84+S for fp16 covariances;
+    +16*Rs per radix pass beyond two)."""
+    sort = 56 + 16 * max(0, (precision + 7) // 8 - 2)
+    proj = (72 if cov_half else 84) + SH_BYTES[sh_degree]
+    return sort * Rs + proj * R + 40 * D + 4 * P
+
+
+def cpu_baseline(scene, mvp, budget_s):
+    """Time the reference's own sorter (oracle/_ref, compiled from the reference's sorter_no_simd.cpp) on this
+    host: 1 thread, the faithful configuration (one Web Worker).  The reference has no CPU rasteriser, so the
+    baseline covers the sort half of the frame only."""
+    import oracle
+    from gaussiansplats3d_amd import util
+    n = scene.count
+    ci = util.integer_centers(scene.centers)
+    idx = np.arange(n, dtype=np.uint32)
+    kind = "reference" if oracle.have_ref() else "port"
+    fn = oracle.ref_sort_indexes if kind == "reference" else oracle.sort_indexes
+    fn(idx[:1000], ci, mvp)                                  # warm the library
+    t_total, reps = 0.0, 0
+    while t_total < budget_s and reps < 200:
+        t0 = time.perf_counter()
+        fn(idx, ci, mvp)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    per = t_total / reps
+    return {"value": round(n / per / 1e6, 2), "unit": "Msplats/s (sort only)", "cores": 1, "kind": kind,
+            "ms_per_sort": round(per * 1e3, 2), "host_cpus": os.cpu_count(),
+            "sample": f"{reps} full sorts of the same {n} splats / same MVP, precision 16, integer static path; "
+                      "the reference has no CPU rasteriser, so raster has no CPU leg"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug only; invalid as a result)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util
+    from gaussiansplats3d_amd import dist as gdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = scenes.CONFIGS[args.config]
+    W, H = cfg["width"], cfg["height"]
+    t_gen = time.perf_counter()
+    scene = scenes.make_config_scene(args.config, args.splats or None)
+    cam = camera.demo_camera(cfg["pose"], W, H)
+    mvp = cam.sort_mvp()
+    N = scene.count
+    t_gen = time.perf_counter() - t_gen
+
+    stream = torch.cuda.Stream(device=device)
+    ctx = Context(local_rank, stream.cuda_stream)
+    worker = create_sort_worker(ctx, N)                       # integerBasedSort, precision 16: Viewer defaults
+    worker.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
+    mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half)
+    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+    mesh.set_camera(cam)
+
+    rows_total = (H + 15) // 16
+    with torch.cuda.stream(stream):
+        full = torch.zeros((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+
+        # probe frame (untimed): full-frame draw gives per-tile-row entry counts to balance the strips, and grows
+        # the entry buffer if the first guess was too small
+        worker.sort_on_device(mvp, N)
+        mesh.use_sorter_result(worker, N)
+        probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
+        _, st_probe = mesh.render(out_device_ptr=probe.data_ptr(), to_host=False, want_stats=True)
+        row_cost = mesh.tile_entry_counts().sum(axis=1)
+        strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
+        my = strips[rank]
+        y0, y1 = gdist.strip_pixel_rows(my, H)
+        strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
+        del probe
+
+        def frame():
+            worker.sort_on_device(mvp, N)
+            mesh.render(tile_rows=my if world > 1 else None, out_device_ptr=strip.data_ptr(), to_host=False,
+                        want_stats=False)
+            if world > 1:
+                gdist.gather_strips(strip, strips, full, rank, world, dist)
+
+        for _ in range(args.warmup):
+            frame()
+        stream.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame()
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # per-stage device times (HIP events recorded by the library on `stream`), one synchronised frame at a time
+        stage = {"sort": [], "project": [], "bin": [], "tile_sort": [], "blend": [], "render": []}
+        D_strip = 0
+        for _ in range(min(args.steps, 10)):
+            worker.sort_on_device(mvp, N)
+            mesh.render(tile_rows=my if world > 1 else None, out_device_ptr=strip.data_ptr(), to_host=False,
+                        want_stats=False)
+            rs = mesh.last_stats()
+            ss, _ = worker.last_stats()
+            stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
+            stage["tile_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
+            stage["render"].append(rs.device_ms)
+            D_strip = int(rs.tile_entries)
+        stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    D_full = int(st_probe.tile_entries)
+    if rank == 0:
+        R = Rs = N
+        P = W * H
+        B = algorithmic_bytes(R, Rs, D_full, P, scene.sh_degree, scene.cov_half)
+        achieved = B / (ms_per_step * 1e-3) / 1e9
+        # per-stage algorithmic bytes (same §8d accounting, split by stage) over the measured stage time
+        stage_bytes = {"sort": 56 * Rs, "project": ((72 if scene.cov_half else 84) + SH_BYTES[scene.sh_degree] - 8) * R,
+                       "bin": 8 * R + 8 * D_strip, "tile_sort": 24 * D_strip, "blend": 8 * D_strip + 4 * P // world}
+        stages = {k: {"ms": round(stage_ms[k], 4), "GBps": round(stage_bytes[k] / max(stage_ms[k], 1e-6) / 1e6, 1)}
+                  for k in stage_bytes}
+        dominant = max(stage_bytes, key=lambda k: stage_ms[k])
+        out = {
+            "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if args.config == "C3"
+                      else f"Msplats/s sorted+rasterized ({cfg['label']})",
+            "value": round(N / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "fps": round(1e3 / ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int32 keys / f32 raster", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
+                       "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
+                       "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
+                       "strips": strips if world > 1 else None},
+            "roofline": {"bound": "hbm", "kernel": "whole frame (sort+project+bin+tile-sort+blend), per SURVEY.md §8d",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_frame": int(B), "bytes_per_splat": round(B / R, 1),
+                         "tile_entries_D": D_full, "D_per_splat": round(D_full / R, 3),
+                         "dominant_stage": dominant, "stages": stages},
+            "cpu_baseline": None,
+            "scene_gen_s": round(t_gen, 1),
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(scene, mvp, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    worker.terminate()
+    mesh.dispose()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

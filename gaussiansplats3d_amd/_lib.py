@@ -1,0 +1,133 @@
+"""ctypes binding of libgsplat_hip.so (the C ABI in include/gsplat_hip.h).
+
+There is no CPU fallback: importing works anywhere (so the symbol table can be checked on a CPU box), but every
+compute entry point needs a gfx950 device and raises :class:`GsError` otherwise.
+"""
+import ctypes as C
+import os
+import subprocess
+import weakref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgsplat_hip.so")
+
+GS_OK, GS_WARN_KEY_CLAMPED = 0, 1
+GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
+GS_MESH_COV_HALF = 1
+GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD = 1, 2
+GS_TILE = 16
+GS_MAX_SCENES = 32
+
+
+class GsError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libgsplat_hip status {status}: {message}")
+        self.status = status
+
+
+class SortStats(C.Structure):
+    _fields_ = [("device_ms", C.c_float), ("key_min", C.c_int32), ("key_max", C.c_int32), ("clamped", C.c_uint32),
+                ("passes", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_pos", C.c_float * 3),
+                ("focal", C.c_float * 2), ("width", C.c_uint32), ("height", C.c_uint32), ("splat_scale", C.c_float),
+                ("kernel2d", C.c_float), ("max_splat_px", C.c_float), ("inv_focal_adj", C.c_float),
+                ("sh_degree", C.c_uint32), ("flags", C.c_uint32), ("tile_row_begin", C.c_uint32),
+                ("tile_row_end", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("device_ms", C.c_float), ("project_ms", C.c_float), ("bin_ms", C.c_float),
+                ("tile_sort_ms", C.c_float), ("blend_ms", C.c_float), ("visible_splats", C.c_uint32),
+                ("tile_entries", C.c_uint64), ("entry_capacity", C.c_uint32), ("overflowed", C.c_uint32)]
+
+
+# every symbol include/gsplat_hip.h declares: (restype, argtypes)
+_VP = C.c_void_p
+SYMBOLS = {
+    "gs_last_error": (C.c_char_p, []),
+    "gs_abi_version": (C.c_int, []),
+    "gs_device_count": (C.c_int, []),
+    "gs_context_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    "gs_context_destroy": (None, [_VP]),
+    "gs_context_synchronize": (C.c_int, [_VP]),
+    "gs_sorter_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "gs_sorter_destroy": (None, [_VP]),
+    "gs_sorter_upload_centers": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP]),
+    "gs_sorter_sort": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
+    "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_sorter_last_stats": (C.c_int, [_VP, C.POINTER(SortStats)]),
+    "gs_mesh_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "gs_mesh_destroy": (None, [_VP]),
+    "gs_mesh_upload": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
+    "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
+    "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libgsplat_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and type every entry point.  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GsError(GS_ERR_HIP, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                      "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    if status < 0:
+        raise GsError(status, load().gs_last_error().decode("utf-8", "replace"))
+    return status
+
+
+class Context:
+    """One per GPU (gs_context).  `stream`: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        self.handle = _VP()
+        check(self.lib.gs_context_create(int(device), _VP(stream) if stream else None, C.byref(self.handle)))
+        self.device = int(device)
+        self._children = weakref.WeakSet()     # sorters / meshes: must be destroyed before the context
+
+    def _adopt(self, child):
+        self._children.add(child)
+
+    def synchronize(self):
+        check(self.lib.gs_context_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            for child in list(self._children):   # a child outliving its context would be a use-after-free
+                child.close()
+            self.lib.gs_context_destroy(self.handle)
+            self.handle = _VP()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,88 @@
+// context.hip — error reporting and the per-GPU context of libgsplat_hip.so.
+#include <stdarg.h>
+
+#include "gs_internal.hpp"
+
+static thread_local char g_err[512] = "";
+
+void gs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char* gs_last_error(void) { return g_err; }
+int gs_abi_version(void) { return GS_ABI_VERSION; }
+
+int gs_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        gs_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return GS_ERR_HIP;
+    }
+    return n;
+}
+
+int gs_context_create(int device, void* hip_stream, gs_context** out) {
+    GS_REQUIRE(out != nullptr, "out == NULL");
+    *out = nullptr;
+    int n = gs_device_count();
+    if (n < 0) return n;
+    if (n == 0) {
+        gs_set_error("no HIP device visible: libgsplat_hip has no CPU fallback");
+        return GS_ERR_HIP;
+    }
+    GS_REQUIRE(device >= 0 && device < n, "device index out of range");
+    GS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GS_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        gs_set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return GS_ERR_HIP;
+    }
+    gs_context* ctx = new (std::nothrow) gs_context();
+    if (!ctx) return GS_ERR_NOMEM;
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            gs_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return GS_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    int st = ctx->radix.init();
+    if (st < 0) {
+        gs_context_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return GS_OK;
+}
+
+void gs_context_destroy(gs_context* ctx) {
+    if (!ctx) return;
+    ScopedDevice sd(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->radix.block_hist.release();
+    ctx->radix.digit_total.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int gs_context_synchronize(gs_context* ctx) {
+    GS_REQUIRE(ctx != nullptr, "ctx == NULL");
+    ScopedDevice sd(ctx->device);
+    GS_HIP(hipStreamSynchronize(ctx->stream));
+    return GS_OK;
+}
+
+}  // extern "C"

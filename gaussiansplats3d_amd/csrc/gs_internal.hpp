@@ -1,0 +1,217 @@
+// gs_internal.hpp — shared host/device declarations of libgsplat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "../../include/gsplat_hip.h"
+
+// ---------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------
+void gs_set_error(const char* fmt, ...);
+
+#define GS_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            gs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GS_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define GS_REQUIRE(cond, msg)                                    \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            gs_set_error("invalid argument: %s", msg);           \
+            return GS_ERR_INVALID;                               \
+        }                                                        \
+    } while (0)
+
+#define GS_TRY(expr)                 \
+    do {                             \
+        int _s = (expr);             \
+        if (_s < 0) return _s;       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// device memory
+// ---------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            gs_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+            return GS_ERR_NOMEM;
+        }
+        bytes = n;
+        return GS_OK;
+    }
+    int ensure(size_t n) { return n <= bytes ? GS_OK : alloc(n); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// radix sort geometry (radix.hpp)
+// ---------------------------------------------------------------------------------------------------
+constexpr int RADIX_THREADS = 256;
+constexpr int RADIX_ITEMS = 16;
+constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;   // keys per block iteration
+constexpr int RADIX_MAX_BLOCKS = 2048;                    // grid cap: 8 blocks per CU
+constexpr int RADIX_BINS = 256;
+constexpr int RADIX_MAX_PASSES = 4;
+
+struct RadixScratch {
+    DevBuf block_hist;    // uint32 [RADIX_BINS][RADIX_MAX_BLOCKS]  (digit-major)
+    DevBuf digit_total;   // uint32 [RADIX_MAX_PASSES][RADIX_BINS]
+    int init() {
+        GS_TRY(block_hist.alloc(sizeof(uint32_t) * RADIX_BINS * RADIX_MAX_BLOCKS));
+        GS_TRY(digit_total.alloc(sizeof(uint32_t) * RADIX_MAX_PASSES * RADIX_BINS));
+        return GS_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+struct gs_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cu_count = 256;
+    RadixScratch radix;
+};
+
+struct ScopedDevice {
+    int prev = -1;
+    explicit ScopedDevice(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~ScopedDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// sorter object (sorter.hip)
+// ---------------------------------------------------------------------------------------------------
+struct SortFrame {            // device-resident per-sort scalars
+    int32_t key_min;          // atomicMin target, initialised to +2147483640 (sorter.cpp:25)
+    int32_t key_max;          // atomicMax target, initialised to -2147483640 (sorter.cpp:24)
+    uint32_t clamped;
+    uint32_t pad;
+};
+
+struct gs_sorter {
+    gs_context* ctx = nullptr;
+    uint32_t max_count = 0, flags = 0, precision = 16, uploaded = 0;
+    // SoA planes of the AoS x4 centres the worker receives (int32 or float bit patterns)
+    DevBuf cx, cy, cz, cw, scene_idx;
+    DevBuf staging;            // upload staging (AoS) / host index list / precomputed distances
+    DevBuf idx_in;             // indexesToSort on device
+    DevBuf precomputed;
+    DevBuf keys;               // int32 depth key per list position (mappedDistances, phase A)
+    DevBuf keyA, keyB, valA, valB;   // radix ping-pong
+    DevBuf sorted;             // uint32 [render_count]: the sortDone payload, stays resident for the mesh
+    DevBuf frame;              // SortFrame
+    DevBuf scene_rows;         // per-scene key coefficients (dynamic mode)
+    DevBuf debug;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t last_render = 0, last_sort = 0, last_passes = 0;
+    bool last_identity = true;
+    bool has_result = false;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// mesh object (mesh.hip + project.hip + tile_bin.hip + tile_blend.hip)
+// ---------------------------------------------------------------------------------------------------
+// Vertex-stage record consumed by the blend (32 B, one aligned sector per gather):
+//   cx, cy         centre in pixels (GL window coordinates, row 0 = bottom)
+//   ax, ay, bx, by K * e1 / |b1|, K * e2 / |b2| with K^2 = 4*log2(e): power = (a.d)^2 + (b.d)^2 =
+//                  0.5*log2(e)*A, alpha = exp2(-power) * a0; discard when power > 4*log2(e) (A > 8)
+//   c0             r | g << 16 (unorm16)
+//   c1             b | a << 16 (unorm16; a = rgba8.a/255, or the antialias-compensated alpha)
+struct __attribute__((aligned(32))) SplatRec {
+    float cx, cy, ax, ay;
+    float bx, by;
+    uint32_t c0, c1;
+};
+static_assert(sizeof(SplatRec) == 32, "SplatRec must be one 32-byte sector");
+
+struct RenderFrame {          // device-resident per-draw scalars
+    uint32_t visible;         // splats passing the vertex-stage rejects
+    uint32_t entries_lo;      // total tile entries D (uint64 split for atomics-free writes)
+    uint32_t entries_hi;
+    uint32_t overflow;        // D exceeded the entry capacity
+    uint32_t entry_count;     // min(D, capacity): what the tile sort and blend consume
+    uint32_t pad[3];
+};
+
+struct ProjectParams {
+    float view[16];
+    float proj[16];
+    float cam_pos[3];
+    float focal_x, focal_y;
+    float width, height;
+    float splat_scale, kernel2d, max_splat_px, inv_focal_adj;
+    uint32_t sh_degree;       // degree evaluated
+    uint32_t sh_stored;       // degree stored
+    uint32_t cov_half;
+    uint32_t flags;
+    uint32_t tiles_x, tiles_y;
+    uint32_t row_begin, row_end;   // tile rows rendered by this rank
+    uint32_t count;
+};
+
+struct gs_mesh {
+    gs_context* ctx = nullptr;
+    uint32_t max_count = 0, sh_degree = 0, flags = 0, uploaded = 0;
+    // SoA planes
+    DevBuf px, py, pz;         // float centres
+    DevBuf covA, covB;         // fp32: float4 + float2 ; fp16: uint2 + uint
+    DevBuf rgba;               // uint32
+    DevBuf sh0, sh1, sh2;      // uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
+    DevBuf staging;
+    // per-draw
+    DevBuf recs;               // SplatRec [n]  (storage order)
+    DevBuf rects;              // uint2 [n]     tile rect per splat (storage order)
+    DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
+    DevBuf rect_q;             // uint2 [render_count] rects in front-to-back traversal order
+    DevBuf bin_sums;           // uint32 [2][BIN_MAX_BLOCKS]: tile entries | visible splats per workgroup
+    DevBuf ekeyA, ekeyB, evalA, evalB;   // tile entries ping-pong (key = tile id, val = splat index)
+    DevBuf tile_ranges;        // uint2 [tiles]
+    DevBuf frame;              // RenderFrame
+    DevBuf fb;                 // internal RGBA8 framebuffer
+    uint32_t entry_capacity = 0;
+    uint32_t sorted_buf = 0;   // ping-pong buffer index holding the tile-sorted entries of the last draw
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    gs_render_stats last = {};
+    bool has_draw = false;
+    uint32_t last_count = 0;
+};
+
+// kernels' host launchers ---------------------------------------------------------------------------
+int gs_launch_frame_init(gs_mesh* m, uint32_t tiles);
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp);
+int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t render_count);
+int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);

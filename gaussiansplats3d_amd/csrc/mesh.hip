@@ -1,0 +1,329 @@
+// mesh.hip — the RENDER SEAM object: device-resident splat data + one draw =
+//   k_project (project.hip) -> binning + tile sort (tile_bin.hip) -> k_tile_blend (tile_blend.hip).
+// Replaces SplatMesh's data textures / uniforms / instanced draw
+// (/root/reference/src/splatmesh/SplatMesh.js:637-898, 1228-1280; src/Viewer.js:1616).
+#include "gs_internal.hpp"
+
+void gs_set_error(const char* fmt, ...);
+
+// AoS upload formats -> SoA planes -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split_centers(const float* __restrict__ c3, uint32_t count, uint32_t from,
+                                                       float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        x[from + i] = c3[3 * (size_t)i];
+        y[from + i] = c3[3 * (size_t)i + 1];
+        z[from + i] = c3[3 * (size_t)i + 2];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split_cov_f32(const float* __restrict__ c6, uint32_t count, uint32_t from,
+                                                       float4* __restrict__ a, float2* __restrict__ b) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float* s = c6 + 6 * (size_t)i;
+        a[from + i] = make_float4(s[0], s[1], s[2], s[3]);
+        b[from + i] = make_float2(s[4], s[5]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_split_cov_f16(const uint16_t* __restrict__ c6, uint32_t count, uint32_t from,
+                                                       uint2* __restrict__ a, uint32_t* __restrict__ b) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint16_t* s = c6 + 6 * (size_t)i;
+        a[from + i] = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
+        b[from + i] = (uint32_t)s[4] | ((uint32_t)s[5] << 16);
+    }
+}
+
+// coefficient-major RGB triples (9 or 24 halfs per splat) -> 16-byte planes
+__global__ __launch_bounds__(256) void k_split_sh(const uint16_t* __restrict__ sh, uint32_t count, uint32_t from,
+                                                  uint32_t ncoef, uint4* __restrict__ p0, void* __restrict__ p1,
+                                                  uint4* __restrict__ p2) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint16_t* s = sh + (size_t)ncoef * i;
+        auto pk = [&](int k) { return (uint32_t)s[k] | ((uint32_t)s[k + 1] << 16); };
+        p0[from + i] = make_uint4(pk(0), pk(2), pk(4), pk(6));
+        if (ncoef == 9) {
+            reinterpret_cast<uint32_t*>(p1)[from + i] = (uint32_t)s[8];
+        } else {
+            reinterpret_cast<uint4*>(p1)[from + i] = make_uint4(pk(8), pk(10), pk(12), pk(14));
+            p2[from + i] = make_uint4(pk(16), pk(18), pk(20), pk(22));
+        }
+    }
+}
+
+static inline uint32_t up_grid(uint32_t n) {
+    uint32_t g = (n + 255u) / 256u;
+    return g < 1 ? 1 : (g > 4096u ? 4096u : g);
+}
+
+static int mesh_alloc_entries(gs_mesh* m, uint32_t capacity) {
+    // keys are sized for 32-bit tile ids so the same buffers serve > 65536-tile strips
+    GS_TRY(m->ekeyA.alloc((size_t)capacity * 4));
+    GS_TRY(m->ekeyB.alloc((size_t)capacity * 4));
+    GS_TRY(m->evalA.alloc((size_t)capacity * 4));
+    GS_TRY(m->evalB.alloc((size_t)capacity * 4));
+    m->entry_capacity = capacity;
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree, uint32_t flags, gs_mesh** out) {
+    GS_REQUIRE(ctx && out, "ctx / out == NULL");
+    *out = nullptr;
+    GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
+    GS_REQUIRE(sh_degree <= 2, "sh_degree > 2 (the reference renders degrees 0..2, src/Viewer.js:154)");
+    GS_REQUIRE((flags & ~GS_MESH_COV_HALF) == 0, "unknown mesh flags");
+    ScopedDevice sd(ctx->device);
+    gs_mesh* m = new (std::nothrow) gs_mesh();
+    if (!m) return GS_ERR_NOMEM;
+    m->ctx = ctx;
+    m->max_count = max_splat_count;
+    m->sh_degree = sh_degree;
+    m->flags = flags;
+    const size_t n = max_splat_count;
+    const bool half = (flags & GS_MESH_COV_HALF) != 0;
+    int st = GS_OK;
+    auto A = [&](DevBuf& b, size_t bytes) { if (st == GS_OK) st = b.alloc(bytes); };
+    A(m->px, n * 4); A(m->py, n * 4); A(m->pz, n * 4);
+    A(m->covA, n * (half ? 8 : 16)); A(m->covB, n * (half ? 4 : 8));
+    A(m->rgba, n * 4);
+    if (sh_degree >= 1) { A(m->sh0, n * 16); A(m->sh1, n * (sh_degree == 2 ? 16 : 4)); }
+    if (sh_degree >= 2) A(m->sh2, n * 16);
+    A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8);
+    A(m->bin_sums, 4 * 2048);
+    A(m->frame, sizeof(RenderFrame));
+    if (st == GS_OK) {
+        // first guess: 8 tile entries per splat, at least 4M; grown on overflow
+        uint64_t cap = (uint64_t)n * 8;
+        if (cap < (4u << 20)) cap = 4u << 20;
+        if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
+        st = mesh_alloc_entries(m, (uint32_t)cap);
+    }
+    for (int i = 0; i < 6 && st == GS_OK; i++)
+        if (hipEventCreate(&m->ev[i]) != hipSuccess) {
+            gs_set_error("hipEventCreate failed");
+            st = GS_ERR_HIP;
+        }
+    if (st != GS_OK) {
+        gs_mesh_destroy(m);
+        return st;
+    }
+    *out = m;
+    return GS_OK;
+}
+
+void gs_mesh_destroy(gs_mesh* m) {
+    if (!m) return;
+    ScopedDevice sd(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    for (int i = 0; i < 6; i++)
+        if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
+    delete m;
+}
+
+int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
+                   const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16) {
+    GS_REQUIRE(m && centers && rgba, "mesh / centers / rgba == NULL");
+    GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    const bool half = (m->flags & GS_MESH_COV_HALF) != 0;
+    GS_REQUIRE(half ? (cov_f16 && !cov_f32) : (cov_f32 && !cov_f16), "covariance format does not match the mesh (GS_MESH_COV_HALF)");
+    GS_REQUIRE(m->sh_degree == 0 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
+    if (count == 0) return GS_OK;
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    const uint32_t ncoef = m->sh_degree == 0 ? 0 : (m->sh_degree == 1 ? 9 : 24);
+    const size_t b_c = (size_t)count * 12, b_cov = (size_t)count * (half ? 12 : 24), b_sh = (size_t)count * ncoef * 2;
+    size_t off_cov = (b_c + 255) & ~(size_t)255, off_sh = (off_cov + b_cov + 255) & ~(size_t)255;
+    GS_TRY(m->staging.ensure(off_sh + b_sh + 256));
+    char* stg = m->staging.as<char>();
+    GS_HIP(hipMemcpyAsync(stg, centers, b_c, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(stg + off_cov, half ? (const void*)cov_f16 : (const void*)cov_f32, b_cov, hipMemcpyHostToDevice, st));
+    if (ncoef) GS_HIP(hipMemcpyAsync(stg + off_sh, sh_f16, b_sh, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(m->rgba.as<uint32_t>() + from, rgba, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    const dim3 g(up_grid(count)), b(256);
+    hipLaunchKernelGGL(k_split_centers, g, b, 0, st, (const float*)stg, count, from, m->px.as<float>(), m->py.as<float>(),
+                       m->pz.as<float>());
+    if (half)
+        hipLaunchKernelGGL(k_split_cov_f16, g, b, 0, st, (const uint16_t*)(stg + off_cov), count, from, m->covA.as<uint2>(),
+                           m->covB.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_split_cov_f32, g, b, 0, st, (const float*)(stg + off_cov), count, from, m->covA.as<float4>(),
+                           m->covB.as<float2>());
+    if (ncoef)
+        hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, ncoef, m->sh0.as<uint4>(),
+                           m->sh1.p, m->sh2.as<uint4>());
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipStreamSynchronize(st));
+    if (from + count > m->uploaded) m->uploaded = from + count;
+    return GS_OK;
+}
+
+static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
+    hipStream_t st = m->ctx->stream;
+    RenderFrame f;
+    GS_HIP(hipMemcpyAsync(&f, m->frame.p, sizeof(f), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    float t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
+    m->last.project_ms = t[0];
+    m->last.bin_ms = t[1];
+    m->last.tile_sort_ms = t[2];
+    m->last.blend_ms = t[3] + t[4];
+    float total = 0;
+    GS_HIP(hipEventElapsedTime(&total, m->ev[0], m->ev[5]));
+    m->last.device_ms = total;
+    m->last.visible_splats = f.visible;
+    m->last.tile_entries = ((uint64_t)f.entries_hi << 32) | f.entries_lo;
+    m->last.entry_capacity = m->entry_capacity;
+    if (stats) *stats = m->last;
+    return f.overflow ? 1 : 0;
+}
+
+static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t R, uint8_t* out_dev) {
+    gs_context* ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t tiles = pp.tiles_x * (pp.row_end - pp.row_begin);
+    GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
+    GS_HIP(hipEventRecord(m->ev[0], st));
+    GS_TRY(gs_launch_frame_init(m, tiles));
+    GS_TRY(gs_launch_project(m, pp));
+    GS_HIP(hipEventRecord(m->ev[1], st));
+    GS_TRY(gs_launch_binning(m, pp, order_dev, R));      // records ev[2] between emit and the tile sort
+    GS_HIP(hipEventRecord(m->ev[3], st));
+    GS_TRY(gs_launch_blend(m, pp, out_dev));
+    GS_HIP(hipEventRecord(m->ev[4], st));
+    GS_HIP(hipEventRecord(m->ev[5], st));
+    return GS_OK;
+}
+
+int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
+                   uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats) {
+    GS_REQUIRE(m && cam, "mesh / camera == NULL");
+    GS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 65535u * GS_TILE && cam->height <= 65535u * GS_TILE,
+               "viewport size");
+    GS_REQUIRE(render_count <= m->uploaded, "render_count exceeds the uploaded splat count");
+    GS_REQUIRE(cam->sh_degree <= 2, "sphericalHarmonicsDegree > 2");
+    GS_REQUIRE(!(sorted_host && sorter), "pass either host indexes or a sorter, not both");
+    GS_REQUIRE(!sorter || (sorter->ctx == m->ctx && sorter->has_result && sorter->last_render >= render_count),
+               "sorter has no device-resident result covering render_count (or lives on another context)");
+    gs_context* ctx = m->ctx;
+    ScopedDevice sd(ctx->device);
+    hipStream_t st = ctx->stream;
+
+    ProjectParams pp = {};
+    memcpy(pp.view, cam->view, sizeof(pp.view));
+    memcpy(pp.proj, cam->proj, sizeof(pp.proj));
+    memcpy(pp.cam_pos, cam->cam_pos, sizeof(pp.cam_pos));
+    pp.focal_x = cam->focal[0];
+    pp.focal_y = cam->focal[1];
+    pp.width = (float)cam->width;
+    pp.height = (float)cam->height;
+    pp.splat_scale = cam->splat_scale;
+    pp.kernel2d = cam->kernel2d;
+    pp.max_splat_px = cam->max_splat_px;
+    pp.inv_focal_adj = cam->inv_focal_adj;
+    pp.sh_degree = cam->sh_degree < m->sh_degree ? cam->sh_degree : m->sh_degree;
+    pp.sh_stored = m->sh_degree;
+    pp.cov_half = (m->flags & GS_MESH_COV_HALF) ? 1u : 0u;
+    pp.flags = cam->flags;
+    pp.tiles_x = (cam->width + GS_TILE - 1) / GS_TILE;
+    pp.tiles_y = (cam->height + GS_TILE - 1) / GS_TILE;
+    pp.row_begin = cam->tile_row_begin;
+    pp.row_end = cam->tile_row_end;
+    if (pp.row_begin == 0 && pp.row_end == 0) pp.row_end = pp.tiles_y;
+    GS_REQUIRE(pp.row_begin <= pp.row_end && pp.row_end <= pp.tiles_y, "tile row range outside the viewport");
+    pp.count = m->uploaded;
+
+    // pixel rows covered by this rank's strip
+    const uint32_t y0 = pp.row_begin * GS_TILE;
+    const uint32_t y1 = pp.row_end * GS_TILE < cam->height ? pp.row_end * GS_TILE : cam->height;
+    const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
+
+    const uint32_t* order_dev = nullptr;
+    if (sorted_host) {
+        GS_TRY(m->order.ensure((size_t)m->max_count * 4));
+        if (render_count) GS_HIP(hipMemcpyAsync(m->order.p, sorted_host, (size_t)render_count * 4, hipMemcpyHostToDevice, st));
+        order_dev = m->order.as<uint32_t>();
+    } else if (sorter) {
+        order_dev = sorter->sorted.as<uint32_t>();
+    }
+    uint8_t* out_dev = reinterpret_cast<uint8_t*>(rgba_out_dev);
+    if (!out_dev) {
+        GS_TRY(m->fb.ensure(out_bytes + 16));
+        out_dev = m->fb.as<uint8_t>();
+    }
+
+    m->last = gs_render_stats();
+    GS_TRY(mesh_draw_once(m, pp, order_dev, render_count, out_dev));
+    m->has_draw = true;
+    m->last_count = pp.count;
+
+    int status = GS_OK;
+    const bool need_sync = rgba_out_host || stats;
+    if (need_sync) {
+        // overflow check: the only host<->device round trip of a draw, and only when the caller syncs anyway
+        int ov = mesh_collect_stats(m, nullptr);
+        if (ov < 0) return ov;
+        int guard = 0;
+        while (ov == 1 && guard++ < 4) {
+            uint64_t want = m->last.tile_entries + m->last.tile_entries / 8 + 1024;
+            if (want > 0x7FFFFFFFull) {
+                gs_set_error("tile entries (%llu) exceed the 2^31 limit", (unsigned long long)m->last.tile_entries);
+                return GS_ERR_CAPACITY;
+            }
+            GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
+            GS_TRY(mesh_draw_once(m, pp, order_dev, render_count, out_dev));
+            ov = mesh_collect_stats(m, nullptr);
+            if (ov < 0) return ov;
+            m->last.overflowed = 1;
+        }
+        if (ov == 1) {
+            gs_set_error("tile entry buffer still overflowing after regrowth");
+            return GS_ERR_CAPACITY;
+        }
+        if (rgba_out_host && out_bytes) {
+            GS_HIP(hipMemcpyAsync(rgba_out_host, out_dev, out_bytes, hipMemcpyDeviceToHost, st));
+            GS_HIP(hipStreamSynchronize(st));
+        }
+        if (stats) *stats = m->last;
+    }
+    return status;
+}
+
+int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats) {
+    GS_REQUIRE(m && stats, "mesh / stats == NULL");
+    GS_REQUIRE(m->has_draw, "no draw has run");
+    ScopedDevice sd(m->ctx->device);
+    const uint32_t was_overflowed = m->last.overflowed;
+    int ov = mesh_collect_stats(m, stats);
+    if (ov < 0) return ov;
+    stats->overflowed = was_overflowed;
+    if (ov == 1) {
+        // an asynchronous draw overflowed its entry buffer: grow now so the next draw fits, and tell the caller
+        uint64_t want = m->last.tile_entries + m->last.tile_entries / 8 + 1024;
+        if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
+        GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
+        gs_set_error("tile entry buffer overflowed (%llu entries); capacity grown, redraw the frame",
+                     (unsigned long long)m->last.tile_entries);
+        return GS_ERR_CAPACITY;
+    }
+    return GS_OK;
+}
+
+int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
+    GS_REQUIRE(m && dst, "mesh / dst == NULL");
+    GS_REQUIRE(m->has_draw && (what == 2 || count <= m->last_count), "no draw / count too large");
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    if (what == 0) GS_HIP(hipMemcpyAsync(dst, m->recs.p, (size_t)count * sizeof(SplatRec), hipMemcpyDeviceToHost, st));
+    else if (what == 1) GS_HIP(hipMemcpyAsync(dst, m->rects.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
+        GS_REQUIRE((size_t)count * 8 <= m->tile_ranges.bytes, "count exceeds the tile count of the last draw");
+        GS_HIP(hipMemcpyAsync(dst, m->tile_ranges.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    } else GS_REQUIRE(false, "unknown debug selector");
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+}  // extern "C"

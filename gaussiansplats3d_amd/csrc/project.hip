@@ -1,0 +1,205 @@
+// project.hip — vertex stage of the RENDER SEAM: one thread per splat in STORAGE order.
+//
+// Restates (never copies) the reference's GLSL vertex shader, executed there 4x per splat by an instanced
+// quad draw:  /root/reference/src/splatmesh/SplatMaterial.js:112-341 (fetch, view/clip transform, 1.2x
+// frustum reject, SH degree 1/2 colour) and /root/reference/src/splatmesh/SplatMaterial3D.js:81-217
+// (3D->2D covariance, +kernel2DSize, eigen basis, 1024-px clamp).
+//
+// MI355X layout: every input is an SoA *plane* whose element is the widest vector the attribute allows
+// (float for x/y/z, float4+float2 for the covariance, uint4 x3 for the 24 fp16 SH coefficients), so a
+// wave64 reads 256 B..1 KiB contiguous per instruction and each byte is fetched from HBM exactly once.
+// Storage order (not depth order) keeps those reads streaming; the depth sort runs concurrently on the
+// keys alone and meets this stage's output only through 8-byte tile rects and 32-byte records.
+//
+// Outputs per splat: SplatRec (32 B, what the blend gathers) and a tile rect (8 B, what the binner gathers).
+// Built with -ffp-contract=off and written in the oracle's operation order so accept/reject decisions agree.
+#include "gs_internal.hpp"
+
+struct MeshPlanes {
+    const float* __restrict__ px;
+    const float* __restrict__ py;
+    const float* __restrict__ pz;
+    const void* __restrict__ covA;      // fp32: float4 (c0..c3)   | fp16: uint2 (c0..c3)
+    const void* __restrict__ covB;      // fp32: float2 (c4,c5)    | fp16: uint  (c4,c5)
+    const uint32_t* __restrict__ rgba;
+    const uint4* __restrict__ sh0;      // halfs 0..7
+    const void* __restrict__ sh1;       // SH2: uint4 halfs 8..15 | SH1: uint (half 8)
+    const uint4* __restrict__ sh2;      // SH2: halfs 16..23
+};
+
+__device__ __forceinline__ float h2f(uint32_t bits16) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(bits16 & 0xFFFFu));
+}
+__device__ __forceinline__ float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+__device__ __forceinline__ uint32_t unorm16(float v) { return (uint32_t)(clamp01(v) * 65535.0f + 0.5f); }
+
+constexpr float GS_K_POWER = 2.4022448f;          // sqrt(4*log2(e)): alpha = exp2(-|K*q|^2) == exp(-0.5*A)
+constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zero tiles
+
+__global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
+                                                 uint2* __restrict__ rects, RenderFrame* frame) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool visible = false;
+    SplatRec rec;
+    rec.cx = rec.cy = rec.ax = rec.ay = rec.bx = rec.by = 0.0f;
+    rec.c0 = rec.c1 = 0u;
+    uint2 rect = make_uint2(RECT_EMPTY_LO, 0u);
+
+    if (i < pp.count) {
+        const float* MV = pp.view;
+        const float* P = pp.proj;
+        const float c0 = mp.px[i], c1 = mp.py[i], c2 = mp.pz[i];
+        // SplatMaterial.js:156,158
+        float v[4], q[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = MV[r] * c0 + MV[4 + r] * c1 + MV[8 + r] * c2 + MV[12 + r];
+#pragma unroll
+        for (int r = 0; r < 4; r++) q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
+        const float clip = 1.2f * q[3];                                               // :160-164
+        bool ok = !(q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip);
+        const float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];       // :166
+        ok = ok && (ndcz >= -1.0f && ndcz <= 1.0f);       // quad z == centre z (SplatMaterial3D.js:209): GL clip
+
+        if (ok) {
+            const uint32_t packed = mp.rgba[i];
+            float col[3] = {(float)(packed & 255u) * (1.0f / 255.0f), (float)((packed >> 8) & 255u) * (1.0f / 255.0f),
+                            (float)((packed >> 16) & 255u) * (1.0f / 255.0f)};                 // :169
+            float alpha = (float)(packed >> 24) * (1.0f / 255.0f);
+
+            if (pp.sh_stored >= 1 && pp.sh_degree >= 1) {
+                float d0 = c0 - pp.cam_pos[0], d1 = c1 - pp.cam_pos[1], d2 = c2 - pp.cam_pos[2];   // :185
+                const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+                const float x = d0 * inv, y = d1 * inv, z = d2 * inv;
+                float sh[24];
+                const uint4 a = mp.sh0[i];
+                sh[0] = h2f(a.x); sh[1] = h2f(a.x >> 16); sh[2] = h2f(a.y); sh[3] = h2f(a.y >> 16);
+                sh[4] = h2f(a.z); sh[5] = h2f(a.z >> 16); sh[6] = h2f(a.w); sh[7] = h2f(a.w >> 16);
+                if (pp.sh_stored >= 2) {
+                    const uint4 b = reinterpret_cast<const uint4*>(mp.sh1)[i];
+                    sh[8] = h2f(b.x); sh[9] = h2f(b.x >> 16); sh[10] = h2f(b.y); sh[11] = h2f(b.y >> 16);
+                    sh[12] = h2f(b.z); sh[13] = h2f(b.z >> 16); sh[14] = h2f(b.w); sh[15] = h2f(b.w >> 16);
+                } else {
+                    sh[8] = h2f(reinterpret_cast<const uint32_t*>(mp.sh1)[i]);
+                }
+                const float SH_C1 = 0.4886025119029199f;                                            // :273
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
+                if (pp.sh_stored >= 2 && pp.sh_degree >= 2) {                                       // :308-330
+                    const uint4 cc = mp.sh2[i];
+                    sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
+                    sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    const float C0 = 1.0925484f, C1 = -1.0925484f, C2 = 0.3153916f, C3 = -1.0925484f, C4 = 0.5462742f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        col[ch] += (C0 * xy) * sh[9 + ch] + (C1 * yz) * sh[12 + ch] + (C2 * (2.0f * zz - xx - yy)) * sh[15 + ch] +
+                                   (C3 * xz) * sh[18 + ch] + (C4 * (xx - yy)) * sh[21 + ch];
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) col[ch] = clamp01(col[ch]);                          // :337
+            }
+
+            // SplatMaterial3D.js:87-109 covariance fetch
+            float V00, V01, V02, V11, V12, V22;
+            if (pp.cov_half) {
+                const uint2 a = reinterpret_cast<const uint2*>(mp.covA)[i];
+                const uint32_t b = reinterpret_cast<const uint32_t*>(mp.covB)[i];
+                V00 = h2f(a.x); V01 = h2f(a.x >> 16); V02 = h2f(a.y); V11 = h2f(a.y >> 16); V12 = h2f(b); V22 = h2f(b >> 16);
+            } else {
+                const float4 a = reinterpret_cast<const float4*>(mp.covA)[i];
+                const float2 b = reinterpret_cast<const float2*>(mp.covB)[i];
+                V00 = a.x; V01 = a.y; V02 = a.z; V11 = a.w; V12 = b.x; V22 = b.y;
+            }
+            // :120-134  J, W = transpose(mat3(MV)), T = W*J, cov2D = T^T * Vrk * T
+            const float s = 1.0f / (v[2] * v[2]);
+            const float j00 = pp.focal_x / v[2], j20 = -(pp.focal_x * v[0]) * s;
+            const float j11 = pp.focal_y / v[2], j21 = -(pp.focal_y * v[1]) * s;
+            float T0[3], T1[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const float w0 = MV[4 * r + 0], w1 = MV[4 * r + 1], w2 = MV[4 * r + 2];
+                T0[r] = w0 * j00 + w2 * j20;
+                T1[r] = w1 * j11 + w2 * j21;
+            }
+            const float VT0[3] = {V00 * T0[0] + V01 * T0[1] + V02 * T0[2], V01 * T0[0] + V11 * T0[1] + V12 * T0[2],
+                                  V02 * T0[0] + V12 * T0[1] + V22 * T0[2]};
+            const float VT1[3] = {V00 * T1[0] + V01 * T1[1] + V02 * T1[2], V01 * T1[0] + V11 * T1[1] + V12 * T1[2],
+                                  V02 * T1[0] + V12 * T1[1] + V22 * T1[2]};
+            float a = T0[0] * VT0[0] + T0[1] * VT0[1] + T0[2] * VT0[2];
+            const float bb = T0[0] * VT1[0] + T0[1] * VT1[1] + T0[2] * VT1[2];
+            float d = T1[0] * VT1[0] + T1[1] * VT1[1] + T1[2] * VT1[2];
+            if (pp.flags & GS_CAM_ANTIALIASED) {                                                    // :137-144
+                const float det0 = a * d - bb * bb;
+                a += pp.kernel2d; d += pp.kernel2d;
+                const float det1 = a * d - bb * bb;
+                const float ratio = det0 / det1;
+                alpha *= sqrtf(ratio > 0.0f ? ratio : 0.0f);
+                if (alpha < (1.0f / 255.0f)) ok = false;
+            } else {                                                                                // :147-150
+                a += pp.kernel2d; d += pp.kernel2d;
+            }
+            // :174-196 eigen decomposition and basis
+            const float D = a * d - bb * bb;
+            const float half_tr = 0.5f * (a + d);
+            const float disc = half_tr * half_tr - D;
+            const float term2 = sqrtf(disc > 0.1f ? disc : 0.1f);
+            float l1 = half_tr + term2, l2 = half_tr - term2;
+            if (pp.flags & GS_CAM_POINT_CLOUD) l1 = l2 = 0.2f;
+            if (l2 <= 0.0f) ok = false;
+            const float ex = bb, ey = l1 - a;
+            const float elen = sqrtf(ex * ex + ey * ey);
+            const float e1x = ex / elen, e1y = ey / elen;
+            if (!(e1x == e1x) || !(e1y == e1y)) ok = false;          // normalize(vec2(0)) -> NaN -> nothing drawn
+            const float e2x = e1y, e2y = -e1x;
+            const float sqrt8 = sqrtf(8.0f);
+            float h1 = sqrt8 * sqrtf(l1); if (h1 > pp.max_splat_px) h1 = pp.max_splat_px;
+            float h2 = sqrt8 * sqrtf(l2); if (h2 > pp.max_splat_px) h2 = pp.max_splat_px;
+            const float k = pp.splat_scale * pp.inv_focal_adj;       // pixel offset = (q.x*b1 + q.y*b2)*invFocalAdj
+            const float b1x = e1x * k * h1, b1y = e1y * k * h1;
+            const float b2x = e2x * k * h2, b2y = e2y * k * h2;
+            const float cx = (ndcx * 0.5f + 0.5f) * pp.width;
+            const float cy = (ndcy * 0.5f + 0.5f) * pp.height;
+
+            if (ok) {
+                // conservative pixel bounds of the ellipse {c + qx*b1 + qy*b2 : |q| <= 1}  (A <= 8)
+                const float ext_x = sqrtf(b1x * b1x + b2x * b2x) * 1.00001f + 1e-3f;
+                const float ext_y = sqrtf(b1y * b1y + b2y * b2y) * 1.00001f + 1e-3f;
+                float fx0 = ceilf(cx - ext_x - 0.5f), fx1 = floorf(cx + ext_x - 0.5f);
+                float fy0 = ceilf(cy - ext_y - 0.5f), fy1 = floorf(cy + ext_y - 0.5f);
+                const float ymin = (float)(pp.row_begin * GS_TILE);
+                const float ymax = fminf(pp.height, (float)(pp.row_end * GS_TILE)) - 1.0f;
+                fx0 = fmaxf(fx0, 0.0f); fx1 = fminf(fx1, pp.width - 1.0f);
+                fy0 = fmaxf(fy0, ymin); fy1 = fminf(fy1, ymax);
+                if (fx0 <= fx1 && fy0 <= fy1) {           // false for NaN as well
+                    visible = true;
+                    const uint32_t tx0 = (uint32_t)fx0 / GS_TILE, tx1 = (uint32_t)fx1 / GS_TILE;
+                    const uint32_t ty0 = (uint32_t)fy0 / GS_TILE, ty1 = (uint32_t)fy1 / GS_TILE;
+                    rect = make_uint2(tx0 | (ty0 << 16), tx1 | (ty1 << 16));
+                    const float n1 = b1x * b1x + b1y * b1y, n2 = b2x * b2x + b2y * b2y;
+                    rec.cx = cx; rec.cy = cy;
+                    rec.ax = GS_K_POWER * (b1x / n1); rec.ay = GS_K_POWER * (b1y / n1);
+                    rec.bx = GS_K_POWER * (b2x / n2); rec.by = GS_K_POWER * (b2y / n2);
+                    rec.c0 = unorm16(col[0]) | (unorm16(col[1]) << 16);
+                    rec.c1 = unorm16(col[2]) | (unorm16(alpha) << 16);
+                }
+            }
+        }
+        recs[i] = rec;
+        rects[i] = rect;
+    }
+    (void)visible;
+    (void)frame;   // no global atomics here: ~90k same-address atomics cost ~1 ms; the binner counts visible splats
+}
+
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp) {
+    MeshPlanes mp;
+    mp.px = m->px.as<float>(); mp.py = m->py.as<float>(); mp.pz = m->pz.as<float>();
+    mp.covA = m->covA.p; mp.covB = m->covB.p;
+    mp.rgba = m->rgba.as<uint32_t>();
+    mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
+    if (pp.count == 0) return GS_OK;
+    hipLaunchKernelGGL(k_project, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->stream, pp, mp,
+                       m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->frame.as<RenderFrame>());
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

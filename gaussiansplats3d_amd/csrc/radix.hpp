@@ -1,0 +1,262 @@
+// radix.hpp — stable LSD radix sort passes (8-bit digits) for gfx950, wave64.
+//
+// Used twice per frame:
+//   * the depth sort that replaces the reference's counting sort (/root/reference/src/worker/sorter.cpp:142-167):
+//     16..24-bit bucket keys, 2..3 passes, payload = global splat index;
+//   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
+//     that each tile's list keeps the depth order established by the first sort.
+//
+// One pass = k_radix_hist -> k_radix_rowsum -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
+// no dependence on dispatch order (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS
+// workgroups walks contiguous runs of 4096-key tiles, so the [256][grid] offset matrix stays <= 2 MB
+// whatever N is, and N may live in device memory (tile-entry count is only known on the device).
+//
+// Ranking inside a tile is wave64-native: 8 ballots build the "same digit" lane mask, the rank is a popcount
+// of the lower lanes plus a per-wave LDS counter; keys are then reordered through LDS so that every digit's
+// run leaves the CU as contiguous stores.
+#pragma once
+#include "gs_internal.hpp"
+
+// ---------------------------------------------------------------------------------------------------
+// small wave / block helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if ((int)lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_tmp /*>=4*/, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v, lane);
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
+    const uint32_t wave_base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
+    if (total) *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return wave_base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// loaders: logical element j in [0, count()) -> (key, payload)
+// ---------------------------------------------------------------------------------------------------
+template <class KeyT>
+struct ArrayLoader {
+    const KeyT* __restrict__ keys;
+    const uint32_t* __restrict__ vals;
+    const uint32_t* __restrict__ n_dev;   // device-resident count (nullable)
+    uint32_t n_host;
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
+    __device__ __forceinline__ uint32_t key(uint32_t j) const { return (uint32_t)keys[j]; }
+    __device__ __forceinline__ uint32_t val(uint32_t j) const { return vals[j]; }
+    __device__ __forceinline__ void note_clamp(bool) const {}
+};
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+struct RadixChunk {
+    uint32_t n, tile_begin, tile_end;
+};
+__device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
+    const uint32_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
+    const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
+    RadixChunk c;
+    c.n = n;
+    c.tile_begin = min(blockIdx.x * per, tiles);
+    c.tile_end = min(c.tile_begin + per, tiles);
+    return c;
+}
+
+template <class Loader>
+__global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shift, uint32_t* __restrict__ block_hist,
+                                                              uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t s_hist[4][RADIX_BINS];
+    ld.prepare();
+    const RadixChunk ch = radix_chunk(ld.count());
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; w++) s_hist[w][tid] = 0;
+    __syncthreads();
+    for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
+        const uint32_t base = tile * RADIX_TILE;
+#pragma unroll
+        for (int r = 0; r < RADIX_ITEMS; r++) {
+            const uint32_t j = base + r * RADIX_THREADS + tid;
+            if (j < ch.n) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+    block_hist[tid * gridDim.x + blockIdx.x] = total;
+    (void)digit_total;   // per-digit totals come from k_radix_rowsum: G*256 same-line atomics would serialise in L2
+}
+
+// block d: digit_total[d] = sum of row d (number of keys whose digit is d)
+static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_rowsum(const uint32_t* __restrict__ block_hist,
+                                                                      uint32_t* __restrict__ digit_total, uint32_t grid) {
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t* row = block_hist + (size_t)blockIdx.x * grid;
+    uint32_t sum = 0;
+    for (uint32_t i = threadIdx.x; i < grid; i += RADIX_THREADS) sum += row[i];
+    uint32_t total = 0;
+    (void)block_excl_scan_256(sum, s_tmp, &total);
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
+}
+
+// block d scans row d of the digit-major matrix and adds the number of keys with a smaller digit
+static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* __restrict__ block_hist,
+                                                              const uint32_t* __restrict__ digit_total, uint32_t grid) {
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t d = blockIdx.x, tid = threadIdx.x;
+    uint32_t below = 0;
+    (void)block_excl_scan_256(tid < d ? digit_total[tid] : 0u, s_tmp, &below);
+    uint32_t* row = block_hist + (size_t)d * grid;
+    const uint32_t per = (grid + RADIX_THREADS - 1) / RADIX_THREADS;   // <= 8
+    uint32_t v[RADIX_MAX_BLOCKS / RADIX_THREADS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
+        const uint32_t i = tid * per + k;
+        v[k] = (k < per && i < grid) ? row[i] : 0u;
+        sum += v[k];
+    }
+    uint32_t run = below + block_excl_scan_256(sum, s_tmp, nullptr);
+#pragma unroll
+    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
+        const uint32_t i = tid * per + k;
+        if (k < per && i < grid) row[i] = run;
+        run += v[k];
+    }
+}
+
+// WRITE_KEYS: also emit the keys (needed by every pass but the last, and by the tile sort's last pass)
+template <class Loader, class KeyOutT, bool WRITE_KEYS>
+__global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int shift,
+                                                                 const uint32_t* __restrict__ block_offsets,
+                                                                 KeyOutT* __restrict__ keys_out,
+                                                                 uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_keys[RADIX_TILE];
+    __shared__ uint32_t s_vals[RADIX_TILE];
+    __shared__ uint32_t s_wave[4][RADIX_BINS];   // per-wave digit counts, then per-wave exclusive offsets
+    __shared__ uint32_t s_base[RADIX_BINS];      // running global offset of each digit for this workgroup
+    __shared__ uint32_t s_local[RADIX_BINS];     // first staging slot of each digit in the current tile
+    __shared__ uint32_t s_total[RADIX_BINS];
+    __shared__ uint32_t s_tmp[4];
+
+    ld.prepare();
+    const RadixChunk ch = radix_chunk(ld.count());
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    volatile uint32_t* my_hist = s_wave[wave];
+
+    s_base[tid] = block_offsets[tid * gridDim.x + blockIdx.x];
+
+    for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
+        const uint32_t tile_base = tile * RADIX_TILE;
+        const uint32_t tile_count = min((uint32_t)RADIX_TILE, ch.n - tile_base);
+        uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
+        // wave-striped load: the stable order inside a tile is (wave, r, lane)
+        const uint32_t wbase = tile_base + wave * (64 * RADIX_ITEMS) + lane;
+#pragma unroll
+        for (int r = 0; r < RADIX_ITEMS; r++) {
+            const uint32_t j = wbase + r * 64;
+            const bool ok = j < ch.n;
+            key[r] = ok ? ld.key(j) : 0xFFFFFFFFu;
+            val[r] = ok ? ld.val(j) : 0u;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) s_wave[w][tid] = 0;
+        __syncthreads();
+
+#pragma unroll
+        for (int r = 0; r < RADIX_ITEMS; r++) {
+            const bool ok = (wbase + r * 64) < ch.n;
+            const uint32_t digit = (key[r] >> shift) & 255u;
+            uint64_t same = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const uint64_t vote = __ballot(ok && ((digit >> b) & 1u));
+                same &= ((digit >> b) & 1u) ? vote : ~vote;
+            }
+            if (ok) {
+                const uint32_t prior = my_hist[digit];
+                rank[r] = prior + __popcll(same & lt_mask);
+                if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);   // highest lane of the group
+            }
+        }
+        __syncthreads();
+
+        {   // thread t owns digit t: wave-exclusive offsets and the tile-local digit base
+            const uint32_t c0 = s_wave[0][tid], c1 = s_wave[1][tid], c2 = s_wave[2][tid], c3 = s_wave[3][tid];
+            s_wave[0][tid] = 0;
+            s_wave[1][tid] = c0;
+            s_wave[2][tid] = c0 + c1;
+            s_wave[3][tid] = c0 + c1 + c2;
+            const uint32_t tot = c0 + c1 + c2 + c3;
+            s_total[tid] = tot;
+            s_local[tid] = block_excl_scan_256(tot, s_tmp, nullptr);   // contains the barriers
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RADIX_ITEMS; r++) {
+            if ((wbase + r * 64) < ch.n) {
+                const uint32_t digit = (key[r] >> shift) & 255u;
+                const uint32_t pos = s_local[digit] + s_wave[wave][digit] + rank[r];
+                s_keys[pos] = key[r];
+                s_vals[pos] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RADIX_ITEMS; k++) {
+            const uint32_t e = k * RADIX_THREADS + tid;
+            if (e < tile_count) {
+                const uint32_t kk = s_keys[e];
+                const uint32_t digit = (kk >> shift) & 255u;
+                const uint32_t g = s_base[digit] + (e - s_local[digit]);
+                if (WRITE_KEYS) keys_out[g] = (KeyOutT)kk;
+                vals_out[g] = s_vals[e];
+            }
+        }
+        __syncthreads();
+        s_base[tid] += s_total[tid];
+        // the next iteration's first barrier orders this update before its use
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host launcher for one pass
+// ---------------------------------------------------------------------------------------------------
+inline uint32_t radix_grid_for(uint32_t n_upper) {
+    uint32_t tiles = (n_upper + RADIX_TILE - 1) / RADIX_TILE;
+    if (tiles < 1) tiles = 1;
+    if (tiles <= (uint32_t)RADIX_MAX_BLOCKS) return tiles;
+    const uint32_t per = (tiles + RADIX_MAX_BLOCKS - 1) / RADIX_MAX_BLOCKS;
+    return (tiles + per - 1) / per;
+}
+
+// n_upper: host-side upper bound of the element count (sizes the grid); pass_slot picks the zeroed
+// digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
+template <class Loader, class KeyOutT, bool WRITE_KEYS>
+int radix_pass(gs_context* ctx, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
+               KeyOutT* keys_out, uint32_t* vals_out) {
+    const uint32_t grid = radix_grid_for(n_upper);
+    uint32_t* bh = ctx->radix.block_hist.as<uint32_t>();
+    uint32_t* dt = ctx->radix.digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
+    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream, ld_hist, shift, bh, dt);
+    hipLaunchKernelGGL(k_radix_rowsum, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
+    hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
+    hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream,
+                       ld, shift, bh, keys_out, vals_out);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}

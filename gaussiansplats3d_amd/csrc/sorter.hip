@@ -1,0 +1,417 @@
+// sorter.hip — the SORT SEAM on gfx950: replaces the reference's Web-Worker + WASM counting sort
+// (/root/reference/src/worker/SortWorker.js:31-81 -> sorter.cpp:17-168) with
+//   k_depth_key      phase A  per-splat int32 view-depth key + device-wide min/max   (sorter.cpp:29-140)
+//   radix passes     phase B-D bucket mapping fused into pass 0 of a stable LSD radix sort over
+//                    key' = range-1-bucket of the REVERSED list, which reproduces the reference's output
+//                    order exactly: buckets far->near, equal buckets in reverse input order
+//                    (sorter.cpp:142-167).
+// Arithmetic that decides the order is spelled with non-contracting intrinsics (__fmul_rn ...) so hipcc's
+// default fp-contract=fast cannot fuse it; this file is also built with -ffp-contract=off.
+#include <math.h>
+
+#include "radix.hpp"
+
+// WASM (emscripten) float->int: NaN / out of range -> INT32_MIN (same rule as oracle/sort_oracle.c)
+__host__ __device__ static inline int32_t trunc_f64_i32(double v) {
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return INT32_MIN;
+    return (int32_t)v;
+}
+
+constexpr uint32_t MODE_INT = 1, MODE_DYNAMIC = 2, MODE_PRECOMPUTED = 4;
+
+struct SceneRows {                 // per-scene clip-z row (mvp * transform)[2], as int x1000 and as float
+    int32_t im[GS_MAX_SCENES][4];
+    float fm[GS_MAX_SCENES][4];
+};
+
+struct KeyParams {
+    const uint32_t *cx, *cy, *cz, *cw;       // SoA planes (int32 or float bit patterns)
+    const uint32_t* scene_idx;
+    const uint32_t* idx_in;                  // nullable: identity
+    const uint32_t* precomputed;             // int32 or float bit patterns
+    const SceneRows* rows;
+    int32_t* keys_out;
+    SortFrame* frame;
+    uint32_t sort_start, render_count, mode;
+    int32_t im0, im1, im2;                   // static path: (int)(mvp[k]*1000.0), k = 2,6,10
+    float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
+};
+
+__global__ void k_sort_frame_init(SortFrame* f, uint32_t* digit_total) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        f->key_min = 2147483640;     // sorter.cpp:25
+        f->key_max = -2147483640;    // sorter.cpp:24
+        f->clamped = 0;
+        f->pad = 0;
+    }
+    if (t < RADIX_MAX_PASSES * RADIX_BINS) digit_total[t] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
+                                                     uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                     uint32_t* __restrict__ z, uint32_t* __restrict__ w) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint4 v = aos[i];
+        x[from + i] = v.x;
+        y[from + i] = v.y;
+        z[from + i] = v.z;
+        if (w) w[from + i] = v.w;
+    }
+}
+
+__device__ __forceinline__ int32_t depth_key_one(const KeyParams& p, uint32_t g) {
+    if (p.mode & MODE_PRECOMPUTED) {
+        const uint32_t raw = p.precomputed[g];
+        if (p.mode & MODE_INT) return (int32_t)raw;                                        // sorter.cpp:31-38
+        return trunc_f64_i32((double)__uint_as_float(raw) * 4096.0);                       // :79-86
+    }
+    if (p.mode & MODE_INT) {
+        const uint32_t x = p.cx[g], y = p.cy[g], z = p.cz[g];                              // wrap-around int32
+        if (p.mode & MODE_DYNAMIC) {                                                       // :41-62
+            const int32_t* r = p.rows->im[p.scene_idx[g]];
+            return (int32_t)(x * (uint32_t)r[0] + y * (uint32_t)r[1] + z * (uint32_t)r[2] + p.cw[g] * (uint32_t)r[3]);
+        }
+        return (int32_t)(x * (uint32_t)p.im0 + y * (uint32_t)p.im1 + z * (uint32_t)p.im2); // :63-75, w lane unused
+    }
+    const float x = __uint_as_float(p.cx[g]), y = __uint_as_float(p.cy[g]), z = __uint_as_float(p.cz[g]);
+    float s;
+    if (p.mode & MODE_DYNAMIC) {                                                           // :110-126
+        const float* r = p.rows->fm[p.scene_idx[g]];
+        s = __fmul_rn(r[0], x);
+        s = __fadd_rn(s, __fmul_rn(r[1], y));
+        s = __fadd_rn(s, __fmul_rn(r[2], z));
+        s = __fadd_rn(s, __fmul_rn(r[3], __uint_as_float(p.cw[g])));
+    } else {                                                                               // :128-138
+        s = __fmul_rn(p.fm0, x);
+        s = __fadd_rn(s, __fmul_rn(p.fm1, y));
+        s = __fadd_rn(s, __fmul_rn(p.fm2, z));
+    }
+    return trunc_f64_i32((double)s * 4096.0);
+}
+
+// Phase A: keys for list positions [sort_start, render_count) + device-wide min / max.
+__global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    int32_t lo = 2147483640, hi = -2147483640;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = p.sort_start + blockIdx.x * blockDim.x + threadIdx.x; i < p.render_count; i += stride) {
+        const uint32_t g = p.idx_in ? p.idx_in[i] : i;
+        const int32_t k = depth_key_one(p, g);
+        p.keys_out[i] = k;
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        atomicMin(&p.frame->key_min, lo);
+        atomicMax(&p.frame->key_max, hi);
+    }
+}
+
+// Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
+// stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
+struct DepthLoader {
+    const int32_t* __restrict__ keys;
+    const uint32_t* __restrict__ idx;      // nullable: identity
+    SortFrame* frame;
+    uint32_t sort_start, render_count, range;
+    uint32_t count_clamps;                 // only the histogram launch counts, so each element counts once
+    int32_t lo;
+    float range_map;
+
+    __device__ __forceinline__ void prepare() {
+        lo = frame->key_min;
+        const int32_t hi = frame->key_max;
+        // sorter.cpp:142-143: (float)(range-1) / ((float)max - (float)min), fp32, correctly rounded
+        range_map = __fdiv_rn((float)(range - 1), __fsub_rn((float)hi, (float)lo));
+    }
+    __device__ __forceinline__ uint32_t count() const { return render_count - sort_start; }
+    __device__ __forceinline__ uint32_t bucket(uint32_t i) const {
+        // sorter.cpp:146: (int)((float)(mapped - min) * rangeMap): int32 wrap, one fp32 multiply, truncation
+        const int32_t diff = (int32_t)((uint32_t)keys[i] - (uint32_t)lo);
+        const float f = __fmul_rn((float)diff, range_map);
+        if (!(f >= -2147483648.0f && f < 2147483648.0f)) return 0u;   // NaN (hi==lo) / overflow: WASM -> bucket 0
+        const int32_t b = (int32_t)f;
+        if (b < 0) {
+            if (count_clamps) atomicAdd(&frame->clamped, 1u);
+            return 0u;
+        }
+        if ((uint32_t)b >= range) {
+            if (count_clamps) atomicAdd(&frame->clamped, 1u);
+            return range - 1;
+        }
+        return (uint32_t)b;
+    }
+    __device__ __forceinline__ uint32_t key(uint32_t j) const { return (range - 1) - bucket(render_count - 1 - j); }
+    __device__ __forceinline__ uint32_t val(uint32_t j) const {
+        const uint32_t i = render_count - 1 - j;
+        return idx ? idx[i] : i;
+    }
+};
+
+__global__ void k_copy_head(const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = idx ? idx[i] : i;
+}
+
+__global__ void k_debug_buckets(DepthLoader ld, int32_t* out) {
+    ld.prepare();
+    for (uint32_t i = ld.sort_start + blockIdx.x * blockDim.x + threadIdx.x; i < ld.render_count;
+         i += gridDim.x * blockDim.x)
+        out[i] = (int32_t)ld.bucket(i);
+}
+
+static inline uint32_t grid_for(uint32_t n, uint32_t per_block, uint32_t cap) {
+    uint32_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return g > cap ? cap : g;
+}
+
+extern "C" {
+
+int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, uint32_t precision_bits,
+                     gs_sorter** out) {
+    GS_REQUIRE(ctx && out, "ctx / out == NULL");
+    *out = nullptr;
+    GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
+    GS_REQUIRE((flags & ~(GS_SORT_INTEGER | GS_SORT_DYNAMIC)) == 0, "unknown sorter flags");
+    const uint32_t max_bits = (flags & GS_SORT_INTEGER) ? 20u : 24u;   // src/Viewer.js:208-210
+    GS_REQUIRE(precision_bits >= 10 && precision_bits <= max_bits, "precision outside the Viewer's clamp (10..20 int, 10..24 float)");
+    ScopedDevice sd(ctx->device);
+    gs_sorter* s = new (std::nothrow) gs_sorter();
+    if (!s) return GS_ERR_NOMEM;
+    s->ctx = ctx;
+    s->max_count = max_splat_count;
+    s->flags = flags;
+    s->precision = precision_bits;
+    const size_t n = max_splat_count, b4 = n * 4;
+    int st = GS_OK;
+    auto A = [&](DevBuf& b, size_t bytes) { if (st == GS_OK) st = b.alloc(bytes); };
+    A(s->cx, b4); A(s->cy, b4); A(s->cz, b4);
+    if (flags & GS_SORT_DYNAMIC) { A(s->cw, b4); A(s->scene_idx, b4); A(s->scene_rows, sizeof(SceneRows)); }
+    A(s->keys, b4); A(s->keyA, b4); A(s->keyB, b4); A(s->valA, b4); A(s->valB, b4); A(s->sorted, b4);
+    A(s->frame, sizeof(SortFrame));
+    if (st == GS_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) {
+        gs_set_error("hipEventCreate failed");
+        st = GS_ERR_HIP;
+    }
+    if (st != GS_OK) {
+        gs_sorter_destroy(s);
+        return st;
+    }
+    *out = s;
+    return GS_OK;
+}
+
+void gs_sorter_destroy(gs_sorter* s) {
+    if (!s) return;
+    ScopedDevice sd(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const void* centers_aos4,
+                             const uint32_t* scene_indexes) {
+    GS_REQUIRE(s && centers_aos4, "sorter / centers == NULL");
+    GS_REQUIRE((uint64_t)from + count <= s->max_count, "range exceeds max_splat_count");
+    GS_REQUIRE(!(s->flags & GS_SORT_DYNAMIC) || scene_indexes, "dynamic sorter needs scene_indexes");
+    if (count == 0) return GS_OK;
+    ScopedDevice sd(s->ctx->device);
+    hipStream_t st = s->ctx->stream;
+    GS_TRY(s->staging.ensure((size_t)count * 16));
+    GS_HIP(hipMemcpyAsync(s->staging.p, centers_aos4, (size_t)count * 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_aos4_to_soa, dim3(grid_for(count, 256, 4096)), dim3(256), 0, st, s->staging.as<uint4>(), count,
+                       from, s->cx.as<uint32_t>(), s->cy.as<uint32_t>(), s->cz.as<uint32_t>(),
+                       (s->flags & GS_SORT_DYNAMIC) ? s->cw.as<uint32_t>() : nullptr);
+    GS_HIP(hipGetLastError());
+    if (s->flags & GS_SORT_DYNAMIC)
+        GS_HIP(hipMemcpyAsync(s->scene_idx.as<uint32_t>() + from, scene_indexes, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipStreamSynchronize(st));   // staging and the caller's buffers are reusable on return
+    if (from + count > s->uploaded) s->uploaded = from + count;   // uploadedSplatCount, SortWorker.js:97
+    return GS_OK;
+}
+
+static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
+    SortFrame f;
+    GS_HIP(hipMemcpyAsync(&f, s->frame.p, sizeof(f), hipMemcpyDeviceToHost, s->ctx->stream));
+    GS_HIP(hipStreamSynchronize(s->ctx->stream));
+    float ms = 0.f;
+    GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->device_ms = ms;
+    stats->key_min = f.key_min;
+    stats->key_max = f.key_max;
+    stats->clamped = f.clamped;
+    stats->passes = s->last_passes;
+    return f.clamped ? GS_WARN_KEY_CLAMPED : GS_OK;
+}
+
+int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, uint32_t sort_count,
+                   uint32_t render_count, const void* precomputed, const float* transforms, uint32_t* sorted_out,
+                   gs_sort_stats* stats) {
+    GS_REQUIRE(s && mvp, "sorter / mvp == NULL");
+    // SortWorker.js:100-101 clamps both counts to the uploaded splat count
+    if (render_count > s->uploaded) render_count = s->uploaded;
+    if (sort_count > s->uploaded) sort_count = s->uploaded;
+    GS_REQUIRE(sort_count <= render_count, "splatSortCount > splatRenderCount");
+    const bool dynamic = (s->flags & GS_SORT_DYNAMIC) != 0;
+    GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
+    gs_context* ctx = s->ctx;
+    ScopedDevice sd(ctx->device);
+    hipStream_t st = ctx->stream;
+    const uint32_t R = render_count, Rs = sort_count, sort_start = R - Rs;
+
+    const uint32_t* idx_dev = nullptr;
+    if (indexes_to_sort) {
+        GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
+        if (R) GS_HIP(hipMemcpyAsync(s->idx_in.p, indexes_to_sort, (size_t)R * 4, hipMemcpyHostToDevice, st));
+        idx_dev = s->idx_in.as<uint32_t>();
+    }
+    KeyParams kp = {};
+    kp.mode = ((s->flags & GS_SORT_INTEGER) ? MODE_INT : 0) | (dynamic ? MODE_DYNAMIC : 0) | (precomputed ? MODE_PRECOMPUTED : 0);
+    if (precomputed) {
+        GS_TRY(s->precomputed.ensure((size_t)s->max_count * 4));
+        GS_HIP(hipMemcpyAsync(s->precomputed.p, precomputed, (size_t)s->uploaded * 4, hipMemcpyHostToDevice, st));
+        kp.precomputed = s->precomputed.as<uint32_t>();
+    }
+    if (dynamic && !precomputed) {
+        // computeMatMul4x4ThirdRow (sorter.cpp:11-15), fp32, left-to-right, no contraction; then x1000 in double
+        SceneRows rows;
+        for (uint32_t sc = 0; sc < GS_MAX_SCENES; sc++) {
+            const float* b = transforms + 16 * sc;
+            for (int c = 0; c < 4; c++) {
+                volatile float acc = mvp[2] * b[4 * c + 0];
+                acc = acc + mvp[6] * b[4 * c + 1];
+                acc = acc + mvp[10] * b[4 * c + 2];
+                acc = acc + mvp[14] * b[4 * c + 3];
+                rows.fm[sc][c] = acc;
+                rows.im[sc][c] = trunc_f64_i32((double)rows.fm[sc][c] * 1000.0);
+            }
+        }
+        GS_HIP(hipMemcpyAsync(s->scene_rows.p, &rows, sizeof(rows), hipMemcpyHostToDevice, st));
+        GS_HIP(hipStreamSynchronize(st));   // `rows` lives on this stack frame
+        kp.rows = s->scene_rows.as<SceneRows>();
+    }
+    kp.cx = s->cx.as<uint32_t>(); kp.cy = s->cy.as<uint32_t>(); kp.cz = s->cz.as<uint32_t>();
+    kp.cw = s->cw.as<uint32_t>(); kp.scene_idx = s->scene_idx.as<uint32_t>();
+    kp.idx_in = idx_dev;
+    kp.keys_out = s->keys.as<int32_t>();
+    kp.frame = s->frame.as<SortFrame>();
+    kp.sort_start = sort_start;
+    kp.render_count = R;
+    kp.im0 = trunc_f64_i32((double)mvp[2] * 1000.0);     // sorter.cpp:64
+    kp.im1 = trunc_f64_i32((double)mvp[6] * 1000.0);
+    kp.im2 = trunc_f64_i32((double)mvp[10] * 1000.0);
+    kp.fm0 = mvp[2]; kp.fm1 = mvp[6]; kp.fm2 = mvp[10];
+
+    GS_HIP(hipEventRecord(s->ev0, st));
+    hipLaunchKernelGGL(k_sort_frame_init, dim3(RADIX_MAX_PASSES), dim3(RADIX_BINS), 0, st, s->frame.as<SortFrame>(),
+                       ctx->radix.digit_total.as<uint32_t>());
+    uint32_t passes = 0;
+    if (Rs > 0) {
+        hipLaunchKernelGGL(k_depth_key, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        GS_HIP(hipGetLastError());
+        DepthLoader dl = {};
+        dl.keys = s->keys.as<int32_t>();
+        dl.idx = idx_dev;
+        dl.frame = s->frame.as<SortFrame>();
+        dl.sort_start = sort_start;
+        dl.render_count = R;
+        dl.range = 1u << s->precision;
+        passes = (s->precision + 7) / 8;
+        uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
+        const bool wide = s->precision > 16;
+        void* kbuf[2] = {s->keyA.p, s->keyB.p};
+        uint32_t* vbuf[2] = {s->valA.as<uint32_t>(), s->valB.as<uint32_t>()};
+        for (uint32_t p = 0; p < passes; p++) {
+            const bool last = (p + 1 == passes);
+            const int shift = 8 * (int)p;
+            uint32_t* vo = last ? out_tail : vbuf[p & 1];
+            if (p == 0) {
+                DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
+                h.count_clamps = 1;
+                if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ctx, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
+                else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ctx, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+            } else if (wide) {
+                ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
+                if (last) GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, false>(ctx, al, al, Rs, shift, (int)p, (uint32_t*)nullptr, vo)));
+                else GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ctx, al, al, Rs, shift, (int)p, (uint32_t*)kbuf[p & 1], vo)));
+            } else {
+                ArrayLoader<uint16_t> al = {(const uint16_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
+                if (last) GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, false>(ctx, al, al, Rs, shift, (int)p, (uint16_t*)nullptr, vo)));
+                else GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, true>(ctx, al, al, Rs, shift, (int)p, (uint16_t*)kbuf[p & 1], vo)));
+            }
+        }
+    }
+    if (sort_start > 0) {
+        hipLaunchKernelGGL(k_copy_head, dim3(grid_for(sort_start, 1024, 2048)), dim3(256), 0, st, idx_dev,
+                           s->sorted.as<uint32_t>(), sort_start);
+    }
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipEventRecord(s->ev1, st));
+    s->last_render = R;
+    s->last_sort = Rs;
+    s->last_passes = passes;
+    s->last_identity = (idx_dev == nullptr);
+    s->has_result = true;
+
+    int status = GS_OK;
+    if (sorted_out && R) {
+        GS_HIP(hipMemcpyAsync(sorted_out, s->sorted.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+    }
+    if (stats) status = sorter_collect_stats(s, stats);
+    return status;
+}
+
+int gs_sorter_last_stats(gs_sorter* s, gs_sort_stats* stats) {
+    GS_REQUIRE(s && stats, "sorter / stats == NULL");
+    GS_REQUIRE(s->has_result, "no sort has run");
+    ScopedDevice sd(s->ctx->device);
+    return sorter_collect_stats(s, stats);
+}
+
+int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
+    GS_REQUIRE(s && dst, "sorter / dst == NULL");
+    GS_REQUIRE(s->has_result, "no sort has run");
+    GS_REQUIRE(count <= s->last_render, "count exceeds the last render_count");
+    ScopedDevice sd(s->ctx->device);
+    hipStream_t st = s->ctx->stream;
+    const void* src = nullptr;
+    if (what == 0) src = s->keys.p;
+    else if (what == 2) src = s->sorted.p;
+    else if (what == 1) {
+        GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
+        DepthLoader dl = {};
+        dl.keys = s->keys.as<int32_t>();
+        dl.frame = s->frame.as<SortFrame>();
+        dl.sort_start = s->last_render - s->last_sort;
+        dl.render_count = s->last_render;
+        dl.range = 1u << s->precision;
+        GS_HIP(hipMemsetAsync(s->debug.p, 0, (size_t)s->last_render * 4, st));
+        if (s->last_sort)
+            hipLaunchKernelGGL(k_debug_buckets, dim3(grid_for(s->last_sort, 1024, 2048)), dim3(256), 0, st, dl, s->debug.as<int32_t>());
+        GS_HIP(hipGetLastError());
+        src = s->debug.p;
+    } else {
+        GS_REQUIRE(false, "unknown debug selector");
+    }
+    if (count) GS_HIP(hipMemcpyAsync(dst, src, (size_t)count * 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+}  // extern "C"

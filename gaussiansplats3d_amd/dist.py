@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of the render seam: one process per GPU, screen tile rows split into strips, strips gathered
+to rank 0 with grouped send/recv over RCCL (torch.distributed backend "nccl" on ROCm) — SURVEY.md §8(e).
+
+The reference is single-GPU (one WebGL context); the scene and the sort are replicated on every rank, the only
+exchange step is the framebuffer gather (W*H*4 bytes per frame in total)."""
+import numpy as np
+
+GS_TILE = 16
+
+
+def balanced_row_strips(row_cost, world_size):
+    """Split tile rows [0, len(row_cost)) into `world_size` contiguous strips of near-equal cost.
+    row_cost: per-tile-row work estimate (tile entries).  Returns [(begin, end)] * world_size, covering all rows;
+    strips may be empty when there are fewer rows than ranks."""
+    rows = len(row_cost)
+    cost = np.asarray(row_cost, dtype=np.float64) + 1.0          # +1: empty rows still cost a launch slot
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    total = csum[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        k = int(np.searchsorted(csum, target, side="left"))
+        if k > 0 and abs(csum[k - 1] - target) <= abs(csum[min(k, rows)] - target):
+            k -= 1
+        k = min(max(k, cuts[-1]), rows)
+        cuts.append(k)
+    cuts.append(rows)
+    return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
+
+
+def equal_row_strips(rows, world_size):
+    return balanced_row_strips(np.zeros(rows), world_size)
+
+
+def strip_pixel_rows(strip, height):
+    y0 = strip[0] * GS_TILE
+    y1 = min(strip[1] * GS_TILE, height)
+    return y0, max(y1, y0)
+
+
+def gather_strips(local_strip, strips, full, rank, world_size, dist, dst=0):
+    """Grouped send/recv (a gatherv): every rank sends its uint8 [h_r, W, 4] strip to `dst`, which receives each
+    one directly into its slice of `full` (uint8 [H, W, 4]).  All tensors live on the calling rank's device
+    (or CPU with the gloo backend).  Returns `full` on dst, None elsewhere."""
+    height = full.shape[0] if full is not None else None
+    ops = []
+    if rank == dst:
+        for r, s in enumerate(strips):
+            y0, y1 = strip_pixel_rows(s, height)
+            if y1 <= y0:
+                continue
+            if r == dst:
+                full[y0:y1].copy_(local_strip)
+            else:
+                ops.append(dist.P2POp(dist.irecv, full[y0:y1], r))
+    elif local_strip is not None and local_strip.numel() > 0:
+        ops.append(dist.P2POp(dist.isend, local_strip, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return full if rank == dst else None

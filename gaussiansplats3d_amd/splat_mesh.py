@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference's SplatMesh render seam, over the HIP engine.
+
+Reference interface (/root/reference/src/splatmesh/SplatMesh.js): ``build`` (:306-405) uploads scene data
+(``setupDataTextures`` :637-898), ``updateRenderIndexes(globalIndexes, renderSplatCount)`` (:1228-1235),
+``updateUniforms(renderDimensions, focalX, focalY, ortho, zoom, inverseFocalAdjustment)`` (:1248-1280),
+``setSplatScale`` / ``setPointCloudModeEnabled`` (:1282-1300); the draw itself is
+``renderer.render(splatMesh, camera)`` (src/Viewer.js:1616).  Here ``render`` returns the RGBA8 framebuffer
+(row 0 = bottom, GL convention) instead of drawing into a WebGL canvas.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .util import to_half_three
+
+
+class SplatMesh:
+    def __init__(self, context, max_splat_count, spherical_harmonics_degree=0, half_precision_covariances=False,
+                 antialiased=False, kernel_2d_size=0.3, max_screen_space_splat_size=1024.0, splat_scale=1.0,
+                 point_cloud_mode=False):
+        self.ctx = context
+        self.lib = context.lib
+        self.max_splat_count = int(max_splat_count)
+        self.sh_degree = int(spherical_harmonics_degree)
+        self.half_cov = bool(half_precision_covariances)
+        self.antialiased = bool(antialiased)
+        self.kernel_2d_size = float(kernel_2d_size)
+        self.max_screen_space_splat_size = float(max_screen_space_splat_size)
+        self.splat_scale = float(splat_scale)
+        self.point_cloud_mode = bool(point_cloud_mode)
+        self.splat_count = 0
+        self.render_count = 0
+        self._indexes = None          # host indexes from updateRenderIndexes
+        self._sorter = None           # or a SortWorker whose result is device resident
+        self._cam = L.Camera()
+        self.handle = C.c_void_p()
+        L.check(self.lib.gs_mesh_create(context.handle, self.max_splat_count, self.sh_degree,
+                                        L.GS_MESH_COV_HALF if self.half_cov else 0, C.byref(self.handle)))
+        context._adopt(self)
+
+    # -- build / data upload ------------------------------------------------------------------------
+    def build(self, centers, covariances, colors, spherical_harmonics=None, start=0):
+        """fillSplatDataArrays output -> device planes.  covariances: float32 [n,6]; narrowed with
+        THREE.DataUtils.toHalfFloat semantics when half_precision_covariances (SplatBuffer.js:469-474).
+        spherical_harmonics: float16 (or uint16 bit patterns) [n, 9|24], coefficient-major RGB triples."""
+        c = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, 3)
+        n = c.shape[0]
+        cov = np.ascontiguousarray(covariances, dtype=np.float32).reshape(n, 6)
+        rgba = np.ascontiguousarray(colors, dtype=np.uint8).reshape(n, 4)
+        cov16 = to_half_three(cov) if self.half_cov else None
+        sh = None
+        if self.sh_degree > 0:
+            sh = np.ascontiguousarray(spherical_harmonics)
+            if sh.dtype != np.uint16:
+                sh = sh.astype(np.float16).view(np.uint16)
+            sh = np.ascontiguousarray(sh.reshape(n, 9 if self.sh_degree == 1 else 24))
+        L.check(self.lib.gs_mesh_upload(self.handle, int(start), n, c.ctypes.data,
+                                        None if self.half_cov else cov.ctypes.data,
+                                        cov16.ctypes.data if self.half_cov else None, rgba.ctypes.data,
+                                        sh.ctypes.data if sh is not None else None))
+        self.splat_count = max(self.splat_count, int(start) + n)
+        return self
+
+    def get_splat_count(self):
+        return self.splat_count
+
+    # -- per-sort / per-frame state -------------------------------------------------------------------
+    def update_render_indexes(self, global_indexes, render_splat_count):
+        """SplatMesh.updateRenderIndexes: host Uint32Array of sorted global indexes (drawn back to front)."""
+        self._indexes = np.ascontiguousarray(global_indexes, dtype=np.uint32)
+        self._sorter = None
+        self.render_count = int(render_splat_count)
+
+    def use_sorter_result(self, sort_worker, render_splat_count):
+        """Device-resident alternative: draw the result the sort worker left in HBM."""
+        self._sorter = sort_worker
+        self._indexes = None
+        self.render_count = int(render_splat_count)
+
+    def update_uniforms(self, render_dimensions, focal_x, focal_y, orthographic_mode=False, orthographic_zoom=1.0,
+                        inverse_focal_adjustment=1.0, model_view=None, projection=None, camera_position=None,
+                        spherical_harmonics_degree=None):
+        """SplatMesh.updateUniforms + three's built-in modelViewMatrix / projectionMatrix / cameraPosition."""
+        if orthographic_mode:
+            raise NotImplementedError("orthographic cameras are a 'next' row (SURVEY.md §8 f4)")
+        cam = self._cam
+        cam.width, cam.height = int(render_dimensions[0]), int(render_dimensions[1])
+        cam.focal[0], cam.focal[1] = float(focal_x), float(focal_y)
+        cam.inv_focal_adj = float(inverse_focal_adjustment)
+        cam.splat_scale = self.splat_scale
+        cam.kernel2d = self.kernel_2d_size
+        cam.max_splat_px = self.max_screen_space_splat_size
+        cam.sh_degree = self.sh_degree if spherical_harmonics_degree is None else int(spherical_harmonics_degree)
+        cam.flags = (L.GS_CAM_ANTIALIASED if self.antialiased else 0) | (L.GS_CAM_POINT_CLOUD if self.point_cloud_mode else 0)
+        if model_view is not None:
+            cam.view[:] = np.asarray(model_view, dtype=np.float64).astype(np.float32).reshape(16).tolist()
+        if projection is not None:
+            cam.proj[:] = np.asarray(projection, dtype=np.float64).astype(np.float32).reshape(16).tolist()
+        if camera_position is not None:
+            cam.cam_pos[:] = np.asarray(camera_position, dtype=np.float32).tolist()
+
+    def set_camera(self, camera, focal_adjustment=1.0, mesh_world=None, spherical_harmonics_degree=None):
+        """Viewer.updateSplatMesh (src/Viewer.js:651-677) for a camera.PerspectiveCamera."""
+        fx, fy = camera.focal(focal_adjustment)
+        self.update_uniforms((camera.width, camera.height), fx, fy, False, 1.0, 1.0 / focal_adjustment,
+                             camera.model_view(mesh_world), camera.projection, camera.position,
+                             spherical_harmonics_degree)
+
+    def set_splat_scale(self, splat_scale=1.0):
+        self.splat_scale = float(splat_scale)
+        self._cam.splat_scale = self.splat_scale
+
+    def set_point_cloud_mode_enabled(self, enabled):
+        self.point_cloud_mode = bool(enabled)
+
+    # -- the draw -----------------------------------------------------------------------------------------
+    def strip_shape(self, tile_rows=None):
+        cam = self._cam
+        rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
+        r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
+        y0, y1 = r0 * L.GS_TILE, min(r1 * L.GS_TILE, cam.height)
+        return max(y1 - y0, 0), cam.width
+
+    def render(self, tile_rows=None, out_device_ptr=None, want_stats=True, to_host=True):
+        """renderer.render(splatMesh, camera).  Returns (uint8[h,w,4] or None, RenderStats or None).
+        tile_rows=(begin,end): render only those 16-px tile rows (multi-GPU strips)."""
+        cam = self._cam
+        cam.tile_row_begin, cam.tile_row_end = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        h, w = self.strip_shape(tile_rows)
+        out = np.empty((h, w, 4), dtype=np.uint8) if to_host else None
+        stats = L.RenderStats() if want_stats else None
+        idx = self._indexes
+        L.check(self.lib.gs_mesh_render(
+            self.handle, C.byref(cam), idx.ctypes.data if idx is not None else None,
+            self._sorter.handle if self._sorter is not None else None, self.render_count,
+            out.ctypes.data if out is not None else None, C.c_void_p(out_device_ptr) if out_device_ptr else None,
+            C.byref(stats) if stats is not None else None))
+        return out, stats
+
+    def last_stats(self):
+        stats = L.RenderStats()
+        L.check(self.lib.gs_mesh_last_stats(self.handle, C.byref(stats)))
+        return stats
+
+    def debug_records(self, count=None):
+        """Vertex-stage outputs of the last draw: (records float32/uint32 [n,8], rects uint32 [n,2])."""
+        n = self.splat_count if count is None else count
+        recs = np.empty((n, 8), dtype=np.uint32)
+        rects = np.empty((n, 2), dtype=np.uint32)
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 0, recs.ctypes.data, n))
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 1, rects.ctypes.data, n))
+        return recs, rects
+
+    def tile_entry_counts(self, tile_rows=None):
+        """Entries per tile of the last draw, shaped [rows, tiles_x] (used to balance multi-GPU strips)."""
+        cam = self._cam
+        tiles_x = (cam.width + L.GS_TILE - 1) // L.GS_TILE
+        rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
+        r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
+        rng = np.empty(((r1 - r0) * tiles_x, 2), dtype=np.uint32)
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 2, rng.ctypes.data, rng.shape[0]))
+        return (rng[:, 1] - rng[:, 0]).reshape(r1 - r0, tiles_x)
+
+    def dispose(self):
+        if self.handle:
+            self.lib.gs_mesh_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    close = dispose
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass

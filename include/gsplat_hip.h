@@ -1,0 +1,179 @@
+/*
+ * gsplat_hip.h — C ABI of libgsplat_hip.so: the MI355X (gfx950) sort-and-rasterize engine that replaces
+ * the two device-facing seams of mkkellogg/GaussianSplats3D.  Plain pointers and sizes only.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to /root/reference).
+ * The reference has no FFI today; INTEGRATION.md shows the N-API / ctypes bindings a maintainer adds.
+ *
+ *   SORT SEAM    src/worker/SortWorker.js:202-256 (createSortWorker + message protocol) over the WASM C ABI
+ *                src/worker/sorter.cpp:17-22 (sortIndexes)                              -> gs_sorter_*
+ *   RENDER SEAM  src/splatmesh/SplatMesh.js (setupDataTextures :637-898, updateRenderIndexes :1228-1235,
+ *                updateUniforms :1248-1280) + the GLSL pair SplatMaterial.js:112-341 /
+ *                SplatMaterial3D.js:81-255 drawn by renderer.render (src/Viewer.js:1616)  -> gs_mesh_*
+ *
+ * Threading: calls on one gs_context (and the objects created from it) must be serialised by the caller,
+ * like the reference's single sort worker + single GL context.  All device work of a context runs on one
+ * HIP stream.  Calls that return data to host memory block until it is there; calls that leave their
+ * result on the device only enqueue work.
+ *
+ * There is NO CPU fallback: every call fails with GS_ERR_HIP if no gfx950 device is usable.
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+/* status codes (negative = error, positive = warning, result still defined) */
+#define GS_OK 0
+#define GS_WARN_KEY_CLAMPED 1   /* a depth bucket fell outside [0,range): the reference corrupts memory here  */
+#define GS_ERR_INVALID (-1)     /* bad argument                                                               */
+#define GS_ERR_HIP (-2)         /* HIP runtime / device failure (see gs_last_error)                            */
+#define GS_ERR_NOMEM (-3)
+#define GS_ERR_CAPACITY (-4)    /* tile-entry buffer overflow even after growing to the configured limit       */
+#define GS_ERR_UNSUPPORTED (-5)
+
+typedef struct gs_context gs_context;
+typedef struct gs_sorter gs_sorter;
+typedef struct gs_mesh gs_mesh;
+
+/* Message of the last failing call on this thread (the reference throws JS Errors, SplatMesh.js:1518-1533). */
+const char* gs_last_error(void);
+int gs_abi_version(void);
+/* Number of visible HIP devices, or a negative status. */
+int gs_device_count(void);
+
+/* One context per GPU.  hip_stream: an existing hipStream_t to enqueue on (e.g. PyTorch's current
+ * stream) or NULL to let the library create its own. */
+int gs_context_create(int device, void* hip_stream, gs_context** out);
+void gs_context_destroy(gs_context* ctx);
+int gs_context_synchronize(gs_context* ctx);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * SORT SEAM
+ * ------------------------------------------------------------------------------------------------ */
+#define GS_SORT_INTEGER 1u  /* integerBasedSort (Viewer option, src/Viewer.js:95-98): int32 centres x1000      */
+#define GS_SORT_DYNAMIC 2u  /* dynamicMode: per-splat scene index + per-scene transform (sorter.cpp:41-62)     */
+#define GS_MAX_SCENES 32u   /* src/Constants.js:7 */
+
+/* createSortWorker(splatCount, useSharedMemory, enableSIMDInSort, integerBasedSort, dynamicMode,
+ * splatSortDistanceMapPrecision) — src/worker/SortWorker.js:202-256.  Shared-memory / SIMD flavours of
+ * the WASM module have no meaning here.  precision_bits: 10..20 (integer) / 10..24 (float),
+ * src/Viewer.js:208-210. */
+int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, uint32_t precision_bits,
+                     gs_sorter** out);
+void gs_sorter_destroy(gs_sorter* s);
+
+/* The {centers, sceneIndexes, range:{from,count}} message — src/worker/SortWorker.js:84-98.
+ * centers_aos4: int32[4*count] (GS_SORT_INTEGER; SplatMesh.getIntegerCenters(padFour), SplatMesh.js:1912-1926)
+ * or float[4*count].  scene_indexes: uint32[count], required iff GS_SORT_DYNAMIC. */
+int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const void* centers_aos4,
+                             const uint32_t* scene_indexes);
+
+typedef struct gs_sort_stats {
+    float device_ms;        /* sortTime of the sortDone message (SortWorker.js:76-78), device clock          */
+    int32_t key_min;        /* minDistance / maxDistance of sorter.cpp:24-25,72-73                           */
+    int32_t key_max;
+    uint32_t clamped;       /* buckets forced into [0,range)                                                  */
+    uint32_t passes;        /* 8-bit LSD radix passes used                                                    */
+} gs_sort_stats;
+
+/* The {sort:{modelViewProj, splatRenderCount, splatSortCount, usePrecomputedDistances, indexesToSort,
+ * transforms, precomputedDistances}} message -> sortIndexes (sorter.cpp:17-22) -> {sortDone, sortedIndexes}.
+ *   mvp              float[16] column-major (fp32 as written into WASM memory, SortWorker.js:54)
+ *   indexes_to_sort  uint32[render_count] host, or NULL = identity list (Viewer.js:2061-2073)
+ *   precomputed      int32/float[splat_count] host or NULL (usePrecomputedDistances)
+ *   transforms       float[16*GS_MAX_SCENES] host, required iff GS_SORT_DYNAMIC
+ *   sorted_out       uint32[render_count] host or NULL (result stays on the device for gs_mesh_render)
+ * Result: [0, render-sort) copied; tail = far->near buckets, ties in reverse input order. */
+int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, uint32_t sort_count,
+                   uint32_t render_count, const void* precomputed, const float* transforms,
+                   uint32_t* sorted_out, gs_sort_stats* stats);
+
+/* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
+ * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted. */
+int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * RENDER SEAM
+ * ------------------------------------------------------------------------------------------------ */
+#define GS_MESH_COV_HALF 1u   /* halfPrecisionCovariancesOnGPU (SplatMesh.js:667-670,735-739)                 */
+#define GS_SH_F16 0u          /* SH as fp16 (compression level <= 1, SplatMesh.js:1064-1066)                  */
+
+/* SplatMesh.build + setupDataTextures (SplatMesh.js:306-405, 637-898): device SoA planes instead of data
+ * textures, so none of the 4096^2-texel limits apply. */
+int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree, uint32_t flags,
+                   gs_mesh** out);
+void gs_mesh_destroy(gs_mesh* m);
+
+/* Upload splats [from, from+count) in the formats fillSplatDataArrays emits (SplatMesh.js:1853-1902):
+ *   centers float[3*count]
+ *   cov     (m00,m01,m02,m11,m12,m22) per splat (SplatBuffer.js:440-486): cov_f32 float[6*count] for a
+ *           full-precision mesh, cov_f16 uint16 (IEEE half bits)[6*count] for a GS_MESH_COV_HALF mesh -
+ *           the caller narrows exactly as THREE.DataUtils.toHalfFloat does (SplatBuffer.js:469-474);
+ *           exactly one of the two is non-NULL
+ *   rgba    uint8[4*count]
+ *   sh_f16  uint16 (IEEE half bits)[ncoef*count], coefficient-major RGB triples, ncoef = 0/9/24
+ *           (SplatBuffer.js:680-728); NULL when the mesh has sh_degree 0. */
+int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
+                   const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16);
+
+/* Uniforms of one draw: three's modelViewMatrix / projectionMatrix / cameraPosition plus
+ * SplatMesh.updateUniforms (SplatMesh.js:1248-1280) as computed by Viewer.updateSplatMesh
+ * (src/Viewer.js:651-677). */
+typedef struct gs_camera {
+    float view[16];          /* modelViewMatrix = viewMatrix * mesh.matrixWorld, column-major                */
+    float proj[16];          /* projectionMatrix                                                            */
+    float cam_pos[3];        /* cameraPosition                                                              */
+    float focal[2];          /* focal.x/.y                                                                  */
+    uint32_t width, height;  /* viewport in pixels (renderDimensions * devicePixelRatio)                    */
+    float splat_scale;       /* setSplatScale, SplatMesh.js:1282                                            */
+    float kernel2d;          /* kernel2DSize, default 0.3                                                   */
+    float max_splat_px;      /* maxScreenSpaceSplatSize, default 1024 (src/Viewer.js:147)                   */
+    float inv_focal_adj;     /* inverseFocalAdjustment                                                      */
+    uint32_t sh_degree;      /* sphericalHarmonicsDegree uniform (<= mesh degree)                           */
+    uint32_t flags;          /* GS_CAM_*                                                                    */
+    uint32_t tile_row_begin; /* multi-GPU: this rank renders 16-px tile rows [begin,end); 0,0 = all rows    */
+    uint32_t tile_row_end;
+} gs_camera;
+#define GS_CAM_ANTIALIASED 1u
+#define GS_CAM_POINT_CLOUD 2u
+#define GS_TILE 16u
+
+typedef struct gs_render_stats {
+    float device_ms;          /* whole draw                                                                  */
+    float project_ms, bin_ms, tile_sort_ms, blend_ms;
+    uint32_t visible_splats;  /* splats that survive the vertex-stage rejects                                */
+    uint64_t tile_entries;    /* D = sum over splats of 16x16 tiles touched                                  */
+    uint32_t entry_capacity;
+    uint32_t overflowed;      /* 1 = frame was re-run after growing the entry buffer                         */
+} gs_render_stats;
+
+/* updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)
+ * (SplatMesh.js:1228-1235, src/Viewer.js:1616).  Draw order = index order = back-to-front.
+ *   sorted_host   uint32[render_count] host, or NULL
+ *   sorter        take the device-resident result of the last gs_sorter_sort (when sorted_host == NULL)
+ *   rgba_out_host uint8[4*W*rows*16...] RGBA8, row 0 = bottom (GL), covering tile rows [begin,end) clipped
+ *                 to the viewport; or NULL
+ *   rgba_out_dev  same, device pointer (e.g. a torch uint8 tensor); or NULL to use an internal buffer */
+int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
+                   uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats);
+
+/* Intermediates of the last draw (tests, strip load-balancing).  what: 0 = per splat (storage order) the
+ * 32-byte vertex-stage record {cx, cy, ax, ay, bx, by, r|g<<16, b|a<<16 (unorm16)}; 1 = per splat the tile
+ * rect {x0|y0<<16, x1|y1<<16}; 2 = per tile of the drawn strip the [begin,end) range of its entry list. */
+int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
+
+/* Statistics of the last draw (synchronises the stream). */
+int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats);
+int gs_sorter_last_stats(gs_sorter* s, gs_sort_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

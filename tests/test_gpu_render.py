@@ -1,0 +1,184 @@
+"""-m gpu: the HIP render seam against the fp32 raster oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle
+from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, util
+
+pytestmark = pytest.mark.gpu
+K_POWER = np.float32(2.4022448)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def build_mesh(ctx, scene, **kw):
+    mesh = SplatMesh(ctx, scene.count, scene.sh_degree, scene.cov_half, **kw)
+    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+    return mesh
+
+
+def sorted_order(scene, cam):
+    ci = util.integer_centers(scene.centers)
+    return oracle.sort_indexes(np.arange(scene.count, dtype=np.uint32), ci, cam.sort_mvp())
+
+
+def oracle_frame(scene, cam, order, sh_degree=None, **kw):
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, cam.width, cam.height,
+                              sh_degree=scene.sh_degree if sh_degree is None else sh_degree,
+                              sh_stored=scene.sh_degree, **kw)
+    return ocam, oracle.render(ocam, c, cov, rgba, sh, order)
+
+
+@pytest.mark.parametrize("sh_degree,cov_half,w,h", [(0, False, 256, 144), (1, False, 200, 120), (2, False, 256, 144),
+                                                    (2, True, 320, 200), (0, True, 130, 70)])
+def test_framebuffer_matches_oracle(ctx, sh_degree, cov_half, w, h):
+    scene = helpers.small_scene(3000, sh_degree, seed=100 + sh_degree, cov_half=cov_half)
+    cam = camera.demo_camera("garden", w, h)
+    order = sorted_order(scene, cam)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(order, scene.count)
+    got, stats = mesh.render()
+    _, (fb, q, amb, frags) = oracle_frame(scene, cam, order)
+    assert frags > 1000 and stats.tile_entries > 0
+    print(helpers.compare_frames(got, fb, amb, f"sh{sh_degree} half={cov_half} {w}x{h}"))
+    mesh.dispose()
+
+
+def test_vertex_stage_records_match_oracle(ctx):
+    scene = helpers.small_scene(5000, 2, seed=7)
+    cam = camera.demo_camera("garden", 640, 360)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(np.arange(scene.count, dtype=np.uint32), scene.count)
+    mesh.render()
+    recs, rects = mesh.debug_records()
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, cam.width, cam.height, 2, 2)
+    o = oracle.project(ocam, c, cov, rgba, sh)
+    f = recs.view(np.float32)
+    on_screen = (rects[:, 0] & 0xFFFF) <= (rects[:, 1] & 0xFFFF)
+    vis = o["visible"] == 1
+    # every splat we keep is visible for the oracle; the ones we drop are invisible or touch no pixel centre
+    assert not (on_screen & ~vis).any()
+    k = on_screen
+    assert k.sum() > 1000
+    np.testing.assert_allclose(f[k, 0], o["cx"][k], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(f[k, 1], o["cy"][k], rtol=0, atol=2e-3)
+    n1 = o["b1x"] ** 2 + o["b1y"] ** 2
+    n2 = o["b2x"] ** 2 + o["b2y"] ** 2
+    for col, num, den in ((2, "b1x", n1), (3, "b1y", n1), (4, "b2x", n2), (5, "b2y", n2)):
+        exp = K_POWER * o[num][k] / den[k]
+        np.testing.assert_allclose(f[k, col], exp, rtol=2e-4, atol=1e-7)
+    r16 = (recs[k, 6] & 0xFFFF) / 65535.0
+    g16 = (recs[k, 6] >> 16) / 65535.0
+    b16 = (recs[k, 7] & 0xFFFF) / 65535.0
+    a16 = (recs[k, 7] >> 16) / 65535.0
+    for got, name in ((r16, "r"), (g16, "g"), (b16, "b"), (a16, "a")):
+        np.testing.assert_allclose(got, o[name][k], rtol=0, atol=1.0 / 65535.0 + 1e-6)
+    mesh.dispose()
+
+
+def test_sorter_result_stays_on_device_and_matches_host_indexes(ctx):
+    scene = helpers.small_scene(4000, 0, seed=21)
+    cam = camera.demo_camera("garden", 320, 180)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    order = sorted_order(scene, cam)
+    mesh.update_render_indexes(order, scene.count)
+    a, _ = mesh.render()
+    w = create_sort_worker(ctx, scene.count)
+    ci = util.integer_centers(scene.centers)
+    w.post_message({"centers": ci, "range": {"from": 0, "to": scene.count - 1, "count": scene.count}})
+    w.sort_on_device(cam.sort_mvp(), scene.count)
+    mesh.use_sorter_result(w, scene.count)
+    b, _ = mesh.render()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(w.debug_read(2, scene.count), order)
+    w.terminate()
+    mesh.dispose()
+
+
+def test_tile_row_strips_tile_the_full_frame(ctx):
+    """Multi-GPU sharding unit: rendering tile-row strips separately reproduces the full frame exactly."""
+    scene = helpers.small_scene(3000, 1, seed=33)
+    cam = camera.demo_camera("garden", 300, 170)           # 11 tile rows, last one partial
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(sorted_order(scene, cam), scene.count)
+    full, _ = mesh.render()
+    parts = [mesh.render(tile_rows=r)[0] for r in ((0, 3), (3, 4), (4, 9), (9, 11))]
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), full)
+    mesh.dispose()
+
+
+def test_draw_order_is_honoured(ctx):
+    """Two overlapping opaque-ish splats: swapping the index order swaps which one is on top."""
+    cam = camera.demo_camera("garden", 64, 64)
+    pos = np.array(camera.DEMO_POSES["garden"][1]); look = np.array(camera.DEMO_POSES["garden"][2])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    centers = np.stack([pos + fwd * 2.0, pos + fwd * 2.5]).astype(np.float32)
+    cov = np.tile(np.array([[0.05, 0, 0, 0.05, 0, 0.05]], np.float32), (2, 1))
+    rgba = np.array([[255, 0, 0, 250], [0, 0, 255, 250]], np.uint8)
+    from gaussiansplats3d_amd import scenes
+    scene = scenes.SplatScene(centers, cov, rgba, np.zeros((2, 0), np.float16), 0)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    c, covo, rg, _ = helpers.oracle_inputs(scene)
+    for order in (np.array([1, 0], np.uint32), np.array([0, 1], np.uint32)):
+        mesh.update_render_indexes(order, 2)
+        got, _ = mesh.render()
+        ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, 64, 64)
+        fb, q, amb, _ = oracle.render(ocam, c, covo, rg, None, order)
+        helpers.compare_frames(got, fb, amb, "order")
+        top = got[32, 32]
+        assert (top[0] > top[2]) == (order[-1] == 0)        # last drawn = on top
+    mesh.dispose()
+
+
+def test_empty_and_offscreen(ctx):
+    scene = helpers.small_scene(500, 0, seed=5)
+    pos = np.array(camera.DEMO_POSES["garden"][1]); look = np.array(camera.DEMO_POSES["garden"][2])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    behind = pos - fwd * np.linspace(0.5, 9.0, 500)[:, None]                # strictly behind the eye
+    scene.centers[:] = (behind + np.cross(fwd, [0.3, 0.1, 0.2]) * np.sin(np.arange(500))[:, None]).astype(np.float32)
+    cam = camera.demo_camera("garden", 128, 72)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(np.arange(500, dtype=np.uint32), 500)
+    got, stats = mesh.render()
+    assert stats.tile_entries == 0 and not got.any()
+    mesh.update_render_indexes(np.zeros(0, np.uint32), 0)   # renderSplatCount == 0
+    got, stats = mesh.render()
+    assert not got.any()
+    mesh.dispose()
+
+
+def test_entry_buffer_grows_on_overflow(ctx):
+    """A few hundred near-camera splats cover the whole 1080p screen: D >> 8*N forces the regrow path."""
+    rng = np.random.default_rng(9)
+    n = 700
+    cam = camera.demo_camera("garden", 1920, 1080)
+    pos = np.array(camera.DEMO_POSES["garden"][1]); look = np.array(camera.DEMO_POSES["garden"][2])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    from gaussiansplats3d_amd import scenes
+    centers = (pos + fwd * rng.uniform(1.0, 2.0, (n, 1)) + rng.normal(size=(n, 3)) * 0.05).astype(np.float32)
+    cov = np.tile(np.array([[0.5, 0, 0, 0.5, 0, 0.5]], np.float32), (n, 1))
+    rgba = rng.integers(1, 255, (n, 4), dtype=np.uint8); rgba[:, 3] = 3
+    scene = scenes.SplatScene(centers, cov, rgba, np.zeros((n, 0), np.float16), 0)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    order = sorted_order(scene, cam)
+    mesh.update_render_indexes(order, n)
+    got, stats = mesh.render()
+    assert stats.overflowed == 1 and stats.tile_entries > 8 * n
+    _, (fb, q, amb, _) = oracle_frame(scene, cam, order)
+    print(helpers.compare_frames(got, fb, amb, "overflow"))
+    mesh.dispose()

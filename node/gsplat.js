@@ -1,0 +1,174 @@
+// gsplat.js — JavaScript face of the MI355X engine: the reference's two seams, unchanged for their callers.
+//
+//   createSortWorker(splatCount, useSharedMemory, enableSIMDInSort, integerBasedSort, dynamicMode, precision)
+//       same signature and message protocol as /root/reference/src/worker/SortWorker.js:83-256; the object it
+//       returns has postMessage / onmessage / terminate / maxSplatCount exactly as Viewer.setupSortWorker and
+//       runSplatSort use them (/root/reference/src/Viewer.js:1235-1320, 1921-1951).
+//   SplatMeshHIP
+//       the render seam of /root/reference/src/splatmesh/SplatMesh.js: build -> updateRenderIndexes (:1228-1235)
+//       -> updateUniforms (:1248-1280) -> render (the draw of src/Viewer.js:1616), returning RGBA8 pixels.
+//
+// ES2019 / CommonJS on purpose: the container's Node is 12.22.  All compute happens in libgsplat_hip.so.
+'use strict';
+const path = require('path');
+const addon = require(path.join(__dirname, 'gsplat_addon.node'));
+
+const Constants = { DefaultSplatSortDistanceMapPrecision: 16, BytesPerInt: 4, BytesPerFloat: 4, MaxScenes: 32 };
+const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2;
+
+let sharedContext = null;
+function getContext(device) {
+  if (!sharedContext) sharedContext = { handle: addon.contextCreate(device || 0), device: device || 0 };
+  return sharedContext;
+}
+
+class HipSortWorker {
+  constructor(splatCount, useSharedMemory, integerBasedSort, dynamicMode, precision, device) {
+    this.maxSplatCount = splatCount;          // written by Viewer.js:1285
+    this.onmessage = null;
+    this.useSharedMemory = !!useSharedMemory;
+    this.integerBasedSort = !!integerBasedSort;
+    this.dynamicMode = !!dynamicMode;
+    this.uploadedSplatCount = 0;
+    this.ctx = getContext(device);
+    const flags = (this.integerBasedSort ? GS_SORT_INTEGER : 0) | (this.dynamicMode ? GS_SORT_DYNAMIC : 0);
+    this.handle = addon.sorterCreate(this.ctx.handle, splatCount, flags, precision);
+    // the reference hands views of its WASM memory back to the Viewer (SortWorker.js:180-191, Viewer.js:1270-1278)
+    const AB = this.useSharedMemory && typeof SharedArrayBuffer !== 'undefined' ? SharedArrayBuffer : ArrayBuffer;
+    this.indexesToSortBuffer = new AB(splatCount * 4);
+    this.sortedIndexesBuffer = new AB(splatCount * 4);
+    this.precomputedDistancesBuffer = new AB(splatCount * 4);
+    this.transformsBuffer = new AB(Constants.MaxScenes * 64);
+    const ready = { sortSetupPhase1Complete: true };
+    if (this.useSharedMemory) {
+      Object.assign(ready, { indexesToSortBuffer: this.indexesToSortBuffer, indexesToSortOffset: 0,
+        sortedIndexesBuffer: this.sortedIndexesBuffer, sortedIndexesOffset: 0,
+        precomputedDistancesBuffer: this.precomputedDistancesBuffer, precomputedDistancesOffset: 0,
+        transformsBuffer: this.transformsBuffer, transformsOffset: 0 });
+    }
+    setImmediate(() => this._emit(ready));
+  }
+
+  _emit(data) { if (this.onmessage) this.onmessage({ data }); }
+
+  postMessage(msg) {
+    if (msg.centers) {                                                    // SortWorker.js:84-98
+      const count = msg.range.count;
+      const centers = this.integerBasedSort ? new Int32Array(msg.centers) : new Float32Array(msg.centers);
+      const scene = this.dynamicMode ? new Uint32Array(msg.sceneIndexes) : null;
+      addon.sorterUploadCenters(this.handle, msg.range.from, count, centers, scene);
+      this.uploadedSplatCount = Math.max(this.uploadedSplatCount, msg.range.from + count);
+    } else if (msg.sort) {                                                // SortWorker.js:99-115, 31-81
+      const s = msg.sort;
+      const renderCount = Math.min(s.splatRenderCount || 0, this.uploadedSplatCount);
+      const sortCount = Math.min(s.splatSortCount || 0, this.uploadedSplatCount);
+      const mvp = new Float32Array(s.modelViewProj);                      // fp64 -> fp32 like SortWorker.js:54
+      let indexes, transforms, pre = null;
+      if (this.useSharedMemory) {
+        indexes = new Uint32Array(this.indexesToSortBuffer, 0, renderCount);
+        transforms = new Float32Array(this.transformsBuffer);
+        if (s.usePrecomputedDistances) pre = this.integerBasedSort ? new Int32Array(this.precomputedDistancesBuffer) : new Float32Array(this.precomputedDistancesBuffer);
+      } else {
+        indexes = s.indexesToSort ? new Uint32Array(s.indexesToSort.buffer || s.indexesToSort, s.indexesToSort.byteOffset || 0, renderCount) : null;
+        transforms = s.transforms ? new Float32Array(Constants.MaxScenes * 16) : null;
+        if (transforms) transforms.set(s.transforms);
+        if (s.usePrecomputedDistances) pre = s.precomputedDistances;
+      }
+      if (this.dynamicMode && !transforms) transforms = new Float32Array(Constants.MaxScenes * 16);
+      const out = this.useSharedMemory ? new Uint32Array(this.sortedIndexesBuffer, 0, renderCount) : new Uint32Array(renderCount);
+      const r = addon.sorterSort(this.handle, mvp, indexes, sortCount, renderCount, pre, this.dynamicMode ? transforms : null, out);
+      const reply = { sortDone: true, splatSortCount: sortCount, splatRenderCount: renderCount, sortTime: r.sortTime, status: r.status };
+      if (!this.useSharedMemory) reply.sortedIndexes = out;
+      setImmediate(() => this._emit(reply));
+    } else if (msg.init) {
+      // the reference ships its WASM bytes through an init message (SortWorker.js:116-199); nothing to do here
+    }
+  }
+
+  terminate() {
+    if (this.handle) { addon.sorterDestroy(this.handle); this.handle = null; }
+  }
+}
+
+function createSortWorker(splatCount, useSharedMemory, enableSIMDInSort, integerBasedSort, dynamicMode,
+                          splatSortDistanceMapPrecision = Constants.DefaultSplatSortDistanceMapPrecision, device = 0) {
+  return new HipSortWorker(splatCount, useSharedMemory, integerBasedSort, dynamicMode, splatSortDistanceMapPrecision, device);
+}
+
+// THREE.DataUtils.toHalfFloat (three r160): clamp, then truncate through the base/shift tables
+const halfTables = (() => {
+  const base = new Uint32Array(512), shift = new Uint32Array(512);
+  for (let i = 0; i < 256; i++) {
+    const e = i - 127;
+    if (e < -27) { base[i] = 0; base[i | 0x100] = 0x8000; shift[i] = 24; shift[i | 0x100] = 24; }
+    else if (e < -14) { base[i] = 0x0400 >> (-e - 14); base[i | 0x100] = (0x0400 >> (-e - 14)) | 0x8000; shift[i] = -e - 1; shift[i | 0x100] = -e - 1; }
+    else if (e <= 15) { base[i] = (e + 15) << 10; base[i | 0x100] = ((e + 15) << 10) | 0x8000; shift[i] = 13; shift[i | 0x100] = 13; }
+    else if (e < 128) { base[i] = 0x7c00; base[i | 0x100] = 0xfc00; shift[i] = 24; shift[i | 0x100] = 24; }
+    else { base[i] = 0x7c00; base[i | 0x100] = 0xfc00; shift[i] = 13; shift[i | 0x100] = 13; }
+  }
+  return { base, shift, f: new Float32Array(1), u: null };
+})();
+halfTables.u = new Uint32Array(halfTables.f.buffer);
+function toHalfFloat(val) {
+  halfTables.f[0] = Math.min(Math.max(val, -65504), 65504);
+  const f = halfTables.u[0], e = (f >> 23) & 0x1ff;
+  return halfTables.base[e] + ((f & 0x007fffff) >> halfTables.shift[e]);
+}
+
+class SplatMeshHIP {
+  constructor(maxSplatCount, options = {}) {
+    this.ctx = getContext(options.device);
+    this.maxSplatCount = maxSplatCount;
+    this.shDegree = options.sphericalHarmonicsDegree || 0;
+    this.halfPrecisionCovariancesOnGPU = !!options.halfPrecisionCovariancesOnGPU;
+    this.antialiased = !!options.antialiased;
+    this.kernel2DSize = options.kernel2DSize === undefined ? 0.3 : options.kernel2DSize;
+    this.maxScreenSpaceSplatSize = options.maxScreenSpaceSplatSize || 1024;
+    this.splatScale = 1.0;
+    this.pointCloudModeEnabled = false;
+    this.handle = addon.meshCreate(this.ctx.handle, maxSplatCount, this.shDegree, this.halfPrecisionCovariancesOnGPU ? GS_MESH_COV_HALF : 0);
+    this.splatCount = 0;
+    this.renderCount = 0;
+    this.indexes = null;
+    this.sortWorker = null;
+    this.cam = { view: new Float32Array(16), proj: new Float32Array(16), camPos: new Float32Array(3), focal: new Float32Array(2),
+      width: 0, height: 0, splatScale: 1, kernel2d: this.kernel2DSize, maxSplatPx: this.maxScreenSpaceSplatSize, invFocalAdj: 1,
+      shDegree: this.shDegree, flags: 0, tileRowBegin: 0, tileRowEnd: 0 };
+  }
+  // fillSplatDataArrays output (SplatMesh.js:1853-1902): centers F32[3n], covariances F32[6n], colors U8[4n], sh Uint16 half bits
+  build(centers, covariances, colors, sphericalHarmonics, start = 0) {
+    const n = centers.length / 3;
+    let cov16 = null;
+    if (this.halfPrecisionCovariancesOnGPU) {
+      cov16 = new Uint16Array(covariances.length);
+      for (let i = 0; i < covariances.length; i++) cov16[i] = toHalfFloat(covariances[i]);
+    }
+    addon.meshUpload(this.handle, start, n, centers, cov16 ? null : covariances, cov16, colors, this.shDegree ? sphericalHarmonics : null);
+    this.splatCount = Math.max(this.splatCount, start + n);
+  }
+  getSplatCount() { return this.splatCount; }
+  updateRenderIndexes(globalIndexes, renderSplatCount) { this.indexes = globalIndexes; this.sortWorker = null; this.renderCount = renderSplatCount; }
+  useSortWorkerResult(worker, renderSplatCount) { this.sortWorker = worker; this.indexes = null; this.renderCount = renderSplatCount; }
+  updateUniforms(renderDimensions, cameraFocalLengthX, cameraFocalLengthY, orthographicMode, orthographicZoom, inverseFocalAdjustment) {
+    if (orthographicMode) throw new Error('orthographic cameras are not supported by the HIP engine yet');
+    this.cam.width = renderDimensions.x; this.cam.height = renderDimensions.y;
+    this.cam.focal[0] = cameraFocalLengthX; this.cam.focal[1] = cameraFocalLengthY;
+    this.cam.invFocalAdj = inverseFocalAdjustment;
+  }
+  setCameraMatrices(modelViewElements, projectionElements, cameraPosition) {  // three's built-in uniforms
+    this.cam.view.set(modelViewElements); this.cam.proj.set(projectionElements); this.cam.camPos.set(cameraPosition);
+  }
+  setSplatScale(s = 1) { this.splatScale = s; }
+  setPointCloudModeEnabled(e) { this.pointCloudModeEnabled = !!e; }
+  render(out) {
+    const c = this.cam;
+    c.splatScale = this.splatScale;
+    c.flags = (this.antialiased ? GS_CAM_ANTIALIASED : 0) | (this.pointCloudModeEnabled ? GS_CAM_POINT_CLOUD : 0);
+    const pixels = out || new Uint8Array(c.width * c.height * 4);
+    const stats = addon.meshRender(this.handle, c, this.indexes, this.sortWorker ? this.sortWorker.handle : null, this.renderCount, pixels);
+    return { pixels, stats };
+  }
+  dispose() { if (this.handle) { addon.meshDestroy(this.handle); this.handle = null; } }
+}
+
+module.exports = { createSortWorker, SplatMeshHIP, toHalfFloat, Constants, addon };

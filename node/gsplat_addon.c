@@ -1,0 +1,264 @@
+/*
+ * gsplat_addon.c — thin Node N-API binding over the C ABI of include/gsplat_hip.h.
+ * JavaScript callers keep the reference's interfaces (node/gsplat.js mirrors createSortWorker and the
+ * SplatMesh render seam); this file only marshals typed arrays into plain pointers.  No compute lives here.
+ * Build: make -C node   (gcc, /usr/include/node/node_api.h; links ../gaussiansplats3d_amd/csrc/libgsplat_hip.so)
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gsplat_hip.h"
+
+#define NAPI_OK(call)                                                        \
+    do {                                                                     \
+        if ((call) != napi_ok) {                                             \
+            napi_throw_error(env, NULL, "N-API call failed: " #call);        \
+            return NULL;                                                     \
+        }                                                                    \
+    } while (0)
+
+static napi_value throw_gs(napi_env env, int status) {
+    char msg[640];
+    snprintf(msg, sizeof msg, "libgsplat_hip status %d: %s", status, gs_last_error());
+    napi_throw_error(env, "GS_ERROR", msg);
+    return NULL;
+}
+
+/* typed array / ArrayBuffer / null -> pointer (+ byte length) */
+static int get_bytes(napi_env env, napi_value v, void** data, size_t* bytes) {
+    napi_valuetype t;
+    *data = NULL;
+    *bytes = 0;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_null || t == napi_undefined) return 1;
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type tt;
+        size_t len, off;
+        napi_value ab;
+        if (napi_get_typedarray_info(env, v, &tt, &len, data, &ab, &off) != napi_ok) return 0;
+        static const size_t w[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+        *bytes = len * w[tt];
+        return 1;
+    }
+    if (napi_is_arraybuffer(env, v, &is) == napi_ok && is) return napi_get_arraybuffer_info(env, v, data, bytes) == napi_ok;
+    return 0;
+}
+
+static void* get_external(napi_env env, napi_value v) {
+    void* p = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_external) return NULL;
+    napi_get_value_external(env, v, &p);
+    return p;
+}
+
+static uint32_t get_u32(napi_env env, napi_value v) {
+    uint32_t x = 0;
+    napi_get_value_uint32(env, v, &x);
+    return x;
+}
+static double get_f64(napi_env env, napi_value v) {
+    double x = 0;
+    napi_get_value_double(env, v, &x);
+    return x;
+}
+static napi_value num(napi_env env, double v) {
+    napi_value r;
+    napi_create_double(env, v, &r);
+    return r;
+}
+static void set(napi_env env, napi_value obj, const char* k, double v) { napi_set_named_property(env, obj, k, num(env, v)); }
+
+#define ARGS(n)                                                             \
+    size_t argc = n;                                                        \
+    napi_value argv[n];                                                     \
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));          \
+    if (argc < n) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+
+static napi_value DeviceCount(napi_env env, napi_callback_info info) {
+    (void)info;
+    int n = gs_device_count();
+    if (n < 0) return throw_gs(env, n);
+    return num(env, n);
+}
+
+static napi_value ContextCreate(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_context* ctx = NULL;
+    int st = gs_context_create((int)get_u32(env, argv[0]), NULL, &ctx);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &r));
+    return r;
+}
+static napi_value ContextDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_context_destroy((gs_context*)get_external(env, argv[0]));
+    return NULL;
+}
+
+/* sorterCreate(ctx, maxSplatCount, flags, precisionBits) */
+static napi_value SorterCreate(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    gs_sorter* s = NULL;
+    int st = gs_sorter_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]),
+                              get_u32(env, argv[3]), &s);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_external(env, s, NULL, NULL, &r));
+    return r;
+}
+static napi_value SorterDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_sorter_destroy((gs_sorter*)get_external(env, argv[0]));
+    return NULL;
+}
+/* sorterUploadCenters(sorter, from, count, centers(Int32Array|Float32Array|ArrayBuffer), sceneIndexes|null) */
+static napi_value SorterUploadCenters(napi_env env, napi_callback_info info) {
+    ARGS(5)
+    void *c, *sc;
+    size_t cb, sb;
+    if (!get_bytes(env, argv[3], &c, &cb) || !get_bytes(env, argv[4], &sc, &sb)) { napi_throw_type_error(env, NULL, "centers / sceneIndexes"); return NULL; }
+    const uint32_t count = get_u32(env, argv[2]);
+    if (cb < (size_t)count * 16 || (sc && sb < (size_t)count * 4)) { napi_throw_range_error(env, NULL, "buffer shorter than count"); return NULL; }
+    int st = gs_sorter_upload_centers((gs_sorter*)get_external(env, argv[0]), get_u32(env, argv[1]), count, c, (const uint32_t*)sc);
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* sorterSort(sorter, mvp Float32Array(16), indexes|null, sortCount, renderCount, precomputed|null, transforms|null,
+ *            out Uint32Array|null) -> {status, sortTime, keyMin, keyMax, clamped, passes} */
+static napi_value SorterSort(napi_env env, napi_callback_info info) {
+    ARGS(8)
+    void *mvp, *idx, *pre, *tr, *out;
+    size_t mb, ib, pb, tb, ob;
+    if (!get_bytes(env, argv[1], &mvp, &mb) || mb < 64 || !get_bytes(env, argv[2], &idx, &ib) ||
+        !get_bytes(env, argv[5], &pre, &pb) || !get_bytes(env, argv[6], &tr, &tb) || !get_bytes(env, argv[7], &out, &ob)) {
+        napi_throw_type_error(env, NULL, "sorterSort: bad buffer argument");
+        return NULL;
+    }
+    const uint32_t sortc = get_u32(env, argv[3]), renderc = get_u32(env, argv[4]);
+    if ((idx && ib < (size_t)renderc * 4) || (out && ob < (size_t)renderc * 4) || (tr && tb < 16 * 4 * GS_MAX_SCENES)) {
+        napi_throw_range_error(env, NULL, "sorterSort: buffer shorter than renderCount");
+        return NULL;
+    }
+    gs_sort_stats stats;
+    memset(&stats, 0, sizeof stats);
+    int st = gs_sorter_sort((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, (const uint32_t*)idx, sortc, renderc,
+                            pre, (const float*)tr, (uint32_t*)out, out ? &stats : NULL);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_object(env, &r));
+    set(env, r, "status", st);
+    set(env, r, "sortTime", stats.device_ms);
+    set(env, r, "keyMin", stats.key_min);
+    set(env, r, "keyMax", stats.key_max);
+    set(env, r, "clamped", stats.clamped);
+    set(env, r, "passes", stats.passes);
+    return r;
+}
+
+/* meshCreate(ctx, maxSplatCount, shDegree, flags) */
+static napi_value MeshCreate(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    gs_mesh* m = NULL;
+    int st = gs_mesh_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3]), &m);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_external(env, m, NULL, NULL, &r));
+    return r;
+}
+static napi_value MeshDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_mesh_destroy((gs_mesh*)get_external(env, argv[0]));
+    return NULL;
+}
+/* meshUpload(mesh, from, count, centers F32, covF32|null, covF16(Uint16)|null, rgba U8, shF16(Uint16)|null) */
+static napi_value MeshUpload(napi_env env, napi_callback_info info) {
+    ARGS(8)
+    void* p[5];
+    size_t b[5];
+    for (int i = 0; i < 5; i++)
+        if (!get_bytes(env, argv[3 + i], &p[i], &b[i])) { napi_throw_type_error(env, NULL, "meshUpload: bad buffer"); return NULL; }
+    const uint32_t count = get_u32(env, argv[2]);
+    if (b[0] < (size_t)count * 12 || b[3] < (size_t)count * 4 || (p[1] && b[1] < (size_t)count * 24) || (p[2] && b[2] < (size_t)count * 12)) {
+        napi_throw_range_error(env, NULL, "meshUpload: buffer shorter than count");
+        return NULL;
+    }
+    int st = gs_mesh_upload((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const float*)p[0], (const float*)p[1],
+                            (const uint16_t*)p[2], (const uint8_t*)p[3], (const uint16_t*)p[4]);
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* meshRender(mesh, cam{view,proj,camPos,focal,width,height,splatScale,kernel2d,maxSplatPx,invFocalAdj,shDegree,flags,
+ *            tileRowBegin,tileRowEnd}, sortedIndexes|null, sorter|null, renderCount, out Uint8Array) -> stats object */
+static napi_value MeshRender(napi_env env, napi_callback_info info) {
+    ARGS(6)
+    gs_camera cam;
+    memset(&cam, 0, sizeof cam);
+    napi_value v;
+    void* d;
+    size_t nb;
+#define F32ARR(key, dst, n)                                                                              \
+    NAPI_OK(napi_get_named_property(env, argv[1], key, &v));                                             \
+    if (!get_bytes(env, v, &d, &nb) || nb < (n) * 4) { napi_throw_type_error(env, NULL, "camera." key); return NULL; } \
+    memcpy(dst, d, (n) * 4);
+    F32ARR("view", cam.view, 16)
+    F32ARR("proj", cam.proj, 16)
+    F32ARR("camPos", cam.cam_pos, 3)
+    F32ARR("focal", cam.focal, 2)
+#define NUM(key, dst, type) NAPI_OK(napi_get_named_property(env, argv[1], key, &v)); dst = (type)get_f64(env, v);
+    NUM("width", cam.width, uint32_t)
+    NUM("height", cam.height, uint32_t)
+    NUM("splatScale", cam.splat_scale, float)
+    NUM("kernel2d", cam.kernel2d, float)
+    NUM("maxSplatPx", cam.max_splat_px, float)
+    NUM("invFocalAdj", cam.inv_focal_adj, float)
+    NUM("shDegree", cam.sh_degree, uint32_t)
+    NUM("flags", cam.flags, uint32_t)
+    NUM("tileRowBegin", cam.tile_row_begin, uint32_t)
+    NUM("tileRowEnd", cam.tile_row_end, uint32_t)
+    void *idx, *out;
+    size_t ib, ob;
+    if (!get_bytes(env, argv[2], &idx, &ib) || !get_bytes(env, argv[5], &out, &ob)) { napi_throw_type_error(env, NULL, "meshRender: bad buffer"); return NULL; }
+    const uint32_t renderc = get_u32(env, argv[4]);
+    if (idx && ib < (size_t)renderc * 4) { napi_throw_range_error(env, NULL, "sortedIndexes shorter than renderCount"); return NULL; }
+    gs_render_stats stats;
+    memset(&stats, 0, sizeof stats);
+    int st = gs_mesh_render((gs_mesh*)get_external(env, argv[0]), &cam, (const uint32_t*)idx, (gs_sorter*)get_external(env, argv[3]),
+                            renderc, (uint8_t*)out, NULL, &stats);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_object(env, &r));
+    set(env, r, "deviceMs", stats.device_ms);
+    set(env, r, "projectMs", stats.project_ms);
+    set(env, r, "binMs", stats.bin_ms);
+    set(env, r, "tileSortMs", stats.tile_sort_ms);
+    set(env, r, "blendMs", stats.blend_ms);
+    set(env, r, "visibleSplats", stats.visible_splats);
+    set(env, r, "tileEntries", (double)stats.tile_entries);
+    set(env, r, "overflowed", stats.overflowed);
+    return r;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"deviceCount", DeviceCount},       {"contextCreate", ContextCreate}, {"contextDestroy", ContextDestroy},
+        {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},
+        {"sorterSort", SorterSort},         {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
+        {"meshUpload", MeshUpload},         {"meshRender", MeshRender},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        napi_set_named_property(env, exports, fns[i].name, f);
+    }
+    napi_value ver;
+    napi_create_int32(env, gs_abi_version(), &ver);
+    napi_set_named_property(env, exports, "abiVersion", ver);
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

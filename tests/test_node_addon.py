@@ -1,0 +1,76 @@
+"""The Node N-API binding (node/gsplat_addon.c + node/gsplat.js): CPU tier checks it builds, loads and exposes the
+reference-shaped interface; the GPU tier pushes real sorts through createSortWorker's message protocol."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import kat_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE_DIR = os.path.join(ROOT, "node")
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+
+
+def _built():
+    subprocess.check_call(["make", "-C", NODE_DIR], stdout=subprocess.DEVNULL)
+    return os.path.join(NODE_DIR, "gsplat_addon.node")
+
+
+def test_addon_loads_and_exports_the_seams():
+    _built()
+    js = ("const g=require('./gsplat.js');"
+          "console.log(JSON.stringify({k:Object.keys(g.addon).sort(),abi:g.addon.abiVersion,"
+          "w:typeof g.createSortWorker,m:typeof g.SplatMeshHIP,args:g.createSortWorker.length}))")
+    out = subprocess.check_output(["node", "-e", js], cwd=NODE_DIR, text=True)
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["abi"] == 1 and info["w"] == "function" and info["m"] == "function"
+    for name in ("contextCreate", "sorterCreate", "sorterUploadCenters", "sorterSort", "meshCreate", "meshUpload",
+                 "meshRender", "sorterDestroy", "meshDestroy", "contextDestroy", "deviceCount"):
+        assert name in info["k"]
+    assert info["args"] == 5          # five positional parameters before the defaulted precision, like the reference
+
+
+def test_js_half_float_matches_host_mirror():
+    _built()
+    from gaussiansplats3d_amd.util import to_half_three
+    vals = [0.0, 1.0, -1.0, 0.1, 65504.0, 1e-5, 6e-8, 1e5, 3.14159, -2.71828e-3, 0.33333, 123.456, -7e-6]
+    js = f"const g=require('./gsplat.js');console.log(JSON.stringify({json.dumps(vals)}.map(g.toHalfFloat)))"
+    got = json.loads(subprocess.check_output(["node", "-e", js], cwd=NODE_DIR, text=True))
+    np.testing.assert_array_equal(np.array(got, dtype=np.uint16), to_half_three(np.array(vals, np.float32)))
+
+
+def _write_case(path, args):
+    n = args["centers4"].shape[0]
+    hdr = np.array([n, args["render_count"], args["sort_count"], 1 << args["precision"], int(args["use_int"]),
+                    int(args["dynamic"]), int(args["precomputed"] is not None), 0], dtype=np.uint32)
+    with open(path, "wb") as f:
+        f.write(hdr.tobytes())
+        f.write(args["indexes"].tobytes())
+        f.write(np.ascontiguousarray(args["centers4"]).tobytes())
+        f.write(np.asarray(args["mvp"], dtype=np.float64).astype(np.float32).tobytes())
+        if args["dynamic"]:
+            f.write(args["scene_indexes"].tobytes())
+            f.write(args["transforms"].tobytes())
+        if args["precomputed"] is not None:
+            f.write(args["precomputed"].tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode", [("small", "copy"), ("permuted_partial", "shared"), ("dynamic_int", "copy"),
+                                        ("float_dynamic", "shared"), ("pre_int", "copy")])
+def test_sort_through_the_js_protocol_is_bit_exact(tmp_path, name, mode):
+    _built()
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "sort_kat.json")))[name]
+    case = [c for c in kat_cases.CASES if c["name"] == name][0]
+    args = kat_cases.make_case(case)
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_case(inp, args)
+    cmd = ["node", "sort_via_js.js", inp, outp] + (["shared"] if mode == "shared" else [])
+    res = subprocess.run(cmd, cwd=NODE_DIR, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(outp, dtype=np.uint32)
+    assert kat_cases.digest(got) == meta["output"]

@@ -10,7 +10,7 @@ import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgsplat_hip.so")
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(CSRC, "libgsplat_hip.so")   # override: A/B of builds
 
 GS_OK, GS_WARN_KEY_CLAMPED = 0, 1
 GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5

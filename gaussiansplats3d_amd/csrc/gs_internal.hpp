@@ -195,8 +195,11 @@ struct gs_mesh {
     // per-draw
     DevBuf recs;               // SplatRec [n]  (storage order)
     DevBuf rects;              // uint2 [n]     tile rect per splat (storage order)
+    DevBuf vis_mask;           // uint64 [ceil(n/64)]  1 = splat survived the vertex stage and touches a pixel
+    DevBuf cidx;               // uint32 [render_count] visible splats in traversal order (compacted per workgroup)
     DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
-    DevBuf rect_q;             // uint2 [render_count] rects in front-to-back traversal order
+    DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx
+    DevBuf coff;               // uint32 [render_count] first entry slot of each, relative to its binning workgroup
     DevBuf bin_sums;           // uint32 [2][BIN_MAX_BLOCKS]: tile entries | visible splats per workgroup
     DevBuf ekeyA, ekeyB, evalA, evalB;   // tile entries ping-pong (key = tile id, val = splat index)
     DevBuf tile_ranges;        // uint2 [tiles]

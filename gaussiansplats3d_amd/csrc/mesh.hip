@@ -90,7 +90,8 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->rgba, n * 4);
     if (sh_degree >= 1) { A(m->sh0, n * 16); A(m->sh1, n * (sh_degree == 2 ? 16 : 4)); }
     if (sh_degree >= 2) A(m->sh2, n * 16);
-    A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8);
+    A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
+    A(m->vis_mask, ((n + 63) / 64) * 8 + 8);
     A(m->bin_sums, 4 * 2048);
     A(m->frame, sizeof(RenderFrame));
     if (st == GS_OK) {
@@ -313,7 +314,7 @@ int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats) {
 
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     GS_REQUIRE(m && dst, "mesh / dst == NULL");
-    GS_REQUIRE(m->has_draw && (what == 2 || count <= m->last_count), "no draw / count too large");
+    GS_REQUIRE(m->has_draw && (what >= 2 || count <= m->last_count), "no draw / count too large");
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     if (what == 0) GS_HIP(hipMemcpyAsync(dst, m->recs.p, (size_t)count * sizeof(SplatRec), hipMemcpyDeviceToHost, st));
@@ -321,6 +322,9 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
         GS_REQUIRE((size_t)count * 8 <= m->tile_ranges.bytes, "count exceeds the tile count of the last draw");
         GS_HIP(hipMemcpyAsync(dst, m->tile_ranges.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    } else if (what == 3) {   // visibility mask of the last draw, count = number of 64-bit words
+        GS_REQUIRE((size_t)count * 8 <= m->vis_mask.bytes, "count exceeds the mask length");
+        GS_HIP(hipMemcpyAsync(dst, m->vis_mask.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;

@@ -138,12 +138,15 @@ static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* _
     }
 }
 
-// WRITE_KEYS: also emit the keys (needed by every pass but the last, and by the tile sort's last pass)
-template <class Loader, class KeyOutT, bool WRITE_KEYS>
+// WRITE_KEYS: also emit the keys (needed by every pass but the last).
+// RANGES: this is the last pass of the tile sort - publish each key's [begin,end) in the sorted output.  Inside a
+// workgroup tile equal keys are contiguous (the earlier passes ordered the lower digits, this pass is stable), so a
+// run boundary costs one atomicMin/atomicMax pair; `ranges` must be pre-set to (0xFFFFFFFF, 0).
+template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES>
 __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int shift,
                                                                  const uint32_t* __restrict__ block_offsets,
                                                                  KeyOutT* __restrict__ keys_out,
-                                                                 uint32_t* __restrict__ vals_out) {
+                                                                 uint32_t* __restrict__ vals_out, uint2* ranges) {
     __shared__ uint32_t s_keys[RADIX_TILE];
     __shared__ uint32_t s_vals[RADIX_TILE];
     __shared__ uint32_t s_wave[4][RADIX_BINS];   // per-wave digit counts, then per-wave exclusive offsets
@@ -225,6 +228,10 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int 
                 const uint32_t g = s_base[digit] + (e - s_local[digit]);
                 if (WRITE_KEYS) keys_out[g] = (KeyOutT)kk;
                 vals_out[g] = s_vals[e];
+                if (RANGES) {
+                    if (e == 0 || s_keys[e - 1] != kk) atomicMin(&ranges[kk].x, g);
+                    if (e + 1 == tile_count || s_keys[e + 1] != kk) atomicMax(&ranges[kk].y, g + 1u);
+                }
             }
         }
         __syncthreads();
@@ -246,17 +253,17 @@ inline uint32_t radix_grid_for(uint32_t n_upper) {
 
 // n_upper: host-side upper bound of the element count (sizes the grid); pass_slot picks the zeroed
 // digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
-template <class Loader, class KeyOutT, bool WRITE_KEYS>
+template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES = false>
 int radix_pass(gs_context* ctx, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
-               KeyOutT* keys_out, uint32_t* vals_out) {
+               KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ctx->radix.block_hist.as<uint32_t>();
     uint32_t* dt = ctx->radix.digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
     hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream, ld_hist, shift, bh, dt);
     hipLaunchKernelGGL(k_radix_rowsum, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
     hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
-    hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream,
-                       ld, shift, bh, keys_out, vals_out);
+    hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES>), dim3(grid), dim3(RADIX_THREADS), 0,
+                       ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

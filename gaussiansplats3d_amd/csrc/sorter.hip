@@ -91,16 +91,57 @@ __device__ __forceinline__ int32_t depth_key_one(const KeyParams& p, uint32_t g)
 }
 
 // Phase A: keys for list positions [sort_start, render_count) + device-wide min / max.
+// VEC4: identity index list + static integer mode (the Viewer's default, cull off): each lane reads 4 consecutive
+// splats per plane as one 16-byte load and writes 4 keys as one 16-byte store.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     __shared__ int32_t s_lo[4], s_hi[4];
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = p.sort_start + blockIdx.x * blockDim.x + threadIdx.x; i < p.render_count; i += stride) {
-        const uint32_t g = p.idx_in ? p.idx_in[i] : i;
-        const int32_t k = depth_key_one(p, g);
-        p.keys_out[i] = k;
-        lo = min(lo, k);
-        hi = max(hi, k);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (VEC4) {
+        // positions [a4*4, b4*4) are handled as vectors, the ragged head/tail as scalars by the first lanes
+        const uint32_t a4 = (p.sort_start + 3u) / 4u, b4 = p.render_count / 4u;
+        const uint4* x4 = reinterpret_cast<const uint4*>(p.cx);
+        const uint4* y4 = reinterpret_cast<const uint4*>(p.cy);
+        const uint4* z4 = reinterpret_cast<const uint4*>(p.cz);
+        int4* o4 = reinterpret_cast<int4*>(p.keys_out);
+        const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
+        for (uint32_t v = a4 + t; v < b4; v += stride) {
+            const uint4 x = x4[v], y = y4[v], z = z4[v];
+            int4 k;
+            k.x = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2);
+            k.y = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
+            k.z = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2);
+            k.w = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
+            o4[v] = k;
+            lo = min(min(lo, k.x), min(min(k.y, k.z), k.w));
+            hi = max(max(hi, k.x), max(max(k.y, k.z), k.w));
+        }
+        if (a4 <= b4) {
+            const uint32_t head_end = min(a4 * 4u, p.render_count), tail_begin = max(b4 * 4u, head_end);
+            for (uint32_t i = p.sort_start + t; i < head_end; i += stride) {
+                const int32_t k = depth_key_one(p, i);
+                p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
+            }
+            for (uint32_t i = tail_begin + t; i < p.render_count; i += stride) {
+                const int32_t k = depth_key_one(p, i);
+                p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
+            }
+        } else {                                           // fewer than one aligned vector: all scalar
+            for (uint32_t i = p.sort_start + t; i < p.render_count; i += stride) {
+                const int32_t k = depth_key_one(p, i);
+                p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
+            }
+        }
+    } else {
+        for (uint32_t i = p.sort_start + t; i < p.render_count; i += stride) {
+            const uint32_t g = p.idx_in ? p.idx_in[i] : i;
+            const int32_t k = depth_key_one(p, g);
+            p.keys_out[i] = k;
+            lo = min(lo, k);
+            hi = max(hi, k);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -322,7 +363,11 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
                        ctx->radix.digit_total.as<uint32_t>());
     uint32_t passes = 0;
     if (Rs > 0) {
-        hipLaunchKernelGGL(k_depth_key, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
+        if (vec4)
+            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        else
+            hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         GS_HIP(hipGetLastError());
         DepthLoader dl = {};
         dl.keys = s->keys.as<int32_t>();

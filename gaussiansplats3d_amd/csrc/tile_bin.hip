@@ -3,16 +3,19 @@
 // The reference has no binning: it draws one instanced quad per splat, back to front, and lets the ROPs blend
 // (/root/reference/src/splatmesh/SplatGeometry.js:11-37, SplatMaterial3D.js:65-75, src/Viewer.js:1616).  A
 // tile rasteriser needs each tile's splats as a list in that same draw order, so:
-//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p), gather each splat's tile rect (8 B),
-//                 write it back in traversal order and reduce the per-workgroup entry counts
-//   k_bin_scan    exclusive scan of <= 1024 workgroup sums; publishes D and min(D, capacity)
-//   k_bin_emit    expands every splat into (tile id, splat index) entries, cooperatively: a 256-splat batch's
-//                 entries are numbered by an LDS prefix sum and each lane finds its owner by binary search, so
-//                 a splat covering 4000 tiles costs the same per entry as one covering 4 (wave64-coalesced
-//                 stores, no per-thread serial loops)
-//   tile sort     stable LSD radix passes on the tile id (radix.hpp) - stability keeps near->far order per tile
-//   k_tile_ranges [begin,end) of every tile in the sorted entry array
-// Entry count D only ever lives on the device; all downstream grids are sized for the capacity and read D there.
+//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p).  A 1-bit-per-splat visibility mask written by
+//                 k_project (725 KB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
+//                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
+//                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
+//   k_bin_scan    exclusive scan of <= 1024 workgroup sums; publishes D, min(D, capacity) and the visible count
+//   k_bin_emit    ENTRY-centric expansion into (tile id, splat index) pairs: every lane owns 16 consecutive output
+//                 slots, finds the splat covering its first slot with two binary searches (workgroup table in LDS,
+//                 then that workgroup's per-splat offsets) and walks forward.  Work per lane is constant, so the
+//                 few near-camera splats that cover thousands of tiles cannot unbalance the grid, and every lane
+//                 stores whole 32-byte sectors.
+//   tile sort     stable LSD radix passes on the tile id (radix.hpp): stability keeps near->far order per tile; the
+//                 last pass also publishes every tile's [begin,end) (no separate range kernel)
+// Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.
 #include "radix.hpp"
 
 constexpr int BIN_THREADS = 256;
@@ -24,7 +27,7 @@ __device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
 }
 
 struct BinChunk {
-    uint32_t begin, end;   // batch indices (256 splats per batch)
+    uint32_t begin, end;   // batch indices (256 list positions per batch)
 };
 __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
     const uint32_t batches = (n + BIN_THREADS - 1) / BIN_THREADS;
@@ -42,33 +45,54 @@ __global__ void k_render_frame_init(RenderFrame* f, uint32_t* digit_total, uint2
         f->pad[0] = f->pad[1] = f->pad[2] = 0;
     }
     if (t < RADIX_MAX_PASSES * RADIX_BINS) digit_total[t] = 0;
-    for (uint32_t i = t; i < tiles; i += gridDim.x * blockDim.x) tile_ranges[i] = make_uint2(0u, 0u);
+    for (uint32_t i = t; i < tiles; i += gridDim.x * blockDim.x) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
 }
 
+// block_sums layout: [0,1024) tile entries per workgroup | [1024,2048) compacted (visible) splats per workgroup
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R,
-                                                           const uint2* __restrict__ rects, uint2* __restrict__ rect_q,
+                                                           const unsigned long long* __restrict__ vis_mask,
+                                                           const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
+                                                           uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_wave_cnt[4];
     const BinChunk ch = bin_chunk(R);
-    uint32_t sum = 0, vis = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint32_t sum = 0;
+    uint32_t out = ch.begin * BIN_THREADS;                 // this workgroup's slice of the compacted list starts here
     for (uint32_t b = ch.begin; b < ch.end; b++) {
         const uint32_t q = b * BIN_THREADS + threadIdx.x;
+        bool keep = false;
+        uint32_t idx = 0;
+        uint2 r = make_uint2(0xFFFFu, 0u);
         if (q < R) {
-            const uint32_t p = R - 1u - q;                     // draw order is back-to-front; we go front-to-back
-            const uint32_t idx = order ? order[p] : p;
-            const uint2 r = rects[idx];
-            rect_q[q] = r;
-            const uint32_t n = rect_tiles(r);
-            sum += n;
-            vis += n ? 1u : 0u;
+            const uint32_t p = R - 1u - q;                 // draw order is back-to-front; we go front-to-back
+            idx = order ? order[p] : p;
+            keep = (vis_mask[idx >> 6] >> (idx & 63u)) & 1ull;
+            if (keep) r = rects[idx];
         }
+        const uint32_t n = keep ? rect_tiles(r) : 0u;
+        uint32_t batch_total = 0;
+        const uint32_t excl = block_excl_scan_256(n, s_tmp, &batch_total);   // contains barriers
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        const uint32_t c0 = s_wave_cnt[0], c1 = s_wave_cnt[1], c2 = s_wave_cnt[2], c3 = s_wave_cnt[3];
+        const uint32_t wbase = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+        if (keep) {
+            const uint32_t o = out + wbase + (uint32_t)__popcll(m & lt_mask);
+            cidx[o] = idx;
+            crect[o] = r;
+            coff[o] = sum + excl;                          // first entry slot of this splat, relative to the workgroup
+        }
+        out += c0 + c1 + c2 + c3;
+        sum += batch_total;
+        __syncthreads();
     }
-    uint32_t total = 0, vtotal = 0;
-    (void)block_excl_scan_256(sum, s_tmp, &total);
-    (void)block_excl_scan_256(vis, s_tmp, &vtotal);
     if (threadIdx.x == 0) {
-        block_sums[blockIdx.x] = total;
-        block_sums[BIN_MAX_BLOCKS + blockIdx.x] = vtotal;      // second half: splats with >= 1 tile entry
+        block_sums[blockIdx.x] = sum;
+        block_sums[BIN_MAX_BLOCKS + blockIdx.x] = out - ch.begin * BIN_THREADS;
     }
 }
 
@@ -76,12 +100,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t grid, uint32_t capacity,
                                                    RenderFrame* frame) {
     __shared__ unsigned long long s_wave[16];
+    __shared__ uint32_t s_vis[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long v = tid < grid ? block_sums[tid] : 0ull;
     uint32_t vis = tid < grid ? block_sums[BIN_MAX_BLOCKS + tid] : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vis += __shfl_xor(vis, o, 64);
-    __shared__ uint32_t s_vis[16];
     if (lane == 0) s_vis[wave] = vis;
     unsigned long long incl = v;
 #pragma unroll
@@ -110,67 +134,102 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_
     }
 }
 
-template <class KeyT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ order, uint32_t R,
-                                                          const uint2* __restrict__ rect_q,
-                                                          const uint32_t* __restrict__ block_offsets, uint32_t capacity,
-                                                          uint32_t tiles_x, uint32_t row_begin, KeyT* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t s_prefix[BIN_THREADS + 1];
-    __shared__ uint2 s_rect[BIN_THREADS];
-    __shared__ uint32_t s_idx[BIN_THREADS];
-    __shared__ uint32_t s_tmp[4];
-    const BinChunk ch = bin_chunk(R);
-    const uint32_t tid = threadIdx.x;
-    uint32_t base = block_offsets[blockIdx.x];
-    for (uint32_t b = ch.begin; b < ch.end; b++) {
-        const uint32_t q = b * BIN_THREADS + tid;
-        uint2 r = make_uint2(0xFFFFu, 0u);
-        uint32_t idx = 0;
-        if (q < R) {
-            const uint32_t p = R - 1u - q;
-            idx = order ? order[p] : p;
-            r = rect_q[q];
-        }
-        const uint32_t n = rect_tiles(r);
-        uint32_t total = 0;
-        const uint32_t excl = block_excl_scan_256(n, s_tmp, &total);
-        s_prefix[tid] = excl;
-        s_rect[tid] = r;
-        s_idx[tid] = idx;
-        if (tid == 0) s_prefix[BIN_THREADS] = total;
-        __syncthreads();
-        for (uint32_t e = tid; e < total; e += BIN_THREADS) {
-            // owner = LARGEST j with s_prefix[j] <= e: empty splats share their prefix with a successor and lose
-            uint32_t lo = 0, hi = BIN_THREADS;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_prefix[mid] <= e) lo = mid; else hi = mid;
-            }
-            const uint2 rr = s_rect[lo];
-            const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, w = (rr.y & 0xFFFFu) - x0 + 1u;
-            const uint32_t k = e - s_prefix[lo];
-            const uint32_t dy = k / w, dx = k - dy * w;
-            const uint32_t g = base + e;
-            if (g < capacity && g >= base) {
-                keys_out[g] = (KeyT)((y0 + dy - row_begin) * tiles_x + x0 + dx);
-                vals_out[g] = s_idx[lo];
-            }
-        }
-        base += total;
-        __syncthreads();
-    }
-}
+constexpr uint32_t EMIT_PER_LANE = 16;
+constexpr uint32_t EMIT_WINDOW = BIN_THREADS * EMIT_PER_LANE;     // entries per workgroup iteration
 
+// block_sums after k_bin_scan: [0,1024) exclusive entry offset of every binning workgroup | [1024,2048) its
+// compacted splat count.  `bin_grid` / `bin_per` describe the grid k_bin_count ran with.
 template <class KeyT>
-__global__ __launch_bounds__(256) void k_tile_ranges(const KeyT* __restrict__ keys, const RenderFrame* frame,
-                                                     uint2* __restrict__ ranges) {
-    const uint32_t n = frame->entry_count;
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const uint32_t k = keys[e];
-        if (e == 0 || (uint32_t)keys[e - 1] != k) ranges[k].x = e;
-        if (e + 1 == n || (uint32_t)keys[e + 1] != k) ranges[k].y = e + 1;
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __restrict__ frame, uint32_t bin_grid,
+                                                          uint32_t bin_per, const uint32_t* __restrict__ cidx,
+                                                          const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
+                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x,
+                                                          uint32_t row_begin, KeyT* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
+    const uint32_t D = frame->entry_count;
+    for (uint32_t i = threadIdx.x; i <= bin_grid; i += BIN_THREADS) s_boff[i] = i < bin_grid ? block_sums[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t win = blockIdx.x; (unsigned long long)win * EMIT_WINDOW < D; win += gridDim.x) {
+        const uint32_t e0 = win * EMIT_WINDOW + threadIdx.x * EMIT_PER_LANE;
+        if (e0 >= D) continue;
+        const uint32_t e1 = min(e0 + EMIT_PER_LANE, D);
+        // level 1: binning workgroup b owning slot e0 = LAST b with s_boff[b] <= e0 (empty workgroups share their
+        // offset with a successor and lose, which is what we want)
+        uint32_t lo = 0, hi = bin_grid;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_boff[mid] <= e0) lo = mid; else hi = mid;
+        }
+        uint32_t b = lo;
+        uint32_t first = b * bin_per * BIN_THREADS;                     // start of b's slice of the compacted list
+        uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
+        uint32_t boff = s_boff[b];
+        // level 2: LAST splat j of that slice with boff + coff[j] <= e0
+        uint32_t jl = 0, jh = cnt;
+        const uint32_t rel = e0 - boff;
+        while (jh - jl > 1) {
+            const uint32_t mid = (jl + jh) >> 1;
+            if (coff[first + mid] <= rel) jl = mid; else jh = mid;
+        }
+        uint32_t j = jl;
+        uint2 r = crect[first + j];
+        uint32_t idx = cidx[first + j];
+        uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
+        uint32_t n = rect_tiles(r);
+        uint32_t k = rel - coff[first + j];
+        uint32_t ty = (r.x >> 16) - row_begin + k / w, tx = x0 + k % w;
+
+        uint32_t kk[EMIT_PER_LANE], vv[EMIT_PER_LANE];
+#pragma unroll
+        for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
+            kk[t] = ty * tiles_x + tx;
+            vv[t] = idx;
+            if (e0 + t + 1 < e1) {
+                if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
+                    if (++j == cnt) {
+                        do {
+                            b++;
+                            cnt = block_sums[BIN_MAX_BLOCKS + b];
+                        } while (cnt == 0);
+                        first = b * bin_per * BIN_THREADS;
+                        j = 0;
+                    }
+                    r = crect[first + j];
+                    idx = cidx[first + j];
+                    x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
+                    n = rect_tiles(r);
+                    k = 0;
+                    tx = x0; ty = (r.x >> 16) - row_begin;
+                } else if (++tx > x1) {
+                    tx = x0; ty++;
+                }
+            }
+        }
+        if (e1 - e0 == EMIT_PER_LANE) {
+            // whole 32-byte (keys, u16) / 64-byte (payload) sectors per lane
+            if (sizeof(KeyT) == 2) {
+                uint4 p0, p1;
+                p0.x = kk[0] | (kk[1] << 16); p0.y = kk[2] | (kk[3] << 16); p0.z = kk[4] | (kk[5] << 16); p0.w = kk[6] | (kk[7] << 16);
+                p1.x = kk[8] | (kk[9] << 16); p1.y = kk[10] | (kk[11] << 16); p1.z = kk[12] | (kk[13] << 16); p1.w = kk[14] | (kk[15] << 16);
+                uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
+                dst[0] = p0; dst[1] = p1;
+            } else {
+                uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) dst[t] = make_uint4(kk[4 * t], kk[4 * t + 1], kk[4 * t + 2], kk[4 * t + 3]);
+            }
+            uint4* vd = reinterpret_cast<uint4*>(vals_out + e0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) vd[t] = make_uint4(vv[4 * t], vv[4 * t + 1], vv[4 * t + 2], vv[4 * t + 3]);
+        } else {
+#pragma unroll
+            for (uint32_t t = 0; t < EMIT_PER_LANE; t++)
+                if (e0 + t < e1) {
+                    keys_out[e0 + t] = (KeyT)kk[t];
+                    vals_out[e0 + t] = vv[t];
+                }
+        }
     }
 }
 
@@ -183,11 +242,18 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     if (grid < 1) grid = 1;
     if (grid > (uint32_t)BIN_MAX_BLOCKS) grid = BIN_MAX_BLOCKS;
     const uint32_t cap = m->entry_capacity;
-    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, m->rects.as<uint2>(),
-                       m->rect_q.as<uint2>(), m->bin_sums.as<uint32_t>());
+    const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
+    const uint32_t bin_per = (batches + grid - 1) / grid;               // must match bin_chunk()
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, m->vis_mask.as<unsigned long long>(),
+                       m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
+                       m->bin_sums.as<uint32_t>());
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame);
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, m->rect_q.as<uint2>(),
-                       m->bin_sums.as<uint32_t>(), cap, pp.tiles_x, pp.row_begin, m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>());
+    uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
+    if (egrid > 4096u) egrid = 4096u;
+    if (egrid < 1u) egrid = 1u;
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, grid, bin_per, m->cidx.as<uint32_t>(),
+                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.tiles_x, pp.row_begin,
+                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
 
@@ -198,11 +264,13 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     uint32_t* vbuf[2] = {m->evalA.as<uint32_t>(), m->evalB.as<uint32_t>()};
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
-        GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true>(ctx, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1], vbuf[(p + 1) & 1])));
+        if (p + 1 == passes)
+            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ctx, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
+                                                                     vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>())));
+        else
+            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true, false>(ctx, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1],
+                                                                     vbuf[(p + 1) & 1])));
     }
-    // after `passes` swaps the sorted entries sit in buffer (passes & 1)
-    hipLaunchKernelGGL((k_tile_ranges<KeyT>), dim3(2048), dim3(256), 0, st, kbuf[passes & 1], frame, m->tile_ranges.as<uint2>());
-    GS_HIP(hipGetLastError());
     m->sorted_buf = (passes & 1);            // which ping-pong buffer holds the tile-sorted entries
     return GS_OK;
 }

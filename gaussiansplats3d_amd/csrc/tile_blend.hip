@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void k_tile_blend(const uint2* __restrict__ ran
     const float strip_lo = (float)(ty * GS_TILE) + 0.5f;       // first pixel-centre row of strip 0
 
     const uint2 range = ranges[tile];
-    const uint32_t begin = range.x, n = range.y - range.x;
+    const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched tiles keep (~0, 0)
 
     float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     float Cr[4] = {0, 0, 0, 0}, Cg[4] = {0, 0, 0, 0}, Cb[4] = {0, 0, 0, 0};

@@ -144,13 +144,18 @@ class SplatMesh:
         return stats
 
     def debug_records(self, count=None):
-        """Vertex-stage outputs of the last draw: (records float32/uint32 [n,8], rects uint32 [n,2])."""
+        """Vertex-stage outputs of the last draw: (records uint32 [n,8], rects uint32 [n,2], visible bool [n]).
+        Records and rects are only defined where `visible` is set."""
         n = self.splat_count if count is None else count
         recs = np.empty((n, 8), dtype=np.uint32)
         rects = np.empty((n, 2), dtype=np.uint32)
+        words = (n + 63) // 64
+        mask = np.empty(words, dtype=np.uint64)
         L.check(self.lib.gs_mesh_debug_read(self.handle, 0, recs.ctypes.data, n))
         L.check(self.lib.gs_mesh_debug_read(self.handle, 1, rects.ctypes.data, n))
-        return recs, rects
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 3, mask.ctypes.data, words))
+        vis = np.unpackbits(mask.view(np.uint8), bitorder="little")[:n].astype(bool)
+        return recs, rects, vis
 
     def tile_entry_counts(self, tile_rows=None):
         """Entries per tile of the last draw, shaped [rows, tiles_x] (used to balance multi-GPU strips)."""
@@ -160,7 +165,8 @@ class SplatMesh:
         r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
         rng = np.empty(((r1 - r0) * tiles_x, 2), dtype=np.uint32)
         L.check(self.lib.gs_mesh_debug_read(self.handle, 2, rng.ctypes.data, rng.shape[0]))
-        return (rng[:, 1] - rng[:, 0]).reshape(r1 - r0, tiles_x)
+        cnt = np.where(rng[:, 1] > rng[:, 0], rng[:, 1] - rng[:, 0], 0).astype(np.uint32)   # untouched: (~0, 0)
+        return cnt.reshape(r1 - r0, tiles_x)
 
     def dispose(self):
         if self.handle:

@@ -59,12 +59,12 @@ def test_vertex_stage_records_match_oracle(ctx):
     mesh.set_camera(cam)
     mesh.update_render_indexes(np.arange(scene.count, dtype=np.uint32), scene.count)
     mesh.render()
-    recs, rects = mesh.debug_records()
+    recs, rects, on_screen = mesh.debug_records()
     c, cov, rgba, sh = helpers.oracle_inputs(scene)
     ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, cam.width, cam.height, 2, 2)
     o = oracle.project(ocam, c, cov, rgba, sh)
     f = recs.view(np.float32)
-    on_screen = (rects[:, 0] & 0xFFFF) <= (rects[:, 1] & 0xFFFF)
+    assert ((rects[on_screen, 0] & 0xFFFF) <= (rects[on_screen, 1] & 0xFFFF)).all()
     vis = o["visible"] == 1
     # every splat we keep is visible for the oracle; the ones we drop are invisible or touch no pixel centre
     assert not (on_screen & ~vis).any()

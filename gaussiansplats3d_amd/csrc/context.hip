@@ -1,5 +1,6 @@
 // context.hip — error reporting and the per-GPU context of libgsplat_hip.so.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "gs_internal.hpp"
 
@@ -60,6 +61,11 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
         ctx->own_stream = true;
     }
     int st = ctx->radix.init();
+    if (st >= 0) {
+        bool ok = false;
+        st = gs_selftest_lds_atomic_order(ctx, &ok);
+        ctx->lds_atomic_lane_order = ok && !getenv("GSPLAT_NO_LDS_ATOMIC_RANK");
+    }
     if (st < 0) {
         gs_context_destroy(ctx);
         return st;

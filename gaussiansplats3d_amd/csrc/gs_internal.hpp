@@ -97,6 +97,7 @@ struct gs_context {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cu_count = 256;
+    bool lds_atomic_lane_order = false;   // self-test result: ds_add_rtn serves same-address lanes in lane order
     RadixScratch radix;
 };
 
@@ -212,6 +213,8 @@ struct gs_mesh {
     bool has_draw = false;
     uint32_t last_count = 0;
 };
+
+int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);
 
 // kernels' host launchers ---------------------------------------------------------------------------
 int gs_launch_frame_init(gs_mesh* m, uint32_t tiles);

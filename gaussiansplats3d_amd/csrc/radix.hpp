@@ -6,14 +6,18 @@
 //   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
 //     that each tile's list keeps the depth order established by the first sort.
 //
-// One pass = k_radix_hist -> k_radix_rowsum -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
+// One pass = k_radix_hist -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
 // no dependence on dispatch order (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS
 // workgroups walks contiguous runs of 4096-key tiles, so the [256][grid] offset matrix stays <= 2 MB
 // whatever N is, and N may live in device memory (tile-entry count is only known on the device).
 //
-// Ranking inside a tile is wave64-native: 8 ballots build the "same digit" lane mask, the rank is a popcount
-// of the lower lanes plus a per-wave LDS counter; keys are then reordered through LDS so that every digit's
-// run leaves the CU as contiguous stores.
+// Ranking inside a tile is wave64-native.  Fast path (ATOMIC_RANK): one `ds_add_rtn_u32` on a per-wave LDS
+// histogram per key.  gfx950's LDS serves the lanes of ONE wave instruction that hit the same address in ascending
+// lane order (tools/probes/lds_atomic_order.hip: 0 mismatches in 3.3e9 checks; re-verified by a self-test at
+// gs_context_create), so the returned value IS the stable rank of the key among equal digits seen so far by its
+// wave.  Portable path (self-test failed): 8 ballots build the "same digit" lane mask, rank = popcount of the
+// lower lanes + the per-wave counter.  Keys are then reordered through LDS so that every digit's run leaves the
+// CU as contiguous stores.
 #pragma once
 #include "gs_internal.hpp"
 
@@ -31,17 +35,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
-// exclusive scan of one value per thread over a 256-thread block; returns exclusive prefix, *total = block sum
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_tmp /*>=4*/, uint32_t* total) {
+// exclusive scan of one value per thread over a WAVES*64-thread block; returns exclusive prefix, *total = block sum
+template <int WAVES>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp /*>=WAVES*/, uint32_t* total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(v, lane);
     if (lane == 63) s_tmp[wave] = incl;
     __syncthreads();
-    const uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
-    const uint32_t wave_base = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0);
-    if (total) *total = w0 + w1 + w2 + w3;
+    uint32_t wave_base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) {
+        const uint32_t c = s_tmp[w];
+        wave_base += ((uint32_t)w < wave) ? c : 0u;
+        sum += c;
+    }
+    if (total) *total = sum;
     __syncthreads();
     return wave_base + incl - v;
+}
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_tmp /*>=4*/, uint32_t* total) {
+    return block_excl_scan<4>(v, s_tmp, total);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -76,6 +89,34 @@ __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
     return c;
 }
 
+// counts the digits of one full 4096-key tile with 16-byte loads (order is irrelevant for a histogram)
+template <class KeyT>
+__device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint32_t base, int shift, uint32_t* hist) {
+    const uint4* src = reinterpret_cast<const uint4*>(ld.keys + base);          // base is a multiple of 4096 keys
+    constexpr int LOADS = RADIX_TILE * (int)sizeof(KeyT) / 16 / RADIX_THREADS;  // 2 (u16) or 4 (u32) per thread
+    uint4 v[LOADS];
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) v[k] = src[k * RADIX_THREADS + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) {
+        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (sizeof(KeyT) == 2) {
+                atomicAdd(&hist[((w[c] & 0xFFFFu) >> shift) & 255u], 1u);
+                atomicAdd(&hist[((w[c] >> 16) >> shift) & 255u], 1u);
+            } else {
+                atomicAdd(&hist[(w[c] >> shift) & 255u], 1u);
+            }
+        }
+    }
+}
+template <class Loader>
+__device__ __forceinline__ void hist_full_tile(const Loader& ld, uint32_t base, int shift, uint32_t* hist) {
+#pragma unroll
+    for (int r = 0; r < RADIX_ITEMS; r++) atomicAdd(&hist[(ld.key(base + r * RADIX_THREADS + threadIdx.x) >> shift) & 255u], 1u);
+}
+
 template <class Loader>
 __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shift, uint32_t* __restrict__ block_hist,
                                                               uint32_t* __restrict__ digit_total) {
@@ -88,28 +129,22 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shi
     __syncthreads();
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t base = tile * RADIX_TILE;
+        if (base + RADIX_TILE <= ch.n) {
+            hist_full_tile(ld, base, shift, s_hist[wave]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RADIX_ITEMS; r++) {
-            const uint32_t j = base + r * RADIX_THREADS + tid;
-            if (j < ch.n) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
+            for (int r = 0; r < RADIX_ITEMS; r++) {
+                const uint32_t j = base + r * RADIX_THREADS + tid;
+                if (j < ch.n) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
+            }
         }
     }
     __syncthreads();
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     block_hist[tid * gridDim.x + blockIdx.x] = total;
-    (void)digit_total;   // per-digit totals come from k_radix_rowsum: G*256 same-line atomics would serialise in L2
-}
-
-// block d: digit_total[d] = sum of row d (number of keys whose digit is d)
-static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_rowsum(const uint32_t* __restrict__ block_hist,
-                                                                      uint32_t* __restrict__ digit_total, uint32_t grid) {
-    __shared__ uint32_t s_tmp[4];
-    const uint32_t* row = block_hist + (size_t)blockIdx.x * grid;
-    uint32_t sum = 0;
-    for (uint32_t i = threadIdx.x; i < grid; i += RADIX_THREADS) sum += row[i];
-    uint32_t total = 0;
-    (void)block_excl_scan_256(sum, s_tmp, &total);
-    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
+    // per-digit totals: G atomics per digit on 256 distinct words; measured free (they drain behind the kernel),
+    // whereas a separate row-sum kernel costs ~5 us per pass
+    if (total) atomicAdd(&digit_total[tid], total);
 }
 
 // block d scans row d of the digit-major matrix and adds the number of keys with a smaller digit
@@ -142,18 +177,26 @@ static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* _
 // RANGES: this is the last pass of the tile sort - publish each key's [begin,end) in the sorted output.  Inside a
 // workgroup tile equal keys are contiguous (the earlier passes ordered the lower digits, this pass is stable), so a
 // run boundary costs one atomicMin/atomicMax pair; `ranges` must be pre-set to (0xFFFFFFFF, 0).
-template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES>
-__global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int shift,
-                                                                 const uint32_t* __restrict__ block_offsets,
-                                                                 KeyOutT* __restrict__ keys_out,
-                                                                 uint32_t* __restrict__ vals_out, uint2* ranges) {
-    __shared__ uint32_t s_keys[RADIX_TILE];
+//
+// Geometry: 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and ~35 KB LDS (16-bit keys
+// are staged as 16 bits), so 4 workgroups = 32 waves fill a CU: the kernel is a chain of load -> rank -> barrier ->
+// reorder -> barrier -> store phases and only occupancy overlaps one workgroup's stalls with another's work.
+constexpr int SCATTER_THREADS = 512;
+constexpr int SCATTER_WAVES = SCATTER_THREADS / 64;
+constexpr int SCATTER_ITEMS = RADIX_TILE / SCATTER_THREADS;
+
+template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
+__global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) void k_radix_scatter(Loader ld, int shift,
+                                                                      const uint32_t* __restrict__ block_offsets,
+                                                                      KeyOutT* __restrict__ keys_out,
+                                                                      uint32_t* __restrict__ vals_out, uint2* ranges) {
+    __shared__ KeyOutT s_keys[RADIX_TILE];                  // staged in the output key width (u16 or u32)
     __shared__ uint32_t s_vals[RADIX_TILE];
-    __shared__ uint32_t s_wave[4][RADIX_BINS];   // per-wave digit counts, then per-wave exclusive offsets
-    __shared__ uint32_t s_base[RADIX_BINS];      // running global offset of each digit for this workgroup
-    __shared__ uint32_t s_local[RADIX_BINS];     // first staging slot of each digit in the current tile
+    __shared__ uint32_t s_wave[SCATTER_WAVES][RADIX_BINS];  // per-wave digit counts, then per-wave exclusive offsets
+    __shared__ uint32_t s_base[RADIX_BINS];                 // running global offset of each digit for this workgroup
+    __shared__ uint32_t s_local[RADIX_BINS];                // first staging slot of each digit in the current tile
     __shared__ uint32_t s_total[RADIX_BINS];
-    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_tmp[SCATTER_WAVES];
 
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
@@ -161,67 +204,80 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int 
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];
 
-    s_base[tid] = block_offsets[tid * gridDim.x + blockIdx.x];
+    if (tid < RADIX_BINS) s_base[tid] = block_offsets[tid * gridDim.x + blockIdx.x];
 
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t tile_base = tile * RADIX_TILE;
         const uint32_t tile_count = min((uint32_t)RADIX_TILE, ch.n - tile_base);
-        uint32_t key[RADIX_ITEMS], val[RADIX_ITEMS], rank[RADIX_ITEMS];
+        uint32_t key[SCATTER_ITEMS], val[SCATTER_ITEMS], rank[SCATTER_ITEMS];
         // wave-striped load: the stable order inside a tile is (wave, r, lane)
-        const uint32_t wbase = tile_base + wave * (64 * RADIX_ITEMS) + lane;
+        const uint32_t wbase = tile_base + wave * (64 * SCATTER_ITEMS) + lane;
 #pragma unroll
-        for (int r = 0; r < RADIX_ITEMS; r++) {
+        for (int r = 0; r < SCATTER_ITEMS; r++) {
             const uint32_t j = wbase + r * 64;
             const bool ok = j < ch.n;
             key[r] = ok ? ld.key(j) : 0xFFFFFFFFu;
             val[r] = ok ? ld.val(j) : 0u;
         }
 #pragma unroll
-        for (int w = 0; w < 4; w++) s_wave[w][tid] = 0;
+        for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;
         __syncthreads();
 
+        if (ATOMIC_RANK) {
 #pragma unroll
-        for (int r = 0; r < RADIX_ITEMS; r++) {
-            const bool ok = (wbase + r * 64) < ch.n;
-            const uint32_t digit = (key[r] >> shift) & 255u;
-            uint64_t same = __ballot(ok);
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const uint64_t vote = __ballot(ok && ((digit >> b) & 1u));
-                same &= ((digit >> b) & 1u) ? vote : ~vote;
+            for (int r = 0; r < SCATTER_ITEMS; r++) {
+                const uint32_t digit = (key[r] >> shift) & 255u;
+                // lanes of this instruction that share `digit` are served in ascending lane order (see header)
+                if ((wbase + r * 64) < ch.n) rank[r] = atomicAdd(&s_wave[wave][digit], 1u);
             }
-            if (ok) {
-                const uint32_t prior = my_hist[digit];
-                rank[r] = prior + __popcll(same & lt_mask);
-                if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);   // highest lane of the group
+        } else {
+#pragma unroll
+            for (int r = 0; r < SCATTER_ITEMS; r++) {
+                const bool ok = (wbase + r * 64) < ch.n;
+                const uint32_t digit = (key[r] >> shift) & 255u;
+                uint64_t same = __ballot(ok);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const uint64_t vote = __ballot(ok && ((digit >> b) & 1u));
+                    same &= ((digit >> b) & 1u) ? vote : ~vote;
+                }
+                if (ok) {
+                    const uint32_t prior = my_hist[digit];
+                    rank[r] = prior + __popcll(same & lt_mask);
+                    if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);   // highest lane of the group
+                }
             }
         }
         __syncthreads();
 
-        {   // thread t owns digit t: wave-exclusive offsets and the tile-local digit base
-            const uint32_t c0 = s_wave[0][tid], c1 = s_wave[1][tid], c2 = s_wave[2][tid], c3 = s_wave[3][tid];
-            s_wave[0][tid] = 0;
-            s_wave[1][tid] = c0;
-            s_wave[2][tid] = c0 + c1;
-            s_wave[3][tid] = c0 + c1 + c2;
-            const uint32_t tot = c0 + c1 + c2 + c3;
-            s_total[tid] = tot;
-            s_local[tid] = block_excl_scan_256(tot, s_tmp, nullptr);   // contains the barriers
+        {   // thread t < 256 owns digit t: wave-exclusive offsets and the tile-local digit base
+            uint32_t tot = 0;
+            if (tid < RADIX_BINS) {
+#pragma unroll
+                for (int w = 0; w < SCATTER_WAVES; w++) {
+                    const uint32_t c = s_wave[w][tid];
+                    s_wave[w][tid] = tot;
+                    tot += c;
+                }
+                s_total[tid] = tot;
+            }
+            const uint32_t excl = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);   // contains the barriers
+            if (tid < RADIX_BINS) s_local[tid] = excl;
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RADIX_ITEMS; r++) {
+        for (int r = 0; r < SCATTER_ITEMS; r++) {
             if ((wbase + r * 64) < ch.n) {
                 const uint32_t digit = (key[r] >> shift) & 255u;
                 const uint32_t pos = s_local[digit] + s_wave[wave][digit] + rank[r];
-                s_keys[pos] = key[r];
+                s_keys[pos] = (KeyOutT)key[r];
                 s_vals[pos] = val[r];
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < RADIX_ITEMS; k++) {
-            const uint32_t e = k * RADIX_THREADS + tid;
+        for (int k = 0; k < SCATTER_ITEMS; k++) {
+            const uint32_t e = k * SCATTER_THREADS + tid;
             if (e < tile_count) {
                 const uint32_t kk = s_keys[e];
                 const uint32_t digit = (kk >> shift) & 255u;
@@ -229,13 +285,13 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scatter(Loader ld, int 
                 if (WRITE_KEYS) keys_out[g] = (KeyOutT)kk;
                 vals_out[g] = s_vals[e];
                 if (RANGES) {
-                    if (e == 0 || s_keys[e - 1] != kk) atomicMin(&ranges[kk].x, g);
-                    if (e + 1 == tile_count || s_keys[e + 1] != kk) atomicMax(&ranges[kk].y, g + 1u);
+                    if (e == 0 || (uint32_t)s_keys[e - 1] != kk) atomicMin(&ranges[kk].x, g);
+                    if (e + 1 == tile_count || (uint32_t)s_keys[e + 1] != kk) atomicMax(&ranges[kk].y, g + 1u);
                 }
             }
         }
         __syncthreads();
-        s_base[tid] += s_total[tid];
+        if (tid < RADIX_BINS) s_base[tid] += s_total[tid];
         // the next iteration's first barrier orders this update before its use
     }
 }
@@ -260,10 +316,13 @@ int radix_pass(gs_context* ctx, const Loader& ld_hist, const Loader& ld, uint32_
     uint32_t* bh = ctx->radix.block_hist.as<uint32_t>();
     uint32_t* dt = ctx->radix.digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
     hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream, ld_hist, shift, bh, dt);
-    hipLaunchKernelGGL(k_radix_rowsum, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
     hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
-    hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES>), dim3(grid), dim3(RADIX_THREADS), 0,
-                       ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
+    if (ctx->lds_atomic_lane_order)
+        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,
+                           ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
+    else
+        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false>), dim3(grid), dim3(SCATTER_THREADS), 0,
+                           ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

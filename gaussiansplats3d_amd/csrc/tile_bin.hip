@@ -49,50 +49,80 @@ __global__ void k_render_frame_init(RenderFrame* f, uint32_t* digit_total, uint2
 }
 
 // block_sums layout: [0,1024) tile entries per workgroup | [1024,2048) compacted (visible) splats per workgroup
+// Each lane owns 4 consecutive list positions per iteration, so 4 index loads, then 4 mask look-ups, then up to 4
+// rect gathers are in flight together (the kernel is a chain of dependent memory round trips), and one packed
+// 64-bit block scan per 1024 positions yields both the compaction slot and the entry offset.
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R,
                                                            const unsigned long long* __restrict__ vis_mask,
                                                            const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t s_tmp[4];
-    __shared__ uint32_t s_wave_cnt[4];
+    __shared__ unsigned long long s_w[4];
     const BinChunk ch = bin_chunk(R);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    uint32_t sum = 0;
-    uint32_t out = ch.begin * BIN_THREADS;                 // this workgroup's slice of the compacted list starts here
-    for (uint32_t b = ch.begin; b < ch.end; b++) {
-        const uint32_t q = b * BIN_THREADS + threadIdx.x;
-        bool keep = false;
-        uint32_t idx = 0;
-        uint2 r = make_uint2(0xFFFFu, 0u);
-        if (q < R) {
-            const uint32_t p = R - 1u - q;                 // draw order is back-to-front; we go front-to-back
-            idx = order ? order[p] : p;
-            keep = (vis_mask[idx >> 6] >> (idx & 63u)) & 1ull;
-            if (keep) r = rects[idx];
+    const uint32_t pos_begin = ch.begin * BIN_THREADS, pos_end = min(ch.end * BIN_THREADS, R);
+    uint32_t sum = 0;                                      // entries emitted so far by this workgroup
+    uint32_t out = pos_begin;                              // next slot of this workgroup's compacted slice
+    for (uint32_t pos0 = pos_begin; pos0 < pos_end; pos0 += 4 * BIN_THREADS) {
+        const uint32_t q0 = pos0 + 4u * threadIdx.x;
+        uint32_t idx[4];
+        bool keep[4];
+        uint2 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t q = q0 + k;
+            keep[k] = q < pos_end;
+            const uint32_t p = R - 1u - min(q, R - 1u);    // draw order is back-to-front; we go front-to-back
+            idx[k] = order ? order[p] : p;
         }
-        const uint32_t n = keep ? rect_tiles(r) : 0u;
-        uint32_t batch_total = 0;
-        const uint32_t excl = block_excl_scan_256(n, s_tmp, &batch_total);   // contains barriers
-        const uint64_t m = __ballot(keep);
-        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(m);
+#pragma unroll
+        for (int k = 0; k < 4; k++) keep[k] = keep[k] && ((vis_mask[idx[k] >> 6] >> (idx[k] & 63u)) & 1ull);
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = keep[k] ? rects[idx[k]] : make_uint2(0xFFFFu, 0u);
+        uint32_t n[4], cnt = 0, ent = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            n[k] = keep[k] ? rect_tiles(r[k]) : 0u;
+            cnt += keep[k] ? 1u : 0u;
+            ent += n[k];
+        }
+        // packed inclusive scan: high word = compacted splats, low word = tile entries (both < 2^31 per workgroup)
+        const unsigned long long mine = ((unsigned long long)cnt << 32) | ent;
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
         __syncthreads();
-        const uint32_t c0 = s_wave_cnt[0], c1 = s_wave_cnt[1], c2 = s_wave_cnt[2], c3 = s_wave_cnt[3];
-        const uint32_t wbase = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
-        if (keep) {
-            const uint32_t o = out + wbase + (uint32_t)__popcll(m & lt_mask);
-            cidx[o] = idx;
-            crect[o] = r;
-            coff[o] = sum + excl;                          // first entry slot of this splat, relative to the workgroup
+        unsigned long long base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long c = s_w[w];
+            base += ((uint32_t)w < wave) ? c : 0ull;
+            total += c;
         }
-        out += c0 + c1 + c2 + c3;
-        sum += batch_total;
+        const unsigned long long excl = base + incl - mine;
+        uint32_t o = out + (uint32_t)(excl >> 32);
+        uint32_t e = sum + (uint32_t)excl;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (keep[k]) {
+                cidx[o] = idx[k];
+                crect[o] = r[k];
+                coff[o] = e;                               // first entry slot of this splat, relative to the workgroup
+                o++;
+                e += n[k];
+            }
+        }
+        out += (uint32_t)(total >> 32);
+        sum += (uint32_t)total;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = sum;
-        block_sums[BIN_MAX_BLOCKS + blockIdx.x] = out - ch.begin * BIN_THREADS;
+        block_sums[BIN_MAX_BLOCKS + blockIdx.x] = out - pos_begin;
     }
 }
 

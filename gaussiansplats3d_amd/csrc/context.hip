@@ -60,6 +60,17 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
         }
         ctx->own_stream = true;
     }
+    ctx->serial = getenv("GSPLAT_SERIAL") != nullptr;
+    if (!ctx->serial) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            gs_set_error("hipStreamCreate(aux) failed: %s", hipGetErrorString(e));
+            gs_context_destroy(ctx);
+            return GS_ERR_HIP;
+        }
+    } else {
+        ctx->aux = ctx->stream;
+    }
     int st = ctx->radix.init();
     if (st >= 0) {
         bool ok = false;
@@ -77,10 +88,14 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
 void gs_context_destroy(gs_context* ctx) {
     if (!ctx) return;
     ScopedDevice sd(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux && ctx->aux != ctx->stream) {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamDestroy(ctx->aux);
+    }
     ctx->radix.block_hist.release();
     ctx->radix.digit_total.release();
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -88,6 +103,7 @@ int gs_context_synchronize(gs_context* ctx) {
     GS_REQUIRE(ctx != nullptr, "ctx == NULL");
     ScopedDevice sd(ctx->device);
     GS_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux != ctx->stream) GS_HIP(hipStreamSynchronize(ctx->aux));
     return GS_OK;
 }
 

@@ -92,13 +92,26 @@ struct RadixScratch {
 // ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------
+// Streams of one context (the reference runs its sort in a Web Worker, concurrently with rendering,
+// /root/reference/src/worker/SortWorker.js; here the "worker thread" is a HIP stream):
+//   stream  the caller-visible stream: binning, tile sort, blend, every copy back to the host
+//   aux     vertex stage (k_project) of a draw, forked from / joined into `stream` with events
+// Each gs_sorter additionally owns a private stream; its result is joined into `stream` where a draw consumes it.
 struct gs_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;
     bool own_stream = false;
+    bool serial = false;                  // GSPLAT_SERIAL=1: everything on `stream` (debugging / per-stage timing)
     int cu_count = 256;
     bool lds_atomic_lane_order = false;   // self-test result: ds_add_rtn serves same-address lanes in lane order
-    RadixScratch radix;
+    RadixScratch radix;                   // scratch of the create-time self-test
+};
+
+struct RadixExec {                        // where and with what scratch a radix pass runs
+    hipStream_t stream;
+    RadixScratch* scratch;
+    bool atomic_rank;
 };
 
 struct ScopedDevice {
@@ -137,7 +150,12 @@ struct gs_sorter {
     DevBuf frame;              // SortFrame
     DevBuf scene_rows;         // per-scene key coefficients (dynamic mode)
     DevBuf debug;
+    RadixScratch radix;
+    hipStream_t stream = nullptr;      // the "worker thread": sorts run here, concurrently with draws on ctx->stream
+    bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_consumed = nullptr;  // recorded on ctx->stream by a draw once it has read `sorted`
+    bool consumer_pending = false;
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
     bool last_identity = true;
     bool has_result = false;
@@ -194,10 +212,10 @@ struct gs_mesh {
     DevBuf sh0, sh1, sh2;      // uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
     DevBuf staging;
     // per-draw
-    DevBuf recs;               // SplatRec [n]  (storage order)
-    DevBuf rects;              // uint2 [n]     tile rect per splat (storage order)
-    DevBuf vis_mask;           // uint64 [ceil(n/64)]  1 = splat survived the vertex stage and touches a pixel
-    DevBuf cidx;               // uint32 [render_count] visible splats in traversal order (compacted per workgroup)
+    DevBuf recs;               // SplatRec [n]  survivors compacted inside each 256-splat block (project.hip)
+    DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
+    DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
+    DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)
     DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
     DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx
     DevBuf coff;               // uint32 [render_count] first entry slot of each, relative to its binning workgroup
@@ -206,9 +224,12 @@ struct gs_mesh {
     DevBuf tile_ranges;        // uint2 [tiles]
     DevBuf frame;              // RenderFrame
     DevBuf fb;                 // internal RGBA8 framebuffer
+    RadixScratch radix;
     uint32_t entry_capacity = 0;
     uint32_t sorted_buf = 0;   // ping-pong buffer index holding the tile-sorted entries of the last draw
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around k_project on ctx->aux
+    hipEvent_t ev_done = nullptr;                  // end of the previous draw on ctx->stream (recs / rects reusable)
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;
@@ -219,5 +240,5 @@ int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);
 // kernels' host launchers ---------------------------------------------------------------------------
 int gs_launch_frame_init(gs_mesh* m, uint32_t tiles);
 int gs_launch_project(gs_mesh* m, const ProjectParams& pp);
-int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t render_count);
+int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count);
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);

@@ -51,6 +51,25 @@ __global__ __launch_bounds__(256) void k_split_sh(const uint16_t* __restrict__ s
     }
 }
 
+// test hook: undo k_project's per-block compaction -> one record / rect per splat in storage order (zeros when culled)
+__global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* __restrict__ vis_mask, uint32_t count,
+                                                      const uint4* __restrict__ recs, const uint2* __restrict__ rects,
+                                                      uint4* __restrict__ out_recs, uint2* __restrict__ out_rects) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const unsigned long long* mw = vis_mask + ((i >> 8) << 2);
+    const uint32_t w = (i >> 6) & 3u, bit = i & 63u;
+    uint32_t slot = (i & ~255u) + (uint32_t)__popcll(mw[w] & ((1ull << bit) - 1ull));
+    for (uint32_t k = 0; k < w; k++) slot += (uint32_t)__popcll(mw[k]);
+    const bool vis = (mw[w] >> bit) & 1ull;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (out_recs) {
+        out_recs[2 * (size_t)i] = vis ? recs[2 * (size_t)slot] : z;
+        out_recs[2 * (size_t)i + 1] = vis ? recs[2 * (size_t)slot + 1] : z;
+    }
+    if (out_rects) out_rects[i] = vis ? rects[slot] : make_uint2(0xFFFFu, 0u);
+}
+
 static inline uint32_t up_grid(uint32_t n) {
     uint32_t g = (n + 255u) / 256u;
     return g < 1 ? 1 : (g > 4096u ? 4096u : g);
@@ -91,9 +110,10 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     if (sh_degree >= 1) { A(m->sh0, n * 16); A(m->sh1, n * (sh_degree == 2 ? 16 : 4)); }
     if (sh_degree >= 2) A(m->sh2, n * 16);
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
-    A(m->vis_mask, ((n + 63) / 64) * 8 + 8);
+    A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->bin_sums, 4 * 2048);
     A(m->frame, sizeof(RenderFrame));
+    if (st == GS_OK) st = m->radix.init();
     if (st == GS_OK) {
         // first guess: 8 tile entries per splat, at least 4M; grown on overflow
         uint64_t cap = (uint64_t)n * 8;
@@ -106,6 +126,11 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
             gs_set_error("hipEventCreate failed");
             st = GS_ERR_HIP;
         }
+    if (st == GS_OK && (hipEventCreate(&m->ev_p0) != hipSuccess || hipEventCreate(&m->ev_p1) != hipSuccess ||
+                        hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess)) {
+        gs_set_error("hipEventCreate failed");
+        st = GS_ERR_HIP;
+    }
     if (st != GS_OK) {
         gs_mesh_destroy(m);
         return st;
@@ -118,8 +143,12 @@ void gs_mesh_destroy(gs_mesh* m) {
     if (!m) return;
     ScopedDevice sd(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->ctx->aux != m->ctx->stream) (void)hipStreamSynchronize(m->ctx->aux);
     for (int i = 0; i < 6; i++)
         if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
+    if (m->ev_p0) (void)hipEventDestroy(m->ev_p0);
+    if (m->ev_p1) (void)hipEventDestroy(m->ev_p1);
+    if (m->ev_done) (void)hipEventDestroy(m->ev_done);
     delete m;
 }
 
@@ -166,7 +195,8 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     GS_HIP(hipMemcpyAsync(&f, m->frame.p, sizeof(f), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     float t[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
+    for (int i = 1; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
+    GS_HIP(hipEventElapsedTime(&t[0], m->ev_p0, m->ev_p1));   // on ctx->aux: may overlap a sort and the tail of the previous draw
     m->last.project_ms = t[0];
     m->last.bin_ms = t[1];
     m->last.tile_sort_ms = t[2];
@@ -181,20 +211,32 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     return f.overflow ? 1 : 0;
 }
 
-static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t R, uint8_t* out_dev) {
+static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R,
+                          uint8_t* out_dev) {
     gs_context* ctx = m->ctx;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream, aux = ctx->aux;
     const uint32_t tiles = pp.tiles_x * (pp.row_end - pp.row_begin);
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     GS_HIP(hipEventRecord(m->ev[0], st));
     GS_TRY(gs_launch_frame_init(m, tiles));
+    // fork: the vertex stage only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
+    // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed
+    // the records / rects / mask it is about to overwrite
+    if (aux != st && m->has_draw) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
+    GS_HIP(hipEventRecord(m->ev_p0, aux));
     GS_TRY(gs_launch_project(m, pp));
+    GS_HIP(hipEventRecord(m->ev_p1, aux));
+    // join: projection and (if a sorter feeds this draw) the sort result
+    if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
+    if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
     GS_HIP(hipEventRecord(m->ev[1], st));
-    GS_TRY(gs_launch_binning(m, pp, order_dev, R));      // records ev[2] between emit and the tile sort
+    GS_TRY(gs_launch_binning(m, pp, order_dev, sorter, R));   // records ev[2] between emit and the tile sort
     GS_HIP(hipEventRecord(m->ev[3], st));
     GS_TRY(gs_launch_blend(m, pp, out_dev));
     GS_HIP(hipEventRecord(m->ev[4], st));
     GS_HIP(hipEventRecord(m->ev[5], st));
+    GS_HIP(hipEventRecord(m->ev_done, st));
+    m->has_draw = true;
     return GS_OK;
 }
 
@@ -256,7 +298,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     }
 
     m->last = gs_render_stats();
-    GS_TRY(mesh_draw_once(m, pp, order_dev, render_count, out_dev));
+    GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev));
     m->has_draw = true;
     m->last_count = pp.count;
 
@@ -274,7 +316,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
                 return GS_ERR_CAPACITY;
             }
             GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
-            GS_TRY(mesh_draw_once(m, pp, order_dev, render_count, out_dev));
+            GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev));
             ov = mesh_collect_stats(m, nullptr);
             if (ov < 0) return ov;
             m->last.overflowed = 1;
@@ -317,9 +359,16 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     GS_REQUIRE(m->has_draw && (what >= 2 || count <= m->last_count), "no draw / count too large");
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
-    if (what == 0) GS_HIP(hipMemcpyAsync(dst, m->recs.p, (size_t)count * sizeof(SplatRec), hipMemcpyDeviceToHost, st));
-    else if (what == 1) GS_HIP(hipMemcpyAsync(dst, m->rects.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
-    else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
+    if (what == 0 || what == 1) {
+        if (count == 0) return GS_OK;
+        const size_t bytes = (size_t)count * (what == 0 ? sizeof(SplatRec) : 8);
+        GS_TRY(m->staging.ensure(bytes));
+        hipLaunchKernelGGL(k_debug_expand, dim3((count + 255u) / 256u), dim3(256), 0, st, m->vis_mask.as<unsigned long long>(), count,
+                           m->recs.as<uint4>(), m->rects.as<uint2>(), what == 0 ? m->staging.as<uint4>() : nullptr,
+                           what == 1 ? m->staging.as<uint2>() : nullptr);
+        GS_HIP(hipGetLastError());
+        GS_HIP(hipMemcpyAsync(dst, m->staging.p, bytes, hipMemcpyDeviceToHost, st));
+    } else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
         GS_REQUIRE((size_t)count * 8 <= m->tile_ranges.bytes, "count exceeds the tile count of the last draw");
         GS_HIP(hipMemcpyAsync(dst, m->tile_ranges.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
     } else if (what == 3) {   // visibility mask of the last draw, count = number of 64-bit words

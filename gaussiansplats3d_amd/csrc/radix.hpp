@@ -6,7 +6,7 @@
 //   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
 //     that each tile's list keeps the depth order established by the first sort.
 //
-// One pass = k_radix_hist -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
+// One pass = k_radix_hist -> k_radix_rowsum -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
 // no dependence on dispatch order (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS
 // workgroups walks contiguous runs of 4096-key tiles, so the [256][grid] offset matrix stays <= 2 MB
 // whatever N is, and N may live in device memory (tile-entry count is only known on the device).
@@ -142,9 +142,20 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shi
     __syncthreads();
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     block_hist[tid * gridDim.x + blockIdx.x] = total;
-    // per-digit totals: G atomics per digit on 256 distinct words; measured free (they drain behind the kernel),
-    // whereas a separate row-sum kernel costs ~5 us per pass
-    if (total) atomicAdd(&digit_total[tid], total);
+    (void)digit_total;   // per-digit totals come from k_radix_rowsum: G same-word atomics per digit serialise in the
+                         // fabric (~12 ns each, MI355X_MICROARCH.md row "fanin") and cost 10-15 us per pass (A/B r01b)
+}
+
+// block d: digit_total[d] = sum of row d (number of keys whose digit is d)
+static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_rowsum(const uint32_t* __restrict__ block_hist,
+                                                                      uint32_t* __restrict__ digit_total, uint32_t grid) {
+    __shared__ uint32_t s_tmp[4];
+    const uint32_t* row = block_hist + (size_t)blockIdx.x * grid;
+    uint32_t sum = 0;
+    for (uint32_t i = threadIdx.x; i < grid; i += RADIX_THREADS) sum += row[i];
+    uint32_t total = 0;
+    (void)block_excl_scan_256(sum, s_tmp, &total);
+    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
 }
 
 // block d scans row d of the digit-major matrix and adds the number of keys with a smaller digit
@@ -310,19 +321,20 @@ inline uint32_t radix_grid_for(uint32_t n_upper) {
 // n_upper: host-side upper bound of the element count (sizes the grid); pass_slot picks the zeroed
 // digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES = false>
-int radix_pass(gs_context* ctx, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
+int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
                KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr) {
     const uint32_t grid = radix_grid_for(n_upper);
-    uint32_t* bh = ctx->radix.block_hist.as<uint32_t>();
-    uint32_t* dt = ctx->radix.digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
-    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ctx->stream, ld_hist, shift, bh, dt);
-    hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ctx->stream, bh, dt, grid);
-    if (ctx->lds_atomic_lane_order)
+    uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
+    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
+    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
+    hipLaunchKernelGGL(k_radix_rowsum, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ex.stream, bh, dt, grid);
+    hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ex.stream, bh, dt, grid);
+    if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
+                           ex.stream, ld, shift, bh, keys_out, vals_out, ranges);
     else
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ctx->stream, ld, shift, bh, keys_out, vals_out, ranges);
+                           ex.stream, ld, shift, bh, keys_out, vals_out, ranges);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -244,9 +244,21 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
     if (flags & GS_SORT_DYNAMIC) { A(s->cw, b4); A(s->scene_idx, b4); A(s->scene_rows, sizeof(SceneRows)); }
     A(s->keys, b4); A(s->keyA, b4); A(s->keyB, b4); A(s->valA, b4); A(s->valB, b4); A(s->sorted, b4);
     A(s->frame, sizeof(SortFrame));
-    if (st == GS_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess)) {
+    if (st == GS_OK) st = s->radix.init();
+    if (st == GS_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess ||
+                        hipEventCreateWithFlags(&s->ev_consumed, hipEventDisableTiming) != hipSuccess)) {
         gs_set_error("hipEventCreate failed");
         st = GS_ERR_HIP;
+    }
+    if (st == GS_OK) {
+        if (ctx->serial) {
+            s->stream = ctx->stream;
+        } else if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess) {
+            s->own_stream = true;
+        } else {
+            gs_set_error("hipStreamCreate(sorter) failed");
+            st = GS_ERR_HIP;
+        }
     }
     if (st != GS_OK) {
         gs_sorter_destroy(s);
@@ -259,9 +271,12 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
 void gs_sorter_destroy(gs_sorter* s) {
     if (!s) return;
     ScopedDevice sd(s->ctx->device);
-    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamSynchronize(s->ctx->stream);        // a draw may still be reading `sorted`
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_consumed) (void)hipEventDestroy(s->ev_consumed);
+    if (s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
@@ -272,7 +287,7 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
     GS_REQUIRE(!(s->flags & GS_SORT_DYNAMIC) || scene_indexes, "dynamic sorter needs scene_indexes");
     if (count == 0) return GS_OK;
     ScopedDevice sd(s->ctx->device);
-    hipStream_t st = s->ctx->stream;
+    hipStream_t st = s->stream;
     GS_TRY(s->staging.ensure((size_t)count * 16));
     GS_HIP(hipMemcpyAsync(s->staging.p, centers_aos4, (size_t)count * 16, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_aos4_to_soa, dim3(grid_for(count, 256, 4096)), dim3(256), 0, st, s->staging.as<uint4>(), count,
@@ -288,8 +303,8 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
 
 static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     SortFrame f;
-    GS_HIP(hipMemcpyAsync(&f, s->frame.p, sizeof(f), hipMemcpyDeviceToHost, s->ctx->stream));
-    GS_HIP(hipStreamSynchronize(s->ctx->stream));
+    GS_HIP(hipMemcpyAsync(&f, s->frame.p, sizeof(f), hipMemcpyDeviceToHost, s->stream));
+    GS_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     stats->device_ms = ms;
@@ -312,8 +327,13 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
     GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
     gs_context* ctx = s->ctx;
     ScopedDevice sd(ctx->device);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = s->stream;
     const uint32_t R = render_count, Rs = sort_count, sort_start = R - Rs;
+    const RadixExec ex = {st, &s->radix, ctx->lds_atomic_lane_order};
+    if (s->consumer_pending) {           // a draw enqueued on ctx->stream still reads the previous result
+        GS_HIP(hipStreamWaitEvent(st, s->ev_consumed, 0));
+        s->consumer_pending = false;
+    }
 
     const uint32_t* idx_dev = nullptr;
     if (indexes_to_sort) {
@@ -360,7 +380,7 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
 
     GS_HIP(hipEventRecord(s->ev0, st));
     hipLaunchKernelGGL(k_sort_frame_init, dim3(RADIX_MAX_PASSES), dim3(RADIX_BINS), 0, st, s->frame.as<SortFrame>(),
-                       ctx->radix.digit_total.as<uint32_t>());
+                       s->radix.digit_total.as<uint32_t>());
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
@@ -388,16 +408,16 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
             if (p == 0) {
                 DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
                 h.count_clamps = 1;
-                if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ctx, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
-                else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ctx, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+                if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
+                else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ex, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
             } else if (wide) {
                 ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
-                if (last) GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, false>(ctx, al, al, Rs, shift, (int)p, (uint32_t*)nullptr, vo)));
-                else GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ctx, al, al, Rs, shift, (int)p, (uint32_t*)kbuf[p & 1], vo)));
+                if (last) GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, false>(ex, al, al, Rs, shift, (int)p, (uint32_t*)nullptr, vo)));
+                else GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ex, al, al, Rs, shift, (int)p, (uint32_t*)kbuf[p & 1], vo)));
             } else {
                 ArrayLoader<uint16_t> al = {(const uint16_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
-                if (last) GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, false>(ctx, al, al, Rs, shift, (int)p, (uint16_t*)nullptr, vo)));
-                else GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, true>(ctx, al, al, Rs, shift, (int)p, (uint16_t*)kbuf[p & 1], vo)));
+                if (last) GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, false>(ex, al, al, Rs, shift, (int)p, (uint16_t*)nullptr, vo)));
+                else GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, true>(ex, al, al, Rs, shift, (int)p, (uint16_t*)kbuf[p & 1], vo)));
             }
         }
     }
@@ -434,7 +454,7 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
     GS_REQUIRE(s->has_result, "no sort has run");
     GS_REQUIRE(count <= s->last_render, "count exceeds the last render_count");
     ScopedDevice sd(s->ctx->device);
-    hipStream_t st = s->ctx->stream;
+    hipStream_t st = s->stream;
     const void* src = nullptr;
     if (what == 0) src = s->keys.p;
     else if (what == 2) src = s->sorted.p;

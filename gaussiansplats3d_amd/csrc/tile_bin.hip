@@ -75,10 +75,21 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
             const uint32_t p = R - 1u - min(q, R - 1u);    // draw order is back-to-front; we go front-to-back
             idx[k] = order ? order[p] : p;
         }
+        // k_project compacts survivors inside their 256-splat block: slot = block base + visible splats before idx,
+        // recomputed here from the block's 4 mask words (one aligned 32-byte sector of an L2-resident array)
+        uint32_t slot[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) keep[k] = keep[k] && ((vis_mask[idx[k] >> 6] >> (idx[k] & 63u)) & 1ull);
+        for (int k = 0; k < 4; k++) {
+            const ulonglong4 mw = *reinterpret_cast<const ulonglong4*>(vis_mask + ((idx[k] >> 8) << 2));
+            const uint32_t w = (idx[k] >> 6) & 3u, bit = idx[k] & 63u;
+            const unsigned long long mine = w == 0 ? mw.x : (w == 1 ? mw.y : (w == 2 ? mw.z : mw.w));
+            keep[k] = keep[k] && ((mine >> bit) & 1ull);
+            slot[k] = (idx[k] & ~255u) + (uint32_t)__popcll(mine & ((1ull << bit) - 1ull)) +
+                      (w > 0 ? (uint32_t)__popcll(mw.x) : 0u) + (w > 1 ? (uint32_t)__popcll(mw.y) : 0u) +
+                      (w > 2 ? (uint32_t)__popcll(mw.z) : 0u);
+        }
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = keep[k] ? rects[idx[k]] : make_uint2(0xFFFFu, 0u);
+        for (int k = 0; k < 4; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
         uint32_t n[4], cnt = 0, ent = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (keep[k]) {
-                cidx[o] = idx[k];
+                cidx[o] = slot[k];                         // what the blend gathers records by
                 crect[o] = r[k];
                 coff[o] = e;                               // first entry slot of this splat, relative to the workgroup
                 o++;
@@ -264,9 +275,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __r
 }
 
 template <class KeyT>
-static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t R, uint32_t tiles) {
+static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R, uint32_t tiles) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream;
+    const RadixExec ex = {st, &m->radix, ctx->lds_atomic_lane_order};
     RenderFrame* frame = m->frame.as<RenderFrame>();
     uint32_t grid = (R + BIN_THREADS - 1) / BIN_THREADS;
     if (grid < 1) grid = 1;
@@ -277,6 +289,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, m->vis_mask.as<unsigned long long>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>());
+    if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
+        GS_HIP(hipEventRecord(sorter->ev_consumed, st));
+        sorter->consumer_pending = true;
+    }
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame);
     uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
     if (egrid > 4096u) egrid = 4096u;
@@ -295,10 +311,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
         if (p + 1 == passes)
-            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ctx, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
+            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ex, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
                                                                      vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>())));
         else
-            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true, false>(ctx, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1],
+            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true, false>(ex, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1],
                                                                      vbuf[(p + 1) & 1])));
     }
     m->sorted_buf = (passes & 1);            // which ping-pong buffer holds the tile-sorted entries
@@ -307,13 +323,13 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
 
 int gs_launch_frame_init(gs_mesh* m, uint32_t tiles) {
     hipLaunchKernelGGL(k_render_frame_init, dim3(64), dim3(256), 0, m->ctx->stream, m->frame.as<RenderFrame>(),
-                       m->ctx->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles);
+                       m->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
 
-int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, uint32_t render_count) {
+int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count) {
     const uint32_t tiles = pp.tiles_x * (pp.row_end - pp.row_begin);
-    if (tiles <= 65536u) return binning_typed<uint16_t>(m, pp, order_dev, render_count, tiles);
-    return binning_typed<uint32_t>(m, pp, order_dev, render_count, tiles);
+    if (tiles <= 65536u) return binning_typed<uint16_t>(m, pp, order_dev, sorter, render_count, tiles);
+    return binning_typed<uint32_t>(m, pp, order_dev, sorter, render_count, tiles);
 }

@@ -113,7 +113,7 @@ def main():
         mesh.use_sorter_result(worker, N)
         probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
         _, st_probe = mesh.render(out_device_ptr=probe.data_ptr(), to_host=False, want_stats=True)
-        row_cost = mesh.tile_entry_counts().sum(axis=1)
+        row_cost = mesh.tile_row_costs()
         strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
         my = strips[rank]
         y0, y1 = gdist.strip_pixel_rows(my, H)

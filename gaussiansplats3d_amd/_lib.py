@@ -18,6 +18,7 @@ GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF = 1
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD = 1, 2
 GS_TILE = 16
+GS_BIN = 32          # entry lists / blend workgroups are per 32-px bin (2x2 tiles)
 GS_MAX_SCENES = 32
 
 
@@ -43,7 +44,8 @@ class Camera(C.Structure):
 class RenderStats(C.Structure):
     _fields_ = [("device_ms", C.c_float), ("project_ms", C.c_float), ("bin_ms", C.c_float),
                 ("tile_sort_ms", C.c_float), ("blend_ms", C.c_float), ("visible_splats", C.c_uint32),
-                ("tile_entries", C.c_uint64), ("entry_capacity", C.c_uint32), ("overflowed", C.c_uint32)]
+                ("tile_entries", C.c_uint64), ("entry_capacity", C.c_uint32), ("overflowed", C.c_uint32),
+                ("tiles16", C.c_uint64)]
 
 
 # every symbol include/gsplat_hip.h declares: (restype, argtypes)

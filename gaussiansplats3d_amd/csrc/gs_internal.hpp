@@ -72,19 +72,24 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------------------
 // radix sort geometry (radix.hpp)
 // ---------------------------------------------------------------------------------------------------
+constexpr uint32_t GS_BIN_SHIFT = 1;                       // a bin is 2x2 tiles of 16 px = 32x32 px
+constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
+
 constexpr int RADIX_THREADS = 256;
 constexpr int RADIX_ITEMS = 16;
 constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;   // keys per block iteration
 constexpr int RADIX_MAX_BLOCKS = 2048;                    // grid cap: 8 blocks per CU
 constexpr int RADIX_BINS = 256;
 constexpr int RADIX_MAX_PASSES = 4;
+constexpr int RADIX_REPLICAS = 16;                        // per-digit totals are accumulated into 16 replicas (see radix.hpp)
+constexpr int RADIX_TOTAL_WORDS = RADIX_MAX_PASSES * RADIX_REPLICAS * RADIX_BINS;
 
 struct RadixScratch {
-    DevBuf block_hist;    // uint32 [RADIX_BINS][RADIX_MAX_BLOCKS]  (digit-major)
-    DevBuf digit_total;   // uint32 [RADIX_MAX_PASSES][RADIX_BINS]
+    DevBuf block_hist;    // uint32 [RADIX_MAX_BLOCKS][RADIX_BINS]  (workgroup-major: 1 KiB coalesced rows)
+    DevBuf digit_total;   // uint32 [RADIX_MAX_PASSES][RADIX_REPLICAS][RADIX_BINS]
     int init() {
         GS_TRY(block_hist.alloc(sizeof(uint32_t) * RADIX_BINS * RADIX_MAX_BLOCKS));
-        GS_TRY(digit_total.alloc(sizeof(uint32_t) * RADIX_MAX_PASSES * RADIX_BINS));
+        GS_TRY(digit_total.alloc(sizeof(uint32_t) * RADIX_TOTAL_WORDS));
         return GS_OK;
     }
 };
@@ -183,7 +188,9 @@ struct RenderFrame {          // device-resident per-draw scalars
     uint32_t entries_hi;
     uint32_t overflow;        // D exceeded the entry capacity
     uint32_t entry_count;     // min(D, capacity): what the tile sort and blend consume
-    uint32_t pad[3];
+    uint32_t tiles16_lo;      // sum over visible splats of 16x16 tiles touched (the D of SURVEY.md section 8d)
+    uint32_t tiles16_hi;
+    uint32_t pad;
 };
 
 struct ProjectParams {
@@ -197,8 +204,11 @@ struct ProjectParams {
     uint32_t sh_stored;       // degree stored
     uint32_t cov_half;
     uint32_t flags;
-    uint32_t tiles_x, tiles_y;
-    uint32_t row_begin, row_end;   // tile rows rendered by this rank
+    uint32_t tiles_x, tiles_y;     // 16-px tile grid (the unit of vertex-stage rects and of the multi-GPU strips)
+    uint32_t row_begin, row_end;   // 16-px tile rows rendered by this rank
+    uint32_t bins_x;               // 32-px bin grid: the unit of the entry lists (one 256-thread workgroup blends a bin)
+    uint32_t bin_row_begin, bin_row_end;
+    uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
 };
 
@@ -219,9 +229,9 @@ struct gs_mesh {
     DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
     DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx
     DevBuf coff;               // uint32 [render_count] first entry slot of each, relative to its binning workgroup
-    DevBuf bin_sums;           // uint32 [2][BIN_MAX_BLOCKS]: tile entries | visible splats per workgroup
+    DevBuf bin_sums;           // uint32 [3][BIN_MAX_BLOCKS]: entries | visible splats | 16-px tiles per workgroup
     DevBuf ekeyA, ekeyB, evalA, evalB;   // tile entries ping-pong (key = tile id, val = splat index)
-    DevBuf tile_ranges;        // uint2 [tiles]
+    DevBuf tile_ranges;        // uint2 [bins]
     DevBuf frame;              // RenderFrame
     DevBuf fb;                 // internal RGBA8 framebuffer
     RadixScratch radix;

@@ -91,6 +91,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     GS_REQUIRE(ctx && out, "ctx / out == NULL");
     *out = nullptr;
     GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
+    GS_REQUIRE(max_splat_count <= (1u << 28), "max_splat_count > 2^28 (entry payload = 28-bit record slot + 4-bit quadrant mask)");
     GS_REQUIRE(sh_degree <= 2, "sh_degree > 2 (the reference renders degrees 0..2, src/Viewer.js:154)");
     GS_REQUIRE((flags & ~GS_MESH_COV_HALF) == 0, "unknown mesh flags");
     ScopedDevice sd(ctx->device);
@@ -111,13 +112,13 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     if (sh_degree >= 2) A(m->sh2, n * 16);
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
-    A(m->bin_sums, 4 * 2048);
+    A(m->bin_sums, 4 * 3 * 2048);                    // uint32 [3][BIN_MAX_BLOCKS]
     A(m->frame, sizeof(RenderFrame));
     if (st == GS_OK) st = m->radix.init();
     if (st == GS_OK) {
-        // first guess: 8 tile entries per splat, at least 4M; grown on overflow
+        // first guess: 8 entries per splat, at least 1M; grown on overflow
         uint64_t cap = (uint64_t)n * 8;
-        if (cap < (4u << 20)) cap = 4u << 20;
+        if (cap < (1u << 20)) cap = 1u << 20;
         if (cap > 0x7FFFFFFFull) cap = 0x7FFFFFFFull;
         st = mesh_alloc_entries(m, (uint32_t)cap);
     }
@@ -206,6 +207,7 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.device_ms = total;
     m->last.visible_splats = f.visible;
     m->last.tile_entries = ((uint64_t)f.entries_hi << 32) | f.entries_lo;
+    m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;
@@ -215,7 +217,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
                           uint8_t* out_dev) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
-    const uint32_t tiles = pp.tiles_x * (pp.row_end - pp.row_begin);
+    const uint32_t tiles = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);     // entry lists are per 32-px bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     GS_HIP(hipEventRecord(m->ev[0], st));
     GS_TRY(gs_launch_frame_init(m, tiles));
@@ -278,9 +280,14 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     GS_REQUIRE(pp.row_begin <= pp.row_end && pp.row_end <= pp.tiles_y, "tile row range outside the viewport");
     pp.count = m->uploaded;
 
-    // pixel rows covered by this rank's strip
+    // pixel rows covered by this rank's strip, and the 32-px bins that cover them
     const uint32_t y0 = pp.row_begin * GS_TILE;
     const uint32_t y1 = pp.row_end * GS_TILE < cam->height ? pp.row_end * GS_TILE : cam->height;
+    pp.y0 = y0;
+    pp.y1 = y1 > y0 ? y1 : y0;
+    pp.bins_x = (cam->width + GS_BIN - 1) / GS_BIN;
+    pp.bin_row_begin = y0 / GS_BIN;
+    pp.bin_row_end = pp.y1 > y0 ? (pp.y1 + GS_BIN - 1) / GS_BIN : pp.bin_row_begin;
     const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
 
     const uint32_t* order_dev = nullptr;

@@ -6,9 +6,9 @@
 //   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
 //     that each tile's list keeps the depth order established by the first sort.
 //
-// One pass = k_radix_hist -> k_radix_rowsum -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
+// One pass = k_radix_hist -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
 // no dependence on dispatch order (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS
-// workgroups walks contiguous runs of 4096-key tiles, so the [256][grid] offset matrix stays <= 2 MB
+// workgroups walks contiguous runs of 4096-key tiles, so the [grid][256] offset matrix stays <= 2 MB
 // whatever N is, and N may live in device memory (tile-entry count is only known on the device).
 //
 // Ranking inside a tile is wave64-native.  Fast path (ATOMIC_RANK): one `ds_add_rtn_u32` on a per-wave LDS
@@ -141,45 +141,39 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shi
     }
     __syncthreads();
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
-    block_hist[tid * gridDim.x + blockIdx.x] = total;
-    (void)digit_total;   // per-digit totals come from k_radix_rowsum: G same-word atomics per digit serialise in the
-                         // fabric (~12 ns each, MI355X_MICROARCH.md row "fanin") and cost 10-15 us per pass (A/B r01b)
+    block_hist[blockIdx.x * RADIX_BINS + tid] = total;           // one coalesced 1 KiB row per workgroup
+    // Per-digit totals.  G atomics on ONE word per digit serialise in the fabric (~12 ns each, MI355X_MICROARCH.md row
+    // "fanin": 10-15 us per pass, A/B r01b); spread over RADIX_REPLICAS words they cost < 2 us and save the separate
+    // row-sum kernel (5 us + a kernel boundary per pass).
+    if (total) atomicAdd(&digit_total[(blockIdx.x % RADIX_REPLICAS) * RADIX_BINS + tid], total);
 }
 
-// block d: digit_total[d] = sum of row d (number of keys whose digit is d)
-static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_rowsum(const uint32_t* __restrict__ block_hist,
-                                                                      uint32_t* __restrict__ digit_total, uint32_t grid) {
-    __shared__ uint32_t s_tmp[4];
-    const uint32_t* row = block_hist + (size_t)blockIdx.x * grid;
-    uint32_t sum = 0;
-    for (uint32_t i = threadIdx.x; i < grid; i += RADIX_THREADS) sum += row[i];
-    uint32_t total = 0;
-    (void)block_excl_scan_256(sum, s_tmp, &total);
-    if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
-}
-
-// block d scans row d of the digit-major matrix and adds the number of keys with a smaller digit
+// block d: exclusive scan of column d of the workgroup-major matrix, plus the number of keys with a smaller digit
 static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* __restrict__ block_hist,
                                                               const uint32_t* __restrict__ digit_total, uint32_t grid) {
     __shared__ uint32_t s_tmp[4];
     const uint32_t d = blockIdx.x, tid = threadIdx.x;
+    uint32_t mine = 0;
+    if (tid < d) {
+#pragma unroll
+        for (int r = 0; r < RADIX_REPLICAS; r++) mine += digit_total[r * RADIX_BINS + tid];
+    }
     uint32_t below = 0;
-    (void)block_excl_scan_256(tid < d ? digit_total[tid] : 0u, s_tmp, &below);
-    uint32_t* row = block_hist + (size_t)d * grid;
+    (void)block_excl_scan_256(mine, s_tmp, &below);
     const uint32_t per = (grid + RADIX_THREADS - 1) / RADIX_THREADS;   // <= 8
     uint32_t v[RADIX_MAX_BLOCKS / RADIX_THREADS];
     uint32_t sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
         const uint32_t i = tid * per + k;
-        v[k] = (k < per && i < grid) ? row[i] : 0u;
+        v[k] = (k < per && i < grid) ? block_hist[(size_t)i * RADIX_BINS + d] : 0u;
         sum += v[k];
     }
     uint32_t run = below + block_excl_scan_256(sum, s_tmp, nullptr);
 #pragma unroll
     for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
         const uint32_t i = tid * per + k;
-        if (k < per && i < grid) row[i] = run;
+        if (k < per && i < grid) block_hist[(size_t)i * RADIX_BINS + d] = run;
         run += v[k];
     }
 }
@@ -215,7 +209,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];
 
-    if (tid < RADIX_BINS) s_base[tid] = block_offsets[tid * gridDim.x + blockIdx.x];
+    if (tid < RADIX_BINS) s_base[tid] = block_offsets[blockIdx.x * RADIX_BINS + tid];
 
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t tile_base = tile * RADIX_TILE;
@@ -325,9 +319,8 @@ int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uin
                KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
-    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_BINS;
+    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_REPLICAS * RADIX_BINS;
     hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
-    hipLaunchKernelGGL(k_radix_rowsum, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ex.stream, bh, dt, grid);
     hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ex.stream, bh, dt, grid);
     if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,

@@ -45,7 +45,7 @@ __global__ void k_sort_frame_init(SortFrame* f, uint32_t* digit_total) {
         f->clamped = 0;
         f->pad = 0;
     }
-    if (t < RADIX_MAX_PASSES * RADIX_BINS) digit_total[t] = 0;
+    if (t < RADIX_TOTAL_WORDS) digit_total[t] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
@@ -379,7 +379,7 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
     kp.fm0 = mvp[2]; kp.fm1 = mvp[6]; kp.fm2 = mvp[10];
 
     GS_HIP(hipEventRecord(s->ev0, st));
-    hipLaunchKernelGGL(k_sort_frame_init, dim3(RADIX_MAX_PASSES), dim3(RADIX_BINS), 0, st, s->frame.as<SortFrame>(),
+    hipLaunchKernelGGL(k_sort_frame_init, dim3(RADIX_TOTAL_WORDS / 256), dim3(256), 0, st, s->frame.as<SortFrame>(),
                        s->radix.digit_total.as<uint32_t>());
     uint32_t passes = 0;
     if (Rs > 0) {

@@ -19,11 +19,25 @@
 #include "radix.hpp"
 
 constexpr int BIN_THREADS = 256;
-constexpr int BIN_MAX_BLOCKS = 1024;
+constexpr int BIN_MAX_BLOCKS = 2048;                      // 8 workgroups of 256 per CU: full wave occupancy
 
+// vertex-stage rects are in 16-px tiles; the entry lists are per 32-px bin (2x2 tiles)
 __device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
     const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
     return (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1u) * (y1 - y0 + 1u) : 0u;
+}
+// which of the 2x2 tiles of bin (bx, by) the 16-px rect touches: bit (qx + 2*qy).  Carried in the top 4 bits of the
+// entry payload, so the blend takes exactly the per-16-px-tile decisions of the vertex stage (a strip of a multi-GPU
+// draw then reproduces the full frame bit for bit).
+__device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32_t by) {
+    const uint32_t x0 = r16.x & 0xFFFFu, y0 = r16.x >> 16, x1 = r16.y & 0xFFFFu, y1 = r16.y >> 16;
+    const uint32_t cx = 2u * bx, cy = 2u * by;
+    const uint32_t mx = ((cx >= x0 && cx <= x1) ? 1u : 0u) | ((cx + 1u >= x0 && cx + 1u <= x1) ? 2u : 0u);
+    const uint32_t my = ((cy >= y0 && cy <= y1) ? 1u : 0u) | ((cy + 1u >= y0 && cy + 1u <= y1) ? 2u : 0u);
+    return (mx & (my & 1u ? 3u : 0u)) | ((mx & (my & 2u ? 3u : 0u)) << 2);
+}
+__device__ __forceinline__ uint2 rect_to_bins(uint2 r) {     // per-field shift: (x|y<<16) >> 1 with the carry bit masked
+    return make_uint2((r.x >> GS_BIN_SHIFT) & 0x7FFF7FFFu, (r.y >> GS_BIN_SHIFT) & 0x7FFF7FFFu);
 }
 
 struct BinChunk {
@@ -42,13 +56,14 @@ __global__ void k_render_frame_init(RenderFrame* f, uint32_t* digit_total, uint2
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
         f->visible = 0; f->entries_lo = 0; f->entries_hi = 0; f->overflow = 0; f->entry_count = 0;
-        f->pad[0] = f->pad[1] = f->pad[2] = 0;
+        f->tiles16_lo = f->tiles16_hi = f->pad = 0;
     }
-    if (t < RADIX_MAX_PASSES * RADIX_BINS) digit_total[t] = 0;
+    if (t < RADIX_TOTAL_WORDS) digit_total[t] = 0;
     for (uint32_t i = t; i < tiles; i += gridDim.x * blockDim.x) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
 }
 
-// block_sums layout: [0,1024) tile entries per workgroup | [1024,2048) compacted (visible) splats per workgroup
+// block_sums layout: [0,BIN_MAX_BLOCKS) entries per workgroup | [BIN_MAX_BLOCKS, 2*BIN_MAX_BLOCKS) compacted (visible) splats per
+// workgroup | [2*BIN_MAX_BLOCKS, 3*BIN_MAX_BLOCKS) 16-px tiles touched (statistics)
 // Each lane owns 4 consecutive list positions per iteration, so 4 index loads, then 4 mask look-ups, then up to 4
 // rect gathers are in flight together (the kernel is a chain of dependent memory round trips), and one packed
 // 64-bit block scan per 1024 positions yields both the compaction slot and the entry offset.
@@ -63,6 +78,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     const uint32_t pos_begin = ch.begin * BIN_THREADS, pos_end = min(ch.end * BIN_THREADS, R);
     uint32_t sum = 0;                                      // entries emitted so far by this workgroup
     uint32_t out = pos_begin;                              // next slot of this workgroup's compacted slice
+    uint32_t t16 = 0;                                      // 16-px tiles touched by this lane's splats (statistics only)
     for (uint32_t pos0 = pos_begin; pos0 < pos_end; pos0 += 4 * BIN_THREADS) {
         const uint32_t q0 = pos0 + 4u * threadIdx.x;
         uint32_t idx[4];
@@ -90,10 +106,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
+#pragma unroll
+        for (int k = 0; k < 4; k++) t16 += rect_tiles(r[k]);
         uint32_t n[4], cnt = 0, ent = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            n[k] = keep[k] ? rect_tiles(r[k]) : 0u;
+            n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k])) : 0u;   // entries = 32-px bins touched
             cnt += keep[k] ? 1u : 0u;
             ent += n[k];
         }
@@ -131,20 +149,33 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         sum += (uint32_t)total;
         __syncthreads();
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t16 += __shfl_xor(t16, o, 64);
+    if (lane == 0) s_w[wave] = t16;                        // the loop's trailing barrier makes s_w reusable
+    __syncthreads();
     if (threadIdx.x == 0) {
         block_sums[blockIdx.x] = sum;
         block_sums[BIN_MAX_BLOCKS + blockIdx.x] = out - pos_begin;
+        block_sums[2 * BIN_MAX_BLOCKS + blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
     }
 }
 
-// one workgroup of 1024 threads: exclusive scan of the workgroup sums, 64-bit total
+// one workgroup of 1024 threads, two binning workgroups per thread: exclusive scan of the workgroup sums, 64-bit total
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t grid, uint32_t capacity,
                                                    RenderFrame* frame) {
     __shared__ unsigned long long s_wave[16];
     __shared__ uint32_t s_vis[16];
+    __shared__ unsigned long long s_t16[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long v = tid < grid ? block_sums[tid] : 0ull;
-    uint32_t vis = tid < grid ? block_sums[BIN_MAX_BLOCKS + tid] : 0u;
+    const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
+    unsigned long long t16 = (i0 < grid ? block_sums[2 * BIN_MAX_BLOCKS + i0] : 0u);
+    t16 += (i1 < grid ? block_sums[2 * BIN_MAX_BLOCKS + i1] : 0u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t16 += __shfl_xor(t16, o, 64);
+    if (lane == 0) s_t16[wave] = t16;
+    const unsigned long long v0 = i0 < grid ? block_sums[i0] : 0ull, v1 = i1 < grid ? block_sums[i1] : 0ull;
+    const unsigned long long v = v0 + v1;
+    uint32_t vis = (i0 < grid ? block_sums[BIN_MAX_BLOCKS + i0] : 0u) + (i1 < grid ? block_sums[BIN_MAX_BLOCKS + i1] : 0u);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vis += __shfl_xor(vis, o, 64);
     if (lane == 0) s_vis[wave] = vis;
@@ -163,10 +194,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_
         total += s_wave[w];
     }
     const unsigned long long excl = base + incl - v;
-    if (tid < grid) block_sums[tid] = excl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl;
+    if (i0 < grid) block_sums[i0] = excl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl;
+    if (i1 < grid) block_sums[i1] = (excl + v0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(excl + v0);
     if (tid == 0) {
         uint32_t vsum = 0;
-        for (int w = 0; w < 16; w++) vsum += s_vis[w];
+        unsigned long long tsum = 0;
+        for (int w = 0; w < 16; w++) { vsum += s_vis[w]; tsum += s_t16[w]; }
+        frame->tiles16_lo = (uint32_t)tsum;
+        frame->tiles16_hi = (uint32_t)(tsum >> 32);
         frame->visible = vsum;
         frame->entries_lo = (uint32_t)total;
         frame->entries_hi = (uint32_t)(total >> 32);
@@ -178,14 +213,14 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_
 constexpr uint32_t EMIT_PER_LANE = 16;
 constexpr uint32_t EMIT_WINDOW = BIN_THREADS * EMIT_PER_LANE;     // entries per workgroup iteration
 
-// block_sums after k_bin_scan: [0,1024) exclusive entry offset of every binning workgroup | [1024,2048) its
+// block_sums after k_bin_scan: [0,BIN_MAX_BLOCKS) exclusive entry offset of every binning workgroup | [BIN_MAX_BLOCKS,..) its
 // compacted splat count.  `bin_grid` / `bin_per` describe the grid k_bin_count ran with.
 template <class KeyT>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __restrict__ frame, uint32_t bin_grid,
                                                           uint32_t bin_per, const uint32_t* __restrict__ cidx,
                                                           const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
-                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x,
-                                                          uint32_t row_begin, KeyT* __restrict__ keys_out,
+                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* bins per row */,
+                                                          uint32_t row_begin /* first bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
     const uint32_t D = frame->entry_count;
@@ -214,18 +249,19 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __r
             if (coff[first + mid] <= rel) jl = mid; else jh = mid;
         }
         uint32_t j = jl;
-        uint2 r = crect[first + j];
+        uint2 r16 = crect[first + j];                                   // 16-px tile rect of the splat
+        uint2 r = rect_to_bins(r16);                                    // the bins it touches
         uint32_t idx = cidx[first + j];
         uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
         uint32_t n = rect_tiles(r);
         uint32_t k = rel - coff[first + j];
-        uint32_t ty = (r.x >> 16) - row_begin + k / w, tx = x0 + k % w;
+        uint32_t ty = (r.x >> 16) + k / w, tx = x0 + k % w;              // absolute bin coordinates
 
         uint32_t kk[EMIT_PER_LANE], vv[EMIT_PER_LANE];
 #pragma unroll
         for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
-            kk[t] = ty * tiles_x + tx;
-            vv[t] = idx;
+            kk[t] = (ty - row_begin) * tiles_x + tx;
+            vv[t] = idx | (quadrant_mask(r16, tx, ty) << 28);
             if (e0 + t + 1 < e1) {
                 if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
                     if (++j == cnt) {
@@ -236,12 +272,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __r
                         first = b * bin_per * BIN_THREADS;
                         j = 0;
                     }
-                    r = crect[first + j];
+                    r16 = crect[first + j];
+                    r = rect_to_bins(r16);
                     idx = cidx[first + j];
                     x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
                     n = rect_tiles(r);
                     k = 0;
-                    tx = x0; ty = (r.x >> 16) - row_begin;
+                    tx = x0; ty = r.x >> 16;
                 } else if (++tx > x1) {
                     tx = x0; ty++;
                 }
@@ -298,7 +335,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, grid, bin_per, m->cidx.as<uint32_t>(),
-                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.tiles_x, pp.row_begin,
+                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.bins_x, pp.bin_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
@@ -329,7 +366,7 @@ int gs_launch_frame_init(gs_mesh* m, uint32_t tiles) {
 }
 
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count) {
-    const uint32_t tiles = pp.tiles_x * (pp.row_end - pp.row_begin);
+    const uint32_t tiles = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
     if (tiles <= 65536u) return binning_typed<uint16_t>(m, pp, order_dev, sorter, render_count, tiles);
     return binning_typed<uint32_t>(m, pp, order_dev, sorter, render_count, tiles);
 }

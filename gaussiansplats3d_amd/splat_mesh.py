@@ -157,16 +157,28 @@ class SplatMesh:
         vis = np.unpackbits(mask.view(np.uint8), bitorder="little")[:n].astype(bool)
         return recs, rects, vis
 
-    def tile_entry_counts(self, tile_rows=None):
-        """Entries per tile of the last draw, shaped [rows, tiles_x] (used to balance multi-GPU strips)."""
+    def bin_entry_counts(self, tile_rows=None):
+        """Entries per 32-px bin of the last draw, shaped [bin_rows, bins_x] (`tile_rows`: the strip it drew)."""
         cam = self._cam
-        tiles_x = (cam.width + L.GS_TILE - 1) // L.GS_TILE
+        bins_x = (cam.width + L.GS_BIN - 1) // L.GS_BIN
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
-        rng = np.empty(((r1 - r0) * tiles_x, 2), dtype=np.uint32)
-        L.check(self.lib.gs_mesh_debug_read(self.handle, 2, rng.ctypes.data, rng.shape[0]))
+        y0, y1 = r0 * L.GS_TILE, min(r1 * L.GS_TILE, cam.height)
+        b0, b1 = y0 // L.GS_BIN, (max(y1, y0) + L.GS_BIN - 1) // L.GS_BIN if y1 > y0 else y0 // L.GS_BIN
+        rng = np.empty(((b1 - b0) * bins_x, 2), dtype=np.uint32)
+        if rng.shape[0]:
+            L.check(self.lib.gs_mesh_debug_read(self.handle, 2, rng.ctypes.data, rng.shape[0]))
         cnt = np.where(rng[:, 1] > rng[:, 0], rng[:, 1] - rng[:, 0], 0).astype(np.uint32)   # untouched: (~0, 0)
-        return cnt.reshape(r1 - r0, tiles_x)
+        return cnt.reshape(b1 - b0, bins_x)
+
+    def tile_row_costs(self):
+        """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips): every
+        32-px bin row's entry count is split evenly between the tile rows it covers."""
+        cam = self._cam
+        rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
+        per_bin_row = self.bin_entry_counts().sum(axis=1).astype(np.float64)
+        ratio = L.GS_BIN // L.GS_TILE
+        return np.repeat(per_bin_row / ratio, ratio)[:rows_total]
 
     def dispose(self):
         if self.handle:

@@ -149,9 +149,10 @@ typedef struct gs_render_stats {
     float device_ms;          /* whole draw                                                                  */
     float project_ms, bin_ms, tile_sort_ms, blend_ms;
     uint32_t visible_splats;  /* splats that survive the vertex-stage rejects                                */
-    uint64_t tile_entries;    /* D = sum over splats of 16x16 tiles touched                                  */
+    uint64_t tile_entries;    /* list entries = sum over splats of 32x32-px bins touched                     */
     uint32_t entry_capacity;
     uint32_t overflowed;      /* 1 = frame was re-run after growing the entry buffer                         */
+    uint64_t tiles16;         /* D of SURVEY.md 8d = sum over splats of 16x16-px tiles touched               */
 } gs_render_stats;
 
 /* updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)
@@ -166,7 +167,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
 
 /* Intermediates of the last draw (tests, strip load-balancing).  what: 0 = per splat (storage order) the
  * 32-byte vertex-stage record {cx, cy, ax, ay, bx, by, r|g<<16, b|a<<16 (unorm16)}; 1 = per splat the tile
- * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per tile of the
+ * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per 32-px bin of the
  * drawn strip the [begin,end) range of its entry list ((~0,0) = untouched); 3 = the visibility mask, 1 bit per
  * splat packed in uint64 words (count = number of words). */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);

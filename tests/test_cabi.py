@@ -31,7 +31,7 @@ def test_struct_layouts_match_the_header():
     import ctypes as C
     assert C.sizeof(_lib.SortStats) == 20
     assert C.sizeof(_lib.Camera) == 188
-    assert C.sizeof(_lib.RenderStats) == 40
+    assert C.sizeof(_lib.RenderStats) == 48
     assert _lib.RenderStats.tile_entries.offset == 24
 
 

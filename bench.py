@@ -3,13 +3,19 @@
 
 One "step" = one frame of the hot path on the garden.ply stand-in (configs[2]: 5.8 M splats, SH-2, 1920x1080):
 depth-key + device-wide stable radix sort of ALL splats (cull off, R = N, the reference's own no-tree path,
-src/Viewer.js:2061-2073), then project -> tile-bin -> tile-sort -> blend into an RGBA8 framebuffer.  Inputs are
+src/Viewer.js:2061-2073), then project -> bin -> entry sort -> blend into an RGBA8 framebuffer.  Inputs are
 resident in HBM before the timed region.  With --gpus N every rank sorts + projects the replicated scene and
 rasterises a strip of tile rows; strips are gathered to rank 0 over RCCL inside the timed region (strong scaling).
+
+Like the reference (sort in a Web Worker, draw on the main thread) the sorter owns a HIP stream of its own: the
+sort of frame k+1 may overlap the tail of frame k's draw.  Every frame still waits for ITS OWN sort before it
+bins (use_sorter_result joins the streams), so `value` is whole frames per second times R; `frame_latency_ms`
+is one isolated frame (sort -> draw, synchronised on both sides).
 
 Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline` objects.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -20,16 +26,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy ceiling)
 SH_BYTES = {0: 0, 1: 18, 2: 48}
 
 
-def algorithmic_bytes(R, Rs, D, P, sh_degree, cov_half, precision=16):
-    """SURVEY.md §8(d): B = 56*Rs + (84+S)*R + 40*D + 4*P (72+S instead of 84+S for fp16 covariances;
-    +16*Rs per radix pass beyond two)."""
+def frame_algorithmic_bytes(R, Rs, D16, P, sh_degree, cov_half, precision=16):
+    """B = 56*Rs + (84+S)*R + 40*D + 4*P with D = 16x16-px tiles touched (72+S instead of 84+S for
+    fp16 covariances; +16*Rs per radix pass beyond two)."""
     sort = 56 + 16 * max(0, (precision + 7) // 8 - 2)
     proj = (72 if cov_half else 84) + SH_BYTES[sh_degree]
-    return sort * Rs + proj * R + 40 * D + 4 * P
+    return sort * Rs + proj * R + 40 * D16 + 4 * P
+
+
+def project_algorithmic_bytes(N, visible, sh_degree, cov_half):
+    """k_project (the dominant kernel), bytes it has to move per launch: every splat's centre 12 + covariance 24 (12 as
+    fp16) + rgba 4 + SH S is read once; every SURVIVOR's 32-byte record + 8-byte tile rect is written once; 1 mask bit
+    per splat."""
+    read = (12 + (12 if cov_half else 24) + 4 + SH_BYTES[sh_degree]) * N
+    return read + 40 * visible + N // 8
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc_traffic.json,
+    written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        k = d["kernels"].get(kernel)
+        return (int(k["hbm_bytes_per_launch"]) if k else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(scene, mvp, budget_s):
@@ -45,7 +73,7 @@ def cpu_baseline(scene, mvp, budget_s):
     fn = oracle.ref_sort_indexes if kind == "reference" else oracle.sort_indexes
     fn(idx[:1000], ci, mvp)                                  # warm the library
     t_total, reps = 0.0, 0
-    while t_total < budget_s and reps < 200:
+    while t_total < budget_s and reps < 2000:
         t0 = time.perf_counter()
         fn(idx, ci, mvp)
         t_total += time.perf_counter() - t0
@@ -53,14 +81,15 @@ def cpu_baseline(scene, mvp, budget_s):
     per = t_total / reps
     return {"value": round(n / per / 1e6, 2), "unit": "Msplats/s (sort only)", "cores": 1, "kind": kind,
             "ms_per_sort": round(per * 1e3, 2), "host_cpus": os.cpu_count(),
-            "sample": f"{reps} full sorts of the same {n} splats / same MVP, precision 16, integer static path; "
-                      "the reference has no CPU rasteriser, so raster has no CPU leg"}
+            "sample": f"{reps} full sorts ({t_total:.1f} s) of the same {n} splats / same MVP, precision 16, integer "
+                      "static path, sorter_no_simd.cpp built -O2; the reference has no CPU rasteriser, so raster has "
+                      "no CPU leg"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug only; invalid as a result)")
@@ -130,6 +159,8 @@ def main():
         for _ in range(args.warmup):
             frame()
         stream.synchronize()
+        torch.cuda.synchronize()
+        mesh.kernel_time(0, reset=True)                       # start the per-launch k_project clock
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -145,52 +176,62 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        proj_ms_sum, proj_launches = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
 
-        # per-stage device times (HIP events recorded by the library on `stream`), one synchronised frame at a time
-        stage = {"sort": [], "project": [], "bin": [], "tile_sort": [], "blend": [], "render": []}
-        D_strip = 0
+        # per-stage device times (HIP events recorded by the library), one synchronised frame at a time; also the
+        # latency of an isolated frame
+        stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
+        latency = []
         for _ in range(min(args.steps, 10)):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
             worker.sort_on_device(mvp, N)
             mesh.render(tile_rows=my if world > 1 else None, out_device_ptr=strip.data_ptr(), to_host=False,
                         want_stats=False)
+            torch.cuda.synchronize()
+            latency.append((time.perf_counter() - t1) * 1e3)
             rs = mesh.last_stats()
             ss, _ = worker.last_stats()
             stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
-            stage["tile_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
-            stage["render"].append(rs.device_ms)
-            D_strip = int(rs.tile_entries)
+            stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
         stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
 
     ms_per_step = elapsed / args.steps * 1e3
-    D_full = int(st_probe.tile_entries)
+    D16 = int(st_probe.tiles16)
+    D32 = int(st_probe.tile_entries)
+    visible = int(st_probe.visible_splats)
     if rank == 0:
         R = Rs = N
         P = W * H
-        B = algorithmic_bytes(R, Rs, D_full, P, scene.sh_degree, scene.cov_half)
-        achieved = B / (ms_per_step * 1e-3) / 1e9
-        # per-stage algorithmic bytes (same §8d accounting, split by stage) over the measured stage time
-        stage_bytes = {"sort": 56 * Rs, "project": ((72 if scene.cov_half else 84) + SH_BYTES[scene.sh_degree] - 8) * R,
-                       "bin": 8 * R + 8 * D_strip, "tile_sort": 24 * D_strip, "blend": 8 * D_strip + 4 * P // world}
-        stages = {k: {"ms": round(stage_ms[k], 4), "GBps": round(stage_bytes[k] / max(stage_ms[k], 1e-6) / 1e6, 1)}
-                  for k in stage_bytes}
-        dominant = max(stage_bytes, key=lambda k: stage_ms[k])
+        B = frame_algorithmic_bytes(R, Rs, D16, P, scene.sh_degree, scene.cov_half)
+        frame_gbs = B / (ms_per_step * 1e-3) / 1e9
+        kb = project_algorithmic_bytes(N, visible, scene.sh_degree, scene.cov_half)
+        k_ms = proj_ms_sum / max(proj_launches, 1)
+        k_gbs = kb / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic("k_project")
         out = {
             "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if args.config == "C3"
                       else f"Msplats/s sorted+rasterized ({cfg['label']})",
             "value": round(N / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "fps": round(1e3 / ms_per_step, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "fps": round(1e3 / ms_per_step, 2), "frame_latency_ms": round(float(np.median(latency)), 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 keys / f32 raster", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
                        "strips": strips if world > 1 else None},
-            "roofline": {"bound": "hbm", "kernel": "whole frame (sort+project+bin+tile-sort+blend), per SURVEY.md §8d",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_frame": int(B), "bytes_per_splat": round(B / R, 1),
-                         "tile_entries_D": D_full, "D_per_splat": round(D_full / R, 3),
-                         "dominant_stage": dominant, "stages": stages},
+            # dominant kernel (largest single kernel of the frame): the vertex stage
+            "roofline": {"bound": "hbm", "kernel": "k_project", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(kb),
+                         "avg_launch_ms": round(k_ms, 5), "launches_timed": proj_launches,
+                         "visible_splats": visible},
+            # whole frame against SURVEY.md §8d's formula
+            "frame": {"algorithmic_bytes": int(B), "bytes_per_splat": round(B / R, 1), "GBps": round(frame_gbs, 1),
+                      "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
+                      "D_per_splat": round(D16 / R, 3), "bin_entries": D32,
+                      "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
             "cpu_baseline": None,
             "scene_gen_s": round(t_gen, 1),
         }

@@ -238,7 +238,14 @@ struct gs_mesh {
     uint32_t entry_capacity = 0;
     uint32_t sorted_buf = 0;   // ping-pong buffer index holding the tile-sorted entries of the last draw
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around k_project on ctx->aux
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;   // around k_project on ctx->aux (= ring slot of the last draw)
+    // ring of event pairs around k_project: per-launch durations over a whole timed region without a sync per frame
+    static constexpr int TIMING_RING = 128;
+    hipEvent_t ring0[TIMING_RING] = {}, ring1[TIMING_RING] = {};
+    bool ring_used[TIMING_RING] = {};
+    uint32_t ring_next = 0;
+    double proj_sum_ms = 0.0;
+    uint32_t proj_launches = 0;
     hipEvent_t ev_done = nullptr;                  // end of the previous draw on ctx->stream (recs / rects reusable)
     gs_render_stats last = {};
     bool has_draw = false;

@@ -127,11 +127,15 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
             gs_set_error("hipEventCreate failed");
             st = GS_ERR_HIP;
         }
-    if (st == GS_OK && (hipEventCreate(&m->ev_p0) != hipSuccess || hipEventCreate(&m->ev_p1) != hipSuccess ||
-                        hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess)) {
+    if (st == GS_OK && hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess) {
         gs_set_error("hipEventCreate failed");
         st = GS_ERR_HIP;
     }
+    for (int i = 0; i < gs_mesh::TIMING_RING && st == GS_OK; i++)
+        if (hipEventCreate(&m->ring0[i]) != hipSuccess || hipEventCreate(&m->ring1[i]) != hipSuccess) {
+            gs_set_error("hipEventCreate failed");
+            st = GS_ERR_HIP;
+        }
     if (st != GS_OK) {
         gs_mesh_destroy(m);
         return st;
@@ -147,8 +151,10 @@ void gs_mesh_destroy(gs_mesh* m) {
     if (m->ctx->aux != m->ctx->stream) (void)hipStreamSynchronize(m->ctx->aux);
     for (int i = 0; i < 6; i++)
         if (m->ev[i]) (void)hipEventDestroy(m->ev[i]);
-    if (m->ev_p0) (void)hipEventDestroy(m->ev_p0);
-    if (m->ev_p1) (void)hipEventDestroy(m->ev_p1);
+    for (int i = 0; i < gs_mesh::TIMING_RING; i++) {
+        if (m->ring0[i]) (void)hipEventDestroy(m->ring0[i]);
+        if (m->ring1[i]) (void)hipEventDestroy(m->ring1[i]);
+    }
     if (m->ev_done) (void)hipEventDestroy(m->ev_done);
     delete m;
 }
@@ -225,6 +231,21 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed
     // the records / rects / mask it is about to overwrite
     if (aux != st && m->has_draw) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
+    {   // next slot of the timing ring; a slot about to be reused is harvested first (skipped if still in flight)
+        const uint32_t slot = m->ring_next++ % gs_mesh::TIMING_RING;
+        if (m->ring_used[slot]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->ring0[slot], m->ring1[slot]) == hipSuccess) {
+                m->proj_sum_ms += ms;
+                m->proj_launches++;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        m->ring_used[slot] = true;
+        m->ev_p0 = m->ring0[slot];
+        m->ev_p1 = m->ring1[slot];
+    }
     GS_HIP(hipEventRecord(m->ev_p0, aux));
     GS_TRY(gs_launch_project(m, pp));
     GS_HIP(hipEventRecord(m->ev_p1, aux));
@@ -357,6 +378,29 @@ int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats) {
         gs_set_error("tile entry buffer overflowed (%llu entries); capacity grown, redraw the frame",
                      (unsigned long long)m->last.tile_entries);
         return GS_ERR_CAPACITY;
+    }
+    return GS_OK;
+}
+
+int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches) {
+    GS_REQUIRE(m && sum_ms && launches, "mesh / outputs == NULL");
+    GS_REQUIRE(which == 0, "unknown kernel selector (0 = k_project)");
+    ScopedDevice sd(m->ctx->device);
+    GS_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->ctx->aux != m->ctx->stream) GS_HIP(hipStreamSynchronize(m->ctx->aux));
+    for (int i = 0; i < gs_mesh::TIMING_RING; i++) {
+        if (!m->ring_used[i]) continue;
+        float ms = 0.f;
+        GS_HIP(hipEventElapsedTime(&ms, m->ring0[i], m->ring1[i]));
+        m->proj_sum_ms += ms;
+        m->proj_launches++;
+        m->ring_used[i] = false;
+    }
+    *sum_ms = m->proj_sum_ms;
+    *launches = m->proj_launches;
+    if (reset) {
+        m->proj_sum_ms = 0.0;
+        m->proj_launches = 0;
     }
     return GS_OK;
 }

@@ -143,6 +143,12 @@ class SplatMesh:
         L.check(self.lib.gs_mesh_last_stats(self.handle, C.byref(stats)))
         return stats
 
+    def kernel_time(self, which=0, reset=True):
+        """(summed device ms, launches) of one kernel since the last reset; which 0 = k_project."""
+        total, n = C.c_double(0.0), C.c_uint32(0)
+        L.check(self.lib.gs_mesh_kernel_time(self.handle, int(which), 1 if reset else 0, C.byref(total), C.byref(n)))
+        return float(total.value), int(n.value)
+
     def debug_records(self, count=None):
         """Vertex-stage outputs of the last draw: (records uint32 [n,8], rects uint32 [n,2], visible bool [n]).
         Records and rects are only defined where `visible` is set."""

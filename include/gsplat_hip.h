@@ -172,6 +172,10 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
  * splat packed in uint64 words (count = number of words). */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 
+/* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of
+ * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams. */
+int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches);
+
 /* Statistics of the last draw (synchronises the stream). */
 int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats);
 int gs_sorter_last_stats(gs_sorter* s, gs_sort_stats* stats);

@@ -7,3 +7,4 @@ from . import camera, scenes, util  # noqa: F401
 from ._lib import Context, GsError, build, load  # noqa: F401
 from .sort_worker import SortWorker, create_sort_worker  # noqa: F401
 from .splat_mesh import SplatMesh  # noqa: F401
+from .splat_tree import SortScheduler, SplatTree  # noqa: F401

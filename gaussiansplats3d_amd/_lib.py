@@ -48,6 +48,16 @@ class RenderStats(C.Structure):
                 ("tiles16", C.c_uint64)]
 
 
+class TreeInfo(C.Structure):
+    _fields_ = [("leaves", C.c_uint32), ("all_leaves", C.c_uint32), ("nodes", C.c_uint32), ("splats", C.c_uint32),
+                ("scene_min", C.c_double * 3), ("scene_max", C.c_double * 3)]
+
+
+class GatherParams(C.Structure):
+    _fields_ = [("model_view", C.c_double * 16), ("fov_y_deg", C.c_double), ("render_width", C.c_double),
+                ("render_height", C.c_double), ("gather_all", C.c_uint32), ("pad", C.c_uint32)]
+
+
 # every symbol include/gsplat_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
@@ -61,7 +71,13 @@ SYMBOLS = {
     "gs_sorter_destroy": (None, [_VP]),
     "gs_sorter_upload_centers": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP]),
     "gs_sorter_sort": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
+    "gs_sorter_sort_gathered": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_tree_create": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "gs_tree_destroy": (None, [_VP]),
+    "gs_tree_get_info": (C.c_int, [_VP, C.POINTER(TreeInfo)]),
+    "gs_tree_read": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "gs_tree_gather": (C.c_int, [_VP, C.POINTER(GatherParams), _VP, C.POINTER(C.c_uint32), _VP]),
     "gs_sorter_last_stats": (C.c_int, [_VP, C.POINTER(SortStats)]),
     "gs_mesh_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_mesh_destroy": (None, [_VP]),

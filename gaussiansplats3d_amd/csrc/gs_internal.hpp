@@ -161,6 +161,8 @@ struct gs_sorter {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_consumed = nullptr;  // recorded on ctx->stream by a draw once it has read `sorted`
     bool consumer_pending = false;
+    uint32_t gathered = 0;             // splatRenderCount of the list gs_tree_gather left in idx_in
+    bool has_gathered = false;
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
     bool last_identity = true;
     bool has_result = false;

@@ -315,9 +315,9 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     return f.clamped ? GS_WARN_KEY_CLAMPED : GS_OK;
 }
 
-int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, uint32_t sort_count,
-                   uint32_t render_count, const void* precomputed, const float* transforms, uint32_t* sorted_out,
-                   gs_sort_stats* stats) {
+static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, bool device_list,
+                            uint32_t sort_count, uint32_t render_count, const void* precomputed, const float* transforms,
+                            uint32_t* sorted_out, gs_sort_stats* stats) {
     GS_REQUIRE(s && mvp, "sorter / mvp == NULL");
     // SortWorker.js:100-101 clamps both counts to the uploaded splat count
     if (render_count > s->uploaded) render_count = s->uploaded;
@@ -336,7 +336,9 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
     }
 
     const uint32_t* idx_dev = nullptr;
-    if (indexes_to_sort) {
+    if (device_list) {
+        idx_dev = s->idx_in.as<uint32_t>();                // written by gs_tree_gather on this stream
+    } else if (indexes_to_sort) {
         GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
         if (R) GS_HIP(hipMemcpyAsync(s->idx_in.p, indexes_to_sort, (size_t)R * 4, hipMemcpyHostToDevice, st));
         idx_dev = s->idx_in.as<uint32_t>();
@@ -440,6 +442,21 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
     }
     if (stats) status = sorter_collect_stats(s, stats);
     return status;
+}
+
+int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, uint32_t sort_count,
+                   uint32_t render_count, const void* precomputed, const float* transforms, uint32_t* sorted_out,
+                   gs_sort_stats* stats) {
+    return sorter_sort_impl(s, mvp, indexes_to_sort, false, sort_count, render_count, precomputed, transforms, sorted_out,
+                            stats);
+}
+
+int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count, const void* precomputed,
+                            const float* transforms, uint32_t* sorted_out, gs_sort_stats* stats) {
+    GS_REQUIRE(s != nullptr, "sorter == NULL");
+    GS_REQUIRE(s->has_gathered, "no gs_tree_gather has filled this sorter's index list");
+    if (sort_count > s->gathered) sort_count = s->gathered;       // Math.min(queuedSorts.shift(), splatRenderCount)
+    return sorter_sort_impl(s, mvp, nullptr, true, sort_count, s->gathered, precomputed, transforms, sorted_out, stats);
 }
 
 int gs_sorter_last_stats(gs_sorter* s, gs_sort_stats* stats) {

@@ -29,6 +29,7 @@ class SortWorker:
         self.precision = int(precision)
         self.onmessage = None
         self.uploaded_splat_count = 0
+        self.gathered_count = 0
         flags = (L.GS_SORT_INTEGER if integer_based_sort else 0) | (L.GS_SORT_DYNAMIC if dynamic_mode else 0)
         self.handle = C.c_void_p()
         L.check(self.lib.gs_sorter_create(context.handle, self.max_splat_count, flags, self.precision,
@@ -106,6 +107,22 @@ class SortWorker:
                               "splatSortCount": render_count if sort_count is None else sort_count,
                               "indexesToSort": indexes, "transforms": np.tile(np.eye(4, dtype=np.float32).reshape(16), 32)},
                              keep_on_device=True)
+
+    def sort_gathered(self, mvp, sort_count=None, keep_on_device=False):
+        """Sort the device-resident indexesToSort list (and splatRenderCount) the last
+        ``SplatTree.gather_scene_nodes_for_sort(..., sort_worker=self)`` produced."""
+        mvp = np.ascontiguousarray(np.asarray(mvp, dtype=np.float64).astype(np.float32))
+        tr = np.tile(np.eye(4, dtype=np.float32).reshape(16), L.GS_MAX_SCENES) if self.dynamic_mode else None
+        stats = L.SortStats()
+        # render count is held by the library; ask for the sorted list only when the caller wants it on the host
+        out = None if keep_on_device else np.empty(self.gathered_count, dtype=np.uint32)
+        sc = 0xFFFFFFFF if sort_count is None else int(sort_count)
+        st = L.check(self.lib.gs_sorter_sort_gathered(self.handle, mvp.ctypes.data, sc, None,
+                                                      tr.ctypes.data if tr is not None else None,
+                                                      out.ctypes.data if out is not None else None,
+                                                      None if keep_on_device else C.byref(stats)))
+        return {"sortDone": True, "status": st, "sortTime": float(stats.device_ms), "sortedIndexes": out, "stats": stats,
+                "splatRenderCount": self.gathered_count}
 
     def last_stats(self):
         stats = L.SortStats()

@@ -41,6 +41,7 @@ extern "C" {
 typedef struct gs_context gs_context;
 typedef struct gs_sorter gs_sorter;
 typedef struct gs_mesh gs_mesh;
+typedef struct gs_tree gs_tree;
 
 /* Message of the last failing call on this thread (the reference throws JS Errors, SplatMesh.js:1518-1533). */
 const char* gs_last_error(void);
@@ -95,9 +96,57 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
                    uint32_t render_count, const void* precomputed, const float* transforms,
                    uint32_t* sorted_out, gs_sort_stats* stats);
 
+/* The same sort, fed by the device-resident indexesToSort list (and splatRenderCount) that the last
+ * gs_tree_gather(tree, ..., s, ...) left in this sorter: no index list crosses PCIe. */
+int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count, const void* precomputed,
+                            const float* transforms, uint32_t* sorted_out, gs_sort_stats* stats);
+
 /* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
  * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted. */
 int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * CULL (feeds the sort seam): the reference's octree and its per-sort frustum cull
+ * ------------------------------------------------------------------------------------------------ */
+/* SplatMesh.buildSplatTree -> SplatTree.processSplatMesh -> worker createSplatTree
+ * (src/splatmesh/SplatMesh.js:231-280, src/splattree/SplatTree.js:132-271, 320-420).
+ *   centers      float[3*count], SplatMesh.getSplatCenter of splats first_index .. first_index+count-1
+ *   keep         uint8[count] or NULL: the alpha filter `splatColor.w >= minAlpha` (SplatMesh.js:239-244)
+ *   max_depth / max_centers_per_node   8 / 1000 in the reference (SplatMesh.js:236)
+ * The tree is built on the host with the reference's arithmetic (leaves, their order and their index lists are
+ * identical); with ctx != NULL it is mirrored to the device for gs_tree_gather, with ctx == NULL it is host-only. */
+int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, uint32_t count, uint32_t first_index,
+                   uint32_t max_depth, uint32_t max_centers_per_node, gs_tree** out);
+void gs_tree_destroy(gs_tree* t);
+
+typedef struct gs_tree_info {
+    uint32_t leaves;        /* subTree.nodesWithIndexes.length (leaves holding >= 1 index)                    */
+    uint32_t all_leaves;    /* countLeaves()                                                                  */
+    uint32_t nodes;
+    uint32_t splats;        /* sum of the leaves' index counts                                                */
+    double scene_min[3], scene_max[3];
+} gs_tree_info;
+int gs_tree_get_info(gs_tree* t, gs_tree_info* info);
+/* Leaves in nodesWithIndexes (depth-first) order; any pointer may be NULL.  bounds double[6*leaves] = min xyz,
+ * max xyz; centers double[3*leaves]; depths uint32[leaves]; offsets uint32[leaves+1]; indexes uint32[splats]. */
+int gs_tree_read(gs_tree* t, double* bounds, double* centers, uint32_t* depths, uint32_t* offsets, uint32_t* indexes);
+
+/* Viewer.gatherSceneNodesForSort (src/Viewer.js:1969-2077). */
+typedef struct gs_gather_params {
+    double model_view[16];   /* inverse(camera.matrixWorld) * splatMesh.matrixWorld, fp64, column-major (:1999-2000) */
+    double fov_y_deg;        /* camera.fov                                                                    */
+    double render_width, render_height;   /* getRenderDimensions                                              */
+    uint32_t gather_all;     /* gatherAllNodes                                                                */
+    uint32_t pad;
+} gs_gather_params;
+/* Tests every leaf, orders the kept ones by distance and lays their index lists out far -> near (the nearest leaf
+ * ends the buffer), on the device.
+ *   dst               sorter whose device-side indexesToSort buffer receives the list (then call
+ *                     gs_sorter_sort_gathered), or NULL
+ *   render_count      out: splatRenderCount
+ *   indexes_out_host  uint32[tree splats] host copy of the list, or NULL */
+int gs_tree_gather(gs_tree* t, const gs_gather_params* params, gs_sorter* dst, uint32_t* render_count,
+                   uint32_t* indexes_out_host);
 
 /* ------------------------------------------------------------------------------------------------ *
  * RENDER SEAM

@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cull", action="store_true", help="skip the secondary cull-on measurement (octree build + gather)")
     args = ap.parse_args()
 
     import torch
@@ -196,6 +197,37 @@ def main():
             stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
         stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
 
+        # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
+        cull = None
+        if world == 1 and not args.no_cull:
+            from gaussiansplats3d_amd import SplatTree
+            t_tree = time.perf_counter()
+            tree = SplatTree(ctx, 8, 1000).process_splat_mesh(scene.centers, alphas=scene.rgba[:, 3])
+            t_tree = time.perf_counter() - t_tree
+
+            def cull_frame():
+                r = tree.gather_scene_nodes_for_sort(cam, sort_worker=worker, to_host=False)   # 4-byte read-back inside
+                worker.sort_gathered(mvp, keep_on_device=True)
+                mesh.use_sorter_result(worker, r["splatRenderCount"])
+                mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                return r["splatRenderCount"]
+
+            for _ in range(3):
+                Rc = cull_frame()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                cull_frame()
+            torch.cuda.synchronize()
+            cull_ms = (time.perf_counter() - t1) / 20 * 1e3
+            cull = {"render_count": int(Rc), "leaves": int(tree.info().leaves), "ms_per_frame": round(cull_ms, 4),
+                    "Msplats_per_s_scene": round(N / (cull_ms * 1e-3) / 1e6, 1),
+                    "Msplats_per_s_rendered": round(Rc / (cull_ms * 1e-3) / 1e6, 1), "tree_build_s": round(t_tree, 2),
+                    "note": "gather + sort + draw of the frustum-culled list; scene = all N splats per frame, "
+                            "rendered = R kept by the cull"}
+            tree.dispose()
+            mesh.use_sorter_result(worker, N)
+
     ms_per_step = elapsed / args.steps * 1e3
     D16 = int(st_probe.tiles16)
     D32 = int(st_probe.tile_entries)
@@ -232,6 +264,7 @@ def main():
                       "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
                       "D_per_splat": round(D16 / R, 3), "bin_entries": D32,
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "cull_on": cull,
             "cpu_baseline": None,
             "scene_gen_s": round(t_gen, 1),
         }

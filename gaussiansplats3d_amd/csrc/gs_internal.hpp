@@ -146,6 +146,7 @@ struct gs_sorter {
     uint32_t max_count = 0, flags = 0, precision = 16, uploaded = 0;
     // SoA planes of the AoS x4 centres the worker receives (int32 or float bit patterns)
     DevBuf cx, cy, cz, cw, scene_idx;
+    DevBuf caos;               // the AoS x4 centres as uploaded (16-byte gathers for index-list sorts)
     DevBuf staging;            // upload staging (AoS) / host index list / precomputed distances
     DevBuf idx_in;             // indexesToSort on device
     DevBuf precomputed;

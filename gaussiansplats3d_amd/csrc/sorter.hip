@@ -25,7 +25,8 @@ struct SceneRows {                 // per-scene clip-z row (mvp * transform)[2],
 };
 
 struct KeyParams {
-    const uint32_t *cx, *cy, *cz, *cw;       // SoA planes (int32 or float bit patterns)
+    const uint32_t *cx, *cy, *cz, *cw;       // SoA planes (int32 or float bit patterns): streaming (identity list) path
+    const uint4* aos;                        // the same centres as uploaded (x,y,z,w): ONE 16-byte gather per index
     const uint32_t* scene_idx;
     const uint32_t* idx_in;                  // nullable: identity
     const uint32_t* precomputed;             // int32 or float bit patterns
@@ -66,22 +67,23 @@ __device__ __forceinline__ int32_t depth_key_one(const KeyParams& p, uint32_t g)
         if (p.mode & MODE_INT) return (int32_t)raw;                                        // sorter.cpp:31-38
         return trunc_f64_i32((double)__uint_as_float(raw) * 4096.0);                       // :79-86
     }
+    const uint4 c = p.aos[g];                                                              // gathered by list index
     if (p.mode & MODE_INT) {
-        const uint32_t x = p.cx[g], y = p.cy[g], z = p.cz[g];                              // wrap-around int32
+        const uint32_t x = c.x, y = c.y, z = c.z;                                          // wrap-around int32
         if (p.mode & MODE_DYNAMIC) {                                                       // :41-62
             const int32_t* r = p.rows->im[p.scene_idx[g]];
-            return (int32_t)(x * (uint32_t)r[0] + y * (uint32_t)r[1] + z * (uint32_t)r[2] + p.cw[g] * (uint32_t)r[3]);
+            return (int32_t)(x * (uint32_t)r[0] + y * (uint32_t)r[1] + z * (uint32_t)r[2] + c.w * (uint32_t)r[3]);
         }
         return (int32_t)(x * (uint32_t)p.im0 + y * (uint32_t)p.im1 + z * (uint32_t)p.im2); // :63-75, w lane unused
     }
-    const float x = __uint_as_float(p.cx[g]), y = __uint_as_float(p.cy[g]), z = __uint_as_float(p.cz[g]);
+    const float x = __uint_as_float(c.x), y = __uint_as_float(c.y), z = __uint_as_float(c.z);
     float s;
     if (p.mode & MODE_DYNAMIC) {                                                           // :110-126
         const float* r = p.rows->fm[p.scene_idx[g]];
         s = __fmul_rn(r[0], x);
         s = __fadd_rn(s, __fmul_rn(r[1], y));
         s = __fadd_rn(s, __fmul_rn(r[2], z));
-        s = __fadd_rn(s, __fmul_rn(r[3], __uint_as_float(p.cw[g])));
+        s = __fadd_rn(s, __fmul_rn(r[3], __uint_as_float(c.w)));
     } else {                                                                               // :128-138
         s = __fmul_rn(p.fm0, x);
         s = __fadd_rn(s, __fmul_rn(p.fm1, y));
@@ -240,7 +242,7 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
     const size_t n = max_splat_count, b4 = n * 4;
     int st = GS_OK;
     auto A = [&](DevBuf& b, size_t bytes) { if (st == GS_OK) st = b.alloc(bytes); };
-    A(s->cx, b4); A(s->cy, b4); A(s->cz, b4);
+    A(s->cx, b4); A(s->cy, b4); A(s->cz, b4); A(s->caos, n * 16);
     if (flags & GS_SORT_DYNAMIC) { A(s->cw, b4); A(s->scene_idx, b4); A(s->scene_rows, sizeof(SceneRows)); }
     A(s->keys, b4); A(s->keyA, b4); A(s->keyB, b4); A(s->valA, b4); A(s->valB, b4); A(s->sorted, b4);
     A(s->frame, sizeof(SortFrame));
@@ -288,9 +290,9 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
     if (count == 0) return GS_OK;
     ScopedDevice sd(s->ctx->device);
     hipStream_t st = s->stream;
-    GS_TRY(s->staging.ensure((size_t)count * 16));
-    GS_HIP(hipMemcpyAsync(s->staging.p, centers_aos4, (size_t)count * 16, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_aos4_to_soa, dim3(grid_for(count, 256, 4096)), dim3(256), 0, st, s->staging.as<uint4>(), count,
+    uint4* aos = s->caos.as<uint4>() + from;               // kept: index-list sorts gather 16 bytes per splat from it
+    GS_HIP(hipMemcpyAsync(aos, centers_aos4, (size_t)count * 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_aos4_to_soa, dim3(grid_for(count, 256, 4096)), dim3(256), 0, st, aos, count,
                        from, s->cx.as<uint32_t>(), s->cy.as<uint32_t>(), s->cz.as<uint32_t>(),
                        (s->flags & GS_SORT_DYNAMIC) ? s->cw.as<uint32_t>() : nullptr);
     GS_HIP(hipGetLastError());
@@ -370,6 +372,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     }
     kp.cx = s->cx.as<uint32_t>(); kp.cy = s->cy.as<uint32_t>(); kp.cz = s->cz.as<uint32_t>();
     kp.cw = s->cw.as<uint32_t>(); kp.scene_idx = s->scene_idx.as<uint32_t>();
+    kp.aos = s->caos.as<uint4>();
     kp.idx_in = idx_dev;
     kp.keys_out = s->keys.as<int32_t>();
     kp.frame = s->frame.as<SortFrame>();

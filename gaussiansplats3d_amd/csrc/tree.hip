@@ -118,9 +118,11 @@ struct GatherParams {
 // Viewer.js:2010-2035 for one leaf
 __global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double* __restrict__ center,
                                                    const double* __restrict__ size, const uint32_t* __restrict__ count,
-                                                   double* __restrict__ key, uint32_t* __restrict__ cnt) {
+                                                   double* __restrict__ key, uint32_t* __restrict__ cnt,
+                                                   uint32_t* __restrict__ rank) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= p.leaves) return;
+    (void)rank;
     const double x = center[3 * (size_t)i], y = center[3 * (size_t)i + 1], z = center[3 * (size_t)i + 2];
     const double* e = p.mv;
     // Vector3.applyMatrix4 (three r160)
@@ -145,23 +147,86 @@ __global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double*
     cnt[i] = skip ? 0u : count[i];
 }
 
-// rank of leaf i in ascending (distance, leaf number) order: O(n^2) compares, n = a few 10^4 leaves
-__global__ __launch_bounds__(256) void k_tree_rank(const double* __restrict__ key, uint32_t n, uint32_t* __restrict__ rank) {
-    __shared__ double s_key[256];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const double mine = i < n ? key[i] : 0.0;
-    uint32_t r = 0;
-    for (uint32_t base = 0; base < n; base += 256u) {
-        __syncthreads();
-        s_key[threadIdx.x] = base + threadIdx.x < n ? key[base + threadIdx.x] : __longlong_as_double(0x7FF0000000000000ll);
-        __syncthreads();
-        const uint32_t lim = min(256u, n - base);
-        for (uint32_t j = 0; j < lim; j++) {
-            const double k = s_key[j];
-            r += (k < mine || (k == mine && base + j < i)) ? 1u : 0u;
+// rank of leaf i in ascending (distance, leaf number) order: O(n^2) compares, n = a few 10^4 leaves.  Distances are
+// non-negative doubles (or +inf), so their bit patterns order like unsigned integers.  blockIdx.y splits the j range;
+// the partial counts land in rank[slice][leaf] and are summed by k_tree_place.
+constexpr uint32_t RANK_SPLIT = 64;
+constexpr uint32_t RANK_PER_THREAD = 4;
+// MODE 0: every key of the slice precedes every leaf of the block (j < i): a tie counts
+// MODE 1: every key follows (j > i): a tie does not count     MODE 2: slices overlap: ties are broken by leaf number
+// Keys are non-negative doubles or +inf, so their bit patterns order like unsigned integers.  64-bit compares run at a
+// fraction of the 32-bit rate here (measured: ~30 cycles per wave and key-leaf pair with v_cmp_f64), so the common path
+// compares the HIGH words only - one full-rate v_cmp + v_addc per pair - and a batch is redone exactly only when some
+// lane saw equal high words (distances within 2^-20 of each other, or a leaf meeting itself).
+template <int MODE>
+__device__ __forceinline__ uint32_t exact_before(unsigned long long kj, unsigned long long mine, uint32_t j, uint32_t i) {
+    if (MODE == 0) return kj <= mine ? 1u : 0u;
+    if (MODE == 1) return kj < mine ? 1u : 0u;
+    return (kj < mine || (kj == mine && j < i)) ? 1u : 0u;
+}
+
+template <int MODE>
+__device__ __forceinline__ void rank_slice(const unsigned long long* __restrict__ key, uint32_t j_begin, uint32_t j_end,
+                                           uint32_t i0, const unsigned long long (&mine)[RANK_PER_THREAD],
+                                           uint32_t (&r)[RANK_PER_THREAD]) {
+    constexpr uint32_t B = 16;                             // keys fetched per round with wave-uniform addresses (scalar loads)
+    uint32_t mine_hi[RANK_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < RANK_PER_THREAD; k++) mine_hi[k] = (uint32_t)(mine[k] >> 32);
+    uint32_t j = j_begin;
+    for (; j + B <= j_end; j += B) {
+        unsigned long long kk[B];
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) kk[u] = key[j + u];
+        uint32_t fast[RANK_PER_THREAD] = {0, 0, 0, 0};
+        bool tie = false;
+#pragma unroll
+        for (uint32_t u = 0; u < B; u++) {
+            const uint32_t hi = (uint32_t)(kk[u] >> 32);
+#pragma unroll
+            for (uint32_t k = 0; k < RANK_PER_THREAD; k++) {
+                fast[k] += hi < mine_hi[k] ? 1u : 0u;
+                tie = tie || (hi == mine_hi[k]);
+            }
         }
+        if (__any(tie)) {                                  // rare, wave-uniform: redo this batch exactly
+#pragma unroll
+            for (uint32_t k = 0; k < RANK_PER_THREAD; k++) fast[k] = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < B; u++)
+#pragma unroll
+                for (uint32_t k = 0; k < RANK_PER_THREAD; k++) fast[k] += exact_before<MODE>(kk[u], mine[k], j + u, i0 + k);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < RANK_PER_THREAD; k++) r[k] += fast[k];
     }
-    if (i < n) rank[i] = r;
+    for (; j < j_end; j++) {
+        const unsigned long long kj = key[j];
+#pragma unroll
+        for (uint32_t k = 0; k < RANK_PER_THREAD; k++) r[k] += exact_before<MODE>(kj, mine[k], j, i0 + k);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tree_rank(const unsigned long long* __restrict__ key, uint32_t n,
+                                                   uint32_t* __restrict__ rank) {
+    // every thread ranks RANK_PER_THREAD leaves against a slice of all keys
+    const uint32_t block_i0 = blockIdx.x * 256u * RANK_PER_THREAD, block_i1 = block_i0 + 256u * RANK_PER_THREAD;
+    const uint32_t i0 = block_i0 + threadIdx.x * RANK_PER_THREAD;
+    unsigned long long mine[RANK_PER_THREAD];
+    uint32_t r[RANK_PER_THREAD];
+#pragma unroll
+    for (uint32_t k = 0; k < RANK_PER_THREAD; k++) {
+        mine[k] = i0 + k < n ? key[i0 + k] : 0ull;
+        r[k] = 0;
+    }
+    const uint32_t per = (n + RANK_SPLIT - 1) / RANK_SPLIT;
+    const uint32_t j_begin = min(n, blockIdx.y * per), j_end = min(n, j_begin + per);
+    if (j_end <= block_i0) rank_slice<0>(key, j_begin, j_end, i0, mine, r);
+    else if (j_begin >= block_i1) rank_slice<1>(key, j_begin, j_end, i0, mine, r);
+    else rank_slice<2>(key, j_begin, j_end, i0, mine, r);
+#pragma unroll
+    for (uint32_t k = 0; k < RANK_PER_THREAD; k++)
+        if (i0 + k < n) rank[(size_t)blockIdx.y * n + i0 + k] = r[k];      // partial count of this key slice
 }
 
 __global__ __launch_bounds__(256) void k_tree_place(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ cnt,
@@ -169,42 +234,51 @@ __global__ __launch_bounds__(256) void k_tree_place(const uint32_t* __restrict__
                                                     uint32_t* __restrict__ sorted_leaf) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    sorted_cnt[rank[i]] = cnt[i];
-    sorted_leaf[rank[i]] = i;
+    uint32_t r = 0;
+#pragma unroll 8
+    for (uint32_t y = 0; y < RANK_SPLIT; y++) r += rank[(size_t)y * n + i];
+    sorted_cnt[r] = cnt[i];
+    sorted_leaf[r] = i;
 }
 
 // one workgroup: offset[r] = total - inclusive_prefix(sorted_cnt)[r]  (nearest leaf, r = 0, ends the buffer:
-// Viewer.js:2046-2055 copies from the END backwards)
+// Viewer.js:2046-2055 copies from the END backwards).  Thread t owns the contiguous ranks [t*per, (t+1)*per).
 __global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restrict__ sorted_cnt, uint32_t n,
                                                        uint32_t* __restrict__ offset, uint32_t* __restrict__ total_out) {
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t CH = 16;                            // values per thread and round, all loads in flight together
+    // pass 1: total
     uint32_t sum = 0;
     for (uint32_t i = tid; i < n; i += 1024u) sum += sorted_cnt[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) total += s_wave[w];
     if (tid == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < 16; w++) t += s_wave[w];
-        s_total = t;
-        *total_out = t;
+        *total_out = total;
+        s_carry = 0;
     }
-    __syncthreads();
-    const uint32_t total = s_total;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < n ? sorted_cnt[i] : 0u;
-        uint32_t incl = v;
+    // pass 2: rounds of 16384 ranks, thread t owns CH consecutive ones
+    for (uint32_t base = 0; base < n; base += 1024u * CH) {
+        const uint32_t b = base + tid * CH;
+        uint32_t v[CH];
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) v[k] = b + k < n ? sorted_cnt[b + k] : 0u;
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) mine += v[k];
+        uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, 64);
             if ((int)lane >= o) incl += t;
         }
-        __syncthreads();
+        __syncthreads();                                   // s_wave / s_carry of the previous round consumed
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
         uint32_t wbase = 0, chunk = 0;
@@ -214,8 +288,14 @@ __global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restric
             wbase += ((uint32_t)w < wave) ? c : 0u;
             chunk += c;
         }
-        if (i < n) offset[i] = total - (carry + wbase + incl);
-        carry += chunk;
+        uint32_t run = s_carry + wbase + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) {
+            run += v[k];
+            if (b + k < n) offset[b + k] = total - run;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry += chunk;
     }
 }
 
@@ -288,7 +368,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         auto A = [&](DevBuf& buf, size_t bytes) { if (st == GS_OK) st = buf.alloc(bytes); };
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
         A(t->d_indexes, 4 * t->indexes.size() + 4);
-        A(t->d_key, 8 * L + 8); A(t->d_cnt, 4 * L + 4); A(t->d_rank, 4 * L + 4); A(t->d_sorted_cnt, 4 * L + 4);
+        A(t->d_key, 8 * L + 8); A(t->d_cnt, 4 * L + 4); A(t->d_rank, 4 * L * RANK_SPLIT + 4); A(t->d_sorted_cnt, 4 * L + 4);
         A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4); A(t->d_total, 16);
         if (st != GS_OK) {
             delete t;
@@ -387,8 +467,9 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     p.leaves = L;
     const dim3 g((L + 255u) / 256u), b(256);
     hipLaunchKernelGGL(k_tree_test, g, b, 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(), t->d_count.as<uint32_t>(),
-                       t->d_key.as<double>(), t->d_cnt.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_rank, g, b, 0, st, t->d_key.as<double>(), L, t->d_rank.as<uint32_t>());
+                       t->d_key.as<double>(), t->d_cnt.as<uint32_t>(), t->d_rank.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_rank, dim3((L + 256u * RANK_PER_THREAD - 1u) / (256u * RANK_PER_THREAD), RANK_SPLIT), b, 0, st, t->d_key.as<unsigned long long>(), L,
+                       t->d_rank.as<uint32_t>());
     hipLaunchKernelGGL(k_tree_place, g, b, 0, st, t->d_rank.as<uint32_t>(), t->d_cnt.as<uint32_t>(), L,
                        t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
     hipLaunchKernelGGL(k_tree_offsets, dim3(1), dim3(1024), 0, st, t->d_sorted_cnt.as<uint32_t>(), L, t->d_offset.as<uint32_t>(),

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(CSRC, "libgsplat_hip
 GS_OK, GS_WARN_KEY_CLAMPED = 0, 1
 GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
-GS_MESH_COV_HALF = 1
-GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD = 1, 2
+GS_MESH_COV_HALF, GS_MESH_SH_U8 = 1, 2
+GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
 GS_TILE = 16
 GS_BIN = 32          # entry lists / blend workgroups are per 32-px bin (2x2 tiles)
 GS_MAX_SCENES = 32
@@ -38,7 +38,15 @@ class Camera(C.Structure):
                 ("focal", C.c_float * 2), ("width", C.c_uint32), ("height", C.c_uint32), ("splat_scale", C.c_float),
                 ("kernel2d", C.c_float), ("max_splat_px", C.c_float), ("inv_focal_adj", C.c_float),
                 ("sh_degree", C.c_uint32), ("flags", C.c_uint32), ("tile_row_begin", C.c_uint32),
-                ("tile_row_end", C.c_uint32)]
+                ("tile_row_end", C.c_uint32),
+                ("ortho_zoom", C.c_float), ("scene_center", C.c_float * 3), ("fade_start_radius", C.c_float),
+                ("view_matrix", C.c_float * 16)]
+
+
+class SceneParams(C.Structure):
+    _fields_ = [("scene_count", C.c_uint32), ("pad", C.c_uint32), ("transforms", (C.c_float * 16) * 32),
+                ("inv_cam_pos", (C.c_float * 4) * 32), ("opacity", C.c_float * 32), ("visible", C.c_uint32 * 32),
+                ("sh8_min", C.c_float * 32), ("sh8_max", C.c_float * 32)]
 
 
 class RenderStats(C.Structure):
@@ -82,6 +90,9 @@ SYMBOLS = {
     "gs_mesh_create": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_mesh_destroy": (None, [_VP]),
     "gs_mesh_upload": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
+    "gs_mesh_upload_sh_u8": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
+    "gs_mesh_upload_scene_indexes": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
+    "gs_mesh_set_scenes": (C.c_int, [_VP, C.POINTER(SceneParams)]),
     "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),

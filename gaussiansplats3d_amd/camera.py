@@ -103,6 +103,33 @@ class PerspectiveCamera:
                 self.projection[5] * 0.5 * dpr * self.height * focal_adjustment)
 
 
+def make_orthographic(left, right, top, bottom, near, far, zoom=1.0):
+    """OrthographicCamera.updateProjectionMatrix + Matrix4.makeOrthographic (three r160, WebGL clip space)."""
+    dx = (right - left) / (2.0 * zoom)
+    dy = (top - bottom) / (2.0 * zoom)
+    cx = (right + left) / 2.0
+    cy = (top + bottom) / 2.0
+    l, r, t, b = cx - dx, cx + dx, cy + dy, cy - dy
+    w, h, p = 1.0 / (r - l), 1.0 / (t - b), 1.0 / (far - near)
+    m = np.zeros((4, 4))
+    m[0, 0] = 2 * w; m[0, 3] = -((r + l) * w)
+    m[1, 1] = 2 * h; m[1, 3] = -((t + b) * h)
+    m[2, 2] = -2 * p; m[2, 3] = -((far + near) * p)
+    m[3, 3] = 1.0
+    return _elements(m)
+
+
+class OrthographicCamera(PerspectiveCamera):
+    """The Viewer's orthographic camera (src/Viewer.js:1488-1530): frustum = render dimensions in pixels / 2, `zoom`
+    set from the look-at distance (setCameraZoomFromPosition, :640-648)."""
+    is_orthographic = True
+
+    def __init__(self, width, height, position, look_at, up, zoom=1.0, near=THREE_NEAR, far=THREE_FAR):
+        super().__init__(width, height, position, look_at, up)
+        self.zoom = float(zoom)
+        self.projection = make_orthographic(width / -2.0, width / 2.0, height / 2.0, height / -2.0, near, far, zoom)
+
+
 # Camera poses of the reference's demo pages (up, position, lookAt): demo/{bonsai,truck,garden}.html
 DEMO_POSES = {
     "bonsai": ((0.01933, -0.75830, -0.65161), (1.54163, 2.68515, -6.37228), (0.45622, 1.95338, 1.51278)),

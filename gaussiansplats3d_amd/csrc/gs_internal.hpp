@@ -209,6 +209,11 @@ struct ProjectParams {
     uint32_t flags;
     uint32_t tiles_x, tiles_y;     // 16-px tile grid (the unit of vertex-stage rects and of the multi-GPU strips)
     uint32_t row_begin, row_end;   // 16-px tile rows rendered by this rank
+    // shader permutations (k_project<true>)
+    float view_matrix[16];
+    float ortho_zoom, fade_start;
+    float scene_center[3];
+    uint32_t scene_count, sh_u8;
     uint32_t bins_x;               // 32-px bin grid: the unit of the entry lists (one 256-thread workgroup blends a bin)
     uint32_t bin_row_begin, bin_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
@@ -222,7 +227,12 @@ struct gs_mesh {
     DevBuf px, py, pz;         // float centres
     DevBuf covA, covB;         // fp32: float4 + float2 ; fp16: uint2 + uint
     DevBuf rgba;               // uint32
-    DevBuf sh0, sh1, sh2;      // uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
+    DevBuf sh0, sh1, sh2;      // fp16: uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
+                               // u8  : sh0 = uint4 (bytes 0..15), sh1 = uint2 (bytes 16..23, SH2 only)
+    DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
+    DevBuf scene_dev;          // gs_scene_params on the device
+    bool has_scenes = false;
+    uint32_t scene_count = 1;
     DevBuf staging;
     // per-draw
     DevBuf recs;               // SplatRec [n]  survivors compacted inside each 256-splat block (project.hip)

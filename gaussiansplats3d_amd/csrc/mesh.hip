@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* 
     if (out_rects) out_rects[i] = vis ? rects[slot] : make_uint2(0xFFFFu, 0u);
 }
 
+// 8-bit SH: 9 or 24 bytes per splat -> one 16-byte plane (+ one 8-byte plane for degree 2)
+__global__ __launch_bounds__(256) void k_split_sh_u8(const uint8_t* __restrict__ sh, uint32_t count, uint32_t from,
+                                                     uint32_t ncoef, uint4* __restrict__ p0, uint2* __restrict__ p1) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const uint8_t* s = sh + (size_t)ncoef * i;
+        auto pk = [&](uint32_t k) {
+            uint32_t v = 0;
+            for (uint32_t t = 0; t < 4; t++)
+                if (k + t < ncoef) v |= (uint32_t)s[k + t] << (8 * t);
+            return v;
+        };
+        p0[from + i] = make_uint4(pk(0), pk(4), pk(8), pk(12));
+        if (ncoef > 16) p1[from + i] = make_uint2(pk(16), pk(20));
+    }
+}
+
 static inline uint32_t up_grid(uint32_t n) {
     uint32_t g = (n + 255u) / 256u;
     return g < 1 ? 1 : (g > 4096u ? 4096u : g);
@@ -93,7 +109,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
     GS_REQUIRE(max_splat_count <= (1u << 28), "max_splat_count > 2^28 (entry payload = 28-bit record slot + 4-bit quadrant mask)");
     GS_REQUIRE(sh_degree <= 2, "sh_degree > 2 (the reference renders degrees 0..2, src/Viewer.js:154)");
-    GS_REQUIRE((flags & ~GS_MESH_COV_HALF) == 0, "unknown mesh flags");
+    GS_REQUIRE((flags & ~(GS_MESH_COV_HALF | GS_MESH_SH_U8)) == 0, "unknown mesh flags");
     ScopedDevice sd(ctx->device);
     gs_mesh* m = new (std::nothrow) gs_mesh();
     if (!m) return GS_ERR_NOMEM;
@@ -108,8 +124,14 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->px, n * 4); A(m->py, n * 4); A(m->pz, n * 4);
     A(m->covA, n * (half ? 8 : 16)); A(m->covB, n * (half ? 4 : 8));
     A(m->rgba, n * 4);
-    if (sh_degree >= 1) { A(m->sh0, n * 16); A(m->sh1, n * (sh_degree == 2 ? 16 : 4)); }
-    if (sh_degree >= 2) A(m->sh2, n * 16);
+    if (flags & GS_MESH_SH_U8) {
+        if (sh_degree >= 1) A(m->sh0, n * 16);
+        if (sh_degree >= 2) A(m->sh1, n * 8);
+    } else {
+        if (sh_degree >= 1) { A(m->sh0, n * 16); A(m->sh1, n * (sh_degree == 2 ? 16 : 4)); }
+        if (sh_degree >= 2) A(m->sh2, n * 16);
+    }
+    A(m->scene_dev, sizeof(gs_scene_params));
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->bin_sums, 4 * 3 * 2048);                    // uint32 [3][BIN_MAX_BLOCKS]
@@ -165,11 +187,13 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
     const bool half = (m->flags & GS_MESH_COV_HALF) != 0;
     GS_REQUIRE(half ? (cov_f16 && !cov_f32) : (cov_f32 && !cov_f16), "covariance format does not match the mesh (GS_MESH_COV_HALF)");
-    GS_REQUIRE(m->sh_degree == 0 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
+    const bool sh_u8 = (m->flags & GS_MESH_SH_U8) != 0;
+    GS_REQUIRE(m->sh_degree == 0 || sh_u8 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
+    GS_REQUIRE(!(sh_u8 && sh_f16), "GS_MESH_SH_U8 mesh: upload SH with gs_mesh_upload_sh_u8");
     if (count == 0) return GS_OK;
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
-    const uint32_t ncoef = m->sh_degree == 0 ? 0 : (m->sh_degree == 1 ? 9 : 24);
+    const uint32_t ncoef = (m->sh_degree == 0 || sh_u8) ? 0 : (m->sh_degree == 1 ? 9 : 24);
     const size_t b_c = (size_t)count * 12, b_cov = (size_t)count * (half ? 12 : 24), b_sh = (size_t)count * ncoef * 2;
     size_t off_cov = (b_c + 255) & ~(size_t)255, off_sh = (off_cov + b_cov + 255) & ~(size_t)255;
     GS_TRY(m->staging.ensure(off_sh + b_sh + 256));
@@ -193,6 +217,52 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     GS_HIP(hipGetLastError());
     GS_HIP(hipStreamSynchronize(st));
     if (from + count > m->uploaded) m->uploaded = from + count;
+    return GS_OK;
+}
+
+int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_t* sh_u8) {
+    GS_REQUIRE(m && sh_u8, "mesh / sh_u8 == NULL");
+    GS_REQUIRE((m->flags & GS_MESH_SH_U8) && m->sh_degree >= 1, "mesh was not created with GS_MESH_SH_U8 and sh_degree >= 1");
+    GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    if (count == 0) return GS_OK;
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    const uint32_t ncoef = m->sh_degree == 1 ? 9 : 24;
+    GS_TRY(m->staging.ensure((size_t)count * ncoef + 256));
+    GS_HIP(hipMemcpyAsync(m->staging.p, sh_u8, (size_t)count * ncoef, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_split_sh_u8, dim3(up_grid(count)), dim3(256), 0, st, m->staging.as<uint8_t>(), count, from, ncoef,
+                       m->sh0.as<uint4>(), m->sh1.as<uint2>());
+    GS_HIP(hipGetLastError());
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, const uint32_t* scene_indexes) {
+    GS_REQUIRE(m && scene_indexes, "mesh / scene_indexes == NULL");
+    GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    if (!m->scene_idx.p) {
+        GS_TRY(m->scene_idx.alloc((size_t)m->max_count * 4));
+        GS_HIP(hipMemsetAsync(m->scene_idx.p, 0, (size_t)m->max_count * 4, st));
+    }
+    for (uint32_t i = 0; i < count; i++) GS_REQUIRE(scene_indexes[i] < GS_MAX_SCENES, "scene index >= GS_MAX_SCENES");
+    if (count) GS_HIP(hipMemcpyAsync(m->scene_idx.as<uint32_t>() + from, scene_indexes, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+int gs_mesh_set_scenes(gs_mesh* m, const gs_scene_params* params) {
+    GS_REQUIRE(m && params, "mesh / params == NULL");
+    GS_REQUIRE(params->scene_count >= 1 && params->scene_count <= GS_MAX_SCENES, "scene_count outside 1..GS_MAX_SCENES");
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    // the vertex stage of an earlier draw may still read the previous values on ctx->aux
+    if (m->ctx->aux != st) GS_HIP(hipStreamSynchronize(m->ctx->aux));
+    GS_HIP(hipMemcpyAsync(m->scene_dev.p, params, sizeof(*params), hipMemcpyHostToDevice, st));
+    GS_HIP(hipStreamSynchronize(st));
+    m->scene_count = params->scene_count;
+    m->has_scenes = true;
     return GS_OK;
 }
 
@@ -293,6 +363,15 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     pp.sh_stored = m->sh_degree;
     pp.cov_half = (m->flags & GS_MESH_COV_HALF) ? 1u : 0u;
     pp.flags = cam->flags;
+    pp.sh_u8 = (m->flags & GS_MESH_SH_U8) ? 1u : 0u;
+    pp.scene_count = m->has_scenes ? m->scene_count : 1u;
+    pp.ortho_zoom = cam->ortho_zoom;
+    pp.fade_start = cam->fade_start_radius;
+    memcpy(pp.scene_center, cam->scene_center, sizeof(pp.scene_center));
+    memcpy(pp.view_matrix, cam->view_matrix, sizeof(pp.view_matrix));
+    const bool needs_scenes = (cam->flags & (GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC)) || (pp.sh_u8 && pp.sh_degree >= 1);
+    GS_REQUIRE(!needs_scenes || m->has_scenes, "this draw needs per-scene uniforms: call gs_mesh_set_scenes first");
+    GS_REQUIRE(pp.scene_count <= 1 || m->scene_idx.p, "several scenes but no scene indexes uploaded");
     pp.tiles_x = (cam->width + GS_TILE - 1) / GS_TILE;
     pp.tiles_y = (cam->height + GS_TILE - 1) / GS_TILE;
     pp.row_begin = cam->tile_row_begin;

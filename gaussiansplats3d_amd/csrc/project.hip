@@ -25,6 +25,8 @@ struct MeshPlanes {
     const uint4* __restrict__ sh0;      // halfs 0..7
     const void* __restrict__ sh1;       // SH2: uint4 halfs 8..15 | SH1: uint (half 8)
     const uint4* __restrict__ sh2;      // SH2: halfs 16..23
+    const uint32_t* __restrict__ scene_idx;          // per-splat scene (EXT, scene_count > 1)
+    const gs_scene_params* __restrict__ scenes;      // per-scene uniforms (EXT)
 };
 
 __device__ __forceinline__ float h2f(uint32_t bits16) {
@@ -36,6 +38,10 @@ __device__ __forceinline__ uint32_t unorm16(float v) { return (uint32_t)(clamp01
 constexpr float GS_K_POWER = 2.4022448f;          // sqrt(4*log2(e)): alpha = exp2(-|K*q|^2) == exp(-0.5*A)
 constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zero tiles
 
+// EXT = false: the static perspective scene with fp16 SH (the benchmark path).  EXT = true adds the reference's shader
+// permutations: orthographic J, per-scene transforms (dynamicMode), per-scene opacity / visibility
+// (enableOptionalEffects), 8-bit SH, distance fade-in.
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -49,6 +55,28 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         const float* MV = pp.view;
         const float* P = pp.proj;
         const float c0 = mp.px[i], c1 = mp.py[i], c2 = mp.pz[i];
+        uint32_t scene = 0;
+        float opacity_from_scene = 1.0f;
+        bool scene_ok = true;
+        float MVd[16];
+        if (EXT) {
+            if (pp.scene_count > 1) scene = mp.scene_idx[i];                          // SplatMaterial.js:123-126
+            if (pp.flags & GS_CAM_SCENE_EFFECTS) {                                    // :129-137
+                opacity_from_scene = mp.scenes->opacity[scene];
+                scene_ok = !(opacity_from_scene <= 0.01f || mp.scenes->visible[scene] == 0u);
+            }
+            if (pp.flags & GS_CAM_DYNAMIC) {                                          // :140-144 viewMatrix * transform
+                const float* A = pp.view_matrix;
+                const float* B = mp.scenes->transforms[scene];
+#pragma unroll
+                for (int col = 0; col < 4; col++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        MVd[4 * col + r] = A[r] * B[4 * col] + A[4 + r] * B[4 * col + 1] + A[8 + r] * B[4 * col + 2] +
+                                           A[12 + r] * B[4 * col + 3];
+                MV = MVd;
+            }
+        }
         // SplatMaterial.js:156,158
         float v[4], q[4];
 #pragma unroll
@@ -56,7 +84,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
 #pragma unroll
         for (int r = 0; r < 4; r++) q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
         const float clip = 1.2f * q[3];                                               // :160-164
-        bool ok = !(q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip);
+        bool ok = scene_ok && !(q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip);
         const float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];       // :166
         ok = ok && (ndcz >= -1.0f && ndcz <= 1.0f);       // quad z == centre z (SplatMaterial3D.js:209): GL clip
 
@@ -67,11 +95,29 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
             float alpha = (float)(packed >> 24) * (1.0f / 255.0f);
 
             if (pp.sh_stored >= 1 && pp.sh_degree >= 1) {
-                float d0 = c0 - pp.cam_pos[0], d1 = c1 - pp.cam_pos[1], d2 = c2 - pp.cam_pos[2];   // :185
+                float cp0 = pp.cam_pos[0], cp1 = pp.cam_pos[1], cp2 = pp.cam_pos[2];
+                if (EXT && (pp.flags & GS_CAM_DYNAMIC)) {                // :179-183 camera in the scene's own frame
+                    cp0 = mp.scenes->inv_cam_pos[scene][0]; cp1 = mp.scenes->inv_cam_pos[scene][1];
+                    cp2 = mp.scenes->inv_cam_pos[scene][2];
+                }
+                float d0 = c0 - cp0, d1 = c1 - cp1, d2 = c2 - cp2;                                 // :185
                 const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
                 const float x = d0 * inv, y = d1 * inv, z = d2 * inv;
                 float sh[24];
                 const uint4 a = mp.sh0[i];
+                if (EXT && pp.sh_u8) {
+                    // 8-bit SH (:150-154,265-269): texel = v/255 (unorm8), sh = texel*range + min; sh0 = bytes 0..15
+                    const float mn = mp.scenes->sh8_min[scene], range = mp.scenes->sh8_max[scene] - mn;
+                    const uint32_t w0[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) sh[k] = ((float)((w0[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
+                    if (pp.sh_stored >= 2) {
+                        const uint2 b = reinterpret_cast<const uint2*>(mp.sh1)[i];
+                        const uint32_t w1[2] = {b.x, b.y};
+#pragma unroll
+                        for (int k = 0; k < 8; k++) sh[16 + k] = ((float)((w1[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
+                    }
+                } else {
                 sh[0] = h2f(a.x); sh[1] = h2f(a.x >> 16); sh[2] = h2f(a.y); sh[3] = h2f(a.y >> 16);
                 sh[4] = h2f(a.z); sh[5] = h2f(a.z >> 16); sh[6] = h2f(a.w); sh[7] = h2f(a.w >> 16);
                 if (pp.sh_stored >= 2) {
@@ -81,13 +127,16 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                 } else {
                     sh[8] = h2f(reinterpret_cast<const uint32_t*>(mp.sh1)[i]);
                 }
+                }
                 const float SH_C1 = 0.4886025119029199f;                                            // :273
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
                 if (pp.sh_stored >= 2 && pp.sh_degree >= 2) {                                       // :308-330
-                    const uint4 cc = mp.sh2[i];
-                    sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
-                    sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
+                    if (!(EXT && pp.sh_u8)) {
+                        const uint4 cc = mp.sh2[i];
+                        sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
+                        sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
+                    }
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                     const float C0 = 1.0925484f, C1 = -1.0925484f, C2 = 0.3153916f, C3 = -1.0925484f, C4 = 0.5462742f;
 #pragma unroll
@@ -111,9 +160,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                 V00 = a.x; V01 = a.y; V02 = a.z; V11 = a.w; V12 = b.x; V22 = b.y;
             }
             // :120-134  J, W = transpose(mat3(MV)), T = W*J, cov2D = T^T * Vrk * T
-            const float s = 1.0f / (v[2] * v[2]);
-            const float j00 = pp.focal_x / v[2], j20 = -(pp.focal_x * v[0]) * s;
-            const float j11 = pp.focal_y / v[2], j21 = -(pp.focal_y * v[1]) * s;
+            float j00, j20, j11, j21;
+            if (EXT && (pp.flags & GS_CAM_ORTHOGRAPHIC)) {       // SplatMaterial3D.js:112-117: J = diag(zoom, zoom, 0)
+                j00 = pp.ortho_zoom; j11 = pp.ortho_zoom; j20 = 0.0f; j21 = 0.0f;
+            } else {
+                const float s = 1.0f / (v[2] * v[2]);
+                j00 = pp.focal_x / v[2]; j20 = -(pp.focal_x * v[0]) * s;
+                j11 = pp.focal_y / v[2]; j21 = -(pp.focal_y * v[1]) * s;
+            }
             float T0[3], T1[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
@@ -154,6 +208,18 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
             const float sqrt8 = sqrtf(8.0f);
             float h1 = sqrt8 * sqrtf(l1); if (h1 > pp.max_splat_px) h1 = pp.max_splat_px;
             float h2 = sqrt8 * sqrtf(l2); if (h2 > pp.max_splat_px) h2 = pp.max_splat_px;
+            if (EXT) {
+                if (pp.flags & GS_CAM_SCENE_EFFECTS) alpha *= opacity_from_scene;          // SplatMaterial3D.js:199-203
+                if (pp.flags & GS_CAM_FADE_IN) {                                           // SplatMaterial.js:347-363
+                    const float fx_ = c0 - pp.scene_center[0], fy_ = c1 - pp.scene_center[1], fz_ = c2 - pp.scene_center[2];
+                    const float center_dist = sqrtf(fx_ * fx_ + fy_ * fy_ + fz_ * fz_);
+                    float f = center_dist < pp.fade_start ? 0.0f : 1.0f;                   // step(edge, x)
+                    float t = (center_dist - pp.fade_start) / 0.75f;
+                    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+                    f = (1.0f - f) + (1.0f - t) * f;
+                    alpha *= 1.0f * f;
+                }
+            }
             const float k = pp.splat_scale * pp.inv_focal_adj;       // pixel offset = (q.x*b1 + q.y*b2)*invFocalAdj
             const float b1x = e1x * k * h1, b1y = e1y * k * h1;
             const float b2x = e2x * k * h2, b2y = e2y * k * h2;
@@ -214,9 +280,17 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp) {
     mp.covA = m->covA.p; mp.covB = m->covB.p;
     mp.rgba = m->rgba.as<uint32_t>();
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
+    mp.scene_idx = m->scene_idx.as<uint32_t>();
+    mp.scenes = m->scene_dev.as<gs_scene_params>();
     if (pp.count == 0) return GS_OK;
-    hipLaunchKernelGGL(k_project, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
-                       m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>());
+    const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
+                     (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
+    if (ext)
+        hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

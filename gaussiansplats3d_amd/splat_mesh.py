@@ -18,7 +18,8 @@ from .util import to_half_three
 class SplatMesh:
     def __init__(self, context, max_splat_count, spherical_harmonics_degree=0, half_precision_covariances=False,
                  antialiased=False, kernel_2d_size=0.3, max_screen_space_splat_size=1024.0, splat_scale=1.0,
-                 point_cloud_mode=False):
+                 point_cloud_mode=False, spherical_harmonics_8bit=False, dynamic_mode=False,
+                 enable_optional_effects=False):
         self.ctx = context
         self.lib = context.lib
         self.max_splat_count = int(max_splat_count)
@@ -29,6 +30,10 @@ class SplatMesh:
         self.max_screen_space_splat_size = float(max_screen_space_splat_size)
         self.splat_scale = float(splat_scale)
         self.point_cloud_mode = bool(point_cloud_mode)
+        self.sh_8bit = bool(spherical_harmonics_8bit)          # sphericalHarmonics8BitMode (compression level 2)
+        self.dynamic_mode = bool(dynamic_mode)
+        self.enable_optional_effects = bool(enable_optional_effects)
+        self.fade_in = None                                    # (sceneCenter, visibleRegionFadeStartRadius) or None
         self.splat_count = 0
         self.render_count = 0
         self._indexes = None          # host indexes from updateRenderIndexes
@@ -36,11 +41,12 @@ class SplatMesh:
         self._cam = L.Camera()
         self.handle = C.c_void_p()
         L.check(self.lib.gs_mesh_create(context.handle, self.max_splat_count, self.sh_degree,
-                                        L.GS_MESH_COV_HALF if self.half_cov else 0, C.byref(self.handle)))
+                                        (L.GS_MESH_COV_HALF if self.half_cov else 0) |
+                                        (L.GS_MESH_SH_U8 if self.sh_8bit else 0), C.byref(self.handle)))
         context._adopt(self)
 
     # -- build / data upload ------------------------------------------------------------------------
-    def build(self, centers, covariances, colors, spherical_harmonics=None, start=0):
+    def build(self, centers, covariances, colors, spherical_harmonics=None, start=0, scene_indexes=None):
         """fillSplatDataArrays output -> device planes.  covariances: float32 [n,6]; narrowed with
         THREE.DataUtils.toHalfFloat semantics when half_precision_covariances (SplatBuffer.js:469-474).
         spherical_harmonics: float16 (or uint16 bit patterns) [n, 9|24], coefficient-major RGB triples."""
@@ -50,7 +56,11 @@ class SplatMesh:
         rgba = np.ascontiguousarray(colors, dtype=np.uint8).reshape(n, 4)
         cov16 = to_half_three(cov) if self.half_cov else None
         sh = None
-        if self.sh_degree > 0:
+        sh8 = None
+        ncoef = 9 if self.sh_degree == 1 else 24
+        if self.sh_degree > 0 and self.sh_8bit:
+            sh8 = np.ascontiguousarray(np.asarray(spherical_harmonics, dtype=np.uint8).reshape(n, ncoef))
+        elif self.sh_degree > 0:
             sh = np.ascontiguousarray(spherical_harmonics)
             if sh.dtype != np.uint16:
                 sh = sh.astype(np.float16).view(np.uint16)
@@ -59,8 +69,37 @@ class SplatMesh:
                                         None if self.half_cov else cov.ctypes.data,
                                         cov16.ctypes.data if self.half_cov else None, rgba.ctypes.data,
                                         sh.ctypes.data if sh is not None else None))
+        if sh8 is not None:
+            L.check(self.lib.gs_mesh_upload_sh_u8(self.handle, int(start), n, sh8.ctypes.data))
+        if scene_indexes is not None:
+            si = np.ascontiguousarray(scene_indexes, dtype=np.uint32).reshape(n)
+            L.check(self.lib.gs_mesh_upload_scene_indexes(self.handle, int(start), n, si.ctypes.data))
         self.splat_count = max(self.splat_count, int(start) + n)
         return self
+
+    def set_scenes(self, transforms=None, camera_position=None, opacity=None, visible=None, sh8_range=None):
+        """Per-scene uniforms: uniforms.transforms (dynamicMode), sceneOpacity / sceneVisibility
+        (enableOptionalEffects), sphericalHarmonics8BitCompressionRangeMin/Max.  transforms: column-major 16-vectors;
+        inverse(transform) * cameraPosition (the dynamic-mode SH view origin) is evaluated here in fp64."""
+        n = max(len(x) for x in (transforms, opacity, visible, sh8_range) if x is not None)
+        sp = L.SceneParams()
+        sp.scene_count = n
+        for s_ in range(n):
+            t = np.eye(4).T.reshape(16) if transforms is None else np.asarray(transforms[s_], np.float64).reshape(16)
+            sp.transforms[s_][:] = t.astype(np.float32).tolist()
+            if camera_position is not None:
+                p = np.linalg.inv(t.reshape(4, 4).T) @ np.array([*np.asarray(camera_position, np.float64), 1.0])
+                sp.inv_cam_pos[s_][:] = [*p[:3].astype(np.float32).tolist(), 1.0]
+            sp.opacity[s_] = 1.0 if opacity is None else float(min(max(opacity[s_], 0.0), 1.0))     # clamp(), SplatMesh.js:1271
+            sp.visible[s_] = 1 if visible is None else int(bool(visible[s_]))
+            if sh8_range is not None:
+                sp.sh8_min[s_], sp.sh8_max[s_] = float(sh8_range[s_][0]), float(sh8_range[s_][1])
+        L.check(self.lib.gs_mesh_set_scenes(self.handle, C.byref(sp)))
+        return self
+
+    def set_fade_in(self, scene_center=None, visible_region_fade_start_radius=0.0):
+        """fadeInComplete == 0 with these uniforms (SplatMesh.updateVisibleRegionFadeDistance); None = complete."""
+        self.fade_in = None if scene_center is None else (np.asarray(scene_center, np.float32), float(visible_region_fade_start_radius))
 
     def get_splat_count(self):
         return self.splat_count
@@ -80,11 +119,10 @@ class SplatMesh:
 
     def update_uniforms(self, render_dimensions, focal_x, focal_y, orthographic_mode=False, orthographic_zoom=1.0,
                         inverse_focal_adjustment=1.0, model_view=None, projection=None, camera_position=None,
-                        spherical_harmonics_degree=None):
+                        spherical_harmonics_degree=None, view_matrix=None):
         """SplatMesh.updateUniforms + three's built-in modelViewMatrix / projectionMatrix / cameraPosition."""
-        if orthographic_mode:
-            raise NotImplementedError("orthographic cameras are a 'next' row (SURVEY.md §8 f4)")
         cam = self._cam
+        cam.ortho_zoom = float(orthographic_zoom)
         cam.width, cam.height = int(render_dimensions[0]), int(render_dimensions[1])
         cam.focal[0], cam.focal[1] = float(focal_x), float(focal_y)
         cam.inv_focal_adj = float(inverse_focal_adjustment)
@@ -92,7 +130,15 @@ class SplatMesh:
         cam.kernel2d = self.kernel_2d_size
         cam.max_splat_px = self.max_screen_space_splat_size
         cam.sh_degree = self.sh_degree if spherical_harmonics_degree is None else int(spherical_harmonics_degree)
-        cam.flags = (L.GS_CAM_ANTIALIASED if self.antialiased else 0) | (L.GS_CAM_POINT_CLOUD if self.point_cloud_mode else 0)
+        cam.flags = ((L.GS_CAM_ANTIALIASED if self.antialiased else 0) | (L.GS_CAM_POINT_CLOUD if self.point_cloud_mode else 0) |
+                     (L.GS_CAM_ORTHOGRAPHIC if orthographic_mode else 0) | (L.GS_CAM_DYNAMIC if self.dynamic_mode else 0) |
+                     (L.GS_CAM_SCENE_EFFECTS if self.enable_optional_effects else 0) |
+                     (L.GS_CAM_FADE_IN if self.fade_in is not None else 0))
+        if self.fade_in is not None:
+            cam.scene_center[:] = self.fade_in[0].tolist()
+            cam.fade_start_radius = self.fade_in[1]
+        if view_matrix is not None:
+            cam.view_matrix[:] = np.asarray(view_matrix, dtype=np.float64).astype(np.float32).reshape(16).tolist()
         if model_view is not None:
             cam.view[:] = np.asarray(model_view, dtype=np.float64).astype(np.float32).reshape(16).tolist()
         if projection is not None:
@@ -103,9 +149,10 @@ class SplatMesh:
     def set_camera(self, camera, focal_adjustment=1.0, mesh_world=None, spherical_harmonics_degree=None):
         """Viewer.updateSplatMesh (src/Viewer.js:651-677) for a camera.PerspectiveCamera."""
         fx, fy = camera.focal(focal_adjustment)
-        self.update_uniforms((camera.width, camera.height), fx, fy, False, 1.0, 1.0 / focal_adjustment,
+        ortho = bool(getattr(camera, "is_orthographic", False))
+        self.update_uniforms((camera.width, camera.height), fx, fy, ortho, getattr(camera, "zoom", 1.0), 1.0 / focal_adjustment,
                              camera.model_view(mesh_world), camera.projection, camera.position,
-                             spherical_harmonics_degree)
+                             spherical_harmonics_degree, view_matrix=camera.view)
 
     def set_splat_scale(self, splat_scale=1.0):
         self.splat_scale = float(splat_scale)

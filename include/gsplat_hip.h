@@ -152,6 +152,8 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* params, gs_sorter* dst, u
  * RENDER SEAM
  * ------------------------------------------------------------------------------------------------ */
 #define GS_MESH_COV_HALF 1u   /* halfPrecisionCovariancesOnGPU (SplatMesh.js:667-670,735-739)                 */
+#define GS_MESH_SH_U8 2u      /* SH stored as uint8 (compression level 2, SplatMesh.js:680-684,789,1064-1066):
+                                 sphericalHarmonics8BitMode, dequantised per scene as v/255*(max-min)+min      */
 #define GS_SH_F16 0u          /* SH as fp16 (compression level <= 1, SplatMesh.js:1064-1066)                  */
 
 /* SplatMesh.build + setupDataTextures (SplatMesh.js:306-405, 637-898): device SoA planes instead of data
@@ -172,6 +174,28 @@ void gs_mesh_destroy(gs_mesh* m);
 int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
                    const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16);
 
+/* 8-bit SH of a GS_MESH_SH_U8 mesh: uint8[ncoef*count], same coefficient order as sh_f16 (pass sh_f16 = NULL to
+ * gs_mesh_upload for such a mesh and call this for the same range). */
+int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_t* sh_u8);
+
+/* Per-splat scene index (sceneIndexesTexture, SplatMesh.js:881-897): needed when more than one scene is loaded. */
+int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, const uint32_t* scene_indexes);
+
+/* Per-scene uniforms (SplatMesh.updateUniforms :1263-1276, setupDataTextures :868-878). */
+typedef struct gs_scene_params {
+    uint32_t scene_count;                       /* sceneCount                                                  */
+    uint32_t pad;
+    float transforms[GS_MAX_SCENES][16];        /* uniforms.transforms (GS_CAM_DYNAMIC)                        */
+    float inv_cam_pos[GS_MAX_SCENES][4];        /* inverse(transform) * cameraPosition per scene; the shader
+                                                   evaluates GLSL inverse() here (precision implementation-
+                                                   defined), the caller passes the fp64 result               */
+    float opacity[GS_MAX_SCENES];               /* sceneOpacity, clamped to [0,1]                              */
+    uint32_t visible[GS_MAX_SCENES];            /* sceneVisibility                                             */
+    float sh8_min[GS_MAX_SCENES];               /* sphericalHarmonics8BitCompressionRangeMin / Max             */
+    float sh8_max[GS_MAX_SCENES];
+} gs_scene_params;
+int gs_mesh_set_scenes(gs_mesh* m, const gs_scene_params* params);
+
 /* Uniforms of one draw: three's modelViewMatrix / projectionMatrix / cameraPosition plus
  * SplatMesh.updateUniforms (SplatMesh.js:1248-1280) as computed by Viewer.updateSplatMesh
  * (src/Viewer.js:651-677). */
@@ -189,9 +213,18 @@ typedef struct gs_camera {
     uint32_t flags;          /* GS_CAM_*                                                                    */
     uint32_t tile_row_begin; /* multi-GPU: this rank renders 16-px tile rows [begin,end); 0,0 = all rows    */
     uint32_t tile_row_end;
+    /* shader permutations (all zero = static perspective scene) */
+    float ortho_zoom;        /* orthoZoom (GS_CAM_ORTHOGRAPHIC)                                             */
+    float scene_center[3];   /* sceneCenter (GS_CAM_FADE_IN)                                                */
+    float fade_start_radius; /* visibleRegionFadeStartRadius (GS_CAM_FADE_IN)                               */
+    float view_matrix[16];   /* viewMatrix (GS_CAM_DYNAMIC: modelView = viewMatrix * transforms[scene])     */
 } gs_camera;
 #define GS_CAM_ANTIALIASED 1u
 #define GS_CAM_POINT_CLOUD 2u
+#define GS_CAM_ORTHOGRAPHIC 4u   /* orthographicMode: J = diag(orthoZoom), SplatMaterial3D.js:112-117           */
+#define GS_CAM_FADE_IN 8u        /* fadeInComplete == 0: distance fade-in, SplatMaterial.js:347-363             */
+#define GS_CAM_SCENE_EFFECTS 16u /* enableOptionalEffects: per-scene opacity / visibility, SplatMaterial.js:129 */
+#define GS_CAM_DYNAMIC 32u       /* dynamicMode: per-scene transforms, SplatMaterial.js:140-144,179-183         */
 #define GS_TILE 16u
 
 typedef struct gs_render_stats {

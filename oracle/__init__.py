@@ -186,7 +186,14 @@ class Camera(C.Structure):
                 ("focal", C.c_float * 2), ("viewport", C.c_float * 2), ("splat_scale", C.c_float),
                 ("kernel2d", C.c_float), ("max_splat_px", C.c_float), ("inv_focal_adj", C.c_float),
                 ("sh_degree", C.c_int32), ("sh_stored", C.c_int32), ("antialiased", C.c_int32),
-                ("point_cloud", C.c_int32)]
+                ("point_cloud", C.c_int32),
+                # shader permutations (see raster_oracle.c)
+                ("orthographic", C.c_int32), ("ortho_zoom", C.c_float), ("fade_in", C.c_int32),
+                ("scene_center", C.c_float * 3), ("fade_start", C.c_float), ("effects", C.c_int32),
+                ("dynamic", C.c_int32), ("sh8", C.c_int32), ("scene_count", C.c_int32),
+                ("view_matrix", C.c_float * 16), ("transforms", (C.c_float * 16) * 32),
+                ("inv_cam_pos", (C.c_float * 3) * 32), ("opacity", C.c_float * 32), ("visible", C.c_int32 * 32),
+                ("sh8_min", C.c_float * 32), ("sh8_max", C.c_float * 32)]
 
 
 SPLAT2D = np.dtype([("visible", np.int32), ("cx", np.float32), ("cy", np.float32), ("b1x", np.float32),
@@ -229,8 +236,43 @@ def _scene_args(centers, cov, rgba, sh):
     return centers, cov, rgba, sh
 
 
-def project(cam, centers, cov, rgba, sh=None, order=None):
+def set_scenes(cam, view_matrix=None, transforms=None, camera_position=None, opacity=None, visible=None,
+               sh8_range=None, dynamic=False, effects=False):
+    """Per-scene uniforms of the dynamic / optional-effects / 8-bit-SH shader permutations.  transforms: list of
+    column-major 16-vectors; inverse(transform) * cameraPosition is evaluated here in fp64."""
+    n = len(transforms) if transforms is not None else (len(opacity) if opacity is not None else 1)
+    cam.scene_count = n
+    cam.dynamic = int(dynamic)
+    cam.effects = int(effects)
+    if view_matrix is not None:
+        cam.view_matrix[:] = np.asarray(view_matrix, np.float64).astype(np.float32).reshape(16).tolist()
+    for s_ in range(n):
+        if transforms is not None:
+            t = np.asarray(transforms[s_], np.float64).reshape(16)
+            cam.transforms[s_][:] = t.astype(np.float32).tolist()
+            if camera_position is not None:
+                inv = np.linalg.inv(t.reshape(4, 4).T)
+                p = inv @ np.array([*np.asarray(camera_position, np.float64), 1.0])
+                cam.inv_cam_pos[s_][:] = (p[:3]).astype(np.float32).tolist()
+        cam.opacity[s_] = 1.0 if opacity is None else float(min(max(opacity[s_], 0.0), 1.0))
+        cam.visible[s_] = 1 if visible is None else int(bool(visible[s_]))
+        if sh8_range is not None:
+            cam.sh8_min[s_], cam.sh8_max[s_] = float(sh8_range[s_][0]), float(sh8_range[s_][1])
+    return cam
+
+
+def _set_scene_idx(scene_indexes):
+    if scene_indexes is None:
+        _lib().gro_set_scene_indexes(None)
+        return None
+    si = np.ascontiguousarray(scene_indexes, dtype=np.uint32)
+    _lib().gro_set_scene_indexes(si.ctypes.data_as(_u32p))
+    return si
+
+
+def project(cam, centers, cov, rgba, sh=None, order=None, scene_indexes=None):
     centers, cov, rgba, sh = _scene_args(centers, cov, rgba, sh)
+    _keep = _set_scene_idx(scene_indexes)  # noqa: F841
     if order is not None:
         order = np.ascontiguousarray(order, dtype=np.uint32)
     count = centers.shape[0] if order is None else order.shape[0]
@@ -240,9 +282,10 @@ def project(cam, centers, cov, rgba, sh=None, order=None):
     return out
 
 
-def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-3):
+def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-3, scene_indexes=None):
     """Returns (fb float32[H,W,4] row0=bottom, rgba8 uint8[H,W,4], ambig uint8[H,W], fragments)."""
     centers, cov, rgba, sh = _scene_args(centers, cov, rgba, sh)
+    _keep = _set_scene_idx(scene_indexes)  # noqa: F841
     if order is not None:
         order = np.ascontiguousarray(order, dtype=np.uint32)
     count = centers.shape[0] if order is None else order.shape[0]

@@ -38,6 +38,22 @@ typedef struct {
     int32_t sh_stored;     /* degree stored: 0,1,2 -> 0,9,24 floats per splat           */
     int32_t antialiased;   /* 0                                                         */
     int32_t point_cloud;   /* 0                                                         */
+    /* --- shader permutations (all off = the static perspective path above) ---------------------------- */
+    int32_t orthographic;  /* orthographicMode, SplatMaterial3D.js:112-117                 */
+    float ortho_zoom;      /* orthoZoom                                                   */
+    int32_t fade_in;       /* fadeInComplete == 0, SplatMaterial.js:347-363               */
+    float scene_center[3];
+    float fade_start;      /* visibleRegionFadeStartRadius                                */
+    int32_t effects;       /* enableOptionalEffects: sceneOpacity / sceneVisibility       */
+    int32_t dynamic;       /* dynamicMode: transformModelViewMatrix = viewMatrix * transforms[scene] */
+    int32_t sh8;           /* sphericalHarmonics8BitMode: sh = (u8/255)*range + min       */
+    int32_t scene_count;
+    float view_matrix[16];              /* viewMatrix (dynamic mode; `view` is unused then)                   */
+    float transforms[32][16];
+    float inv_cam_pos[32][3];           /* inverse(transform) * cameraPosition, precomputed by the host in fp64 */
+    float opacity[32];
+    int32_t visible[32];
+    float sh8_min[32], sh8_max[32];
 } gro_camera;
 
 /* Per-splat result of the vertex stage. */
@@ -54,10 +70,34 @@ static float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); 
 
 /* Vertex stage for one splat.  Every line cites the shader line it restates. */
 static void project_one(const gro_camera* cam, const float* c, const float* cov, const uint8_t* rgba,
-                        const float* sh, gro_splat2d* o) {
+                        const float* sh_in, uint32_t scene, gro_splat2d* o) {
     const float* MV = cam->view;
     const float* P = cam->proj;
     memset(o, 0, sizeof(*o));
+    if (cam->scene_count <= 1) scene = 0;                      /* SplatMaterial.js:123-126 */
+    float opacity_from_scene = 1.0f;
+    if (cam->effects) {                                        /* :129-137 */
+        opacity_from_scene = cam->opacity[scene];
+        if (opacity_from_scene <= 0.01f || cam->visible[scene] == 0) return;
+    }
+    float MVd[16];
+    if (cam->dynamic) {                                        /* :140-144 viewMatrix * transform */
+        const float* A = cam->view_matrix;
+        const float* B = cam->transforms[scene];
+        for (int col = 0; col < 4; col++)
+            for (int r = 0; r < 4; r++)
+                MVd[4 * col + r] = A[r] * B[4 * col] + A[4 + r] * B[4 * col + 1] + A[8 + r] * B[4 * col + 2] + A[12 + r] * B[4 * col + 3];
+        MV = MVd;
+    }
+    /* :150-154 8-bit SH: texel (unorm8 -> v/255) * range + min, with range = max - min */
+    float shbuf[24];
+    const float* sh = sh_in;
+    if (cam->sh8 && sh_in) {
+        const float range = cam->sh8_max[scene] - cam->sh8_min[scene];
+        const int shn = cam->sh_stored == 0 ? 0 : (cam->sh_stored == 1 ? 9 : 24);
+        for (int k = 0; k < shn; k++) shbuf[k] = (sh_in[k] / 255.0f) * range + cam->sh8_min[scene];
+        sh = shbuf;
+    }
 
     /* SplatMaterial.js:156  viewCenter = MV * vec4(c,1) */
     float v[4], q[4];
@@ -78,8 +118,10 @@ static void project_one(const gro_camera* cam, const float* c, const float* cov,
     float alpha = (float)rgba[3] * (1.0f / 255.0f);
 
     if (cam->sh_stored >= 1 && cam->sh_degree >= 1) {
-        /* :185 worldViewDir = normalize(splatCenter - cameraPosition) */
-        float d[3] = {c[0] - cam->cam_pos[0], c[1] - cam->cam_pos[1], c[2] - cam->cam_pos[2]};
+        /* :185 worldViewDir = normalize(splatCenter - cameraPosition); dynamic mode (:179-183): the camera position
+         * in the scene's frame, inverse(transform) * cameraPosition */
+        const float* cp = cam->dynamic ? cam->inv_cam_pos[scene] : cam->cam_pos;
+        float d[3] = {c[0] - cp[0], c[1] - cp[1], c[2] - cp[2]};
         const float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
         const float SH_C1 = 0.4886025119029199f;
@@ -103,9 +145,14 @@ static void project_one(const gro_camera* cam, const float* c, const float* cov,
     const float V00 = cov[0], V01 = cov[1], V02 = cov[2], V11 = cov[3], V12 = cov[4], V22 = cov[5];
     /* :120-126  J (GLSL column-major constructor) as math matrix Jm[row][col]:
      *   col0 = (fx/z, 0, -(fx*x)*s), col1 = (0, fy/z, -(fy*y)*s), col2 = 0 */
-    const float s = 1.0f / (v[2] * v[2]);
-    const float j00 = cam->focal[0] / v[2], j20 = -(cam->focal[0] * v[0]) * s;
-    const float j11 = cam->focal[1] / v[2], j21 = -(cam->focal[1] * v[1]) * s;
+    float j00, j20, j11, j21;
+    if (cam->orthographic) {                                   /* :112-117 J = diag(zoom, zoom, 0) */
+        j00 = cam->ortho_zoom; j11 = cam->ortho_zoom; j20 = 0.0f; j21 = 0.0f;
+    } else {
+        const float s = 1.0f / (v[2] * v[2]);
+        j00 = cam->focal[0] / v[2]; j20 = -(cam->focal[0] * v[0]) * s;
+        j11 = cam->focal[1] / v[2]; j21 = -(cam->focal[1] * v[1]) * s;
+    }
     /* :130 W = transpose(mat3(MV)) -> Wm[r][c] = MV3[c][r] = MV[4*r + c]  (MV[4*col+row]) */
     /* :131 T = W * J : T[r][c] = sum_k Wm[r][k] * Jm[k][c]; only columns 0 and 1 are non-zero */
     float T0[3], T1[3];
@@ -151,6 +198,17 @@ static void project_one(const gro_camera* cam, const float* c, const float* cov,
     const float sqrt8 = sqrtf(8.0f);
     float h1 = sqrt8 * sqrtf(l1); if (h1 > cam->max_splat_px) h1 = cam->max_splat_px;
     float h2 = sqrt8 * sqrtf(l2); if (h2 > cam->max_splat_px) h2 = cam->max_splat_px;
+    if (cam->effects) alpha *= opacity_from_scene;             /* SplatMaterial3D.js:199-203 */
+    if (cam->fade_in) {                                        /* SplatMaterial.js:347-363 */
+        const float dx = c[0] - cam->scene_center[0], dy = c[1] - cam->scene_center[1], dz = c[2] - cam->scene_center[2];
+        const float center_dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float fade_distance = 0.75f;
+        float f = center_dist < cam->fade_start ? 0.0f : 1.0f;              /* step(edge, x) */
+        float t = (center_dist - cam->fade_start) / fade_distance;
+        t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        f = (1.0f - f) + (1.0f - t) * f;
+        alpha *= 1.0f * f;
+    }
     /* ndcOffset = (q.x*b1 + q.y*b2) * (1/viewport) * 2 * invFocalAdj  (:206-207)  => pixel offset =
      * ndcOffset * viewport/2 = (q.x*b1 + q.y*b2) * invFocalAdj */
     const float k = cam->splat_scale * cam->inv_focal_adj;
@@ -164,12 +222,16 @@ static void project_one(const gro_camera* cam, const float* c, const float* cov,
 }
 
 /* Vertex stage for splats order[0..count) (order==NULL -> identity). */
+static const uint32_t* g_scene_idx = 0;     /* per-splat scene indexes for the next call (set by gro_set_scene_indexes) */
+void gro_set_scene_indexes(const uint32_t* scene_idx) { g_scene_idx = scene_idx; }
+
 void gro_project(const gro_camera* cam, const float* centers, const float* cov, const uint8_t* rgba,
                  const float* sh, const uint32_t* order, uint32_t count, gro_splat2d* out) {
     const int shn = cam->sh_stored == 0 ? 0 : (cam->sh_stored == 1 ? 9 : 24);
     for (uint32_t i = 0; i < count; i++) {
         const size_t g = order ? order[i] : i;
-        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL, out + i);
+        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL,
+                    g_scene_idx ? g_scene_idx[g] : 0u, out + i);
     }
 }
 
@@ -190,7 +252,8 @@ uint64_t gro_render(const gro_camera* cam, const float* centers, const float* co
     for (uint32_t i = 0; i < count; i++) {
         const size_t g = order ? order[i] : i;
         gro_splat2d s;
-        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL, &s);
+        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL,
+                    g_scene_idx ? g_scene_idx[g] : 0u, &s);
         if (!s.visible) continue;
         /* bounding box of the quad centre +- b1 +- b2 */
         const float ext_x = fabsf(s.b1x) + fabsf(s.b2x), ext_y = fabsf(s.b1y) + fabsf(s.b2y);

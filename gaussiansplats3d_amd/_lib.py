@@ -66,6 +66,13 @@ class GatherParams(C.Structure):
                 ("render_height", C.c_double), ("gather_all", C.c_uint32), ("pad", C.c_uint32)]
 
 
+class AssetInfo(C.Structure):
+    _fields_ = [("splat_count", C.c_uint32), ("sh_degree", C.c_uint32), ("compression_level", C.c_uint32),
+                ("sh_level", C.c_uint32), ("scene_center", C.c_float * 3), ("sh_min", C.c_float), ("sh_max", C.c_float)]
+
+
+GS_ASSET_PLY, GS_ASSET_KSPLAT = 1, 2
+
 # every symbol include/gsplat_hip.h declares: (restype, argtypes)
 _VP = C.c_void_p
 SYMBOLS = {
@@ -81,6 +88,10 @@ SYMBOLS = {
     "gs_sorter_sort": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_sort_gathered": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_asset_open": (C.c_int, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "gs_asset_close": (None, [_VP]),
+    "gs_asset_get_info": (C.c_int, [_VP, C.POINTER(AssetInfo)]),
+    "gs_asset_fill": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gs_tree_create": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_tree_destroy": (None, [_VP]),
     "gs_tree_get_info": (C.c_int, [_VP, C.POINTER(TreeInfo)]),

@@ -149,6 +149,32 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* params, gs_sorter* dst, u
                    uint32_t* indexes_out_host);
 
 /* ------------------------------------------------------------------------------------------------ *
+ * ASSETS (host side, no GPU needed): the reference's file readers up to the arrays the seams consume
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct gs_asset gs_asset;
+#define GS_ASSET_PLY 1u      /* INRIA-v1 .ply, binary little endian: src/loaders/ply/INRIAV1PlyParser.js            */
+#define GS_ASSET_KSPLAT 2u   /* .ksplat, compression levels 0/1/2: src/loaders/SplatBuffer.js                        */
+/* Parses `data` (the bytes of the file).  max_sh_degree: outSphericalHarmonicsDegree (Viewer option
+ * sphericalHarmonicsDegree); splats keep FILE order (the reference's optimizeSplatData:false). */
+int gs_asset_open(const void* data, uint64_t bytes, uint32_t format, uint32_t max_sh_degree, gs_asset** out);
+void gs_asset_close(gs_asset* a);
+typedef struct gs_asset_info {
+    uint32_t splat_count;
+    uint32_t sh_degree;          /* degree the fill arrays carry                                                */
+    uint32_t compression_level;  /* of the splat buffer: 0 (also every PLY), 1, 2                                */
+    uint32_t sh_level;           /* getTargetSphericalHarmonicsCompressionLevel: 1 = fp16 output, 2 = uint8      */
+    float scene_center[3];
+    float sh_min, sh_max;        /* min/maxSphericalHarmonicsCoeff of the file (8-bit SH range)                  */
+} gs_asset_info;
+int gs_asset_get_info(gs_asset* a, gs_asset_info* info);
+/* SplatMesh.fillSplatDataArrays (src/splatmesh/SplatMesh.js:1853-1902) without a scene transform; any pointer may
+ * be NULL.  centers float[3n]; cov_f32 float[6n] / cov_f16 half bits[6n] (covariance compression level 0 / 1);
+ * rgba uint8[4n] with alpha zeroed below min_alpha; sh_f16 half bits[ncoef*n] (sh_level 1) or sh_u8 uint8[ncoef*n]
+ * (sh_level 2), coefficient-major RGB triples; scales float[3n], rotations float[4n] (x,y,z,w) as stored. */
+int gs_asset_fill(gs_asset* a, uint32_t min_alpha, float* centers, float* cov_f32, uint16_t* cov_f16, uint8_t* rgba,
+                  uint16_t* sh_f16, uint8_t* sh_u8, float* scales, float* rotations);
+
+/* ------------------------------------------------------------------------------------------------ *
  * RENDER SEAM
  * ------------------------------------------------------------------------------------------------ */
 #define GS_MESH_COV_HALF 1u   /* halfPrecisionCovariancesOnGPU (SplatMesh.js:667-670,735-739)                 */

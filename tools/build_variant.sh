@@ -9,8 +9,8 @@ OUT=$ROOT/gpurun_ab; OBJ=/tmp/gsvar_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $*"
 pids=()
-for f in context selftest sorter mesh project tile_bin tile_blend tree; do
-  extra=""; [ $f = sorter -o $f = project -o $f = tree ] && extra="-ffp-contract=off"
+for f in context selftest sorter mesh project tile_bin tile_blend tree assets; do
+  extra=""; [ $f = sorter -o $f = project -o $f = tree -o $f = assets ] && extra="-ffp-contract=off"
   ( /opt/rocm/bin/hipcc $FLAGS $extra -c $SRC/$f.hip -o $OBJ/$f.o ) &
   pids+=($!)
 done

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(CSRC, "libgsplat_hip
 GS_OK, GS_WARN_KEY_CLAMPED = 0, 1
 GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
-GS_MESH_COV_HALF, GS_MESH_SH_U8 = 1, 2
+GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
 GS_TILE = 16
 GS_BIN = 32          # entry lists / blend workgroups are per 32-px bin (2x2 tiles)
@@ -87,6 +87,7 @@ SYMBOLS = {
     "gs_sorter_upload_centers": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP, _VP]),
     "gs_sorter_sort": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_sort_gathered": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
+    "gs_sorter_bind_mesh": (C.c_int, [_VP, _VP]),
     "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_asset_open": (C.c_int, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_asset_close": (None, [_VP]),

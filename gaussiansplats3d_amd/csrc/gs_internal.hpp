@@ -102,6 +102,7 @@ struct RadixScratch {
 //   stream  the caller-visible stream: binning, tile sort, blend, every copy back to the host
 //   aux     vertex stage (k_project) of a draw, forked from / joined into `stream` with events
 // Each gs_sorter additionally owns a private stream; its result is joined into `stream` where a draw consumes it.
+struct gs_mesh;
 struct gs_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -111,6 +112,7 @@ struct gs_context {
     int cu_count = 256;
     bool lds_atomic_lane_order = false;   // self-test result: ds_add_rtn serves same-address lanes in lane order
     RadixScratch radix;                   // scratch of the create-time self-test
+    std::vector<gs_mesh*> live_meshes;    // so that a sorter bound to a mesh never dereferences a destroyed one
 };
 
 struct RadixExec {                        // where and with what scratch a radix pass runs
@@ -162,6 +164,9 @@ struct gs_sorter {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_consumed = nullptr;  // recorded on ctx->stream by a draw once it has read `sorted`
     bool consumer_pending = false;
+    gs_mesh* bound_mesh = nullptr;     // gs_sorter_bind_mesh: results are positions in this mesh's storage order
+    gs_mesh* result_mesh = nullptr;    // ... as it was when the last sort ran (nullptr = plain splat indexes)
+    const uint32_t* result_unmap = nullptr;
     uint32_t gathered = 0;             // splatRenderCount of the list gs_tree_gather left in idx_in
     bool has_gathered = false;
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
@@ -229,6 +234,10 @@ struct gs_mesh {
     DevBuf rgba;               // uint32
     DevBuf sh0, sh1, sh2;      // fp16: uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
                                // u8  : sh0 = uint4 (bytes 0..15), sh1 = uint2 (bytes 16..23, SH2 only)
+    DevBuf perm;               // uint32 [n]: original splat index -> internal (Morton-ordered) position
+    DevBuf inv_perm;           // uint32 [n]: internal position -> original splat index
+    bool reorder = true;
+    bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
     DevBuf scene_dev;          // gs_scene_params on the device
     bool has_scenes = false;
@@ -266,6 +275,10 @@ struct gs_mesh {
 };
 
 int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);
+
+// payload maps of a mesh for a bound sorter (nullptr when the mesh keeps upload order or covers fewer splats)
+const uint32_t* gs_mesh_payload_map(gs_mesh* m, uint32_t splats);
+const uint32_t* gs_mesh_payload_unmap(gs_mesh* m);
 
 // kernels' host launchers ---------------------------------------------------------------------------
 int gs_launch_frame_init(gs_mesh* m, uint32_t tiles);

@@ -2,77 +2,139 @@
 //   k_project (project.hip) -> binning + tile sort (tile_bin.hip) -> k_tile_blend (tile_blend.hip).
 // Replaces SplatMesh's data textures / uniforms / instanced draw
 // (/root/reference/src/splatmesh/SplatMesh.js:637-898, 1228-1280; src/Viewer.js:1616).
-#include "gs_internal.hpp"
+#include <math.h>
+#include <stdlib.h>
+
+#include "radix.hpp"
 
 void gs_set_error(const char* fmt, ...);
 
+// Storage order.  Splats of one upload are re-ordered along a 30-bit Morton curve of their centres:
+// `perm[original] = internal`.  Neighbours in memory are then neighbours in space, so whole waves of k_project fail
+// the frustum test together and never fetch their covariance / SH bytes.  Every index that crosses the C ABI stays
+// an ORIGINAL splat index; the binner translates once per list position.
+#define DST(i) (perm ? perm[from + (i)] : from + (i))
+
+__global__ __launch_bounds__(256) void k_morton_keys(const float* __restrict__ c3, uint32_t count, float3 mn, float3 inv_extent,
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        auto q = [](float v, float lo, float inv) {
+            const float t = (v - lo) * inv * 1023.0f;
+            return (uint32_t)(t < 0.0f ? 0.0f : (t > 1023.0f ? 1023.0f : t));        // NaN -> 0
+        };
+        auto spread = [](uint32_t v) {                                               // 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FFu;
+            v = (v | (v << 8)) & 0x0300F00Fu;
+            v = (v | (v << 4)) & 0x030C30C3u;
+            v = (v | (v << 2)) & 0x09249249u;
+            return v;
+        };
+        const uint32_t x = q(c3[3 * (size_t)i], mn.x, inv_extent.x), y = q(c3[3 * (size_t)i + 1], mn.y, inv_extent.y),
+                       z = q(c3[3 * (size_t)i + 2], mn.z, inv_extent.z);
+        keys[i] = spread(x) | (spread(y) << 1) | (spread(z) << 2);
+        vals[i] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_perm_from_sorted(const uint32_t* __restrict__ sorted_local, uint32_t count, uint32_t from,
+                                                          uint32_t* __restrict__ perm, uint32_t* __restrict__ inv_perm) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < count; p += gridDim.x * blockDim.x) {
+        perm[from + sorted_local[p]] = from + p;
+        inv_perm[from + p] = from + sorted_local[p];
+    }
+}
+
+const uint32_t* gs_mesh_payload_map(gs_mesh* m, uint32_t splats) {
+    return (m->reorder && splats <= m->uploaded) ? m->perm.as<uint32_t>() : nullptr;
+}
+const uint32_t* gs_mesh_payload_unmap(gs_mesh* m) { return m->reorder ? m->inv_perm.as<uint32_t>() : nullptr; }
+
+__global__ __launch_bounds__(256) void k_scatter_u32(const uint32_t* __restrict__ src, uint32_t count, uint32_t from,
+                                                     const uint32_t* __restrict__ perm, uint32_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) dst[DST(i)] = src[i];
+}
+
 // AoS upload formats -> SoA planes -----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_split_centers(const float* __restrict__ c3, uint32_t count, uint32_t from,
-                                                       float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+                                                       const uint32_t* __restrict__ perm, float* __restrict__ x,
+                                                       float* __restrict__ y, float* __restrict__ z) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        x[from + i] = c3[3 * (size_t)i];
-        y[from + i] = c3[3 * (size_t)i + 1];
-        z[from + i] = c3[3 * (size_t)i + 2];
+        const uint32_t d = DST(i);
+        x[d] = c3[3 * (size_t)i];
+        y[d] = c3[3 * (size_t)i + 1];
+        z[d] = c3[3 * (size_t)i + 2];
     }
 }
 
 __global__ __launch_bounds__(256) void k_split_cov_f32(const float* __restrict__ c6, uint32_t count, uint32_t from,
-                                                       float4* __restrict__ a, float2* __restrict__ b) {
+                                                       const uint32_t* __restrict__ perm, float4* __restrict__ a,
+                                                       float2* __restrict__ b) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const float* s = c6 + 6 * (size_t)i;
-        a[from + i] = make_float4(s[0], s[1], s[2], s[3]);
-        b[from + i] = make_float2(s[4], s[5]);
+        const uint32_t d = DST(i);
+        a[d] = make_float4(s[0], s[1], s[2], s[3]);
+        b[d] = make_float2(s[4], s[5]);
     }
 }
 
 __global__ __launch_bounds__(256) void k_split_cov_f16(const uint16_t* __restrict__ c6, uint32_t count, uint32_t from,
-                                                       uint2* __restrict__ a, uint32_t* __restrict__ b) {
+                                                       const uint32_t* __restrict__ perm, uint2* __restrict__ a,
+                                                       uint32_t* __restrict__ b) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const uint16_t* s = c6 + 6 * (size_t)i;
-        a[from + i] = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
-        b[from + i] = (uint32_t)s[4] | ((uint32_t)s[5] << 16);
+        const uint32_t d = DST(i);
+        a[d] = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
+        b[d] = (uint32_t)s[4] | ((uint32_t)s[5] << 16);
     }
 }
 
 // coefficient-major RGB triples (9 or 24 halfs per splat) -> 16-byte planes
 __global__ __launch_bounds__(256) void k_split_sh(const uint16_t* __restrict__ sh, uint32_t count, uint32_t from,
-                                                  uint32_t ncoef, uint4* __restrict__ p0, void* __restrict__ p1,
-                                                  uint4* __restrict__ p2) {
+                                                  const uint32_t* __restrict__ perm, uint32_t ncoef, uint4* __restrict__ p0,
+                                                  void* __restrict__ p1, uint4* __restrict__ p2) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const uint16_t* s = sh + (size_t)ncoef * i;
         auto pk = [&](int k) { return (uint32_t)s[k] | ((uint32_t)s[k + 1] << 16); };
-        p0[from + i] = make_uint4(pk(0), pk(2), pk(4), pk(6));
+        const uint32_t d = DST(i);
+        p0[d] = make_uint4(pk(0), pk(2), pk(4), pk(6));
         if (ncoef == 9) {
-            reinterpret_cast<uint32_t*>(p1)[from + i] = (uint32_t)s[8];
+            reinterpret_cast<uint32_t*>(p1)[d] = (uint32_t)s[8];
         } else {
-            reinterpret_cast<uint4*>(p1)[from + i] = make_uint4(pk(8), pk(10), pk(12), pk(14));
-            p2[from + i] = make_uint4(pk(16), pk(18), pk(20), pk(22));
+            reinterpret_cast<uint4*>(p1)[d] = make_uint4(pk(8), pk(10), pk(12), pk(14));
+            p2[d] = make_uint4(pk(16), pk(18), pk(20), pk(22));
         }
     }
 }
 
 // test hook: undo k_project's per-block compaction -> one record / rect per splat in storage order (zeros when culled)
 __global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* __restrict__ vis_mask, uint32_t count,
-                                                      const uint4* __restrict__ recs, const uint2* __restrict__ rects,
-                                                      uint4* __restrict__ out_recs, uint2* __restrict__ out_rects) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
+                                                      const uint32_t* __restrict__ perm, const uint4* __restrict__ recs,
+                                                      const uint2* __restrict__ rects, uint4* __restrict__ out_recs,
+                                                      uint2* __restrict__ out_rects, unsigned long long* __restrict__ out_mask) {
+    const uint32_t orig = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = orig < count ? (perm ? perm[orig] : orig) : 0u;     // internal position of this original splat
     const unsigned long long* mw = vis_mask + ((i >> 8) << 2);
     const uint32_t w = (i >> 6) & 3u, bit = i & 63u;
     uint32_t slot = (i & ~255u) + (uint32_t)__popcll(mw[w] & ((1ull << bit) - 1ull));
     for (uint32_t k = 0; k < w; k++) slot += (uint32_t)__popcll(mw[k]);
-    const bool vis = (mw[w] >> bit) & 1ull;
+    const bool vis = orig < count && ((mw[w] >> bit) & 1ull);
+    if (out_mask) {                                                         // the mask in ORIGINAL splat order
+        const unsigned long long b = __ballot(vis);
+        if ((threadIdx.x & 63u) == 0u) out_mask[orig >> 6] = b;
+    }
+    if (orig >= count) return;
     const uint4 z = make_uint4(0, 0, 0, 0);
     if (out_recs) {
-        out_recs[2 * (size_t)i] = vis ? recs[2 * (size_t)slot] : z;
-        out_recs[2 * (size_t)i + 1] = vis ? recs[2 * (size_t)slot + 1] : z;
+        out_recs[2 * (size_t)orig] = vis ? recs[2 * (size_t)slot] : z;
+        out_recs[2 * (size_t)orig + 1] = vis ? recs[2 * (size_t)slot + 1] : z;
     }
-    if (out_rects) out_rects[i] = vis ? rects[slot] : make_uint2(0xFFFFu, 0u);
+    if (out_rects) out_rects[orig] = vis ? rects[slot] : make_uint2(0xFFFFu, 0u);
 }
 
 // 8-bit SH: 9 or 24 bytes per splat -> one 16-byte plane (+ one 8-byte plane for degree 2)
 __global__ __launch_bounds__(256) void k_split_sh_u8(const uint8_t* __restrict__ sh, uint32_t count, uint32_t from,
-                                                     uint32_t ncoef, uint4* __restrict__ p0, uint2* __restrict__ p1) {
+                                                     const uint32_t* __restrict__ perm, uint32_t ncoef, uint4* __restrict__ p0,
+                                                     uint2* __restrict__ p1) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const uint8_t* s = sh + (size_t)ncoef * i;
         auto pk = [&](uint32_t k) {
@@ -81,8 +143,9 @@ __global__ __launch_bounds__(256) void k_split_sh_u8(const uint8_t* __restrict__
                 if (k + t < ncoef) v |= (uint32_t)s[k + t] << (8 * t);
             return v;
         };
-        p0[from + i] = make_uint4(pk(0), pk(4), pk(8), pk(12));
-        if (ncoef > 16) p1[from + i] = make_uint2(pk(16), pk(20));
+        const uint32_t d = DST(i);
+        p0[d] = make_uint4(pk(0), pk(4), pk(8), pk(12));
+        if (ncoef > 16) p1[d] = make_uint2(pk(16), pk(20));
     }
 }
 
@@ -109,7 +172,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
     GS_REQUIRE(max_splat_count <= (1u << 28), "max_splat_count > 2^28 (entry payload = 28-bit record slot + 4-bit quadrant mask)");
     GS_REQUIRE(sh_degree <= 2, "sh_degree > 2 (the reference renders degrees 0..2, src/Viewer.js:154)");
-    GS_REQUIRE((flags & ~(GS_MESH_COV_HALF | GS_MESH_SH_U8)) == 0, "unknown mesh flags");
+    GS_REQUIRE((flags & ~(GS_MESH_COV_HALF | GS_MESH_SH_U8 | GS_MESH_KEEP_ORDER)) == 0, "unknown mesh flags");
     ScopedDevice sd(ctx->device);
     gs_mesh* m = new (std::nothrow) gs_mesh();
     if (!m) return GS_ERR_NOMEM;
@@ -132,6 +195,8 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
         if (sh_degree >= 2) A(m->sh2, n * 16);
     }
     A(m->scene_dev, sizeof(gs_scene_params));
+    m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
+    if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->bin_sums, 4 * 3 * 2048);                    // uint32 [3][BIN_MAX_BLOCKS]
@@ -162,12 +227,18 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
         gs_mesh_destroy(m);
         return st;
     }
+    ctx->live_meshes.push_back(m);
     *out = m;
     return GS_OK;
 }
 
 void gs_mesh_destroy(gs_mesh* m) {
     if (!m) return;
+    for (size_t i = 0; i < m->ctx->live_meshes.size(); i++)
+        if (m->ctx->live_meshes[i] == m) {
+            m->ctx->live_meshes.erase(m->ctx->live_meshes.begin() + i);
+            break;
+        }
     ScopedDevice sd(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->ctx->aux != m->ctx->stream) (void)hipStreamSynchronize(m->ctx->aux);
@@ -196,23 +267,54 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     const uint32_t ncoef = (m->sh_degree == 0 || sh_u8) ? 0 : (m->sh_degree == 1 ? 9 : 24);
     const size_t b_c = (size_t)count * 12, b_cov = (size_t)count * (half ? 12 : 24), b_sh = (size_t)count * ncoef * 2;
     size_t off_cov = (b_c + 255) & ~(size_t)255, off_sh = (off_cov + b_cov + 255) & ~(size_t)255;
-    GS_TRY(m->staging.ensure(off_sh + b_sh + 256));
+    GS_TRY(m->staging.ensure(off_sh + b_sh + 512 + (size_t)count * 4));
     char* stg = m->staging.as<char>();
     GS_HIP(hipMemcpyAsync(stg, centers, b_c, hipMemcpyHostToDevice, st));
     GS_HIP(hipMemcpyAsync(stg + off_cov, half ? (const void*)cov_f16 : (const void*)cov_f32, b_cov, hipMemcpyHostToDevice, st));
     if (ncoef) GS_HIP(hipMemcpyAsync(stg + off_sh, sh_f16, b_sh, hipMemcpyHostToDevice, st));
-    GS_HIP(hipMemcpyAsync(m->rgba.as<uint32_t>() + from, rgba, (size_t)count * 4, hipMemcpyHostToDevice, st));
     const dim3 g(up_grid(count)), b(256);
-    hipLaunchKernelGGL(k_split_centers, g, b, 0, st, (const float*)stg, count, from, m->px.as<float>(), m->py.as<float>(),
+    const uint32_t* perm = nullptr;
+    if (m->reorder) {
+        // Morton order of this upload: bounds on the host (the centres are host memory anyway), 30-bit codes, 4 stable
+        // radix passes with the entry ping-pong buffers as scratch, then perm[original] = internal
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < count; i++)
+            for (int k = 0; k < 3; k++) {
+                const float v = centers[3 * (size_t)i + k];
+                if (v < mn[k]) mn[k] = v;
+                if (v > mx[k]) mx[k] = v;
+            }
+        float3 lo = make_float3(mn[0], mn[1], mn[2]), inv;
+        inv.x = mx[0] > mn[0] ? 1.0f / (mx[0] - mn[0]) : 0.0f;
+        inv.y = mx[1] > mn[1] ? 1.0f / (mx[1] - mn[1]) : 0.0f;
+        inv.z = mx[2] > mn[2] ? 1.0f / (mx[2] - mn[2]) : 0.0f;
+        if (count > m->entry_capacity) GS_TRY(mesh_alloc_entries(m, count));
+        uint32_t* kbuf[2] = {m->ekeyA.as<uint32_t>(), m->ekeyB.as<uint32_t>()};
+        uint32_t* vbuf[2] = {m->evalA.as<uint32_t>(), m->evalB.as<uint32_t>()};
+        hipLaunchKernelGGL(k_morton_keys, g, b, 0, st, (const float*)stg, count, lo, inv, kbuf[0], vbuf[0]);
+        GS_HIP(hipMemsetAsync(m->radix.digit_total.p, 0, sizeof(uint32_t) * RADIX_TOTAL_WORDS, st));
+        const RadixExec ex = {st, &m->radix, m->ctx->lds_atomic_lane_order};
+        for (int pass = 0; pass < 4; pass++) {
+            ArrayLoader<uint32_t> al = {kbuf[pass & 1], vbuf[pass & 1], nullptr, count};
+            GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ex, al, al, count, 8 * pass, pass, kbuf[(pass + 1) & 1],
+                                                                     vbuf[(pass + 1) & 1])));
+        }
+        hipLaunchKernelGGL(k_perm_from_sorted, g, b, 0, st, vbuf[0], count, from, m->perm.as<uint32_t>(), m->inv_perm.as<uint32_t>());
+        perm = m->perm.as<uint32_t>();
+    }
+    const size_t off_rgba = (off_sh + b_sh + 255) & ~(size_t)255;
+    GS_HIP(hipMemcpyAsync(stg + off_rgba, rgba, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_scatter_u32, g, b, 0, st, (const uint32_t*)(stg + off_rgba), count, from, perm, m->rgba.as<uint32_t>());
+    hipLaunchKernelGGL(k_split_centers, g, b, 0, st, (const float*)stg, count, from, perm, m->px.as<float>(), m->py.as<float>(),
                        m->pz.as<float>());
     if (half)
-        hipLaunchKernelGGL(k_split_cov_f16, g, b, 0, st, (const uint16_t*)(stg + off_cov), count, from, m->covA.as<uint2>(),
+        hipLaunchKernelGGL(k_split_cov_f16, g, b, 0, st, (const uint16_t*)(stg + off_cov), count, from, perm, m->covA.as<uint2>(),
                            m->covB.as<uint32_t>());
     else
-        hipLaunchKernelGGL(k_split_cov_f32, g, b, 0, st, (const float*)(stg + off_cov), count, from, m->covA.as<float4>(),
+        hipLaunchKernelGGL(k_split_cov_f32, g, b, 0, st, (const float*)(stg + off_cov), count, from, perm, m->covA.as<float4>(),
                            m->covB.as<float2>());
     if (ncoef)
-        hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, ncoef, m->sh0.as<uint4>(),
+        hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, perm, ncoef, m->sh0.as<uint4>(),
                            m->sh1.p, m->sh2.as<uint4>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipStreamSynchronize(st));
@@ -230,8 +332,8 @@ int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_
     const uint32_t ncoef = m->sh_degree == 1 ? 9 : 24;
     GS_TRY(m->staging.ensure((size_t)count * ncoef + 256));
     GS_HIP(hipMemcpyAsync(m->staging.p, sh_u8, (size_t)count * ncoef, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_split_sh_u8, dim3(up_grid(count)), dim3(256), 0, st, m->staging.as<uint8_t>(), count, from, ncoef,
-                       m->sh0.as<uint4>(), m->sh1.as<uint2>());
+    hipLaunchKernelGGL(k_split_sh_u8, dim3(up_grid(count)), dim3(256), 0, st, m->staging.as<uint8_t>(), count, from,
+                       m->reorder ? m->perm.as<uint32_t>() : nullptr, ncoef, m->sh0.as<uint4>(), m->sh1.as<uint2>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;
@@ -247,7 +349,13 @@ int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, cons
         GS_HIP(hipMemsetAsync(m->scene_idx.p, 0, (size_t)m->max_count * 4, st));
     }
     for (uint32_t i = 0; i < count; i++) GS_REQUIRE(scene_indexes[i] < GS_MAX_SCENES, "scene index >= GS_MAX_SCENES");
-    if (count) GS_HIP(hipMemcpyAsync(m->scene_idx.as<uint32_t>() + from, scene_indexes, (size_t)count * 4, hipMemcpyHostToDevice, st));
+    if (count) {
+        GS_TRY(m->staging.ensure((size_t)count * 4));
+        GS_HIP(hipMemcpyAsync(m->staging.p, scene_indexes, (size_t)count * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scatter_u32, dim3(up_grid(count)), dim3(256), 0, st, m->staging.as<uint32_t>(), count, from,
+                           m->reorder ? m->perm.as<uint32_t>() : nullptr, m->scene_idx.as<uint32_t>());
+        GS_HIP(hipGetLastError());
+    }
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;
 }
@@ -323,6 +431,8 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
     if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
     GS_HIP(hipEventRecord(m->ev[1], st));
+    // the index list is in the caller's splat numbering unless it comes from a sorter bound to this mesh
+    m->translate = m->reorder && !(sorter && sorter->result_mesh == m);
     GS_TRY(gs_launch_binning(m, pp, order_dev, sorter, R));   // records ev[2] between emit and the tile sort
     GS_HIP(hipEventRecord(m->ev[3], st));
     GS_TRY(gs_launch_blend(m, pp, out_dev));
@@ -489,21 +599,22 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     GS_REQUIRE(m->has_draw && (what >= 2 || count <= m->last_count), "no draw / count too large");
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
-    if (what == 0 || what == 1) {
+    if (what == 0 || what == 1 || what == 3) {
         if (count == 0) return GS_OK;
-        const size_t bytes = (size_t)count * (what == 0 ? sizeof(SplatRec) : 8);
-        GS_TRY(m->staging.ensure(bytes));
-        hipLaunchKernelGGL(k_debug_expand, dim3((count + 255u) / 256u), dim3(256), 0, st, m->vis_mask.as<unsigned long long>(), count,
-                           m->recs.as<uint4>(), m->rects.as<uint2>(), what == 0 ? m->staging.as<uint4>() : nullptr,
-                           what == 1 ? m->staging.as<uint2>() : nullptr);
+        const uint32_t splats = what == 3 ? (count * 64u < m->last_count ? count * 64u : m->last_count) : count;
+        const size_t bytes = what == 3 ? (size_t)count * 8 : (size_t)count * (what == 0 ? sizeof(SplatRec) : 8);
+        GS_REQUIRE(what != 3 || (size_t)count * 8 <= m->vis_mask.bytes, "count exceeds the mask length");
+        GS_TRY(m->staging.ensure(bytes + 64));
+        if (what == 3) GS_HIP(hipMemsetAsync(m->staging.p, 0, bytes, st));
+        hipLaunchKernelGGL(k_debug_expand, dim3((splats + 255u) / 256u), dim3(256), 0, st, m->vis_mask.as<unsigned long long>(), splats,
+                           m->reorder ? m->perm.as<uint32_t>() : nullptr, m->recs.as<uint4>(), m->rects.as<uint2>(),
+                           what == 0 ? m->staging.as<uint4>() : nullptr, what == 1 ? m->staging.as<uint2>() : nullptr,
+                           what == 3 ? m->staging.as<unsigned long long>() : nullptr);
         GS_HIP(hipGetLastError());
         GS_HIP(hipMemcpyAsync(dst, m->staging.p, bytes, hipMemcpyDeviceToHost, st));
     } else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
         GS_REQUIRE((size_t)count * 8 <= m->tile_ranges.bytes, "count exceeds the tile count of the last draw");
         GS_HIP(hipMemcpyAsync(dst, m->tile_ranges.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
-    } else if (what == 3) {   // visibility mask of the last draw, count = number of 64-bit words
-        GS_REQUIRE((size_t)count * 8 <= m->vis_mask.bytes, "count exceeds the mask length");
-        GS_HIP(hipMemcpyAsync(dst, m->vis_mask.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
 struct DepthLoader {
     const int32_t* __restrict__ keys;
     const uint32_t* __restrict__ idx;      // nullable: identity
+    const uint32_t* __restrict__ map;      // nullable: payload = map[splat index] (a bound mesh's internal position)
     SortFrame* frame;
     uint32_t sort_start, render_count, range;
     uint32_t count_clamps;                 // only the histogram launch counts, so each element counts once
@@ -201,12 +202,22 @@ struct DepthLoader {
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (range - 1) - bucket(render_count - 1 - j); }
     __device__ __forceinline__ uint32_t val(uint32_t j) const {
         const uint32_t i = render_count - 1 - j;
-        return idx ? idx[i] : i;
+        const uint32_t o = idx ? idx[i] : i;
+        return map ? map[o] : o;
     }
 };
 
-__global__ void k_copy_head(const uint32_t* __restrict__ idx, uint32_t* __restrict__ out, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = idx ? idx[i] : i;
+__global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ map, uint32_t* __restrict__ out,
+                            uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t o = idx ? idx[i] : i;
+        out[i] = map ? map[o] : o;
+    }
+}
+
+__global__ void k_unmap(const uint32_t* __restrict__ in, const uint32_t* __restrict__ unmap, uint32_t* __restrict__ out,
+                        uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = unmap[in[i]];
 }
 
 __global__ void k_debug_buckets(DepthLoader ld, int32_t* out) {
@@ -332,6 +343,14 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     hipStream_t st = s->stream;
     const uint32_t R = render_count, Rs = sort_count, sort_start = R - Rs;
     const RadixExec ex = {st, &s->radix, ctx->lds_atomic_lane_order};
+    // a bound mesh stores its splats in its own (Morton) order: hand it positions in that order
+    if (s->bound_mesh) {                           // the mesh may have been destroyed since the bind
+        bool alive = false;
+        for (gs_mesh* m : ctx->live_meshes) alive = alive || (m == s->bound_mesh);
+        if (!alive) s->bound_mesh = nullptr;
+    }
+    const uint32_t* map = s->bound_mesh ? gs_mesh_payload_map(s->bound_mesh, s->uploaded) : nullptr;
+    const uint32_t* unmap = map ? gs_mesh_payload_unmap(s->bound_mesh) : nullptr;
     if (s->consumer_pending) {           // a draw enqueued on ctx->stream still reads the previous result
         GS_HIP(hipStreamWaitEvent(st, s->ev_consumed, 0));
         s->consumer_pending = false;
@@ -397,6 +416,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         DepthLoader dl = {};
         dl.keys = s->keys.as<int32_t>();
         dl.idx = idx_dev;
+        dl.map = map;
         dl.frame = s->frame.as<SortFrame>();
         dl.sort_start = sort_start;
         dl.render_count = R;
@@ -427,7 +447,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         }
     }
     if (sort_start > 0) {
-        hipLaunchKernelGGL(k_copy_head, dim3(grid_for(sort_start, 1024, 2048)), dim3(256), 0, st, idx_dev,
+        hipLaunchKernelGGL(k_copy_head, dim3(grid_for(sort_start, 1024, 2048)), dim3(256), 0, st, idx_dev, map,
                            s->sorted.as<uint32_t>(), sort_start);
     }
     GS_HIP(hipGetLastError());
@@ -436,11 +456,21 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     s->last_sort = Rs;
     s->last_passes = passes;
     s->last_identity = (idx_dev == nullptr);
+    s->result_mesh = map ? s->bound_mesh : nullptr;
+    s->result_unmap = unmap;
     s->has_result = true;
 
     int status = GS_OK;
     if (sorted_out && R) {
-        GS_HIP(hipMemcpyAsync(sorted_out, s->sorted.p, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+        const void* src = s->sorted.p;
+        if (unmap) {                               // the host always sees the caller's splat indexes
+            GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
+            hipLaunchKernelGGL(k_unmap, dim3(grid_for(R, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(), unmap,
+                               s->debug.as<uint32_t>(), R);
+            GS_HIP(hipGetLastError());
+            src = s->debug.p;
+        }
+        GS_HIP(hipMemcpyAsync(sorted_out, src, (size_t)R * 4, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
     }
     if (stats) status = sorter_collect_stats(s, stats);
@@ -462,6 +492,13 @@ int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count,
     return sorter_sort_impl(s, mvp, nullptr, true, sort_count, s->gathered, precomputed, transforms, sorted_out, stats);
 }
 
+int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m) {
+    GS_REQUIRE(s != nullptr, "sorter == NULL");
+    GS_REQUIRE(!m || m->ctx == s->ctx, "mesh lives on another context");
+    s->bound_mesh = m;
+    return GS_OK;
+}
+
 int gs_sorter_last_stats(gs_sorter* s, gs_sort_stats* stats) {
     GS_REQUIRE(s && stats, "sorter / stats == NULL");
     GS_REQUIRE(s->has_result, "no sort has run");
@@ -477,7 +514,18 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
     hipStream_t st = s->stream;
     const void* src = nullptr;
     if (what == 0) src = s->keys.p;
-    else if (what == 2) src = s->sorted.p;
+    else if (what == 2) {
+        src = s->sorted.p;
+        bool alive = false;
+        for (gs_mesh* m : s->ctx->live_meshes) alive = alive || (m == s->result_mesh);
+        if (alive && s->result_unmap && count) {
+            GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
+            hipLaunchKernelGGL(k_unmap, dim3(grid_for(count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(),
+                               s->result_unmap, s->debug.as<uint32_t>(), count);
+            GS_HIP(hipGetLastError());
+            src = s->debug.p;
+        }
+    }
     else if (what == 1) {
         GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
         DepthLoader dl = {};

@@ -68,6 +68,7 @@ __global__ void k_render_frame_init(RenderFrame* f, uint32_t* digit_total, uint2
 // rect gathers are in flight together (the kernel is a chain of dependent memory round trips), and one packed
 // 64-bit block scan per 1024 positions yields both the compaction slot and the entry offset.
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R,
+                                                           const uint32_t* __restrict__ perm,
                                                            const unsigned long long* __restrict__ vis_mask,
                                                            const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
@@ -90,6 +91,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
             keep[k] = q < pos_end;
             const uint32_t p = R - 1u - min(q, R - 1u);    // draw order is back-to-front; we go front-to-back
             idx[k] = order ? order[p] : p;
+        }
+        if (perm) {                                        // caller's splat index -> internal (Morton) position
+#pragma unroll
+            for (int k = 0; k < 4; k++) idx[k] = perm[idx[k]];
         }
         // k_project compacts survivors inside their 256-splat block: slot = block base + visible splats before idx,
         // recomputed here from the block's 4 mask words (one aligned 32-byte sector of an L2-resident array)
@@ -323,7 +328,8 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const uint32_t cap = m->entry_capacity;
     const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
     const uint32_t bin_per = (batches + grid - 1) / grid;               // must match bin_chunk()
-    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, m->vis_mask.as<unsigned long long>(),
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R,
+                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis_mask.as<unsigned long long>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>());
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on

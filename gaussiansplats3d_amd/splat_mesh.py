@@ -113,6 +113,10 @@ class SplatMesh:
 
     def use_sorter_result(self, sort_worker, render_splat_count):
         """Device-resident alternative: draw the result the sort worker left in HBM."""
+        if sort_worker is not None and getattr(sort_worker, "_bound_mesh", None) is not self:
+            # from its next sort on, the worker hands over positions in this mesh's storage order (no per-frame translation)
+            L.check(self.lib.gs_sorter_bind_mesh(sort_worker.handle, self.handle))
+            sort_worker._bound_mesh = self
         self._sorter = sort_worker
         self._indexes = None
         self.render_count = int(render_splat_count)

@@ -101,6 +101,11 @@ int gs_sorter_sort(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_so
 int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count, const void* precomputed,
                             const float* transforms, uint32_t* sorted_out, gs_sort_stats* stats);
 
+/* Optional coupling of the two seams: a sorter bound to a mesh leaves its device-resident result as positions in
+ * that mesh's internal storage order, so gs_mesh_render(m, ..., sorter = s, ...) needs no per-frame index translation.
+ * Host-visible results (sorted_out, gs_sorter_debug_read) are always the caller's splat indexes.  m = NULL unbinds. */
+int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m);
+
 /* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
  * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted. */
 int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count);
@@ -178,6 +183,8 @@ int gs_asset_fill(gs_asset* a, uint32_t min_alpha, float* centers, float* cov_f3
  * RENDER SEAM
  * ------------------------------------------------------------------------------------------------ */
 #define GS_MESH_COV_HALF 1u   /* halfPrecisionCovariancesOnGPU (SplatMesh.js:667-670,735-739)                 */
+#define GS_MESH_KEEP_ORDER 4u /* keep splats in upload order on the device (default: each upload is re-ordered along a
+                                 Morton curve internally; indexes at this ABI are always the caller's)            */
 #define GS_MESH_SH_U8 2u      /* SH stored as uint8 (compression level 2, SplatMesh.js:680-684,789,1064-1066):
                                  sphericalHarmonics8BitMode, dequantised per scene as v/255*(max-min)+min      */
 #define GS_SH_F16 0u          /* SH as fp16 (compression level <= 1, SplatMesh.js:1064-1066)                  */

@@ -39,11 +39,12 @@ def frame_algorithmic_bytes(R, Rs, D16, P, sh_degree, cov_half, precision=16):
 
 
 def project_algorithmic_bytes(N, visible, sh_degree, cov_half):
-    """k_project (the dominant kernel), bytes it has to move per launch: every splat's centre 12 + covariance 24 (12 as
-    fp16) + rgba 4 + SH S is read once; every SURVIVOR's 32-byte record + 8-byte tile rect is written once; 1 mask bit
-    per splat."""
-    read = (12 + (12 if cov_half else 24) + 4 + SH_BYTES[sh_degree]) * N
-    return read + 40 * visible + N // 8
+    """k_project (the largest HBM-bound kernel), bytes it HAS to move per launch: every splat's centre (12 B) is read to
+    decide visibility; covariance 24 (12 as fp16) + rgba 4 + SH S are needed only for the splats that survive, each of
+    which writes a 32-byte record + 8-byte tile rect; 1 mask bit per splat.  Bytes fetched for culled
+    splats that share a wave with a survivor are waste, not algorithmic bytes."""
+    per_visible = (12 if cov_half else 24) + 4 + SH_BYTES[sh_degree] + 40
+    return 12 * N + per_visible * visible + N // 8
 
 
 def pmc_traffic(kernel):

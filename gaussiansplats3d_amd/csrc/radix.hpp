@@ -153,22 +153,24 @@ static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* _
                                                               const uint32_t* __restrict__ digit_total, uint32_t grid) {
     __shared__ uint32_t s_tmp[4];
     const uint32_t d = blockIdx.x, tid = threadIdx.x;
-    uint32_t mine = 0;
-    if (tid < d) {
-#pragma unroll
-        for (int r = 0; r < RADIX_REPLICAS; r++) mine += digit_total[r * RADIX_BINS + tid];
-    }
-    uint32_t below = 0;
-    (void)block_excl_scan_256(mine, s_tmp, &below);
+    // every load of this kernel is issued before the first barrier: one memory round trip instead of two
     const uint32_t per = (grid + RADIX_THREADS - 1) / RADIX_THREADS;   // <= 8
     uint32_t v[RADIX_MAX_BLOCKS / RADIX_THREADS];
-    uint32_t sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
         const uint32_t i = tid * per + k;
         v[k] = (k < per && i < grid) ? block_hist[(size_t)i * RADIX_BINS + d] : 0u;
-        sum += v[k];
     }
+    uint32_t rep[RADIX_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < RADIX_REPLICAS; r++) rep[r] = tid < d ? digit_total[r * RADIX_BINS + tid] : 0u;
+    uint32_t mine = 0, sum = 0;
+#pragma unroll
+    for (int r = 0; r < RADIX_REPLICAS; r++) mine += rep[r];
+#pragma unroll
+    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) sum += v[k];
+    uint32_t below = 0;
+    (void)block_excl_scan_256(mine, s_tmp, &below);
     uint32_t run = below + block_excl_scan_256(sum, s_tmp, nullptr);
 #pragma unroll
     for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {

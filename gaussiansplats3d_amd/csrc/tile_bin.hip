@@ -19,6 +19,9 @@
 #include "radix.hpp"
 
 constexpr int BIN_THREADS = 256;
+#ifndef BIN_PER_LANE
+#define BIN_PER_LANE 4
+#endif
 constexpr int BIN_MAX_BLOCKS = 2048;                      // 8 workgroups of 256 per CU: full wave occupancy
 
 // vertex-stage rects are in 16-px tiles; the entry lists are per 32-px bin (2x2 tiles)
@@ -80,13 +83,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     uint32_t sum = 0;                                      // entries emitted so far by this workgroup
     uint32_t out = pos_begin;                              // next slot of this workgroup's compacted slice
     uint32_t t16 = 0;                                      // 16-px tiles touched by this lane's splats (statistics only)
-    for (uint32_t pos0 = pos_begin; pos0 < pos_end; pos0 += 4 * BIN_THREADS) {
-        const uint32_t q0 = pos0 + 4u * threadIdx.x;
-        uint32_t idx[4];
-        bool keep[4];
-        uint2 r[4];
+    for (uint32_t pos0 = pos_begin; pos0 < pos_end; pos0 += BIN_PER_LANE * BIN_THREADS) {
+        const uint32_t q0 = pos0 + (uint32_t)BIN_PER_LANE * threadIdx.x;
+        uint32_t idx[BIN_PER_LANE];
+        bool keep[BIN_PER_LANE];
+        uint2 r[BIN_PER_LANE];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < BIN_PER_LANE; k++) {
             const uint32_t q = q0 + k;
             keep[k] = q < pos_end;
             const uint32_t p = R - 1u - min(q, R - 1u);    // draw order is back-to-front; we go front-to-back
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         }
         if (perm) {                                        // caller's splat index -> internal (Morton) position
 #pragma unroll
-            for (int k = 0; k < 4; k++) idx[k] = perm[idx[k]];
+            for (int k = 0; k < BIN_PER_LANE; k++) idx[k] = perm[idx[k]];
         }
         // k_project compacts survivors inside their 256-splat block: slot = block base + visible splats before idx,
         // recomputed here from the block's 4 mask words (one aligned 32-byte sector of an L2-resident array)
-        uint32_t slot[4];
+        uint32_t slot[BIN_PER_LANE];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < BIN_PER_LANE; k++) {
             const ulonglong4 mw = *reinterpret_cast<const ulonglong4*>(vis_mask + ((idx[k] >> 8) << 2));
             const uint32_t w = (idx[k] >> 6) & 3u, bit = idx[k] & 63u;
             const unsigned long long mine = w == 0 ? mw.x : (w == 1 ? mw.y : (w == 2 ? mw.z : mw.w));
@@ -110,12 +113,12 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
                       (w > 2 ? (uint32_t)__popcll(mw.z) : 0u);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
+        for (int k = 0; k < BIN_PER_LANE; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
 #pragma unroll
-        for (int k = 0; k < 4; k++) t16 += rect_tiles(r[k]);
-        uint32_t n[4], cnt = 0, ent = 0;
+        for (int k = 0; k < BIN_PER_LANE; k++) t16 += rect_tiles(r[k]);
+        uint32_t n[BIN_PER_LANE], cnt = 0, ent = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < BIN_PER_LANE; k++) {
             n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k])) : 0u;   // entries = 32-px bins touched
             cnt += keep[k] ? 1u : 0u;
             ent += n[k];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         uint32_t o = out + (uint32_t)(excl >> 32);
         uint32_t e = sum + (uint32_t)excl;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < BIN_PER_LANE; k++) {
             if (keep[k]) {
                 cidx[o] = slot[k];                         // what the blend gathers records by
                 crect[o] = r[k];

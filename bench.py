@@ -56,6 +56,8 @@ def pmc_traffic(kernel):
     try:
         d = json.load(open(files[-1]))
         k = d["kernels"].get(kernel)
+        if k is None:                                           # template instances: "k_project<false>"
+            k = next((v for name, v in sorted(d["kernels"].items()) if name.split("<")[0] == kernel), None)
         return (int(k["hbm_bytes_per_launch"]) if k else None), os.path.basename(files[-1])
     except Exception:
         return None, None

@@ -16,7 +16,8 @@
 // packed into the entry, and every wave
 // walks only its own survivors of the batch (4 ballots + s_ff1 per 256 entries).  Each lane owns 4 pixels
 // (x = lane&15, y = (lane>>4) + 4g); the inner loop reads a splat as three wave-uniform ds_read_b128 broadcasts,
-// rejects whole 16x4 strips with scalar tests, and spends ~14 VALU ops per pixel.
+// and runs the four 16x4 strips of a lane as independent, branch-free chains (~17 VALU ops per pixel; the kernel's duration is the
+// dependent chain of the heaviest quadrant, so ILP matters more than skipped work).
 #include "gs_internal.hpp"
 
 constexpr float GS_POWER_CUT = 5.7707801636f;    // 4*log2(e)  <=>  A > 8
@@ -63,7 +64,6 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
     const uint32_t py0 = qy0 + (lane >> 4);
     const float fx = (float)px + 0.5f;
     const float fy0 = (float)py0 + 0.5f;
-    const float strip_lo = (float)qy0 + 0.5f;                   // first pixel-centre row of strip 0
 
     const uint2 range = ranges[bin];
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
@@ -114,9 +114,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
                     const float adx = q0.z * dx, bdx = q1.x * dx;
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
-                        // wave-uniform: does the ellipse reach this 16x4 strip at all?
-                        const float s_lo = strip_lo + (float)(4 * g), s_hi = s_lo + 3.0f;
-                        if (q1.w < s_lo || q1.z > s_hi) continue;
+                        // no per-strip bounds test: a wave-uniform branch per strip serialises the four independent strips
+                        // (blend 0.137 -> 0.117 ms without it); outside the ellipse the discard select yields alpha = 0
                         const float dy = (fy0 + (float)(4 * g)) - q0.y;
                         const float u = fmaf(q0.w, dy, adx);
                         const float w = fmaf(q1.y, dy, bdx);

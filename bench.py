@@ -113,11 +113,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # GS_BENCH_BACKEND=gloo + fewer GPUs than ranks: dry run of the N > 1 path on a 1-GPU box (ranks share the device)
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = scenes.CONFIGS[args.config]
     W, H = cfg["width"], cfg["height"]
@@ -177,7 +183,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         proj_ms_sum, proj_launches = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream

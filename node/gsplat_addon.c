@@ -244,12 +244,142 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* sorterBindMesh(sorter, mesh|null) */
+static napi_value SorterBindMesh(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    int st = gs_sorter_bind_mesh((gs_sorter*)get_external(env, argv[0]), (gs_mesh*)get_external(env, argv[1]));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* sorterSortGathered(sorter, mvp Float32Array(16), sortCount, out Uint32Array|null) -> {status, sortTime} */
+static napi_value SorterSortGathered(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    void *mvp, *out;
+    size_t mb, ob;
+    if (!get_bytes(env, argv[1], &mvp, &mb) || mb < 64 || !get_bytes(env, argv[3], &out, &ob)) {
+        napi_throw_type_error(env, NULL, "sorterSortGathered: bad buffer argument");
+        return NULL;
+    }
+    gs_sort_stats stats;
+    memset(&stats, 0, sizeof stats);
+    int st = gs_sorter_sort_gathered((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, get_u32(env, argv[2]), NULL, NULL,
+                                     (uint32_t*)out, out ? &stats : NULL);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_object(env, &r));
+    set(env, r, "status", st);
+    set(env, r, "sortTime", stats.device_ms);
+    return r;
+}
+
+/* treeCreate(ctx|null, centers Float32Array(3n), keep Uint8Array|null, count, firstIndex, maxDepth, maxCentersPerNode) */
+static napi_value TreeCreate(napi_env env, napi_callback_info info) {
+    ARGS(7)
+    void *c, *k;
+    size_t cb, kb;
+    if (!get_bytes(env, argv[1], &c, &cb) || !get_bytes(env, argv[2], &k, &kb)) { napi_throw_type_error(env, NULL, "treeCreate: bad buffer"); return NULL; }
+    const uint32_t count = get_u32(env, argv[3]);
+    if (cb < (size_t)count * 12 || (k && kb < count)) { napi_throw_range_error(env, NULL, "treeCreate: buffer shorter than count"); return NULL; }
+    gs_tree* t = NULL;
+    int st = gs_tree_create((gs_context*)get_external(env, argv[0]), (const float*)c, (const uint8_t*)k, count, get_u32(env, argv[4]),
+                            get_u32(env, argv[5]), get_u32(env, argv[6]), &t);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_external(env, t, NULL, NULL, &r));
+    return r;
+}
+static napi_value TreeDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_tree_destroy((gs_tree*)get_external(env, argv[0]));
+    return NULL;
+}
+/* treeInfo(tree) -> {leaves, allLeaves, nodes, splats} */
+static napi_value TreeInfo(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_tree_info ti;
+    int st = gs_tree_get_info((gs_tree*)get_external(env, argv[0]), &ti);
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_object(env, &r));
+    set(env, r, "leaves", ti.leaves);
+    set(env, r, "allLeaves", ti.all_leaves);
+    set(env, r, "nodes", ti.nodes);
+    set(env, r, "splats", ti.splats);
+    return r;
+}
+/* treeGather(tree, modelView Float64Array(16), fovYDeg, renderWidth, renderHeight, gatherAll, sorter|null,
+ *            out Uint32Array|null) -> splatRenderCount */
+static napi_value TreeGather(napi_env env, napi_callback_info info) {
+    ARGS(8)
+    gs_gather_params gp;
+    memset(&gp, 0, sizeof gp);
+    void *mv, *out;
+    size_t mb, ob;
+    if (!get_bytes(env, argv[1], &mv, &mb) || mb < 128 || !get_bytes(env, argv[7], &out, &ob)) {
+        napi_throw_type_error(env, NULL, "treeGather: modelView must be a Float64Array(16)");
+        return NULL;
+    }
+    memcpy(gp.model_view, mv, 128);
+    gp.fov_y_deg = get_f64(env, argv[2]);
+    gp.render_width = get_f64(env, argv[3]);
+    gp.render_height = get_f64(env, argv[4]);
+    gp.gather_all = get_u32(env, argv[5]);
+    gs_tree_info ti;
+    gs_tree* t = (gs_tree*)get_external(env, argv[0]);
+    if (gs_tree_get_info(t, &ti) < 0) return throw_gs(env, GS_ERR_INVALID);
+    if (out && ob < (size_t)ti.splats * 4) { napi_throw_range_error(env, NULL, "treeGather: out shorter than the tree's splat count"); return NULL; }
+    uint32_t render_count = 0;
+    int st = gs_tree_gather(t, &gp, (gs_sorter*)get_external(env, argv[6]), &render_count, (uint32_t*)out);
+    if (st < 0) return throw_gs(env, st);
+    return num(env, render_count);
+}
+
+/* assetLoad(bytes ArrayBuffer|Uint8Array, format 1=ply 2=ksplat, maxShDegree, minAlpha, halfCov)
+ *   -> {splatCount, shDegree, compressionLevel, shLevel, shMin, shMax, centers F32, cov F32|U16, rgba U8, sh U16|U8|null} */
+static napi_value AssetLoad(napi_env env, napi_callback_info info) {
+    ARGS(5)
+    void* data;
+    size_t nb;
+    if (!get_bytes(env, argv[0], &data, &nb) || !data) { napi_throw_type_error(env, NULL, "assetLoad: bytes"); return NULL; }
+    gs_asset* a = NULL;
+    int st = gs_asset_open(data, nb, get_u32(env, argv[1]), get_u32(env, argv[2]), &a);
+    if (st < 0) return throw_gs(env, st);
+    gs_asset_info ai;
+    gs_asset_get_info(a, &ai);
+    const uint32_t n = ai.splat_count, ncoef = ai.sh_degree == 0 ? 0 : (ai.sh_degree == 1 ? 9 : 24);
+    const uint32_t half = get_u32(env, argv[4]);
+    napi_value r, ab, ta;
+    void *centers, *cov, *rgba, *sh = NULL;
+    NAPI_OK(napi_create_object(env, &r));
+#define NEWARR(key, type, elems, esize, ptr)                                                       NAPI_OK(napi_create_arraybuffer(env, (size_t)(elems) * (esize), &ptr, &ab));                   NAPI_OK(napi_create_typedarray(env, type, (size_t)(elems), ab, 0, &ta));                        napi_set_named_property(env, r, key, ta);
+    NEWARR("centers", napi_float32_array, (size_t)n * 3, 4, centers)
+    if (half) { NEWARR("cov", napi_uint16_array, (size_t)n * 6, 2, cov) } else { NEWARR("cov", napi_float32_array, (size_t)n * 6, 4, cov) }
+    NEWARR("rgba", napi_uint8_array, (size_t)n * 4, 1, rgba)
+    if (ncoef) {
+        if (ai.sh_level == 2) { NEWARR("sh", napi_uint8_array, (size_t)n * ncoef, 1, sh) } else { NEWARR("sh", napi_uint16_array, (size_t)n * ncoef, 2, sh) }
+    }
+    st = gs_asset_fill(a, get_u32(env, argv[3]), (float*)centers, half ? NULL : (float*)cov, half ? (uint16_t*)cov : NULL, (uint8_t*)rgba,
+                       (ncoef && ai.sh_level != 2) ? (uint16_t*)sh : NULL, (ncoef && ai.sh_level == 2) ? (uint8_t*)sh : NULL, NULL, NULL);
+    gs_asset_close(a);
+    if (st < 0) return throw_gs(env, st);
+    set(env, r, "splatCount", n);
+    set(env, r, "shDegree", ai.sh_degree);
+    set(env, r, "compressionLevel", ai.compression_level);
+    set(env, r, "shLevel", ai.sh_level);
+    set(env, r, "shMin", ai.sh_min);
+    set(env, r, "shMax", ai.sh_max);
+    return r;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount},       {"contextCreate", ContextCreate}, {"contextDestroy", ContextDestroy},
         {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},
         {"sorterSort", SorterSort},         {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
         {"meshUpload", MeshUpload},         {"meshRender", MeshRender},
+        {"sorterBindMesh", SorterBindMesh}, {"sorterSortGathered", SorterSortGathered},
+        {"treeCreate", TreeCreate},         {"treeDestroy", TreeDestroy},     {"treeInfo", TreeInfo},
+        {"treeGather", TreeGather},         {"assetLoad", AssetLoad},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -74,3 +74,49 @@ def test_sort_through_the_js_protocol_is_bit_exact(tmp_path, name, mode):
     assert res.returncode == 0, res.stderr
     got = np.fromfile(outp, dtype=np.uint32)
     assert kat_cases.digest(got) == meta["output"]
+
+
+def test_tree_and_asset_bindings_on_the_host(tmp_path):
+    """treeCreate (host-only tree, ctx = null) and assetLoad through Node: same answers as the Python mirrors."""
+    _built()
+    import tree_cases
+    import asset_cases
+    from gaussiansplats3d_amd import assets
+    case = tree_cases.make_case("clusters40k")
+    cpath = str(tmp_path / "c.f32")
+    case["centers"].astype(np.float32).tofile(cpath)
+    out = subprocess.check_output(["node", "tree_asset_via_js.js", "tree", cpath, str(case["max_depth"]), str(case["max_centers"])],
+                                  cwd=NODE_DIR, text=True)
+    info = json.loads(out.strip().splitlines()[-1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tree_kat.json")))["clusters40k"]
+    assert (info["leaves"], info["allLeaves"], info["splats"]) == (gold["leaves"], gold["all_leaves"], gold["splats"])
+    data, _ = asset_cases.make_case("sh2_45")
+    ppath, opath = str(tmp_path / "a.ply"), str(tmp_path / "a.bin")
+    open(ppath, "wb").write(data)
+    meta = json.loads(subprocess.check_output(["node", "tree_asset_via_js.js", "asset", ppath, "1", "2", opath],
+                                              cwd=NODE_DIR, text=True).strip().splitlines()[-1])
+    exp = assets.load(data, 2)
+    assert (meta["splatCount"], meta["shDegree"], meta["compressionLevel"], meta["shLevel"]) == (64, 2, 0, 1)
+    want = exp["centers"].tobytes() + exp["cov"].tobytes() + exp["rgba"].tobytes() + exp["sh_f16"].tobytes()
+    assert open(opath, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_tree_gather_through_node_matches_oracle(tmp_path):
+    _built()
+    import tree_cases
+    from oracle import tree_oracle
+    from gaussiansplats3d_amd import camera
+    case = tree_cases.make_case("clusters40k")
+    cam = camera.demo_camera("garden", 1920, 1080)
+    cpath, mpath, opath = str(tmp_path / "c.f32"), str(tmp_path / "mv.f64"), str(tmp_path / "o.u32")
+    case["centers"].astype(np.float32).tofile(cpath)
+    np.asarray(cam.view, np.float64).tofile(mpath)
+    res = subprocess.run(["node", "tree_asset_via_js.js", "tree", cpath, "8", "300", "gather", mpath, "1920", "1080", opath],
+                         cwd=NODE_DIR, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    leaves, _ = tree_oracle.build_tree(case["centers"], None, 8, 300)
+    expect = tree_oracle.gather(leaves, cam.view, 50.0, 1920, 1080)
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["renderCount"] == len(expect)
+    np.testing.assert_array_equal(np.fromfile(opath, dtype=np.uint32), expect)

@@ -113,3 +113,18 @@ def test_full_size_properties_and_oracle(ctx, n, precision):
     assert np.array_equal(np.bincount(got, minlength=n), np.ones(n, dtype=np.int64))
     np.testing.assert_array_equal(got, exp)
     w.terminate()
+
+
+def test_ballot_ranking_fallback_is_bit_exact(monkeypatch):
+    """The radix scatter ranks keys with LDS atomics only after a create-time self-test of their lane order; the portable
+    ballot path (forced here) must give the same answers."""
+    monkeypatch.setenv("GSPLAT_NO_LDS_ATOMIC_RANK", "1")
+    c = Context(0)
+    meta = json.load(open(os.path.join(GOLD, "sort_kat.json")))
+    for name in ("million", "permuted_partial", "float_p22"):
+        case = [k for k in kat_cases.CASES if k["name"] == name][0]
+        args = kat_cases.make_case(case)
+        w, reply = run_worker(c, args)
+        assert kat_cases.digest(reply["sortedIndexes"]) == meta[name]["output"]
+        w.terminate()
+    c.close()

@@ -155,7 +155,8 @@ struct gs_sorter {
     DevBuf keys;               // int32 depth key per list position (mappedDistances, phase A)
     DevBuf keyA, keyB, valA, valB;   // radix ping-pong
     DevBuf sorted;             // uint32 [render_count]: the sortDone payload, stays resident for the mesh
-    DevBuf frame;              // SortFrame
+    DevBuf frame;              // SortFrame [2]: the sort in flight uses one, its first kernel resets the other
+    uint32_t frame_index = 0;
     DevBuf scene_rows;         // per-scene key coefficients (dynamic mode)
     DevBuf debug;
     RadixScratch radix;
@@ -281,7 +282,6 @@ const uint32_t* gs_mesh_payload_map(gs_mesh* m, uint32_t splats);
 const uint32_t* gs_mesh_payload_unmap(gs_mesh* m);
 
 // kernels' host launchers ---------------------------------------------------------------------------
-int gs_launch_frame_init(gs_mesh* m, uint32_t tiles);
 int gs_launch_project(gs_mesh* m, const ProjectParams& pp);
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count);
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);

@@ -404,7 +404,6 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     const uint32_t tiles = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);     // entry lists are per 32-px bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     GS_HIP(hipEventRecord(m->ev[0], st));
-    GS_TRY(gs_launch_frame_init(m, tiles));
     // fork: the vertex stage only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
     // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed
     // the records / rects / mask it is about to overwrite

@@ -32,22 +32,13 @@ struct KeyParams {
     const uint32_t* precomputed;             // int32 or float bit patterns
     const SceneRows* rows;
     int32_t* keys_out;
-    SortFrame* frame;
+    SortFrame* frame;                        // min / max / clamp counter of THIS sort (pre-initialised, see below)
+    SortFrame* next_frame;                   // the other buffer: reset here for the next sort (no separate init kernel)
+    uint32_t* digit_total;                   // radix digit totals of this sort's passes: zeroed here, before any histogram
     uint32_t sort_start, render_count, mode;
     int32_t im0, im1, im2;                   // static path: (int)(mvp[k]*1000.0), k = 2,6,10
     float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
 };
-
-__global__ void k_sort_frame_init(SortFrame* f, uint32_t* digit_total) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        f->key_min = 2147483640;     // sorter.cpp:25
-        f->key_max = -2147483640;    // sorter.cpp:24
-        f->clamped = 0;
-        f->pad = 0;
-    }
-    if (t < RADIX_TOTAL_WORDS) digit_total[t] = 0;
-}
 
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
                                                      uint32_t* __restrict__ x, uint32_t* __restrict__ y,
@@ -101,6 +92,14 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    // housekeeping folded into the first kernel of a sort (two launches and their boundaries saved per sort)
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t == 0) {
+        p.next_frame->key_min = 2147483640;      // sorter.cpp:25
+        p.next_frame->key_max = -2147483640;     // sorter.cpp:24
+        p.next_frame->clamped = 0;
+        p.next_frame->pad = 0;
+    }
     if (VEC4) {
         // positions [a4*4, b4*4) are handled as vectors, the ragged head/tail as scalars by the first lanes
         const uint32_t a4 = (p.sort_start + 3u) / 4u, b4 = p.render_count / 4u;
@@ -256,12 +255,20 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
     A(s->cx, b4); A(s->cy, b4); A(s->cz, b4); A(s->caos, n * 16);
     if (flags & GS_SORT_DYNAMIC) { A(s->cw, b4); A(s->scene_idx, b4); A(s->scene_rows, sizeof(SceneRows)); }
     A(s->keys, b4); A(s->keyA, b4); A(s->keyB, b4); A(s->valA, b4); A(s->valB, b4); A(s->sorted, b4);
-    A(s->frame, sizeof(SortFrame));
+    A(s->frame, 2 * sizeof(SortFrame));
     if (st == GS_OK) st = s->radix.init();
     if (st == GS_OK && (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess ||
                         hipEventCreateWithFlags(&s->ev_consumed, hipEventDisableTiming) != hipSuccess)) {
         gs_set_error("hipEventCreate failed");
         st = GS_ERR_HIP;
+    }
+    if (st == GS_OK) {
+        const SortFrame init[2] = {{2147483640, -2147483640, 0, 0}, {2147483640, -2147483640, 0, 0}};
+        if (hipMemcpy(s->frame.p, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(s->radix.digit_total.p, 0, sizeof(uint32_t) * RADIX_TOTAL_WORDS) != hipSuccess) {
+            gs_set_error("initialising the sorter scratch failed");
+            st = GS_ERR_HIP;
+        }
     }
     if (st == GS_OK) {
         if (ctx->serial) {
@@ -316,10 +323,15 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
 
 static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     SortFrame f;
-    GS_HIP(hipMemcpyAsync(&f, s->frame.p, sizeof(f), hipMemcpyDeviceToHost, s->stream));
+    GS_HIP(hipMemcpyAsync(&f, s->frame.as<SortFrame>() + s->frame_index, sizeof(f), hipMemcpyDeviceToHost, s->stream));
     GS_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (s->last_sort == 0) {                       // nothing was keyed: the frame belongs to an earlier sort
+        f.key_min = 2147483640;
+        f.key_max = -2147483640;
+        f.clamped = 0;
+    }
     stats->device_ms = ms;
     stats->key_min = f.key_min;
     stats->key_max = f.key_max;
@@ -394,7 +406,10 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     kp.aos = s->caos.as<uint4>();
     kp.idx_in = idx_dev;
     kp.keys_out = s->keys.as<int32_t>();
-    kp.frame = s->frame.as<SortFrame>();
+    if (Rs > 0) s->frame_index ^= 1u;          // this sort's frame was reset by the previous sort's k_depth_key (or at create)
+    kp.frame = s->frame.as<SortFrame>() + s->frame_index;
+    kp.next_frame = s->frame.as<SortFrame>() + (s->frame_index ^ 1u);
+    kp.digit_total = s->radix.digit_total.as<uint32_t>();
     kp.sort_start = sort_start;
     kp.render_count = R;
     kp.im0 = trunc_f64_i32((double)mvp[2] * 1000.0);     // sorter.cpp:64
@@ -403,8 +418,6 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     kp.fm0 = mvp[2]; kp.fm1 = mvp[6]; kp.fm2 = mvp[10];
 
     GS_HIP(hipEventRecord(s->ev0, st));
-    hipLaunchKernelGGL(k_sort_frame_init, dim3(RADIX_TOTAL_WORDS / 256), dim3(256), 0, st, s->frame.as<SortFrame>(),
-                       s->radix.digit_total.as<uint32_t>());
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
@@ -417,7 +430,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         dl.keys = s->keys.as<int32_t>();
         dl.idx = idx_dev;
         dl.map = map;
-        dl.frame = s->frame.as<SortFrame>();
+        dl.frame = kp.frame;
         dl.sort_start = sort_start;
         dl.render_count = R;
         dl.range = 1u << s->precision;
@@ -530,7 +543,7 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
         GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
         DepthLoader dl = {};
         dl.keys = s->keys.as<int32_t>();
-        dl.frame = s->frame.as<SortFrame>();
+        dl.frame = s->frame.as<SortFrame>() + s->frame_index;
         dl.sort_start = s->last_render - s->last_sort;
         dl.render_count = s->last_render;
         dl.range = 1u << s->precision;

@@ -55,16 +55,6 @@ __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
     return c;
 }
 
-__global__ void k_render_frame_init(RenderFrame* f, uint32_t* digit_total, uint2* tile_ranges, uint32_t tiles) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        f->visible = 0; f->entries_lo = 0; f->entries_hi = 0; f->overflow = 0; f->entry_count = 0;
-        f->tiles16_lo = f->tiles16_hi = f->pad = 0;
-    }
-    if (t < RADIX_TOTAL_WORDS) digit_total[t] = 0;
-    for (uint32_t i = t; i < tiles; i += gridDim.x * blockDim.x) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
-}
-
 // block_sums layout: [0,BIN_MAX_BLOCKS) entries per workgroup | [BIN_MAX_BLOCKS, 2*BIN_MAX_BLOCKS) compacted (visible) splats per
 // workgroup | [2*BIN_MAX_BLOCKS, 3*BIN_MAX_BLOCKS) 16-px tiles touched (statistics)
 // Each lane owns 4 consecutive list positions per iteration, so 4 index loads, then 4 mask look-ups, then up to 4
@@ -169,8 +159,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 }
 
 // one workgroup of 1024 threads, two binning workgroups per thread: exclusive scan of the workgroup sums, 64-bit total
+// It also does the draw's housekeeping (no separate init kernel): digit totals of the entry sort zeroed, bin ranges
+// reset to (~0, 0), every RenderFrame field written.
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t grid, uint32_t capacity,
-                                                   RenderFrame* frame) {
+                                                   RenderFrame* frame, uint32_t* __restrict__ digit_total,
+                                                   uint2* __restrict__ tile_ranges, uint32_t tiles) {
+    for (uint32_t w = threadIdx.x; w < (uint32_t)RADIX_TOTAL_WORDS; w += 1024u) digit_total[w] = 0u;
+    for (uint32_t i = threadIdx.x; i < tiles; i += 1024u) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
     __shared__ unsigned long long s_wave[16];
     __shared__ uint32_t s_vis[16];
     __shared__ unsigned long long s_t16[16];
@@ -215,6 +210,7 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_
         frame->entries_hi = (uint32_t)(total >> 32);
         frame->overflow = total > capacity ? 1u : 0u;
         frame->entry_count = total > capacity ? capacity : (uint32_t)total;
+        frame->pad = 0;
     }
 }
 
@@ -339,7 +335,8 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
     }
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame,
+                       m->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles);
     uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;
@@ -364,13 +361,6 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                                                                      vbuf[(p + 1) & 1])));
     }
     m->sorted_buf = (passes & 1);            // which ping-pong buffer holds the tile-sorted entries
-    return GS_OK;
-}
-
-int gs_launch_frame_init(gs_mesh* m, uint32_t tiles) {
-    hipLaunchKernelGGL(k_render_frame_init, dim3(64), dim3(256), 0, m->ctx->stream, m->frame.as<RenderFrame>(),
-                       m->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles);
-    GS_HIP(hipGetLastError());
     return GS_OK;
 }
 

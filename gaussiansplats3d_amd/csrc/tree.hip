@@ -9,7 +9,7 @@
 //   gather  Viewer.gatherSceneNodesForSort (src/Viewer.js:1969-2077): per leaf, centre -> view space (three.js
 //           Vector3.applyMatrix4 / normalize, fp64, same operation order), keep unless outside fov-0.6 AND farther than
 //           its own diagonal, order kept leaves by distance, lay their index lists out far -> near.  The reference does
-//           this in JS on the main thread and memcpy's up to R indexes per sort; here it is three small kernels plus a
+//           this in JS on the main thread and memcpy's up to R indexes per sort; here it is a handful of small kernels plus a
 //           coalesced copy, and the list lands directly in the sorter's device buffer.
 // Built with -ffp-contract=off: every fp64 product and sum rounds once, like the JS engine's.
 #include <algorithm>
@@ -35,6 +35,7 @@ struct gs_tree {
     std::vector<uint32_t> indexes;
     // device mirror
     DevBuf d_center, d_size, d_begin, d_count, d_indexes;
+    DevBuf d_bucket;            // uint32 [hist 65536 | fill 65536 | start 65537]
     DevBuf d_key, d_cnt, d_rank, d_sorted_cnt, d_sorted_leaf, d_offset, d_total, d_out;
 };
 
@@ -115,14 +116,17 @@ struct GatherParams {
     uint32_t gather_all, leaves;
 };
 
+constexpr uint32_t TREE_BUCKETS = 1u << 16;
+// bucket of a distance key: top 16 bits of (float)key, monotonic in key; any bit pattern stays below TREE_BUCKETS
+__device__ __forceinline__ uint32_t tree_bucket(double key) { return __float_as_uint((float)key) >> 16; }
+
 // Viewer.js:2010-2035 for one leaf
 __global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double* __restrict__ center,
                                                    const double* __restrict__ size, const uint32_t* __restrict__ count,
                                                    double* __restrict__ key, uint32_t* __restrict__ cnt,
-                                                   uint32_t* __restrict__ rank) {
+                                                   uint32_t* __restrict__ bucket_hist) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= p.leaves) return;
-    (void)rank;
     const double x = center[3 * (size_t)i], y = center[3 * (size_t)i + 1], z = center[3 * (size_t)i + 2];
     const double* e = p.mv;
     // Vector3.applyMatrix4 (three r160)
@@ -143,100 +147,73 @@ __global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double*
     const double dot_xz = -xz_z, dot_yz = -yz_z;                           // forward.dot(v) = -v.z
     const bool out_y = dot_yz < p.thr_y, out_x = dot_xz < p.thr_x;
     const bool skip = !p.gather_all && ((out_x || out_y) && dist > size[i]);
-    key[i] = skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;      // +inf sorts behind every kept leaf
+    const double k = skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;   // +inf sorts behind every kept leaf
+    key[i] = k;
     cnt[i] = skip ? 0u : count[i];
+    if (!skip) atomicAdd(&bucket_hist[tree_bucket(k)], 1u);   // culled leaves take no part in the ranking (their count is 0)
 }
 
-// rank of leaf i in ascending (distance, leaf number) order: O(n^2) compares, n = a few 10^4 leaves.  Distances are
-// non-negative doubles (or +inf), so their bit patterns order like unsigned integers.  blockIdx.y splits the j range;
-// the partial counts land in rank[slice][leaf] and are summed by k_tree_place.
-constexpr uint32_t RANK_SPLIT = 64;
-constexpr uint32_t RANK_PER_THREAD = 4;
-// MODE 0: every key of the slice precedes every leaf of the block (j < i): a tie counts
-// MODE 1: every key follows (j > i): a tie does not count     MODE 2: slices overlap: ties are broken by leaf number
-// Keys are non-negative doubles or +inf, so their bit patterns order like unsigned integers.  64-bit compares run at a
-// fraction of the 32-bit rate here (measured: ~30 cycles per wave and key-leaf pair with v_cmp_f64), so the common path
-// compares the HIGH words only - one full-rate v_cmp + v_addc per pair - and a batch is redone exactly only when some
-// lane saw equal high words (distances within 2^-20 of each other, or a leaf meeting itself).
-template <int MODE>
-__device__ __forceinline__ uint32_t exact_before(unsigned long long kj, unsigned long long mine, uint32_t j, uint32_t i) {
-    if (MODE == 0) return kj <= mine ? 1u : 0u;
-    if (MODE == 1) return kj < mine ? 1u : 0u;
-    return (kj < mine || (kj == mine && j < i)) ? 1u : 0u;
-}
-
-template <int MODE>
-__device__ __forceinline__ void rank_slice(const unsigned long long* __restrict__ key, uint32_t j_begin, uint32_t j_end,
-                                           uint32_t i0, const unsigned long long (&mine)[RANK_PER_THREAD],
-                                           uint32_t (&r)[RANK_PER_THREAD]) {
-    constexpr uint32_t B = 16;                             // keys fetched per round with wave-uniform addresses (scalar loads)
-    uint32_t mine_hi[RANK_PER_THREAD];
+// Rank of leaf i in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2) (26 k leaves: ~0.15 ms);
+// instead the leaves are bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa
+// bits, i.e. 0.8 % wide buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number -
+// only against the members of its own bucket.  The result is the same total order; only the work is smaller.
+// one workgroup: exclusive scan of the bucket histogram (thread t owns 64 consecutive buckets)
+__global__ __launch_bounds__(1024) void k_tree_bucket_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t CH = TREE_BUCKETS / 1024u;
+    uint32_t v[CH], sum = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < RANK_PER_THREAD; k++) mine_hi[k] = (uint32_t)(mine[k] >> 32);
-    uint32_t j = j_begin;
-    for (; j + B <= j_end; j += B) {
-        unsigned long long kk[B];
-#pragma unroll
-        for (uint32_t u = 0; u < B; u++) kk[u] = key[j + u];
-        uint32_t fast[RANK_PER_THREAD] = {0, 0, 0, 0};
-        bool tie = false;
-#pragma unroll
-        for (uint32_t u = 0; u < B; u++) {
-            const uint32_t hi = (uint32_t)(kk[u] >> 32);
-#pragma unroll
-            for (uint32_t k = 0; k < RANK_PER_THREAD; k++) {
-                fast[k] += hi < mine_hi[k] ? 1u : 0u;
-                tie = tie || (hi == mine_hi[k]);
-            }
-        }
-        if (__any(tie)) {                                  // rare, wave-uniform: redo this batch exactly
-#pragma unroll
-            for (uint32_t k = 0; k < RANK_PER_THREAD; k++) fast[k] = 0;
-#pragma unroll
-            for (uint32_t u = 0; u < B; u++)
-#pragma unroll
-                for (uint32_t k = 0; k < RANK_PER_THREAD; k++) fast[k] += exact_before<MODE>(kk[u], mine[k], j + u, i0 + k);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < RANK_PER_THREAD; k++) r[k] += fast[k];
+    for (uint32_t k = 0; k < CH; k += 4) {
+        const uint4 q = *reinterpret_cast<const uint4*>(hist + tid * CH + k);
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        sum += q.x + q.y + q.z + q.w;
     }
-    for (; j < j_end; j++) {
-        const unsigned long long kj = key[j];
+    uint32_t incl = sum;
 #pragma unroll
-        for (uint32_t k = 0; k < RANK_PER_THREAD; k++) r[k] += exact_before<MODE>(kj, mine[k], j, i0 + k);
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
     }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < CH; k++) {
+        start[tid * CH + k] = run;
+        run += v[k];
+    }
+    if (tid == 1023u) start[TREE_BUCKETS] = run;
 }
 
-__global__ __launch_bounds__(256) void k_tree_rank(const unsigned long long* __restrict__ key, uint32_t n,
-                                                   uint32_t* __restrict__ rank) {
-    // every thread ranks RANK_PER_THREAD leaves against a slice of all keys
-    const uint32_t block_i0 = blockIdx.x * 256u * RANK_PER_THREAD, block_i1 = block_i0 + 256u * RANK_PER_THREAD;
-    const uint32_t i0 = block_i0 + threadIdx.x * RANK_PER_THREAD;
-    unsigned long long mine[RANK_PER_THREAD];
-    uint32_t r[RANK_PER_THREAD];
-#pragma unroll
-    for (uint32_t k = 0; k < RANK_PER_THREAD; k++) {
-        mine[k] = i0 + k < n ? key[i0 + k] : 0ull;
-        r[k] = 0;
-    }
-    const uint32_t per = (n + RANK_SPLIT - 1) / RANK_SPLIT;
-    const uint32_t j_begin = min(n, blockIdx.y * per), j_end = min(n, j_begin + per);
-    if (j_end <= block_i0) rank_slice<0>(key, j_begin, j_end, i0, mine, r);
-    else if (j_begin >= block_i1) rank_slice<1>(key, j_begin, j_end, i0, mine, r);
-    else rank_slice<2>(key, j_begin, j_end, i0, mine, r);
-#pragma unroll
-    for (uint32_t k = 0; k < RANK_PER_THREAD; k++)
-        if (i0 + k < n) rank[(size_t)blockIdx.y * n + i0 + k] = r[k];      // partial count of this key slice
-}
-
-__global__ __launch_bounds__(256) void k_tree_place(const uint32_t* __restrict__ rank, const uint32_t* __restrict__ cnt,
-                                                    uint32_t n, uint32_t* __restrict__ sorted_cnt,
-                                                    uint32_t* __restrict__ sorted_leaf) {
+__global__ __launch_bounds__(256) void k_tree_fill(const double* __restrict__ key, uint32_t n, const uint32_t* __restrict__ start,
+                                                   uint32_t* __restrict__ fill, uint32_t* __restrict__ members) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    uint32_t r = 0;
-#pragma unroll 8
-    for (uint32_t y = 0; y < RANK_SPLIT; y++) r += rank[(size_t)y * n + i];
+    const double k = key[i];
+    if (k == __longlong_as_double(0x7FF0000000000000ll)) return;          // culled
+    const uint32_t b = tree_bucket(k);
+    members[start[b] + atomicAdd(&fill[b], 1u)] = i;       // order inside a bucket is arbitrary: the rank below is exact
+}
+
+__global__ __launch_bounds__(256) void k_tree_rank_place(const unsigned long long* __restrict__ key, uint32_t n,
+                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ members,
+                                                         const uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted_cnt,
+                                                         uint32_t* __restrict__ sorted_leaf) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long mine = key[i];                // non-negative doubles order like their bit patterns
+    if (mine == 0x7FF0000000000000ull) return;             // culled: sorted_cnt stays 0 behind the kept leaves
+    const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
+    const uint32_t lo = start[b], hi = start[b + 1];
+    uint32_t r = lo;
+    for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t m = members[p];
+        const unsigned long long k = key[m];
+        r += (k < mine || (k == mine && m < i)) ? 1u : 0u;
+    }
     sorted_cnt[r] = cnt[i];
     sorted_leaf[r] = i;
 }
@@ -299,8 +276,8 @@ __global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restric
     }
 }
 
-// one workgroup per rank: coalesced copy of the leaf's index list to its place in indexesToSort
-__global__ __launch_bounds__(256) void k_tree_copy(const uint32_t* __restrict__ sorted_leaf, const uint32_t* __restrict__ sorted_cnt,
+// one wave per rank: coalesced copy of the leaf's index list (<= ~1000 indexes) to its place in indexesToSort
+__global__ __launch_bounds__(64) void k_tree_copy(const uint32_t* __restrict__ sorted_leaf, const uint32_t* __restrict__ sorted_cnt,
                                                    const uint32_t* __restrict__ offset, const uint32_t* __restrict__ leaf_begin,
                                                    const uint32_t* __restrict__ leaf_indexes, uint32_t* __restrict__ out) {
     const uint32_t r = blockIdx.x;
@@ -308,7 +285,7 @@ __global__ __launch_bounds__(256) void k_tree_copy(const uint32_t* __restrict__ 
     if (n == 0) return;
     const uint32_t* src = leaf_indexes + leaf_begin[sorted_leaf[r]];
     uint32_t* dst = out + offset[r];
-    for (uint32_t t = threadIdx.x; t < n; t += 256u) dst[t] = src[t];
+    for (uint32_t t = threadIdx.x; t < n; t += 64u) dst[t] = src[t];
 }
 
 extern "C" {
@@ -368,7 +345,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         auto A = [&](DevBuf& buf, size_t bytes) { if (st == GS_OK) st = buf.alloc(bytes); };
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
         A(t->d_indexes, 4 * t->indexes.size() + 4);
-        A(t->d_key, 8 * L + 8); A(t->d_cnt, 4 * L + 4); A(t->d_rank, 4 * L * RANK_SPLIT + 4); A(t->d_sorted_cnt, 4 * L + 4);
+        A(t->d_key, 8 * L + 8); A(t->d_cnt, 4 * L + 4); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
         A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4); A(t->d_total, 16);
         if (st != GS_OK) {
             delete t;
@@ -466,15 +443,20 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     p.gather_all = gp->gather_all ? 1u : 0u;
     p.leaves = L;
     const dim3 g((L + 255u) / 256u), b(256);
+    uint32_t* bhist = t->d_bucket.as<uint32_t>();
+    uint32_t* bfill = bhist + TREE_BUCKETS;
+    uint32_t* bstart = bfill + TREE_BUCKETS;
+    GS_HIP(hipMemsetAsync(bhist, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, st));
+    GS_HIP(hipMemsetAsync(t->d_sorted_cnt.p, 0, sizeof(uint32_t) * L, st));
     hipLaunchKernelGGL(k_tree_test, g, b, 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(), t->d_count.as<uint32_t>(),
-                       t->d_key.as<double>(), t->d_cnt.as<uint32_t>(), t->d_rank.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_rank, dim3((L + 256u * RANK_PER_THREAD - 1u) / (256u * RANK_PER_THREAD), RANK_SPLIT), b, 0, st, t->d_key.as<unsigned long long>(), L,
-                       t->d_rank.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_place, g, b, 0, st, t->d_rank.as<uint32_t>(), t->d_cnt.as<uint32_t>(), L,
-                       t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
+                       t->d_key.as<double>(), t->d_cnt.as<uint32_t>(), bhist);
+    hipLaunchKernelGGL(k_tree_bucket_scan, dim3(1), dim3(1024), 0, st, bhist, bstart);
+    hipLaunchKernelGGL(k_tree_fill, g, b, 0, st, t->d_key.as<double>(), L, bstart, bfill, t->d_rank.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_rank_place, g, b, 0, st, t->d_key.as<unsigned long long>(), L, bstart, t->d_rank.as<uint32_t>(),
+                       t->d_cnt.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
     hipLaunchKernelGGL(k_tree_offsets, dim3(1), dim3(1024), 0, st, t->d_sorted_cnt.as<uint32_t>(), L, t->d_offset.as<uint32_t>(),
                        t->d_total.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_copy, dim3(L), b, 0, st, t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(),
+    hipLaunchKernelGGL(k_tree_copy, dim3(L), dim3(64), 0, st, t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(),
                        t->d_offset.as<uint32_t>(), t->d_begin.as<uint32_t>(), t->d_indexes.as<uint32_t>(), out_dev);
     GS_HIP(hipGetLastError());
     uint32_t total = 0;

@@ -149,3 +149,42 @@ def test_8bit_spherical_harmonics(ctx, sh_degree):
     fb, q, amb, _ = oracle.render(ocam, c, cov, rgba, sh8.astype(np.float32), order)
     print(helpers.compare_frames(got, fb, amb, f"sh8 degree {sh_degree}"))
     mesh.dispose()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(antialiased=True),
+    dict(point_cloud_mode=True),
+    dict(splat_scale=0.5),
+    dict(splat_scale=2.5),
+    dict(kernel_2d_size=0.1),
+    dict(max_screen_space_splat_size=24.0),          # the 1024-px clamp of SplatMaterial3D.js:195-196, made active
+    dict(focal_adjustment=2.0),
+    dict(evaluate_sh_degree=1),                      # sphericalHarmonicsDegree uniform below the stored degree
+    dict(evaluate_sh_degree=0),
+    dict(antialiased=True, splat_scale=1.5, focal_adjustment=0.5),
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_viewer_options(ctx, opts):
+    """Viewer / SplatMesh options that reach the shaders as uniforms or #defines: antialiased, pointCloudMode, splatScale,
+    kernel2DSize, maxScreenSpaceSplatSize, focalAdjustment, sphericalHarmonicsDegree."""
+    opts = dict(opts)
+    scene = helpers.small_scene(2500, 2, seed=60)
+    cam = camera.demo_camera("garden", 256, 144)
+    order = _order(scene, cam)
+    focal_adj = opts.pop("focal_adjustment", 1.0)
+    eval_deg = opts.pop("evaluate_sh_degree", None)
+    mesh = SplatMesh(ctx, scene.count, 2, **opts).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(cam, focal_adjustment=focal_adj, spherical_harmonics_degree=eval_deg)
+    mesh.update_render_indexes(order, scene.count)
+    got, _ = mesh.render()
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, cam.width, cam.height,
+                              sh_degree=2 if eval_deg is None else eval_deg, sh_stored=2,
+                              splat_scale=opts.get("splat_scale", 1.0), kernel2d=opts.get("kernel_2d_size", 0.3),
+                              max_splat_px=opts.get("max_screen_space_splat_size", 1024.0), focal_adjustment=focal_adj,
+                              antialiased=opts.get("antialiased", False), point_cloud=opts.get("point_cloud_mode", False))
+    fb, q, amb, frags = oracle.render(ocam, c, cov, rgba, sh, order)
+    assert frags > 200
+    print(helpers.compare_frames(got, fb, amb, str(opts)))
+    base = oracle.render(_ocam(scene, cam), c, cov, rgba, sh, order)[1]
+    assert np.abs(base.astype(int) - q.astype(int)).max() > 8, "the option should change the image"
+    mesh.dispose()

@@ -1,0 +1,116 @@
+"""CPU tier: the fp32 C raster oracle (oracle/raster_oracle.c, a line-by-line restatement of the GLSL) against an
+INDEPENDENT fp64 numpy restatement written from the formulas of SURVEY.md Appendix A.2 — different language, different
+precision, different structure (matrix algebra instead of scalar code).  Catches transcription errors in either; it cannot
+pin the oracle to the reference (WebGL cannot run here: parity stays 'unpinned')."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle
+from gaussiansplats3d_amd import camera
+
+
+def numpy_project(cam, centers, cov6, rgba, sh, sh_degree, W, H, kernel=0.3, max_px=1024.0):
+    MV = np.asarray(cam.model_view(), np.float64).reshape(4, 4).T
+    P = np.asarray(cam.projection, np.float64).reshape(4, 4).T
+    n = centers.shape[0]
+    c = centers.astype(np.float64)
+    v = (MV @ np.c_[c, np.ones(n)].T).T
+    q = (P @ v.T).T
+    w = q[:, 3]
+    ok = ~((q[:, 2] < -1.2 * w) | (np.abs(q[:, 0]) > 1.2 * w) | (np.abs(q[:, 1]) > 1.2 * w))
+    ndc = q[:, :3] / w[:, None]
+    ok &= (ndc[:, 2] >= -1) & (ndc[:, 2] <= 1)
+    col = rgba[:, :3].astype(np.float64) / 255.0
+    if sh_degree >= 1:
+        d = c - np.asarray(cam.position, np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+        s = sh.astype(np.float64).reshape(n, -1, 3)                    # coefficient-major RGB triples
+        col = col + 0.4886025119029199 * (-s[:, 0] * y + s[:, 1] * z - s[:, 2] * x)
+        if sh_degree >= 2:
+            col = col + (1.0925484 * x * y) * s[:, 3] - (1.0925484 * y * z) * s[:, 4] + \
+                (0.3153916 * (2 * z * z - x * x - y * y)) * s[:, 5] - (1.0925484 * x * z) * s[:, 6] + \
+                (0.5462742 * (x * x - y * y)) * s[:, 7]
+        col = np.clip(col, 0, 1)
+    fx, fy = P[0, 0] * 0.5 * W, P[1, 1] * 0.5 * H
+    Vrk = np.zeros((n, 3, 3))
+    c6 = cov6.astype(np.float64)
+    Vrk[:, 0, 0], Vrk[:, 0, 1], Vrk[:, 0, 2] = c6[:, 0], c6[:, 1], c6[:, 2]
+    Vrk[:, 1, 0], Vrk[:, 1, 1], Vrk[:, 1, 2] = c6[:, 1], c6[:, 3], c6[:, 4]
+    Vrk[:, 2, 0], Vrk[:, 2, 1], Vrk[:, 2, 2] = c6[:, 2], c6[:, 4], c6[:, 5]
+    J = np.zeros((n, 3, 3))                                            # math matrix of the GLSL column constructor
+    J[:, 0, 0] = fx / v[:, 2]; J[:, 2, 0] = -fx * v[:, 0] / v[:, 2] ** 2
+    J[:, 1, 1] = fy / v[:, 2]; J[:, 2, 1] = -fy * v[:, 1] / v[:, 2] ** 2
+    Wm = MV[:3, :3].T                                                  # transpose(mat3(MV))
+    T = Wm[None] @ J
+    S2 = np.transpose(T, (0, 2, 1)) @ Vrk @ T
+    A, B, D = S2[:, 0, 0] + kernel, S2[:, 0, 1], S2[:, 1, 1] + kernel
+    t = 0.5 * (A + D)
+    r = np.sqrt(np.maximum(0.1, t * t - (A * D - B * B)))
+    l1, l2 = t + r, t - r
+    ok &= l2 > 0
+    e1 = np.stack([B, l1 - A], axis=1)
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.stack([e1[:, 1], -e1[:, 0]], axis=1)
+    h1 = np.minimum(np.sqrt(8 * np.maximum(l1, 0)), max_px)
+    h2 = np.minimum(np.sqrt(8 * np.maximum(l2, 1e-300)), max_px)
+    centre = np.stack([(ndc[:, 0] * 0.5 + 0.5) * W, (ndc[:, 1] * 0.5 + 0.5) * H], axis=1)
+    return ok, centre, e1 * h1[:, None], e2 * h2[:, None], col, rgba[:, 3] / 255.0
+
+
+@pytest.mark.parametrize("sh_degree", [0, 1, 2])
+def test_vertex_stage_matches_independent_numpy_restatement(sh_degree):
+    scene = helpers.small_scene(4000, sh_degree, seed=300 + sh_degree)
+    cam = camera.demo_camera("garden", 640, 360)
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, 640, 360, sh_degree, sh_degree)
+    got = oracle.project(ocam, c, cov, rgba, sh)
+    ok, centre, b1, b2, col, a = numpy_project(cam, c, cov, rgba, sh, sh_degree, 640, 360)
+    vis = got["visible"].astype(bool)
+    # accept / reject may differ only for splats sitting on a threshold: allow a handful
+    assert (vis != ok).sum() <= 3
+    both = vis & ok
+    assert both.sum() > 1500
+    np.testing.assert_allclose(np.c_[got["cx"], got["cy"]][both], centre[both], atol=2e-2)
+    # the basis is defined up to a common sign per vector
+    for gx, gy, ref in ((got["b1x"], got["b1y"], b1), (got["b2x"], got["b2y"], b2)):
+        g = np.c_[gx, gy][both].astype(np.float64)
+        r = ref[both]
+        sign = np.sign((g * r).sum(axis=1))[:, None]
+        scale = np.maximum(np.linalg.norm(r, axis=1, keepdims=True), 1e-3)
+        # near-degenerate 2D covariances (l1 ~ l2) make the eigenvector direction ill-conditioned: compare lengths there
+        cond = np.abs(np.linalg.norm(b1[both], axis=1) - np.linalg.norm(b2[both], axis=1)) > 1e-2 * np.linalg.norm(b1[both], axis=1)
+        assert np.abs(g * sign - r)[cond].max() / scale[cond].max() < 5e-3 or np.abs((g * sign - r) / scale)[cond].max() < 5e-3
+        np.testing.assert_allclose(np.linalg.norm(g, axis=1), np.linalg.norm(r, axis=1), rtol=2e-3, atol=1e-3)
+    np.testing.assert_allclose(np.c_[got["r"], got["g"], got["b"]][both], col[both], atol=2e-5)
+    np.testing.assert_allclose(got["a"][both], a[both], atol=1e-6)
+
+
+def test_small_frame_matches_independent_numpy_compositor():
+    """Fragment stage + blend: brute-force fp64 compositing of the oracle's own 2D splats over a 48x32 frame."""
+    scene = helpers.small_scene(400, 0, seed=310)
+    cam = camera.demo_camera("garden", 48, 32)
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, 48, 32, 0, 0)
+    order = np.arange(scene.count, dtype=np.uint32)
+    fb, q, amb, frags = oracle.render(ocam, c, cov, rgba, sh, order)
+    p2 = oracle.project(ocam, c, cov, rgba, sh)
+    ys, xs = np.mgrid[0:32, 0:48]
+    px, py = xs + 0.5, ys + 0.5
+    ref = np.zeros((32, 48, 4))
+    for s in p2:
+        if not s["visible"]:
+            continue
+        b1 = np.array([s["b1x"], s["b1y"]], np.float64); b2 = np.array([s["b2x"], s["b2y"]], np.float64)
+        dx, dy = px - s["cx"], py - s["cy"]
+        u = (dx * b1[0] + dy * b1[1]) / (b1 @ b1)
+        w = (dx * b2[0] + dy * b2[1]) / (b2 @ b2)
+        A = 8 * (u * u + w * w)
+        alpha = np.where(A <= 8, np.exp(-0.5 * A) * s["a"], 0.0)[..., None]
+        rgb = np.array([s["r"], s["g"], s["b"]], np.float64)
+        ref[..., :3] = alpha * rgb + (1 - alpha) * ref[..., :3]
+        ref[..., 3:] = alpha + (1 - alpha) * ref[..., 3:]
+    clear = ~amb.astype(bool)
+    assert np.abs(fb - ref)[clear].max() < 2e-4
+    assert frags > 100

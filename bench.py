@@ -177,6 +177,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             frame()
+        t_enqueued = time.perf_counter() - t0                # host time to enqueue the K frames (no device wait in it)
         stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -237,6 +238,33 @@ def main():
             tree.dispose()
             mesh.use_sorter_result(worker, N)
 
+        # third column: the per-splat frustum cull fused into pass 0 of the sort (gs_sorter_set_frustum_cull).  Keys,
+        # range and buckets still span all N splats, so the frame must be bit-identical to the headline path's
+        fused = None
+        if world == 1 and not args.no_cull:
+            frame()
+            torch.cuda.synchronize()
+            ref_img = strip.clone()
+            worker.set_frustum_cull(True)
+            for _ in range(3):
+                frame()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                frame()
+            f_enq = (time.perf_counter() - t1) / args.steps * 1e3
+            torch.cuda.synchronize()
+            f_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            fs, _ = worker.last_stats()
+            fused = {"kept": int(fs.result_count), "ms_per_frame": round(f_ms, 4),
+                     "Msplats_per_s_scene": round(N / (f_ms * 1e-3) / 1e6, 1),
+                     "host_enqueue_ms_per_frame": round(f_enq, 4), "sort_ms_last": round(float(fs.device_ms), 4),
+                     "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
+                     "note": "keys + min/max over all N, then pass 0 of the radix sort drops the splats whose centre is "
+                             "outside 1.25x the clip volume; the list is the full sort's list minus those splats"}
+            worker.set_frustum_cull(False)
+            del ref_img
+
     ms_per_step = elapsed / args.steps * 1e3
     D16 = int(st_probe.tiles16)
     D32 = int(st_probe.tile_entries)
@@ -256,6 +284,7 @@ def main():
             "value": round(N / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "fps": round(1e3 / ms_per_step, 2), "frame_latency_ms": round(float(np.median(latency)), 4),
+            "host_enqueue_ms_per_frame": round(t_enqueued / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 keys / f32 raster", "data": "synthetic",
             "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
@@ -274,6 +303,7 @@ def main():
                       "D_per_splat": round(D16 / R, 3), "bin_entries": D32,
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
             "cull_on": cull,
+            "frustum_cull_fused": fused,
             "cpu_baseline": None,
             "scene_gen_s": round(t_gen, 1),
         }

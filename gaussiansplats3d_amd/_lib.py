@@ -30,7 +30,7 @@ class GsError(RuntimeError):
 
 class SortStats(C.Structure):
     _fields_ = [("device_ms", C.c_float), ("key_min", C.c_int32), ("key_max", C.c_int32), ("clamped", C.c_uint32),
-                ("passes", C.c_uint32)]
+                ("passes", C.c_uint32), ("result_count", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -88,6 +88,7 @@ SYMBOLS = {
     "gs_sorter_sort": (C.c_int, [_VP, _VP, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_sort_gathered": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_bind_mesh": (C.c_int, [_VP, _VP]),
+    "gs_sorter_set_frustum_cull": (C.c_int, [_VP, C.c_int]),
     "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_asset_open": (C.c_int, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_asset_close": (None, [_VP]),

@@ -140,7 +140,7 @@ struct SortFrame {            // device-resident per-sort scalars
     int32_t key_min;          // atomicMin target, initialised to +2147483640 (sorter.cpp:25)
     int32_t key_max;          // atomicMax target, initialised to -2147483640 (sorter.cpp:24)
     uint32_t clamped;
-    uint32_t pad;
+    uint32_t kept;            // frustum-cull variant: list positions that survive = length of the sorted result
 };
 
 struct gs_sorter {
@@ -173,6 +173,10 @@ struct gs_sorter {
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
     bool last_identity = true;
     bool has_result = false;
+    bool frustum_cull = false;         // gs_sorter_set_frustum_cull
+    bool last_culled = false;          // the resident result holds only the kept splats; its length lives in result_frame
+    const SortFrame* result_frame = nullptr;
+    DevBuf keep_mask;                  // 1 bit per list position (frustum-cull variant)
 };
 
 // ---------------------------------------------------------------------------------------------------

@@ -70,6 +70,7 @@ struct ArrayLoader {
     __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (uint32_t)keys[j]; }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return vals[j]; }
+    __device__ __forceinline__ bool valid(uint32_t) const { return true; }
     __device__ __forceinline__ void note_clamp(bool) const {}
 };
 
@@ -114,7 +115,10 @@ __device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint
 template <class Loader>
 __device__ __forceinline__ void hist_full_tile(const Loader& ld, uint32_t base, int shift, uint32_t* hist) {
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; r++) atomicAdd(&hist[(ld.key(base + r * RADIX_THREADS + threadIdx.x) >> shift) & 255u], 1u);
+    for (int r = 0; r < RADIX_ITEMS; r++) {
+        const uint32_t j = base + r * RADIX_THREADS + threadIdx.x;
+        if (ld.valid(j)) atomicAdd(&hist[(ld.key(j) >> shift) & 255u], 1u);
+    }
 }
 
 template <class Loader>
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shi
 #pragma unroll
             for (int r = 0; r < RADIX_ITEMS; r++) {
                 const uint32_t j = base + r * RADIX_THREADS + tid;
-                if (j < ch.n) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
+                if (j < ch.n && ld.valid(j)) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
             }
         }
     }
@@ -215,16 +219,16 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
 
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t tile_base = tile * RADIX_TILE;
-        const uint32_t tile_count = min((uint32_t)RADIX_TILE, ch.n - tile_base);
         uint32_t key[SCATTER_ITEMS], val[SCATTER_ITEMS], rank[SCATTER_ITEMS];
+        bool ok[SCATTER_ITEMS];
         // wave-striped load: the stable order inside a tile is (wave, r, lane)
         const uint32_t wbase = tile_base + wave * (64 * SCATTER_ITEMS) + lane;
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
             const uint32_t j = wbase + r * 64;
-            const bool ok = j < ch.n;
-            key[r] = ok ? ld.key(j) : 0xFFFFFFFFu;
-            val[r] = ok ? ld.val(j) : 0u;
+            ok[r] = j < ch.n && ld.valid(j);      // a loader that drops elements turns the pass into a stable compaction
+            key[r] = ok[r] ? ld.key(j) : 0xFFFFFFFFu;
+            val[r] = ok[r] ? ld.val(j) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;
@@ -235,20 +239,19 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
             for (int r = 0; r < SCATTER_ITEMS; r++) {
                 const uint32_t digit = (key[r] >> shift) & 255u;
                 // lanes of this instruction that share `digit` are served in ascending lane order (see header)
-                if ((wbase + r * 64) < ch.n) rank[r] = atomicAdd(&s_wave[wave][digit], 1u);
+                if (ok[r]) rank[r] = atomicAdd(&s_wave[wave][digit], 1u);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < SCATTER_ITEMS; r++) {
-                const bool ok = (wbase + r * 64) < ch.n;
                 const uint32_t digit = (key[r] >> shift) & 255u;
-                uint64_t same = __ballot(ok);
+                uint64_t same = __ballot(ok[r]);
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const uint64_t vote = __ballot(ok && ((digit >> b) & 1u));
+                    const uint64_t vote = __ballot(ok[r] && ((digit >> b) & 1u));
                     same &= ((digit >> b) & 1u) ? vote : ~vote;
                 }
-                if (ok) {
+                if (ok[r]) {
                     const uint32_t prior = my_hist[digit];
                     rank[r] = prior + __popcll(same & lt_mask);
                     if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);   // highest lane of the group
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
         }
         __syncthreads();
 
+        uint32_t tile_count = 0;                    // keys staged by this tile (= its length unless the loader drops some)
         {   // thread t < 256 owns digit t: wave-exclusive offsets and the tile-local digit base
             uint32_t tot = 0;
             if (tid < RADIX_BINS) {
@@ -268,13 +272,13 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
                 }
                 s_total[tid] = tot;
             }
-            const uint32_t excl = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);   // contains the barriers
+            const uint32_t excl = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, &tile_count);   // contains the barriers
             if (tid < RADIX_BINS) s_local[tid] = excl;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
-            if ((wbase + r * 64) < ch.n) {
+            if (ok[r]) {
                 const uint32_t digit = (key[r] >> shift) & 255u;
                 const uint32_t pos = s_local[digit] + s_wave[wave][digit] + rank[r];
                 s_keys[pos] = (KeyOutT)key[r];

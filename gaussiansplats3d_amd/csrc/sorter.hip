@@ -38,6 +38,8 @@ struct KeyParams {
     uint32_t sort_start, render_count, mode;
     int32_t im0, im1, im2;                   // static path: (int)(mvp[k]*1000.0), k = 2,6,10
     float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
+    float mvp[16];                           // frustum-cull variant only: the whole modelViewProj, fp32 column-major
+    unsigned long long* keep;                // frustum-cull variant only: 1 bit per list position
 };
 
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
         p.next_frame->key_min = 2147483640;      // sorter.cpp:25
         p.next_frame->key_max = -2147483640;     // sorter.cpp:24
         p.next_frame->clamped = 0;
-        p.next_frame->pad = 0;
+        p.next_frame->kept = 0;
     }
     if (VEC4) {
         // positions [a4*4, b4*4) are handled as vectors, the ragged head/tail as scalars by the first lanes
@@ -163,10 +165,163 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     }
 }
 
+// Phase A with the per-splat frustum cull (gs_sorter_set_frustum_cull).  Same keys, same min / max over EVERY list
+// position (so the bucket of a kept splat is the one the full sort gives it), plus one keep bit per position:
+//     q = mvp * (x, y, z, 1)    fp32, ((m0*x + m4*y) + m8*z) + m12 per row, no contraction
+//     drop  <=>  |q.x| > 1.25*q.w + 0.01  or  |q.y| > 1.25*q.w + 0.01  or  q.z < -(1.01*q.w + 0.01)  or  q.z > 1.01*q.w + 0.01
+// with (x, y, z) = the sorter's own centres as floats (integer mode: (float)int * 0.001f).  The vertex stage drops a
+// splat on |clip.xy| > 1.2 w, clip.z < -1.2 w or ndc.z outside [-1, 1] (SplatMaterial.js:160-164 and the GL clip of a
+// quad that sits at its centre's depth), so for the same camera the kept set is a superset of what can reach the
+// frame, and the frame is bit-identical to the one the full sort produces.  Restated in oracle.frustum_keep.
+__device__ __forceinline__ bool frustum_keep_one(const float* m, float x, float y, float z) {
+    float q[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        q[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(m[r], x), __fmul_rn(m[4 + r], y)), __fmul_rn(m[8 + r], z)), m[12 + r]);
+    const float lim_xy = __fadd_rn(__fmul_rn(1.25f, q[3]), 0.01f);
+    const float lim_z = __fadd_rn(__fmul_rn(1.01f, q[3]), 0.01f);
+    return !(fabsf(q[0]) > lim_xy || fabsf(q[1]) > lim_xy || q[2] < -lim_z || q[2] > lim_z);
+}
+
+__device__ __forceinline__ bool frustum_keep_int(const float* m, uint32_t x, uint32_t y, uint32_t z) {
+    return frustum_keep_one(m, __fmul_rn((float)(int32_t)x, 0.001f), __fmul_rn((float)(int32_t)y, 0.001f),
+                            __fmul_rn((float)(int32_t)z, 0.001f));
+}
+
+// VEC4 (identity list, static integer mode): lane l of a wave owns positions 4*(v0 + l) .. +3 of a 256-position window,
+// read as three 16-byte plane loads; the 4 keep bits of 16 neighbouring lanes are OR-combined into one mask word.
+// Otherwise: 4 positions per lane, 64 apart, so 4 index loads and then 4 centre gathers are in flight per lane and
+// every ballot is one mask word.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    __shared__ uint32_t s_kept[4];
+    int32_t lo = 2147483640, hi = -2147483640;
+    uint32_t kept = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;               // a multiple of 64
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t == 0) {
+        p.next_frame->key_min = 2147483640;
+        p.next_frame->key_max = -2147483640;
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t R = p.render_count;                             // sort_start == 0 in this variant
+    if (VEC4) {
+        const uint32_t nvec = (R + 3u) / 4u, full = R / 4u, padded = (nvec + 63u) & ~63u;
+        const uint4* x4 = reinterpret_cast<const uint4*>(p.cx);
+        const uint4* y4 = reinterpret_cast<const uint4*>(p.cy);
+        const uint4* z4 = reinterpret_cast<const uint4*>(p.cz);
+        int4* o4 = reinterpret_cast<int4*>(p.keys_out);
+        const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
+        for (uint32_t v = t; v < padded; v += stride) {
+            uint32_t nib = 0;
+            if (v < full) {
+                const uint4 x = x4[v], y = y4[v], z = z4[v];
+                int4 k;
+                k.x = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2);
+                k.y = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
+                k.z = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2);
+                k.w = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
+                o4[v] = k;
+                lo = min(min(lo, k.x), min(min(k.y, k.z), k.w));
+                hi = max(max(hi, k.x), max(max(k.y, k.z), k.w));
+                nib = (frustum_keep_int(p.mvp, x.x, y.x, z.x) ? 1u : 0u) | (frustum_keep_int(p.mvp, x.y, y.y, z.y) ? 2u : 0u) |
+                      (frustum_keep_int(p.mvp, x.z, y.z, z.z) ? 4u : 0u) | (frustum_keep_int(p.mvp, x.w, y.w, z.w) ? 8u : 0u);
+            } else if (v < nvec) {                                 // the ragged last vector
+                for (uint32_t c = 0; c < 4u; c++) {
+                    const uint32_t i = 4u * v + c;
+                    if (i < R) {
+                        const uint32_t x = p.cx[i], y = p.cy[i], z = p.cz[i];
+                        const int32_t k = (int32_t)(x * m0 + y * m1 + z * m2);
+                        p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
+                        nib |= frustum_keep_int(p.mvp, x, y, z) ? (1u << c) : 0u;
+                    }
+                }
+            }
+            kept += (uint32_t)__popc(nib);
+            unsigned long long word = (unsigned long long)nib << (4u * (lane & 15u));
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) word |= __shfl_xor(word, o, 64);
+            if ((lane & 15u) == 0u) p.keep[v >> 4] = word;          // positions 4v .. 4v+63
+        }
+    } else {
+        const uint32_t padded = (R + 255u) & ~255u;
+        for (uint32_t base = (t >> 6) * 256u; base < padded; base += (stride >> 6) * 256u) {
+            uint32_t g[4];
+            bool in[4], keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = base + 64u * k + lane;
+                in[k] = i < R;
+                g[k] = in[k] ? (p.idx_in ? p.idx_in[i] : i) : 0u;
+            }
+            uint4 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = in[k] ? p.aos[g[k]] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                keep[k] = false;
+                if (in[k]) {
+                    const uint32_t i = base + 64u * k + lane;
+                    int32_t key;
+                    float x, y, z;
+                    if (p.mode & MODE_INT) {
+                        key = (int32_t)(c[k].x * (uint32_t)p.im0 + c[k].y * (uint32_t)p.im1 + c[k].z * (uint32_t)p.im2);
+                        x = __fmul_rn((float)(int32_t)c[k].x, 0.001f); y = __fmul_rn((float)(int32_t)c[k].y, 0.001f);
+                        z = __fmul_rn((float)(int32_t)c[k].z, 0.001f);
+                    } else {
+                        x = __uint_as_float(c[k].x); y = __uint_as_float(c[k].y); z = __uint_as_float(c[k].z);
+                        float s = __fmul_rn(p.fm0, x);
+                        s = __fadd_rn(s, __fmul_rn(p.fm1, y));
+                        s = __fadd_rn(s, __fmul_rn(p.fm2, z));
+                        key = trunc_f64_i32((double)s * 4096.0);
+                    }
+                    p.keys_out[i] = key;
+                    lo = min(lo, key);
+                    hi = max(hi, key);
+                    keep[k] = frustum_keep_one(p.mvp, x, y, z);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long word = __ballot(keep[k]);
+                if (lane == 0 && base + 64u * k < padded) {
+                    p.keep[(base >> 6) + k] = word;
+                    kept += (uint32_t)__popcll(word);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+        kept += __shfl_xor(kept, o, 64);
+    }
+    if (lane == 0) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+        s_kept[wave] = kept;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        atomicMin(&p.frame->key_min, lo);
+        atomicMax(&p.frame->key_max, hi);
+        atomicAdd(&p.frame->kept, s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3]);
+    }
+}
+
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
-struct DepthLoader {
+template <bool CULL>
+struct DepthLoaderT {
     const int32_t* __restrict__ keys;
+    const unsigned long long* __restrict__ keep;   // CULL: 1 bit per list position (k_depth_key_cull)
     const uint32_t* __restrict__ idx;      // nullable: identity
     const uint32_t* __restrict__ map;      // nullable: payload = map[splat index] (a bound mesh's internal position)
     SortFrame* frame;
@@ -204,7 +359,14 @@ struct DepthLoader {
         const uint32_t o = idx ? idx[i] : i;
         return map ? map[o] : o;
     }
+    __device__ __forceinline__ bool valid(uint32_t j) const {
+        if (!CULL) return true;
+        const uint32_t i = render_count - 1 - j;
+        return (keep[i >> 6] >> (i & 63u)) & 1ull;
+    }
 };
+typedef DepthLoaderT<false> DepthLoader;
+typedef DepthLoaderT<true> DepthLoaderCull;
 
 __global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ map, uint32_t* __restrict__ out,
                             uint32_t n) {
@@ -337,6 +499,7 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     stats->key_max = f.key_max;
     stats->clamped = f.clamped;
     stats->passes = s->last_passes;
+    stats->result_count = s->last_culled ? f.kept : s->last_render;
     return f.clamped ? GS_WARN_KEY_CLAMPED : GS_OK;
 }
 
@@ -350,6 +513,9 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     GS_REQUIRE(sort_count <= render_count, "splatSortCount > splatRenderCount");
     const bool dynamic = (s->flags & GS_SORT_DYNAMIC) != 0;
     GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
+    const bool cull = s->frustum_cull;
+    GS_REQUIRE(!cull || (sort_count == render_count && !dynamic && !precomputed),
+               "the per-splat frustum cull needs a full sort (splatSortCount == splatRenderCount) of a static scene without precomputed distances");
     gs_context* ctx = s->ctx;
     ScopedDevice sd(ctx->device);
     hipStream_t st = s->stream;
@@ -417,11 +583,21 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     kp.im2 = trunc_f64_i32((double)mvp[10] * 1000.0);
     kp.fm0 = mvp[2]; kp.fm1 = mvp[6]; kp.fm2 = mvp[10];
 
+    if (cull) {
+        GS_TRY(s->keep_mask.ensure((((size_t)s->max_count + 63) / 64 + 8) * 8));   // the key kernel writes whole 256-position windows
+        kp.keep = s->keep_mask.as<unsigned long long>();
+        memcpy(kp.mvp, mvp, sizeof(kp.mvp));
+    }
+
     GS_HIP(hipEventRecord(s->ev0, st));
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
-        if (vec4)
+        if (cull && vec4)
+            hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        else if (cull)
+            hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
+        else if (vec4)
             hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else
             hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
@@ -443,17 +619,27 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             const bool last = (p + 1 == passes);
             const int shift = 8 * (int)p;
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
-            if (p == 0) {
+            // after a culling pass 0 the element count is the device-resident kept count
+            const uint32_t* n_dev = cull ? &kp.frame->kept : nullptr;
+            if (p == 0 && cull) {
+                DepthLoaderCull dc = {};
+                dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
+                dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range;
+                DepthLoaderCull h = dc;
+                h.count_clamps = 1;
+                if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
+                else GS_TRY((radix_pass<DepthLoaderCull, uint16_t, true>(ex, h, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+            } else if (p == 0) {
                 DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
                 h.count_clamps = 1;
                 if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
                 else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ex, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
             } else if (wide) {
-                ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
+                ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], n_dev, Rs};
                 if (last) GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, false>(ex, al, al, Rs, shift, (int)p, (uint32_t*)nullptr, vo)));
                 else GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ex, al, al, Rs, shift, (int)p, (uint32_t*)kbuf[p & 1], vo)));
             } else {
-                ArrayLoader<uint16_t> al = {(const uint16_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], nullptr, Rs};
+                ArrayLoader<uint16_t> al = {(const uint16_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], n_dev, Rs};
                 if (last) GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, false>(ex, al, al, Rs, shift, (int)p, (uint16_t*)nullptr, vo)));
                 else GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, true>(ex, al, al, Rs, shift, (int)p, (uint16_t*)kbuf[p & 1], vo)));
             }
@@ -469,21 +655,30 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     s->last_sort = Rs;
     s->last_passes = passes;
     s->last_identity = (idx_dev == nullptr);
+    s->last_culled = cull && Rs > 0;
+    s->result_frame = kp.frame;
     s->result_mesh = map ? s->bound_mesh : nullptr;
     s->result_unmap = unmap;
     s->has_result = true;
 
     int status = GS_OK;
-    if (sorted_out && R) {
+    uint32_t out_count = R;
+    if (sorted_out && s->last_culled) {            // the result's length is only known on the device
+        SortFrame f;
+        GS_HIP(hipMemcpyAsync(&f, kp.frame, sizeof(f), hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        out_count = f.kept;
+    }
+    if (sorted_out && out_count) {
         const void* src = s->sorted.p;
         if (unmap) {                               // the host always sees the caller's splat indexes
             GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
-            hipLaunchKernelGGL(k_unmap, dim3(grid_for(R, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(), unmap,
-                               s->debug.as<uint32_t>(), R);
+            hipLaunchKernelGGL(k_unmap, dim3(grid_for(out_count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(), unmap,
+                               s->debug.as<uint32_t>(), out_count);
             GS_HIP(hipGetLastError());
             src = s->debug.p;
         }
-        GS_HIP(hipMemcpyAsync(sorted_out, src, (size_t)R * 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipMemcpyAsync(sorted_out, src, (size_t)out_count * 4, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
     }
     if (stats) status = sorter_collect_stats(s, stats);
@@ -509,6 +704,13 @@ int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m) {
     GS_REQUIRE(s != nullptr, "sorter == NULL");
     GS_REQUIRE(!m || m->ctx == s->ctx, "mesh lives on another context");
     s->bound_mesh = m;
+    return GS_OK;
+}
+
+int gs_sorter_set_frustum_cull(gs_sorter* s, int enable) {
+    GS_REQUIRE(s != nullptr, "sorter == NULL");
+    GS_REQUIRE(!enable || !(s->flags & GS_SORT_DYNAMIC), "the per-splat frustum cull is not available to a dynamic-mode sorter");
+    s->frustum_cull = enable != 0;
     return GS_OK;
 }
 
@@ -552,6 +754,10 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
             hipLaunchKernelGGL(k_debug_buckets, dim3(grid_for(s->last_sort, 1024, 2048)), dim3(256), 0, st, dl, s->debug.as<int32_t>());
         GS_HIP(hipGetLastError());
         src = s->debug.p;
+    } else if (what == 3) {
+        GS_REQUIRE(s->last_culled, "the last sort did not cull");
+        GS_REQUIRE((size_t)count * 4 <= s->keep_mask.bytes, "count exceeds the mask length");
+        src = s->keep_mask.p;
     } else {
         GS_REQUIRE(false, "unknown debug selector");
     }

@@ -60,14 +60,22 @@ __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
 // Each lane owns 4 consecutive list positions per iteration, so 4 index loads, then 4 mask look-ups, then up to 4
 // rect gathers are in flight together (the kernel is a chain of dependent memory round trips), and one packed
 // 64-bit block scan per 1024 positions yields both the compaction slot and the entry offset.
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
+                                                           const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
                                                            const unsigned long long* __restrict__ vis_mask,
                                                            const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums) {
     __shared__ unsigned long long s_w[4];
+    // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
+    // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
+    const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
     const BinChunk ch = bin_chunk(R);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
+        block_sums[3 * BIN_MAX_BLOCKS] = (batches + gridDim.x - 1) / gridDim.x;      // = bin_chunk()'s `per`
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t pos_begin = ch.begin * BIN_THREADS, pos_end = min(ch.end * BIN_THREADS, R);
     uint32_t sum = 0;                                      // entries emitted so far by this workgroup
@@ -218,16 +226,17 @@ constexpr uint32_t EMIT_PER_LANE = 16;
 constexpr uint32_t EMIT_WINDOW = BIN_THREADS * EMIT_PER_LANE;     // entries per workgroup iteration
 
 // block_sums after k_bin_scan: [0,BIN_MAX_BLOCKS) exclusive entry offset of every binning workgroup | [BIN_MAX_BLOCKS,..) its
-// compacted splat count.  `bin_grid` / `bin_per` describe the grid k_bin_count ran with.
+// compacted splat count | [3*BIN_MAX_BLOCKS] batches per binning workgroup.  `bin_grid` = the grid k_bin_count ran with.
 template <class KeyT>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __restrict__ frame, uint32_t bin_grid,
-                                                          uint32_t bin_per, const uint32_t* __restrict__ cidx,
+                                                          const uint32_t* __restrict__ cidx,
                                                           const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
                                                           const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* bins per row */,
                                                           uint32_t row_begin /* first bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out) {
     __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
     const uint32_t D = frame->entry_count;
+    const uint32_t bin_per = block_sums[3 * BIN_MAX_BLOCKS];             // batches per binning workgroup (k_bin_count)
     for (uint32_t i = threadIdx.x; i <= bin_grid; i += BIN_THREADS) s_boff[i] = i < bin_grid ? block_sums[i] : 0xFFFFFFFFu;
     __syncthreads();
     for (uint32_t win = blockIdx.x; (unsigned long long)win * EMIT_WINDOW < D; win += gridDim.x) {
@@ -325,9 +334,8 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     if (grid < 1) grid = 1;
     if (grid > (uint32_t)BIN_MAX_BLOCKS) grid = BIN_MAX_BLOCKS;
     const uint32_t cap = m->entry_capacity;
-    const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
-    const uint32_t bin_per = (batches + grid - 1) / grid;               // must match bin_chunk()
-    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R,
+    const uint32_t* R_dev = (sorter && sorter->last_culled) ? &sorter->result_frame->kept : nullptr;
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis_mask.as<unsigned long long>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>());
@@ -340,7 +348,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, grid, bin_per, m->cidx.as<uint32_t>(),
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, grid, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.bins_x, pp.bin_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>());
     GS_HIP(hipGetLastError());

@@ -30,6 +30,7 @@ class SortWorker:
         self.onmessage = None
         self.uploaded_splat_count = 0
         self.gathered_count = 0
+        self.frustum_cull = False
         flags = (L.GS_SORT_INTEGER if integer_based_sort else 0) | (L.GS_SORT_DYNAMIC if dynamic_mode else 0)
         self.handle = C.c_void_p()
         L.check(self.lib.gs_sorter_create(context.handle, self.max_splat_count, flags, self.precision,
@@ -96,7 +97,8 @@ class SortWorker:
         reply = {"sortDone": True, "splatSortCount": sort, "splatRenderCount": render,
                  "sortTime": float(stats.device_ms), "status": st}
         if out is not None:
-            reply["sortedIndexes"] = out
+            # under the per-splat frustum cull the list holds only the kept splats (stats.result_count of them)
+            reply["sortedIndexes"] = out[:stats.result_count] if self.frustum_cull else out
             reply["stats"] = stats
         return self._reply(reply)
 
@@ -121,8 +123,22 @@ class SortWorker:
                                                       tr.ctypes.data if tr is not None else None,
                                                       out.ctypes.data if out is not None else None,
                                                       None if keep_on_device else C.byref(stats)))
+        if out is not None and self.frustum_cull:
+            out = out[:stats.result_count]
         return {"sortDone": True, "status": st, "sortTime": float(stats.device_ms), "sortedIndexes": out, "stats": stats,
                 "splatRenderCount": self.gathered_count}
+
+    def set_frustum_cull(self, enable=True):
+        """Fuse a per-splat frustum cull into full sorts (gs_sorter_set_frustum_cull): the result is the reference's
+        sorted list restricted to the splats that can reach the frame for this modelViewProj."""
+        L.check(self.lib.gs_sorter_set_frustum_cull(self.handle, 1 if enable else 0))
+        self.frustum_cull = bool(enable)
+
+    def keep_bits(self, count):
+        """Test hook: the cull's keep flag per list position of the last sort."""
+        words = np.empty((count + 31) // 32, dtype=np.uint32)
+        L.check(self.lib.gs_sorter_debug_read(self.handle, 3, words.ctypes.data, words.size))
+        return np.unpackbits(words.view(np.uint8), bitorder="little")[:count].astype(bool)
 
     def last_stats(self):
         stats = L.SortStats()

@@ -82,6 +82,8 @@ typedef struct gs_sort_stats {
     int32_t key_max;
     uint32_t clamped;       /* buckets forced into [0,range)                                                  */
     uint32_t passes;        /* 8-bit LSD radix passes used                                                    */
+    uint32_t result_count;  /* length of the sorted result: splatRenderCount, or the kept count under
+                               gs_sorter_set_frustum_cull                                                     */
 } gs_sort_stats;
 
 /* The {sort:{modelViewProj, splatRenderCount, splatSortCount, usePrecomputedDistances, indexesToSort,
@@ -106,8 +108,20 @@ int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count,
  * Host-visible results (sorted_out, gs_sorter_debug_read) are always the caller's splat indexes.  m = NULL unbinds. */
 int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m);
 
+/* Per-splat frustum cull fused into the sort (no counterpart in the reference, whose cull works on octree nodes,
+ * src/Viewer.js:1969-2077; composes with gs_tree_gather).  With enable != 0 a full sort (sort_count == render_count,
+ * static scene, no precomputed distances) keeps only the list positions whose centre passes
+ *     q = mvp * (x, y, z, 1) in fp32;  |q.x| <= 1.25 q.w + 0.01,  |q.y| <= 1.25 q.w + 0.01,  |q.z| <= 1.01 q.w + 0.01
+ * which for the same camera is a superset of what the vertex stage can draw (it drops at 1.2 w, SplatMaterial.js:160-164).
+ * Keys, min / max and buckets are still taken over every list position, so the result is exactly the reference's sorted
+ * list with the dropped splats removed and a frame drawn from it is bit-identical to one drawn from the full list.
+ * The result's length lives on the device (gs_sort_stats.result_count after a sync); gs_mesh_render reads it there:
+ * pass the sort's render_count as usual. */
+int gs_sorter_set_frustum_cull(gs_sorter* s, int enable);
+
 /* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
- * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted. */
+ * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted,
+ *       3 = keep bits of the frustum cull, bit (i & 31) of uint32 word i >> 5 per list position i. */
 int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count);
 
 /* ------------------------------------------------------------------------------------------------ *

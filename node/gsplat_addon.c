@@ -158,6 +158,7 @@ static napi_value SorterSort(napi_env env, napi_callback_info info) {
     set(env, r, "keyMax", stats.key_max);
     set(env, r, "clamped", stats.clamped);
     set(env, r, "passes", stats.passes);
+    set(env, r, "resultCount", stats.result_count);
     return r;
 }
 
@@ -251,6 +252,13 @@ static napi_value SorterBindMesh(napi_env env, napi_callback_info info) {
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
+/* sorterSetFrustumCull(sorter, enable) */
+static napi_value SorterSetFrustumCull(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    int st = gs_sorter_set_frustum_cull((gs_sorter*)get_external(env, argv[0]), (int)get_u32(env, argv[1]));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
 /* sorterSortGathered(sorter, mvp Float32Array(16), sortCount, out Uint32Array|null) -> {status, sortTime} */
 static napi_value SorterSortGathered(napi_env env, napi_callback_info info) {
     ARGS(4)
@@ -269,6 +277,7 @@ static napi_value SorterSortGathered(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_object(env, &r));
     set(env, r, "status", st);
     set(env, r, "sortTime", stats.device_ms);
+    set(env, r, "resultCount", stats.result_count);
     return r;
 }
 
@@ -377,7 +386,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},
         {"sorterSort", SorterSort},         {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
         {"meshUpload", MeshUpload},         {"meshRender", MeshRender},
-        {"sorterBindMesh", SorterBindMesh}, {"sorterSortGathered", SorterSortGathered},
+        {"sorterBindMesh", SorterBindMesh}, {"sorterSetFrustumCull", SorterSetFrustumCull}, {"sorterSortGathered", SorterSortGathered},
         {"treeCreate", TreeCreate},         {"treeDestroy", TreeDestroy},     {"treeInfo", TreeInfo},
         {"treeGather", TreeGather},         {"assetLoad", AssetLoad},
     };

@@ -180,6 +180,39 @@ def sort_indexes_numpy(indexes, int_centers4, mvp, sort_count=None, render_count
     return out
 
 
+def frustum_keep(mvp, centers4, indexes=None, use_int=True):
+    """numpy fp32 restatement of the engine's per-splat frustum cull (include/gsplat_hip.h, gs_sorter_set_frustum_cull;
+    no counterpart in the reference).  Every operation is a separate fp32 multiply / add in the kernel's order
+    (numpy never contracts).  Returns bool[len(indexes)]: list positions the culled sort keeps."""
+    m = np.asarray(mvp, dtype=np.float64).astype(np.float32).reshape(16)
+    c = np.ascontiguousarray(centers4)
+    if indexes is not None:
+        c = c[np.asarray(indexes, dtype=np.int64)]
+    if use_int:
+        xyz = [c[:, k].astype(np.int32).astype(np.float32) * np.float32(0.001) for k in range(3)]
+    else:
+        xyz = [c[:, k].astype(np.float32) for k in range(3)]
+    q = [((m[r] * xyz[0] + m[4 + r] * xyz[1]) + m[8 + r] * xyz[2]) + m[12 + r] for r in range(4)]
+    for v in q:
+        assert v.dtype == np.float32
+    lim_xy = np.float32(1.25) * q[3] + np.float32(0.01)
+    lim_z = np.float32(1.01) * q[3] + np.float32(0.01)
+    drop = (np.abs(q[0]) > lim_xy) | (np.abs(q[1]) > lim_xy) | (q[2] < -lim_z) | (q[2] > lim_z)
+    return ~drop
+
+
+def culled_sort(indexes, centers4, mvp, precision=16, use_int=True):
+    """What a frustum-culled full sort must return: the reference's sorted list (keys, range and buckets over every
+    list position) with the dropped positions removed.  Returns (sorted_kept uint32[], keep bool[])."""
+    full = sort_indexes(indexes, centers4, mvp, precision=precision, use_int=use_int)
+    keep = frustum_keep(mvp, centers4, indexes, use_int)
+    idx = np.asarray(indexes, dtype=np.uint32)
+    # the same splat index may appear at several list positions: keep / drop is per splat, so filtering by index is exact
+    kept_of_splat = np.zeros(int(np.asarray(centers4).shape[0]), dtype=bool)
+    kept_of_splat[idx[keep]] = True
+    return full[kept_of_splat[full]], keep
+
+
 # --------------------------------------------------------------------------- raster
 class Camera(C.Structure):
     _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_pos", C.c_float * 3),

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     import ctypes as C
-    assert C.sizeof(_lib.SortStats) == 20
+    assert C.sizeof(_lib.SortStats) == 24
     assert C.sizeof(_lib.Camera) == 272
     assert C.sizeof(_lib.SceneParams) == 8 + 32 * (64 + 16 + 4 + 4 + 4 + 4)
     assert C.sizeof(_lib.GatherParams) == 160 and C.sizeof(_lib.TreeInfo) == 64

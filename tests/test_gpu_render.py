@@ -182,3 +182,83 @@ def test_entry_buffer_grows_on_overflow(ctx):
     _, (fb, q, amb, _) = oracle_frame(scene, cam, order)
     print(helpers.compare_frames(got, fb, amb, "overflow"))
     mesh.dispose()
+
+
+def _rot(axis, deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    x, y, z = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                     [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                     [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+
+
+def _cov6(scale, R=np.eye(3)):
+    M = R @ np.diag(np.asarray(scale, np.float64))
+    S = M @ M.T
+    return [S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]]
+
+
+# (label, centre in view space of a camera at the origin looking down -z, cov6, expected to be drawn)
+_TANX = np.tan(np.radians(25.0)) * 640 / 360
+HAND_PICKED = [
+    ("axis aligned", (0.0, 0.0, -5.0), _cov6((0.1, 0.2, 0.05)), True),
+    ("rotated", (0.7, -0.4, -4.0), _cov6((0.3, 0.05, 0.1), _rot((1, 2, 3), 37.0)), True),
+    ("needle seen end-on", (-0.5, 0.3, -3.0), _cov6((0.01, 0.01, 0.6)), True),
+    ("behind the camera", (0.0, 0.0, 5.0), _cov6((0.1, 0.1, 0.1)), False),
+    ("inside the 1.2x guard band", (1.19 * _TANX * 6.0, 0.4, -6.0), _cov6((0.5, 0.5, 0.5)), True),   # centre off screen, quad on
+    ("outside the 1.2x guard band", (1.21 * _TANX * 6.0, 0.4, -6.0), _cov6((0.2, 0.2, 0.2)), False),
+    ("outside the guard band in y", (0.0, -1.21 * np.tan(np.radians(25.0)) * 6.0, -6.0), _cov6((0.2, 0.2, 0.2)), False),
+    ("beyond the far plane", (0.0, 0.0, -1500.0), _cov6((5.0, 5.0, 5.0)), False),
+    ("nearer than the near plane", (0.0, 0.0, -0.05), _cov6((0.001, 0.001, 0.001)), False),
+    # r = sqrt(max(0.1, .)) makes lambda2 = t - r negative for sub-pixel splats (a ~ d ~ 0.3): the reference drops them
+    ("eigenvalue floor, lambda2 < 0", (0.2, 0.2, -40.0), _cov6((1e-4, 1e-4, 1e-4)), False),
+    ("zero covariance", (-0.3, 0.1, -2.0), _cov6((0.0, 0.0, 0.0)), False),
+    ("eigenvalue floor active, kept", (0.2, 0.2, -40.0), _cov6((0.0463, 0.0463, 0.0463)), True),
+    ("1024 px clamp active", (0.1, 0.0, -0.4), _cov6((3.0, 0.002, 0.002), _rot((0, 0, 1), 20.0)), True),
+    ("large and close, both axes clamped", (0.0, 0.05, -0.3), _cov6((2.0, 2.0, 0.01)), True),
+    ("taller than wide at the centre", (0.0, 0.0, -3.0), _cov6((0.05, 0.3, 0.05)), True),
+    ("far and faint", (3.0, 2.0, -600.0), _cov6((2.0, 1.0, 3.0), _rot((1, 0, 1), 60.0)), True),
+]
+
+
+def test_hand_picked_projection_cases(ctx):
+    """vertex-stage known answers on hand-picked splats — accept / reject decisions must be
+    identical and the kept records equal to the oracle's; then the composited frame of the same set."""
+    W, H = 640, 360
+    cam = camera.PerspectiveCamera(W, H, (0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))
+    n = len(HAND_PICKED)
+    centers = np.array([c for _, c, _, _ in HAND_PICKED], dtype=np.float32)
+    cov = np.array([v for _, _, v, _ in HAND_PICKED], dtype=np.float32)
+    rng = np.random.default_rng(5)
+    rgba = rng.integers(40, 256, size=(n, 4), dtype=np.uint8)
+    mesh = SplatMesh(ctx, n, 0, False)
+    mesh.build(centers, cov, rgba, None)
+    mesh.set_camera(cam)
+    order = np.argsort(centers[:, 2], kind="stable").astype(np.uint32)        # far -> near (view z ascending)
+    mesh.update_render_indexes(order, n)
+    got, stats = mesh.render()
+    recs, rects, kept = mesh.debug_records()
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0)
+    o = oracle.project(ocam, centers, cov, rgba, None)
+    f = recs.view(np.float32)
+    for i, (label, _, _, drawn) in enumerate(HAND_PICKED):
+        assert bool(o["visible"][i]) == drawn, f"oracle: {label}"
+        assert bool(kept[i]) == drawn, f"device: {label}"       # every drawn case of the table touches pixel centres
+        if not drawn:
+            continue
+        assert abs(f[i, 0] - o["cx"][i]) <= 2e-3 and abs(f[i, 1] - o["cy"][i]) <= 2e-3, label
+        n1 = o["b1x"][i] ** 2 + o["b1y"][i] ** 2
+        n2 = o["b2x"][i] ** 2 + o["b2y"][i] ** 2
+        exp = K_POWER * np.array([o["b1x"][i] / n1, o["b1y"][i] / n1, o["b2x"][i] / n2, o["b2y"][i] / n2])
+        np.testing.assert_allclose(f[i, 2:6], exp, rtol=3e-4, atol=1e-6, err_msg=label)
+    # the clamp and the floor really are active in the cases that claim it
+    i = [l for l, *_ in HAND_PICKED].index("1024 px clamp active")
+    assert abs(np.hypot(o["b1x"][i], o["b1y"][i]) - 1024.0) < 1e-2
+    i = [l for l, *_ in HAND_PICKED].index("eigenvalue floor active, kept")
+    l1 = (o["b1x"][i] ** 2 + o["b1y"][i] ** 2) / 8.0
+    l2 = (o["b2x"][i] ** 2 + o["b2y"][i] ** 2) / 8.0
+    assert abs((l1 - l2) - 2.0 * np.sqrt(0.1)) < 1e-4          # lambda1 - lambda2 = 2 r with r pinned at sqrt(0.1)
+    fb, q, amb, frags = oracle.render(ocam, centers, cov, rgba, None, order)
+    print(helpers.compare_frames(got, fb, amb, "hand-picked"))
+    mesh.dispose()

@@ -75,18 +75,22 @@ struct DevBuf {
 constexpr uint32_t GS_BIN_SHIFT = 1;                       // a bin is 2x2 tiles of 16 px = 32x32 px
 constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 
-constexpr int RADIX_THREADS = 256;
-constexpr int RADIX_ITEMS = 16;
-constexpr int RADIX_TILE = RADIX_THREADS * RADIX_ITEMS;   // keys per block iteration
-constexpr int RADIX_MAX_BLOCKS = 2048;                    // grid cap: 8 blocks per CU
+#ifndef RADIX_TILE_CFG
+#define RADIX_TILE_CFG 4096
+#endif
+constexpr int RADIX_TILE = RADIX_TILE_CFG;                // keys per workgroup iteration
+// Grid cap of a radix pass.  Every scatter workgroup starts by summing rows of the two-level offset table, so fewer,
+// longer workgroups win: same-box A/B on C3 (r01e) 2048: 0.498 ms/frame, 1024: 0.477, 512: 0.471, 384: 0.489, 256: 0.483.
+constexpr int RADIX_MAX_BLOCKS = 512;
 constexpr int RADIX_BINS = 256;
 constexpr int RADIX_MAX_PASSES = 4;
-constexpr int RADIX_REPLICAS = 16;                        // per-digit totals are accumulated into 16 replicas (see radix.hpp)
-constexpr int RADIX_TOTAL_WORDS = RADIX_MAX_PASSES * RADIX_REPLICAS * RADIX_BINS;
+constexpr int RADIX_GROUP = 32;                           // workgroups per group row of the two-level offset table (radix.hpp)
+constexpr int RADIX_MAX_GROUPS = RADIX_MAX_BLOCKS / RADIX_GROUP;
+constexpr int RADIX_TOTAL_WORDS = RADIX_MAX_PASSES * RADIX_MAX_GROUPS * RADIX_BINS;
 
 struct RadixScratch {
     DevBuf block_hist;    // uint32 [RADIX_MAX_BLOCKS][RADIX_BINS]  (workgroup-major: 1 KiB coalesced rows)
-    DevBuf digit_total;   // uint32 [RADIX_MAX_PASSES][RADIX_REPLICAS][RADIX_BINS]
+    DevBuf digit_total;   // uint32 [RADIX_MAX_PASSES][RADIX_MAX_GROUPS][RADIX_BINS]: digit counts per group of 32 workgroups
     int init() {
         GS_TRY(block_hist.alloc(sizeof(uint32_t) * RADIX_BINS * RADIX_MAX_BLOCKS));
         GS_TRY(digit_total.alloc(sizeof(uint32_t) * RADIX_TOTAL_WORDS));
@@ -252,6 +256,7 @@ struct gs_mesh {
     DevBuf recs;               // SplatRec [n]  survivors compacted inside each 256-splat block (project.hip)
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
+    DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
     DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)
     DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
     DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx

@@ -43,7 +43,8 @@ constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zer
 // (enableOptionalEffects), 8-bit SH, distance fade-in.
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
-                                                 uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask) {
+                                                 uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
+                                                 uint2* __restrict__ vis32) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     SplatRec rec;
@@ -265,10 +266,17 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         vis_mask[i >> 6] = vis;                      // the buffer covers whole blocks
     }
     __syncthreads();
-    if (visible) {
-        uint32_t slot = blockIdx.x * 256u + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
+    uint32_t wave_base = blockIdx.x * 256u;
 #pragma unroll
-        for (uint32_t w = 0; w < 3; w++) slot += (w < wave) ? s_cnt[w] : 0u;
+    for (uint32_t w = 0; w < 3; w++) wave_base += (w < wave) ? s_cnt[w] : 0u;
+    // the binner's look-up table: per 32 splats one 8-byte record {mask, slot of the first visible one} - a single
+    // 8-byte load per sorted index there (1.45 MB for 5.8 M splats, L2 resident)
+    if ((lane & 31u) == 0u) {
+        const uint32_t lo = (uint32_t)vis, hi = (uint32_t)(vis >> 32);
+        vis32[i >> 5] = lane == 0u ? make_uint2(lo, wave_base) : make_uint2(hi, wave_base + (uint32_t)__popc(lo));
+    }
+    if (visible) {
+        const uint32_t slot = wave_base + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
         recs[slot] = rec;
         rects[slot] = rect;
     }
@@ -287,10 +295,10 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp) {
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
-                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>());
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>());
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
-                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>());
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

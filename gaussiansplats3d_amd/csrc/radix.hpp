@@ -6,10 +6,14 @@
 //   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
 //     that each tile's list keeps the depth order established by the first sort.
 //
-// One pass = k_radix_hist -> k_radix_scan -> k_radix_scatter.  Deterministic: no inter-workgroup spinning,
-// no dependence on dispatch order (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS
-// workgroups walks contiguous runs of 4096-key tiles, so the [grid][256] offset matrix stays <= 2 MB
-// whatever N is, and N may live in device memory (tile-entry count is only known on the device).
+// One pass = k_radix_hist -> k_radix_scatter.  The histogram kernel leaves a two-level table: one 1 KiB row of digit
+// counts per workgroup plus one row per GROUP of 32 workgroups (atomics, 32 adders per word); every scatter workgroup
+// sums the <= 16 group rows and the <= 31 rows of its own group that precede it (coalesced 1 KiB rows) and scans the
+// 256 digit totals itself, so no separate scan kernel (10.7 us and two kernel boundaries per pass on MI355X) sits
+// between the two.  Deterministic: integer sums only, no inter-workgroup spinning, no dependence on dispatch order
+// (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS = 512 workgroups walks contiguous runs of
+// 4096-key tiles (C3's depth sort: 472 workgroups x 3 tiles), so the table stays <= 0.5 MB whatever N is, and N may
+// live in device memory (the tile-entry count and the length of a frustum-culled list only exist on the device).
 //
 // Ranking inside a tile is wave64-native.  Fast path (ATOMIC_RANK): one `ds_add_rtn_u32` on a per-wave LDS
 // histogram per key.  gfx950's LDS serves the lanes of ONE wave instruction that hit the same address in ascending
@@ -90,17 +94,21 @@ __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
     return c;
 }
 
+// The histogram kernel runs 1024-thread workgroups: its grid is the scatter's (one table row per workgroup, <= 512 of
+// them), and a gather-type loader (the depth keys) needs more waves in flight than 4 per workgroup to hide its latency
+// (r01e: 20.5 us with 256 threads).
+constexpr int HIST_THREADS = 1024;
+constexpr int HIST_ITEMS = RADIX_TILE / HIST_THREADS;
+
 // counts the digits of one full 4096-key tile with 16-byte loads (order is irrelevant for a histogram)
 template <class KeyT>
 __device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint32_t base, int shift, uint32_t* hist) {
     const uint4* src = reinterpret_cast<const uint4*>(ld.keys + base);          // base is a multiple of 4096 keys
-    constexpr int LOADS = RADIX_TILE * (int)sizeof(KeyT) / 16 / RADIX_THREADS;  // 2 (u16) or 4 (u32) per thread
-    uint4 v[LOADS];
+    constexpr uint32_t LOADS = RADIX_TILE * (uint32_t)sizeof(KeyT) / 16u;        // 16-byte loads per tile
 #pragma unroll
-    for (int k = 0; k < LOADS; k++) v[k] = src[k * RADIX_THREADS + threadIdx.x];
-#pragma unroll
-    for (int k = 0; k < LOADS; k++) {
-        const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    for (uint32_t l = threadIdx.x; l < LOADS; l += HIST_THREADS) {
+        const uint4 v = src[l];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             if (sizeof(KeyT) == 2) {
@@ -115,21 +123,20 @@ __device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint
 template <class Loader>
 __device__ __forceinline__ void hist_full_tile(const Loader& ld, uint32_t base, int shift, uint32_t* hist) {
 #pragma unroll
-    for (int r = 0; r < RADIX_ITEMS; r++) {
-        const uint32_t j = base + r * RADIX_THREADS + threadIdx.x;
+    for (int r = 0; r < HIST_ITEMS; r++) {
+        const uint32_t j = base + r * HIST_THREADS + threadIdx.x;
         if (ld.valid(j)) atomicAdd(&hist[(ld.key(j) >> shift) & 255u], 1u);
     }
 }
 
 template <class Loader>
-__global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shift, uint32_t* __restrict__ block_hist,
-                                                              uint32_t* __restrict__ digit_total) {
-    __shared__ uint32_t s_hist[4][RADIX_BINS];
+__global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shift, uint32_t* __restrict__ block_hist,
+                                                             uint32_t* __restrict__ digit_total) {
+    __shared__ uint32_t s_hist[4][RADIX_BINS];               // waves w, w+4, w+8, w+12 share one
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
-    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-#pragma unroll
-    for (int w = 0; w < 4; w++) s_hist[w][tid] = 0;
+    const uint32_t tid = threadIdx.x, wave = (tid >> 6) & 3u;
+    (&s_hist[0][0])[tid] = 0;
     __syncthreads();
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t base = tile * RADIX_TILE;
@@ -137,52 +144,21 @@ __global__ __launch_bounds__(RADIX_THREADS) void k_radix_hist(Loader ld, int shi
             hist_full_tile(ld, base, shift, s_hist[wave]);
         } else {
 #pragma unroll
-            for (int r = 0; r < RADIX_ITEMS; r++) {
-                const uint32_t j = base + r * RADIX_THREADS + tid;
+            for (int r = 0; r < HIST_ITEMS; r++) {
+                const uint32_t j = base + r * HIST_THREADS + tid;
                 if (j < ch.n && ld.valid(j)) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
             }
         }
     }
     __syncthreads();
+    if (tid >= RADIX_BINS) return;
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     block_hist[blockIdx.x * RADIX_BINS + tid] = total;           // one coalesced 1 KiB row per workgroup
-    // Per-digit totals.  G atomics on ONE word per digit serialise in the fabric (~12 ns each, MI355X_MICROARCH.md row
-    // "fanin": 10-15 us per pass, A/B r01b); spread over RADIX_REPLICAS words they cost < 2 us and save the separate
-    // row-sum kernel (5 us + a kernel boundary per pass).
-    if (total) atomicAdd(&digit_total[(blockIdx.x % RADIX_REPLICAS) * RADIX_BINS + tid], total);
+    // Group rows.  Same-address atomics serialise in the fabric (~12 ns each, MI355X_MICROARCH.md row "fanin"): with 32
+    // adders per word they stay < 1 us, where one word per digit for the whole grid cost 10-15 us per pass (A/B r01b).
+    if (total) atomicAdd(&digit_total[(blockIdx.x / RADIX_GROUP) * RADIX_BINS + tid], total);
 }
 
-// block d: exclusive scan of column d of the workgroup-major matrix, plus the number of keys with a smaller digit
-static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* __restrict__ block_hist,
-                                                              const uint32_t* __restrict__ digit_total, uint32_t grid) {
-    __shared__ uint32_t s_tmp[4];
-    const uint32_t d = blockIdx.x, tid = threadIdx.x;
-    // every load of this kernel is issued before the first barrier: one memory round trip instead of two
-    const uint32_t per = (grid + RADIX_THREADS - 1) / RADIX_THREADS;   // <= 8
-    uint32_t v[RADIX_MAX_BLOCKS / RADIX_THREADS];
-#pragma unroll
-    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
-        const uint32_t i = tid * per + k;
-        v[k] = (k < per && i < grid) ? block_hist[(size_t)i * RADIX_BINS + d] : 0u;
-    }
-    uint32_t rep[RADIX_REPLICAS];
-#pragma unroll
-    for (int r = 0; r < RADIX_REPLICAS; r++) rep[r] = tid < d ? digit_total[r * RADIX_BINS + tid] : 0u;
-    uint32_t mine = 0, sum = 0;
-#pragma unroll
-    for (int r = 0; r < RADIX_REPLICAS; r++) mine += rep[r];
-#pragma unroll
-    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) sum += v[k];
-    uint32_t below = 0;
-    (void)block_excl_scan_256(mine, s_tmp, &below);
-    uint32_t run = below + block_excl_scan_256(sum, s_tmp, nullptr);
-#pragma unroll
-    for (uint32_t k = 0; k < RADIX_MAX_BLOCKS / RADIX_THREADS; k++) {
-        const uint32_t i = tid * per + k;
-        if (k < per && i < grid) block_hist[(size_t)i * RADIX_BINS + d] = run;
-        run += v[k];
-    }
-}
 
 // WRITE_KEYS: also emit the keys (needed by every pass but the last).
 // RANGES: this is the last pass of the tile sort - publish each key's [begin,end) in the sorted output.  Inside a
@@ -190,15 +166,17 @@ static __global__ __launch_bounds__(RADIX_THREADS) void k_radix_scan(uint32_t* _
 // run boundary costs one atomicMin/atomicMax pair; `ranges` must be pre-set to (0xFFFFFFFF, 0).
 //
 // Geometry: 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and ~35 KB LDS (16-bit keys
-// are staged as 16 bits), so 4 workgroups = 32 waves fill a CU: the kernel is a chain of load -> rank -> barrier ->
-// reorder -> barrier -> store phases and only occupancy overlaps one workgroup's stalls with another's work.
+// are staged as 16 bits).  The kernel is a chain of load -> rank -> barrier -> reorder -> barrier -> store phases per
+// tile; with the grid capped at 512 a CU holds two workgroups (16 waves) whose phases overlap each other.
 constexpr int SCATTER_THREADS = 512;
 constexpr int SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_ITEMS = RADIX_TILE / SCATTER_THREADS;
+static_assert(SCATTER_THREADS == 2 * RADIX_BINS, "the offset prologue assigns two threads per digit");
 
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
-__global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) void k_radix_scatter(Loader ld, int shift,
-                                                                      const uint32_t* __restrict__ block_offsets,
+__global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_ITEMS > 8 ? 4 : (sizeof(KeyOutT) == 2 ? 8 : 6))) void k_radix_scatter(Loader ld, int shift,
+                                                                      const uint32_t* __restrict__ block_hist,
+                                                                      const uint32_t* __restrict__ group_hist,
                                                                       KeyOutT* __restrict__ keys_out,
                                                                       uint32_t* __restrict__ vals_out, uint2* ranges) {
     __shared__ KeyOutT s_keys[RADIX_TILE];                  // staged in the output key width (u16 or u32)
@@ -215,7 +193,29 @@ __global__ __launch_bounds__(SCATTER_THREADS, (sizeof(KeyOutT) == 2 ? 8 : 6)) vo
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];
 
-    if (tid < RADIX_BINS) s_base[tid] = block_offsets[blockIdx.x * RADIX_BINS + tid];
+    {   // this workgroup's first output slot per digit = keys with a smaller digit + keys of this digit in earlier
+        // workgroups; two threads per digit split the rows, every load is independent of the others
+        const uint32_t d = tid & 255u, half = tid >> 8;
+        const uint32_t g = blockIdx.x / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
+        uint32_t before = 0, all = 0;
+#pragma unroll 8
+        for (uint32_t r = half; r < groups; r += 2u) {
+            const uint32_t v = group_hist[r * RADIX_BINS + d];
+            all += v;
+            before += r < g ? v : 0u;
+        }
+#pragma unroll 8
+        for (uint32_t r = g * RADIX_GROUP + half; r < blockIdx.x; r += 2u) before += block_hist[r * RADIX_BINS + d];
+        uint32_t* s_before = &s_wave[0][0];                  // [2][256], free until the tile loop zeroes it
+        uint32_t* s_all = &s_wave[2][0];
+        s_before[tid] = before;
+        s_all[tid] = all;
+        __syncthreads();
+        const uint32_t tot = tid < RADIX_BINS ? s_all[tid] + s_all[RADIX_BINS + tid] : 0u;
+        const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);
+        if (tid < RADIX_BINS) s_base[tid] = smaller + s_before[tid] + s_before[RADIX_BINS + tid];
+        __syncthreads();                                     // s_wave is rewritten below
+    }
 
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const uint32_t tile_base = tile * RADIX_TILE;
@@ -325,15 +325,14 @@ int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uin
                KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
-    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_REPLICAS * RADIX_BINS;
-    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(RADIX_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
-    hipLaunchKernelGGL(k_radix_scan, dim3(RADIX_BINS), dim3(RADIX_THREADS), 0, ex.stream, bh, dt, grid);
+    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
+    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
     if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, keys_out, vals_out, ranges);
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges);
     else
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, keys_out, vals_out, ranges);
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

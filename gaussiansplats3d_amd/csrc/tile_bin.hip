@@ -3,8 +3,8 @@
 // The reference has no binning: it draws one instanced quad per splat, back to front, and lets the ROPs blend
 // (/root/reference/src/splatmesh/SplatGeometry.js:11-37, SplatMaterial3D.js:65-75, src/Viewer.js:1616).  A
 // tile rasteriser needs each tile's splats as a list in that same draw order, so:
-//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p).  A 1-bit-per-splat visibility mask written by
-//                 k_project (725 KB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
+//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p).  A visibility table written by k_project (8 bytes
+//                 per 32 splats, 1.45 MB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
 //                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
 //                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
 //   k_bin_scan    exclusive scan of <= 1024 workgroup sums; publishes D, min(D, capacity) and the visible count
@@ -63,11 +63,15 @@ __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
                                                            const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
-                                                           const unsigned long long* __restrict__ vis_mask,
+                                                           const uint2* __restrict__ vis32,
                                                            const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
-                                                           uint32_t* __restrict__ block_sums) {
+                                                           uint32_t* __restrict__ block_sums,
+                                                           uint32_t* __restrict__ digit_total) {
     __shared__ unsigned long long s_w[4];
+    // housekeeping for the entry sort that follows (its table is idle now): zero the group rows of every pass
+    for (uint32_t w = blockIdx.x * BIN_THREADS + threadIdx.x; w < (uint32_t)RADIX_TOTAL_WORDS; w += gridDim.x * BIN_THREADS)
+        digit_total[w] = 0u;
     // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
     // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
     const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
@@ -97,18 +101,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 #pragma unroll
             for (int k = 0; k < BIN_PER_LANE; k++) idx[k] = perm[idx[k]];
         }
-        // k_project compacts survivors inside their 256-splat block: slot = block base + visible splats before idx,
-        // recomputed here from the block's 4 mask words (one aligned 32-byte sector of an L2-resident array)
+        // k_project compacts survivors inside their 256-splat block and leaves, per 32 splats, {visibility mask, slot of
+        // the first visible one}: one 8-byte look-up in an L2-resident table gives both the filter and the slot
         uint32_t slot[BIN_PER_LANE];
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) {
-            const ulonglong4 mw = *reinterpret_cast<const ulonglong4*>(vis_mask + ((idx[k] >> 8) << 2));
-            const uint32_t w = (idx[k] >> 6) & 3u, bit = idx[k] & 63u;
-            const unsigned long long mine = w == 0 ? mw.x : (w == 1 ? mw.y : (w == 2 ? mw.z : mw.w));
-            keep[k] = keep[k] && ((mine >> bit) & 1ull);
-            slot[k] = (idx[k] & ~255u) + (uint32_t)__popcll(mine & ((1ull << bit) - 1ull)) +
-                      (w > 0 ? (uint32_t)__popcll(mw.x) : 0u) + (w > 1 ? (uint32_t)__popcll(mw.y) : 0u) +
-                      (w > 2 ? (uint32_t)__popcll(mw.z) : 0u);
+            const uint2 m = vis32[idx[k] >> 5];
+            const uint32_t bit = idx[k] & 31u;
+            keep[k] = keep[k] && ((m.x >> bit) & 1u);
+            slot[k] = m.y + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
         }
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
@@ -167,12 +168,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
 }
 
 // one workgroup of 1024 threads, two binning workgroups per thread: exclusive scan of the workgroup sums, 64-bit total
-// It also does the draw's housekeeping (no separate init kernel): digit totals of the entry sort zeroed, bin ranges
-// reset to (~0, 0), every RenderFrame field written.
+// It also does part of the draw's housekeeping (no separate init kernel): bin ranges reset to (~0, 0), every RenderFrame
+// field written (k_bin_count zeroes the entry sort's group rows).
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t grid, uint32_t capacity,
-                                                   RenderFrame* frame, uint32_t* __restrict__ digit_total,
-                                                   uint2* __restrict__ tile_ranges, uint32_t tiles) {
-    for (uint32_t w = threadIdx.x; w < (uint32_t)RADIX_TOTAL_WORDS; w += 1024u) digit_total[w] = 0u;
+                                                   RenderFrame* frame, uint2* __restrict__ tile_ranges, uint32_t tiles) {
     for (uint32_t i = threadIdx.x; i < tiles; i += 1024u) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
     __shared__ unsigned long long s_wave[16];
     __shared__ uint32_t s_vis[16];
@@ -336,15 +335,15 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const uint32_t cap = m->entry_capacity;
     const uint32_t* R_dev = (sorter && sorter->last_culled) ? &sorter->result_frame->kept : nullptr;
     hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
-                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis_mask.as<unsigned long long>(),
+                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
-                       m->bin_sums.as<uint32_t>());
+                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>());
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
     }
     hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame,
-                       m->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles);
+                       m->tile_ranges.as<uint2>(), tiles);
     uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;

@@ -168,13 +168,19 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
 // Geometry: 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and ~35 KB LDS (16-bit keys
 // are staged as 16 bits).  The kernel is a chain of load -> rank -> barrier -> reorder -> barrier -> store phases per
 // tile; with the grid capped at 512 a CU holds two workgroups (16 waves) whose phases overlap each other.
-constexpr int SCATTER_THREADS = 512;
+// 1024-thread workgroups sort faster in isolation (0.173 vs 0.186 ms for C3) but pipeline worse against the draw of the
+// previous frame (0.483 vs 0.468 ms per frame, same-box A/B r01e): 512 it is.
+#ifndef SCATTER_THREADS_CFG
+#define SCATTER_THREADS_CFG 512
+#endif
+constexpr int SCATTER_THREADS = SCATTER_THREADS_CFG;
 constexpr int SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_ITEMS = RADIX_TILE / SCATTER_THREADS;
-static_assert(SCATTER_THREADS == 2 * RADIX_BINS, "the offset prologue assigns two threads per digit");
+constexpr int SCATTER_PARTS = SCATTER_THREADS / RADIX_BINS;     // threads per digit in the offset prologue
+static_assert(SCATTER_THREADS % RADIX_BINS == 0 && 2 * SCATTER_PARTS <= SCATTER_WAVES, "offset prologue layout");
 
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
-__global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_ITEMS > 8 ? 4 : (sizeof(KeyOutT) == 2 ? 8 : 6))) void k_radix_scatter(Loader ld, int shift,
+__global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (sizeof(KeyOutT) == 2 ? 8 : 6))) void k_radix_scatter(Loader ld, int shift,
                                                                       const uint32_t* __restrict__ block_hist,
                                                                       const uint32_t* __restrict__ group_hist,
                                                                       KeyOutT* __restrict__ keys_out,
@@ -195,25 +201,32 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_ITEMS > 8 ? 4 : (sizeof(K
 
     {   // this workgroup's first output slot per digit = keys with a smaller digit + keys of this digit in earlier
         // workgroups; two threads per digit split the rows, every load is independent of the others
-        const uint32_t d = tid & 255u, half = tid >> 8;
+        const uint32_t d = tid & 255u, half = tid >> 8;      // `half` = which of the SCATTER_PARTS row subsets
         const uint32_t g = blockIdx.x / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
         uint32_t before = 0, all = 0;
 #pragma unroll 8
-        for (uint32_t r = half; r < groups; r += 2u) {
+        for (uint32_t r = half; r < groups; r += (uint32_t)SCATTER_PARTS) {
             const uint32_t v = group_hist[r * RADIX_BINS + d];
             all += v;
             before += r < g ? v : 0u;
         }
 #pragma unroll 8
-        for (uint32_t r = g * RADIX_GROUP + half; r < blockIdx.x; r += 2u) before += block_hist[r * RADIX_BINS + d];
-        uint32_t* s_before = &s_wave[0][0];                  // [2][256], free until the tile loop zeroes it
-        uint32_t* s_all = &s_wave[2][0];
+        for (uint32_t r = g * RADIX_GROUP + half; r < blockIdx.x; r += (uint32_t)SCATTER_PARTS) before += block_hist[r * RADIX_BINS + d];
+        uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop zeroes it
+        uint32_t* s_all = &s_wave[SCATTER_PARTS][0];
         s_before[tid] = before;
         s_all[tid] = all;
         __syncthreads();
-        const uint32_t tot = tid < RADIX_BINS ? s_all[tid] + s_all[RADIX_BINS + tid] : 0u;
+        uint32_t tot = 0, mine = 0;
+        if (tid < RADIX_BINS) {
+#pragma unroll
+            for (int q = 0; q < SCATTER_PARTS; q++) {
+                tot += s_all[q * RADIX_BINS + tid];
+                mine += s_before[q * RADIX_BINS + tid];
+            }
+        }
         const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);
-        if (tid < RADIX_BINS) s_base[tid] = smaller + s_before[tid] + s_before[RADIX_BINS + tid];
+        if (tid < RADIX_BINS) s_base[tid] = smaller + mine;
         __syncthreads();                                     // s_wave is rewritten below
     }
 

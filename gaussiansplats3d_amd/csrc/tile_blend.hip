@@ -16,18 +16,27 @@
 // packed into the entry, and every wave
 // walks only its own survivors of the batch (4 ballots + s_ff1 per 256 entries).  Each lane owns 4 pixels
 // (x = lane&15, y = (lane>>4) + 4g); the inner loop reads a splat as three wave-uniform ds_read_b128 broadcasts,
-// and runs the four 16x4 strips of a lane as independent, branch-free chains (~17 VALU ops per pixel; the kernel's duration is the
-// dependent chain of the heaviest quadrant, so ILP matters more than skipped work).
+// and runs the four 16x4 strips of a lane as two packed, branch-free chains (v_pk_*_f32).  Every bin of a 1080p frame is
+// resident at once (8 workgroups per CU) and a wave walks only ~90 splats before its quadrant saturates, so the kernel is
+// bound by VALU issue slots per walked splat, not by the length of the lists (tools/blend_profile.py).
 #include "gs_internal.hpp"
 
 constexpr float GS_POWER_CUT = 5.7707801636f;    // 4*log2(e)  <=>  A > 8
 constexpr float GS_T_EPS = 1e-4f;
-constexpr float GS_K_POWER_B = 2.4022448f;
+constexpr float GS_HUGE = 1.2676506e30f;         // 2^100
 constexpr int BLEND_THREADS = 256;
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+// clamp(a * b + c, 0, 1) on both lanes in one VALU slot
+__device__ __forceinline__ v2f pk_fma_sat(v2f a, v2f b, v2f c) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "s"(b), "v"(c));   // b: a wave-uniform constant pair
+    return d;
+}
 
 struct __attribute__((aligned(16))) LdsSplat {
     float cx, cy, ax, ay;
-    float bx, by, ymin, ymax;      // ymin/ymax: pixel-centre range the ellipse can touch
+    float bx, by, pad0, pad1;      // 48-byte stride keeps the three reads of a splat 16-byte aligned
     float r, g, b, a;
 };
 
@@ -37,11 +46,7 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
     s.cx = __uint_as_float(lo.x); s.cy = __uint_as_float(lo.y);
     s.ax = __uint_as_float(lo.z); s.ay = __uint_as_float(lo.w);
     s.bx = __uint_as_float(hi.x); s.by = __uint_as_float(hi.y);
-    const float na = s.ax * s.ax + s.ay * s.ay, nb = s.bx * s.bx + s.by * s.by;
-    const float b1y = GS_K_POWER_B * s.ay / na, b2y = GS_K_POWER_B * s.by / nb;
-    const float ext_y = sqrtf(b1y * b1y + b2y * b2y) * 1.00001f + 1e-3f;     // same conservative bounds as k_project
-    s.ymin = s.cy - ext_y;
-    s.ymax = s.cy + ext_y;
+    s.pad0 = 0.0f; s.pad1 = 0.0f;
     s.r = (float)(hi.z & 0xFFFFu) * (1.0f / 65535.0f);
     s.g = (float)(hi.z >> 16) * (1.0f / 65535.0f);
     s.b = (float)(hi.w & 0xFFFFu) * (1.0f / 65535.0f);
@@ -49,7 +54,15 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
     *dst = s;
 }
 
-__global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
+#ifdef GS_BLEND_PROFILE
+// tools/blend_profile.py: per bin {start, end} of s_memrealtime (100 MHz), list length, survivors walked by wave 0..3
+__device__ unsigned long long g_blend_prof[8 * 8192];
+extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_blend_prof), (size_t)bins * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+__global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, uint32_t* __restrict__ out,
                                                               uint32_t width, uint32_t y0, uint32_t y1, uint32_t bins_x,
                                                               uint32_t bin_row_begin) {
@@ -65,18 +78,28 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
     const float fx = (float)px + 0.5f;
     const float fy0 = (float)py0 + 0.5f;
 
+#ifdef GS_BLEND_PROFILE
+    const unsigned long long t_start = wall_clock64();
+    uint32_t walked = 0;
+#endif
     const uint2 range = ranges[bin];
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
 
     // a quadrant outside the viewport / this rank's strip of pixel rows has nothing to draw
     bool live_wave = qx0 < width && qy0 < y1 && qy0 + GS_TILE > y0;
 
-    float T[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-    float Cr[4] = {0, 0, 0, 0}, Cg[4] = {0, 0, 0, 0}, Cb[4] = {0, 0, 0, 0};
+    // strips g = 0..3 of a lane (rows py0 + 4g) as two packed pairs: [h].x = strip 2h, [h].y = strip 2h + 1
+    v2f T[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+    v2f Cr[2] = {{0, 0}, {0, 0}}, Cg[2] = {{0, 0}, {0, 0}}, Cb[2] = {{0, 0}, {0, 0}};
+    const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
 
     // entry payload = record slot | quadrant mask << 28 (k_bin_emit)
+    // Software pipeline over batches of 256 entries: the entry word is fetched two batches ahead and the record it names
+    // one batch ahead, so a batch waits for ONE gather latency, not for two dependent ones.  Long lists whose pixels do not
+    // saturate are bound by exactly that latency (tools/blend_profile.py: ~8 us per batch before, a wave only walks
+    // ~10 survivors of a batch).
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-    uint32_t qm = 0;
+    uint32_t qm = 0, v_next = 0;
     if (tid < n) {
         const uint32_t v = vals[begin + tid];
         const uint32_t slot = v & 0x0FFFFFFFu;
@@ -84,20 +107,21 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
         lo = recs[2 * (size_t)slot];
         hi = recs[2 * (size_t)slot + 1];
     }
+    if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid];
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
         __syncthreads();                               // previous batch fully consumed, s_live read by everyone
         s_qmask[tid] = tid < cnt ? qm : 0u;
         if (tid < cnt) stage_entry(&s_batch[tid], lo, hi);
         if (tid == 0) s_live = 0u;
-        const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch the next batch while this one is blended
+        const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
         if (nxt < n) {
-            const uint32_t v = vals[begin + nxt];
-            const uint32_t slot = v & 0x0FFFFFFFu;
-            qm = v >> 28;
+            const uint32_t slot = v_next & 0x0FFFFFFFu;
+            qm = v_next >> 28;
             lo = recs[2 * (size_t)slot];
             hi = recs[2 * (size_t)slot + 1];
         }
+        if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS];
         __syncthreads();
         if (live_wave) {
             uint32_t since_check = 0;
@@ -107,36 +131,45 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
                 while (m) {
                     const uint32_t j = g0 + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1ull;
+#ifdef GS_BLEND_PROFILE
+                    walked++;
+#endif
                     const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].cx);
                     const float4 q1 = *reinterpret_cast<const float4*>(&s_batch[j].bx);
                     const float4 q2 = *reinterpret_cast<const float4*>(&s_batch[j].r);
                     const float dx = fx - q0.x;
                     const float adx = q0.z * dx, bdx = q1.x * dx;
+                    // The four 16x4 strips of a lane are two packed pairs (v_pk_*_f32 does two fp32 lanes per VALU slot).
+                    // `if (A > 8.0) discard` and the freeze are saturated multiply-adds instead of compare + select pairs
+                    // (which do not pack and stall on VCC): keep = sat((CUT - pw) * 2^100) is exactly 1 for pw < CUT and 0
+                    // for pw >= CUT - fp32 cannot represent a positive difference below 2^-100 here.
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        // no per-strip bounds test: a wave-uniform branch per strip serialises the four independent strips
-                        // (blend 0.137 -> 0.117 ms without it); outside the ellipse the discard select yields alpha = 0
-                        const float dy = (fy0 + (float)(4 * g)) - q0.y;
-                        const float u = fmaf(q0.w, dy, adx);
-                        const float w = fmaf(q1.y, dy, bdx);
-                        const float pw = fmaf(w, w, u * u);
-                        float alpha = __builtin_amdgcn_exp2f(-pw) * q2.w;
-                        alpha = pw <= GS_POWER_CUT ? alpha : 0.0f;          // `if (A > 8.0) discard`
-                        const float wgt = T[g] * alpha;
-                        Cr[g] = fmaf(wgt, q2.x, Cr[g]);
-                        Cg[g] = fmaf(wgt, q2.y, Cg[g]);
-                        Cb[g] = fmaf(wgt, q2.z, Cb[g]);
-                        // a pixel freezes the moment it saturates, so its value depends only on its own ordered list of
-                        // contributing splats - not on how lists are batched (strips of a multi-GPU draw stay bit-exact)
-                        const float t_new = T[g] - wgt;
-                        T[g] = t_new < GS_T_EPS ? 0.0f : t_new;
+                    for (int h = 0; h < 2; h++) {
+                        const v2f dy = fy[h] - q0.y;
+                        const v2f u = q0.w * dy + adx;                       // contracted to v_pk_fma_f32
+                        const v2f w = q1.y * dy + bdx;
+                        const v2f pw = w * w + u * u;
+                        v2f e;
+                        e.x = __builtin_amdgcn_exp2f(-pw.x);
+                        e.y = __builtin_amdgcn_exp2f(-pw.y);
+                        const v2f keep = pk_fma_sat(pw, v2f{-GS_HUGE, -GS_HUGE}, v2f{GS_POWER_CUT * GS_HUGE, GS_POWER_CUT * GS_HUGE});
+                        const v2f alpha = e * (q2.w * keep);
+                        const v2f wgt = T[h] * alpha;
+                        Cr[h] += wgt * q2.x;
+                        Cg[h] += wgt * q2.y;
+                        Cb[h] += wgt * q2.z;
+                        // a pixel freezes the moment it saturates (T <= 1e-4 -> 0), so its value depends only on its own
+                        // ordered list of contributing splats - not on how lists are batched (strips of a multi-GPU draw
+                        // stay bit-exact)
+                        const v2f t_new = T[h] - wgt;
+                        T[h] = t_new * pk_fma_sat(t_new, v2f{GS_HUGE, GS_HUGE}, v2f{-GS_T_EPS * GS_HUGE, -GS_T_EPS * GS_HUGE});
                     }
                     if (++since_check == 16u || m == 0ull) {
                         // retire the wave when its whole quadrant is saturated
                         since_check = 0;
                         bool live = false;
 #pragma unroll
-                        for (int g = 0; g < 4; g++) live = live || (T[g] > 0.0f);
+                        for (int h = 0; h < 2; h++) live = live || (T[h].x > 0.0f) || (T[h].y > 0.0f);
                         if (__ballot(live) == 0ull) {
                             live_wave = false;
                             break;
@@ -149,14 +182,25 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend(const uint2* __res
         __syncthreads();
         if (s_live == 0u) break;                       // every quadrant saturated (or clipped): skip the rest of the list
     }
+#ifdef GS_BLEND_PROFILE
+    if (bin < 8192u && lane == 0u) {
+        if (wave == 0u) {
+            g_blend_prof[8 * bin + 0] = t_start;
+            g_blend_prof[8 * bin + 2] = n;
+        }
+        g_blend_prof[8 * bin + 4 + wave] = walked;
+    }
+    __syncthreads();
+    if (bin < 8192u && tid == 0u) g_blend_prof[8 * bin + 1] = wall_clock64();
+#endif
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
         if (px < width && py >= y0 && py < y1) {
-            const float a = 1.0f - T[g];
-            const uint32_t r8 = (uint32_t)(fminf(fmaxf(Cr[g], 0.0f), 1.0f) * 255.0f + 0.5f);
-            const uint32_t g8 = (uint32_t)(fminf(fmaxf(Cg[g], 0.0f), 1.0f) * 255.0f + 0.5f);
-            const uint32_t b8 = (uint32_t)(fminf(fmaxf(Cb[g], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const float a = 1.0f - T[g >> 1][g & 1];
+            const uint32_t r8 = (uint32_t)(fminf(fmaxf(Cr[g >> 1][g & 1], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t g8 = (uint32_t)(fminf(fmaxf(Cg[g >> 1][g & 1], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t b8 = (uint32_t)(fminf(fmaxf(Cb[g >> 1][g & 1], 0.0f), 1.0f) * 255.0f + 0.5f);
             const uint32_t a8 = (uint32_t)(fminf(fmaxf(a, 0.0f), 1.0f) * 255.0f + 0.5f);
             out[(size_t)(py - y0) * width + px] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
         }

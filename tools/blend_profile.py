@@ -1,0 +1,43 @@
+"""Per-bin timeline of k_tile_blend (variant built with -DGS_BLEND_PROFILE, selected through GSPLAT_HIP_LIB)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util, _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+cfg = scenes.CONFIGS[name]
+scene = scenes.make_config_scene(name)
+cam = camera.demo_camera(cfg["pose"], cfg["width"], cfg["height"])
+N = scene.count
+ctx = Context(0)
+w = create_sort_worker(ctx, N)
+w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
+mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half).build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+mesh.set_camera(cam)
+mesh.use_sorter_result(w, N)
+for _ in range(3):
+    w.sort_on_device(cam.sort_mvp(), N)
+    _, st = mesh.render(to_host=False, want_stats=True)
+ctx.synchronize()
+bins = ((cfg["width"] + 31) // 32) * ((cfg["height"] + 31) // 32)
+bins = min(bins, 8192)
+buf = np.zeros((bins, 8), dtype=np.uint64)
+lib = _lib.load()
+lib.gs_debug_blend_prof.argtypes = [C.c_void_p, C.c_uint]
+assert lib.gs_debug_blend_prof(buf.ctypes.data, bins) == 0
+t0, t1, n = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64), buf[:, 2].astype(np.int64)
+walked = buf[:, 4:8].astype(np.int64)
+start = t0.min()
+dur = (t1 - t0) / 100.0          # us (100 MHz)
+rel0, rel1 = (t0 - start) / 100.0, (t1 - start) / 100.0
+print(f"{name}: blend_ms(stats)={st.blend_ms:.4f} bins={bins} span={rel1.max():.1f} us  sum(dur)={dur.sum():.0f} us  "
+      f"mean={dur.mean():.2f} max={dur.max():.1f} p99={np.percentile(dur, 99):.1f} p90={np.percentile(dur, 90):.1f}")
+print("list length: mean %.0f max %d | walked per wave: mean %.0f max %d | walked/len %.3f" %
+      (n.mean(), n.max(), walked.mean(), walked.max(), walked.sum() / max(4 * n.sum(), 1)))
+# concurrency over time
+edges = np.linspace(0, rel1.max(), 23)
+for a, b in zip(edges[:-1], edges[1:]):
+    act = ((rel0 < b) & (rel1 > a)).sum()
+    print(f"  {a:6.1f}-{b:6.1f} us  active bins {act}")
+late = np.argsort(rel1)[-8:]
+for i in late[::-1]:
+    print(f"  bin {i} ({i % ((cfg['width']+31)//32)},{i // ((cfg['width']+31)//32)}) start {rel0[i]:.1f} end {rel1[i]:.1f} dur {dur[i]:.1f} n {n[i]} walked {walked[i].tolist()}")

@@ -207,6 +207,29 @@ def main():
             stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
         stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
 
+        # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the
+        # headline stays the fixed demo pose so rounds remain comparable)
+        orbit = None
+        if world == 1 and not args.no_cull:
+            ms, vis = [], []
+            for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
+                mesh.set_camera(oc)
+                o_mvp = oc.sort_mvp()
+                worker.sort_on_device(o_mvp, N)                # untimed: this draw may grow the entry buffer
+                _, o_st = mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                worker.sort_on_device(o_mvp, N)
+                mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t1) * 1e3)
+                vis.append(int(o_st.visible_splats))
+            mesh.set_camera(cam)
+            orbit = {"poses": 60, "frame_latency_ms_median": round(float(np.median(ms)), 4),
+                     "frame_latency_ms_min": round(float(np.min(ms)), 4), "frame_latency_ms_max": round(float(np.max(ms)), 4),
+                     "visible_splats_median": int(np.median(vis)), "visible_splats_max": int(np.max(vis)),
+                     "note": "isolated (synchronised) frames, so compare with frame_latency_ms, not ms_per_step"}
+
         # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
         cull = None
         if world == 1 and not args.no_cull:
@@ -302,6 +325,7 @@ def main():
                       "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
                       "D_per_splat": round(D16 / R, 3), "bin_entries": D32,
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "orbit": orbit,
             "cull_on": cull,
             "frustum_cull_fused": fused,
             "cpu_baseline": None,

@@ -142,3 +142,18 @@ DEMO_POSES = {
 def demo_camera(name, width, height):
     up, pos, look = DEMO_POSES[name]
     return PerspectiveCamera(width, height, pos, look, up)
+
+
+def orbit_cameras(name, width, height, poses=60):
+    """a `poses`-step orbit of the demo camera about its look-at point (rotation about the demo's up
+    axis, same distance and height), for per-pose medians.  Pose 0 is the demo pose itself."""
+    up, pos, look = (np.asarray(v, dtype=np.float64) for v in DEMO_POSES[name])
+    axis = up / np.linalg.norm(up)
+    rel = pos - look
+    out = []
+    for k in range(poses):
+        a = 2.0 * np.pi * k / poses
+        # Rodrigues rotation of the eye offset about the up axis
+        r = rel * np.cos(a) + np.cross(axis, rel) * np.sin(a) + axis * np.dot(axis, rel) * (1.0 - np.cos(a))
+        out.append(PerspectiveCamera(width, height, tuple(look + r), tuple(look), tuple(up)))
+    return out

@@ -77,12 +77,21 @@ class HipSortWorker {
       if (this.dynamicMode && !transforms) transforms = new Float32Array(Constants.MaxScenes * 16);
       const out = this.useSharedMemory ? new Uint32Array(this.sortedIndexesBuffer, 0, renderCount) : new Uint32Array(renderCount);
       const r = addon.sorterSort(this.handle, mvp, indexes, sortCount, renderCount, pre, this.dynamicMode ? transforms : null, out);
-      const reply = { sortDone: true, splatSortCount: sortCount, splatRenderCount: renderCount, sortTime: r.sortTime, status: r.status };
-      if (!this.useSharedMemory) reply.sortedIndexes = out;
+      // under setFrustumCull the list holds only the kept splats: the Viewer draws `splatRenderCount` of them
+      // (Viewer.js:1251-1262 passes e.data.splatRenderCount to updateRenderIndexes)
+      const drawCount = this.frustumCull ? r.resultCount : renderCount;
+      const reply = { sortDone: true, splatSortCount: Math.min(sortCount, drawCount), splatRenderCount: drawCount, sortTime: r.sortTime, status: r.status };
+      if (!this.useSharedMemory) reply.sortedIndexes = this.frustumCull ? out.subarray(0, drawCount) : out;
       setImmediate(() => this._emit(reply));
     } else if (msg.init) {
       // the reference ships its WASM bytes through an init message (SortWorker.js:116-199); nothing to do here
     }
+  }
+
+  // HIP-engine extra (no counterpart in the reference): fuse a per-splat frustum cull into full sorts
+  setFrustumCull(enable) {
+    addon.sorterSetFrustumCull(this.handle, enable ? 1 : 0);
+    this.frustumCull = !!enable;
   }
 
   terminate() {

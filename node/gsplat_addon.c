@@ -245,6 +245,64 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* meshUploadShU8(mesh, from, count, sh Uint8Array(9|24 per splat)) — 8-bit SH of a GS_MESH_SH_U8 mesh */
+static napi_value MeshUploadShU8(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    void* p;
+    size_t b;
+    if (!get_bytes(env, argv[3], &p, &b) || !p) { napi_throw_type_error(env, NULL, "meshUploadShU8: bad buffer"); return NULL; }
+    const uint32_t count = get_u32(env, argv[2]);
+    if (b < (size_t)count * 9) { napi_throw_range_error(env, NULL, "meshUploadShU8: buffer shorter than count"); return NULL; }
+    int st = gs_mesh_upload_sh_u8((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint8_t*)p);
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* meshUploadSceneIndexes(mesh, from, count, Uint32Array) — sceneIndexesTexture, SplatMesh.js:881-897 */
+static napi_value MeshUploadSceneIndexes(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    void* p;
+    size_t b;
+    if (!get_bytes(env, argv[3], &p, &b) || !p) { napi_throw_type_error(env, NULL, "meshUploadSceneIndexes: bad buffer"); return NULL; }
+    const uint32_t count = get_u32(env, argv[2]);
+    if (b < (size_t)count * 4) { napi_throw_range_error(env, NULL, "meshUploadSceneIndexes: buffer shorter than count"); return NULL; }
+    int st = gs_mesh_upload_scene_indexes((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint32_t*)p);
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* meshSetScenes(mesh, {sceneCount, transforms F32(16*n), invCamPos F32(4*n), opacity F32(n), visible U32(n), sh8Min F32(n),
+ *               sh8Max F32(n)}) — the per-scene uniforms of SplatMesh.updateUniforms (SplatMesh.js:1263-1276) */
+static napi_value MeshSetScenes(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    static gs_scene_params sp;                 /* 2.9 KB: keep it off the stack of the JS thread's callback */
+    memset(&sp, 0, sizeof sp);
+    napi_value v;
+    NAPI_OK(napi_get_named_property(env, argv[1], "sceneCount", &v));
+    sp.scene_count = get_u32(env, v);
+    if (sp.scene_count < 1 || sp.scene_count > GS_MAX_SCENES) { napi_throw_range_error(env, NULL, "meshSetScenes: sceneCount"); return NULL; }
+    for (uint32_t i = 0; i < GS_MAX_SCENES; i++) {
+        sp.opacity[i] = 1.0f; sp.visible[i] = 1u; sp.sh8_min[i] = -1.0f; sp.sh8_max[i] = 1.0f;
+        for (int k = 0; k < 4; k++) sp.transforms[i][5 * k] = 1.0f;
+    }
+    const struct { const char* key; void* dst; size_t per; } fields[] = {
+        {"transforms", sp.transforms, 64}, {"invCamPos", sp.inv_cam_pos, 16}, {"opacity", sp.opacity, 4},
+        {"visible", sp.visible, 4},        {"sh8Min", sp.sh8_min, 4},         {"sh8Max", sp.sh8_max, 4}};
+    for (size_t f = 0; f < sizeof fields / sizeof fields[0]; f++) {
+        bool has = false;
+        NAPI_OK(napi_has_named_property(env, argv[1], fields[f].key, &has));
+        if (!has) continue;
+        void* d;
+        size_t nb;
+        NAPI_OK(napi_get_named_property(env, argv[1], fields[f].key, &v));
+        if (!get_bytes(env, v, &d, &nb) || !d) continue;
+        const size_t want = fields[f].per * sp.scene_count;
+        if (nb < want) { napi_throw_range_error(env, NULL, "meshSetScenes: array shorter than sceneCount"); return NULL; }
+        memcpy(fields[f].dst, d, want);
+    }
+    int st = gs_mesh_set_scenes((gs_mesh*)get_external(env, argv[0]), &sp);
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+
 /* sorterBindMesh(sorter, mesh|null) */
 static napi_value SorterBindMesh(napi_env env, napi_callback_info info) {
     ARGS(2)
@@ -385,7 +443,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"deviceCount", DeviceCount},       {"contextCreate", ContextCreate}, {"contextDestroy", ContextDestroy},
         {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},
         {"sorterSort", SorterSort},         {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
-        {"meshUpload", MeshUpload},         {"meshRender", MeshRender},
+        {"meshUpload", MeshUpload},         {"meshRender", MeshRender},       {"meshUploadShU8", MeshUploadShU8},
+        {"meshUploadSceneIndexes", MeshUploadSceneIndexes},                   {"meshSetScenes", MeshSetScenes},
         {"sorterBindMesh", SorterBindMesh}, {"sorterSetFrustumCull", SorterSetFrustumCull}, {"sorterSortGathered", SorterSortGathered},
         {"treeCreate", TreeCreate},         {"treeDestroy", TreeDestroy},     {"treeInfo", TreeInfo},
         {"treeGather", TreeGather},         {"assetLoad", AssetLoad},

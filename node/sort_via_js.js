@@ -1,10 +1,10 @@
 // Runs one sort through the JS shim's createSortWorker protocol (test driver; same input file format as
-// oracle/wasm_ref.js).  usage: node sort_via_js.js <in.bin> <out.bin> [shared]
+// oracle/wasm_ref.js).  usage: node sort_via_js.js <in.bin> <out.bin> [shared|cull]
 'use strict';
 const fs = require('fs');
 const gs = require('./gsplat.js');
 const [inPath, outPath, sharedArg] = process.argv.slice(2);
-const shared = sharedArg === 'shared';
+const shared = sharedArg === 'shared', cull = sharedArg === 'cull';
 const buf = fs.readFileSync(inPath);
 const ab = buf.buffer.slice(buf.byteOffset, buf.byteOffset + buf.byteLength);
 const [n, renderCount, sortCount, range, useInt, dynamic, usePre] = new Uint32Array(ab, 0, 8);
@@ -15,6 +15,7 @@ const sceneIdx = dynamic ? take(4 * n) : null, transforms = dynamic ? new Float3
 const pre = usePre ? take(4 * n) : null;
 const precision = Math.round(Math.log2(range));
 const worker = gs.createSortWorker(n, shared, true, !!useInt, !!dynamic, precision);
+if (cull) worker.setFrustumCull(true);
 worker.onmessage = (e) => {
   if (e.data.sortSetupPhase1Complete) {
     worker.postMessage({ centers: centers, sceneIndexes: sceneIdx, range: { from: 0, to: n - 1, count: n } });
@@ -29,9 +30,9 @@ worker.onmessage = (e) => {
     }
     worker.postMessage({ sort });
   } else if (e.data.sortDone) {
-    const out = shared ? new Uint32Array(worker.sortedIndexesBuffer, 0, renderCount) : e.data.sortedIndexes;
+    const out = shared ? new Uint32Array(worker.sortedIndexesBuffer, 0, e.data.splatRenderCount) : e.data.sortedIndexes;
     fs.writeFileSync(outPath, Buffer.from(out.buffer, out.byteOffset, out.byteLength));
-    console.log(JSON.stringify({ sortTime: e.data.sortTime, status: e.data.status }));
+    console.log(JSON.stringify({ sortTime: e.data.sortTime, status: e.data.status, splatRenderCount: e.data.splatRenderCount }));
     worker.terminate();
   }
 };

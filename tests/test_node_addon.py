@@ -29,7 +29,9 @@ def test_addon_loads_and_exports_the_seams():
     info = json.loads(out.strip().splitlines()[-1])
     assert info["abi"] == 1 and info["w"] == "function" and info["m"] == "function"
     for name in ("contextCreate", "sorterCreate", "sorterUploadCenters", "sorterSort", "meshCreate", "meshUpload",
-                 "meshRender", "sorterDestroy", "meshDestroy", "contextDestroy", "deviceCount"):
+                 "meshRender", "sorterDestroy", "meshDestroy", "contextDestroy", "deviceCount", "sorterBindMesh",
+                 "sorterSetFrustumCull", "sorterSortGathered", "treeCreate", "treeGather", "assetLoad", "meshSetScenes",
+                 "meshUploadSceneIndexes", "meshUploadShU8"):
         assert name in info["k"]
     assert info["args"] == 5          # five positional parameters before the defaulted precision, like the reference
 
@@ -74,6 +76,31 @@ def test_sort_through_the_js_protocol_is_bit_exact(tmp_path, name, mode):
     assert res.returncode == 0, res.stderr
     got = np.fromfile(outp, dtype=np.uint32)
     assert kat_cases.digest(got) == meta["output"]
+
+
+@pytest.mark.gpu
+def test_frustum_culled_sort_through_the_js_protocol(tmp_path):
+    """worker.setFrustumCull(true): the sortDone reply carries the kept list and its length as splatRenderCount."""
+    import oracle
+    import helpers
+    from gaussiansplats3d_amd import camera, util
+    _built()
+    scene = helpers.small_scene(20000, 0, seed=77)
+    rng = np.random.default_rng(78)
+    scene.centers[:8000] += rng.normal(size=(8000, 3)).astype(np.float32) * 6.0          # push many out of the frustum
+    ci = util.integer_centers(scene.centers)
+    cam = camera.demo_camera("garden", 1280, 720)
+    idx = np.arange(scene.count, dtype=np.uint32)
+    args = {"centers4": ci, "render_count": scene.count, "sort_count": scene.count, "precision": 16, "use_int": True,
+            "dynamic": False, "precomputed": None, "indexes": idx, "mvp": cam.sort_mvp()}
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _write_case(inp, args)
+    res = subprocess.run(["node", "sort_via_js.js", inp, outp, "cull"], cwd=NODE_DIR, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    reply = json.loads(res.stdout.strip().splitlines()[-1])
+    expect, keep = oracle.culled_sort(idx, ci, cam.sort_mvp())
+    assert 0 < keep.sum() < scene.count and reply["splatRenderCount"] == len(expect)
+    np.testing.assert_array_equal(np.fromfile(outp, dtype=np.uint32), expect)
 
 
 def test_tree_and_asset_bindings_on_the_host(tmp_path):

@@ -7,7 +7,6 @@
 //                 per 32 splats, 1.45 MB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
 //                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
 //                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
-//   k_bin_scan    exclusive scan of <= 1024 workgroup sums; publishes D, min(D, capacity) and the visible count
 //   k_bin_emit    ENTRY-centric expansion into (tile id, splat index) pairs: every lane owns 16 consecutive output
 //                 slots, finds the splat covering its first slot with two binary searches (workgroup table in LDS,
 //                 then that workgroup's per-splat offsets) and walks forward.  Work per lane is constant, so the
@@ -67,11 +66,18 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
                                                            const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums,
-                                                           uint32_t* __restrict__ digit_total) {
+                                                           uint32_t* __restrict__ digit_total,
+                                                           uint32_t* __restrict__ block_hist,
+                                                           uint2* __restrict__ tile_ranges, uint32_t tiles) {
     __shared__ unsigned long long s_w[4];
-    // housekeeping for the entry sort that follows (its table is idle now): zero the group rows of every pass
-    for (uint32_t w = blockIdx.x * BIN_THREADS + threadIdx.x; w < (uint32_t)RADIX_TOTAL_WORDS; w += gridDim.x * BIN_THREADS)
-        digit_total[w] = 0u;
+    // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
+    // pass and the workgroup rows of its first pass (k_bin_emit accumulates that histogram), reset the bin ranges.
+    {
+        const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
+        for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
+        for (uint32_t w = t; w < (uint32_t)(RADIX_MAX_BLOCKS * RADIX_BINS); w += stride) block_hist[w] = 0u;
+        for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
+    }
     // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
     // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
     const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
@@ -167,159 +173,195 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     }
 }
 
-// one workgroup of 1024 threads, two binning workgroups per thread: exclusive scan of the workgroup sums, 64-bit total
-// It also does part of the draw's housekeeping (no separate init kernel): bin ranges reset to (~0, 0), every RenderFrame
-// field written (k_bin_count zeroes the entry sort's group rows).
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t grid, uint32_t capacity,
-                                                   RenderFrame* frame, uint2* __restrict__ tile_ranges, uint32_t tiles) {
-    for (uint32_t i = threadIdx.x; i < tiles; i += 1024u) tile_ranges[i] = make_uint2(0xFFFFFFFFu, 0u);
-    __shared__ unsigned long long s_wave[16];
-    __shared__ uint32_t s_vis[16];
-    __shared__ unsigned long long s_t16[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t i0 = 2u * tid, i1 = i0 + 1u;
-    unsigned long long t16 = (i0 < grid ? block_sums[2 * BIN_MAX_BLOCKS + i0] : 0u);
-    t16 += (i1 < grid ? block_sums[2 * BIN_MAX_BLOCKS + i1] : 0u);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t16 += __shfl_xor(t16, o, 64);
-    if (lane == 0) s_t16[wave] = t16;
-    const unsigned long long v0 = i0 < grid ? block_sums[i0] : 0ull, v1 = i1 < grid ? block_sums[i1] : 0ull;
-    const unsigned long long v = v0 + v1;
-    uint32_t vis = (i0 < grid ? block_sums[BIN_MAX_BLOCKS + i0] : 0u) + (i1 < grid ? block_sums[BIN_MAX_BLOCKS + i1] : 0u);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vis += __shfl_xor(vis, o, 64);
-    if (lane == 0) s_vis[wave] = vis;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long t = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-        if ((uint32_t)w < wave) base += s_wave[w];
-        total += s_wave[w];
-    }
-    const unsigned long long excl = base + incl - v;
-    if (i0 < grid) block_sums[i0] = excl > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)excl;
-    if (i1 < grid) block_sums[i1] = (excl + v0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(excl + v0);
-    if (tid == 0) {
-        uint32_t vsum = 0;
-        unsigned long long tsum = 0;
-        for (int w = 0; w < 16; w++) { vsum += s_vis[w]; tsum += s_t16[w]; }
-        frame->tiles16_lo = (uint32_t)tsum;
-        frame->tiles16_hi = (uint32_t)(tsum >> 32);
-        frame->visible = vsum;
-        frame->entries_lo = (uint32_t)total;
-        frame->entries_hi = (uint32_t)(total >> 32);
-        frame->overflow = total > capacity ? 1u : 0u;
-        frame->entry_count = total > capacity ? capacity : (uint32_t)total;
-        frame->pad = 0;
-    }
-}
-
 constexpr uint32_t EMIT_PER_LANE = 16;
 constexpr uint32_t EMIT_WINDOW = BIN_THREADS * EMIT_PER_LANE;     // entries per workgroup iteration
 
-// block_sums after k_bin_scan: [0,BIN_MAX_BLOCKS) exclusive entry offset of every binning workgroup | [BIN_MAX_BLOCKS,..) its
-// compacted splat count | [3*BIN_MAX_BLOCKS] batches per binning workgroup.  `bin_grid` = the grid k_bin_count ran with.
+// block_sums: [0,BIN_MAX_BLOCKS) entries of every binning workgroup | [BIN_MAX_BLOCKS,..) its compacted splat count |
+// [2*BIN_MAX_BLOCKS,..) its 16-px tiles | [3*BIN_MAX_BLOCKS] batches per binning workgroup.  `bin_grid` = k_bin_count's grid.
+// Every workgroup scans the <= 2048 workgroup sums itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan kernel
+// and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
+// It also accumulates the first entry-sort pass's histogram: an emit window is exactly one 4096-key radix tile, so the
+// window's low-digit counts go straight into the row of the radix workgroup that will scatter it (`radix_grid` = that
+// pass's grid; rows and group rows were zeroed by k_bin_count) and the pass runs without its histogram kernel.
 template <class KeyT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const RenderFrame* __restrict__ frame, uint32_t bin_grid,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restrict__ frame, uint32_t capacity, uint32_t bin_grid,
                                                           const uint32_t* __restrict__ cidx,
                                                           const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
                                                           const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* bins per row */,
                                                           uint32_t row_begin /* first bin row */, KeyT* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out) {
+                                                          uint32_t* __restrict__ vals_out, uint32_t radix_grid,
+                                                          uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist) {
+    static_assert(BIN_THREADS * 16 == RADIX_TILE, "an emit window must be one radix tile");
     __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
-    const uint32_t D = frame->entry_count;
+    __shared__ unsigned long long s_scan[4];
+    __shared__ uint32_t s_hist[RADIX_BINS];
+    __shared__ unsigned long long s_t16[4];
+    __shared__ uint32_t s_vis[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;            // 8 consecutive workgroup sums per thread
+    unsigned long long D64;
+    {
+        uint32_t v[PER_T];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER_T; k++) {
+            const uint32_t i = threadIdx.x * PER_T + k;
+            v[k] = i < bin_grid ? block_sums[i] : 0u;
+            mine += v[k];
+        }
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += t;
+        }
+        if (lane == 63u) s_scan[wave] = incl;
+        __syncthreads();
+        unsigned long long base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned long long c = s_scan[w];
+            base += ((uint32_t)w < wave) ? c : 0ull;
+            total += c;
+        }
+        unsigned long long run = base + incl - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < PER_T; k++) {
+            const uint32_t i = threadIdx.x * PER_T + k;
+            if (i < bin_grid) s_boff[i] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+            run += v[k];
+        }
+        if (threadIdx.x == 0) s_boff[bin_grid] = 0xFFFFFFFFu;
+        D64 = total;
+    }
+    const uint32_t D = D64 > capacity ? capacity : (uint32_t)D64;
+    if (blockIdx.x == 0) {                                   // the frame's scalars (read by the sort passes and the host)
+        unsigned long long t16 = 0;
+        uint32_t vis = 0;
+        for (uint32_t i = threadIdx.x; i < bin_grid; i += BIN_THREADS) {
+            vis += block_sums[BIN_MAX_BLOCKS + i];
+            t16 += block_sums[2 * BIN_MAX_BLOCKS + i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            vis += __shfl_xor(vis, o, 64);
+            t16 += __shfl_xor(t16, o, 64);
+        }
+        if (lane == 0u) { s_t16[wave] = t16; s_vis[wave] = vis; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long tsum = s_t16[0] + s_t16[1] + s_t16[2] + s_t16[3];
+            frame->tiles16_lo = (uint32_t)tsum;
+            frame->tiles16_hi = (uint32_t)(tsum >> 32);
+            frame->visible = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+            frame->entries_lo = (uint32_t)D64;
+            frame->entries_hi = (uint32_t)(D64 >> 32);
+            frame->overflow = D64 > capacity ? 1u : 0u;
+            frame->entry_count = D;
+            frame->pad = 0;
+        }
+    }
     const uint32_t bin_per = block_sums[3 * BIN_MAX_BLOCKS];             // batches per binning workgroup (k_bin_count)
-    for (uint32_t i = threadIdx.x; i <= bin_grid; i += BIN_THREADS) s_boff[i] = i < bin_grid ? block_sums[i] : 0xFFFFFFFFu;
+    const uint32_t radix_tiles = (D + EMIT_WINDOW - 1u) / EMIT_WINDOW;
+    const uint32_t radix_per = max((radix_tiles + radix_grid - 1u) / radix_grid, 1u);   // = radix_chunk()'s tiles per workgroup
     __syncthreads();
     for (uint32_t win = blockIdx.x; (unsigned long long)win * EMIT_WINDOW < D; win += gridDim.x) {
         const uint32_t e0 = win * EMIT_WINDOW + threadIdx.x * EMIT_PER_LANE;
-        if (e0 >= D) continue;
         const uint32_t e1 = min(e0 + EMIT_PER_LANE, D);
-        // level 1: binning workgroup b owning slot e0 = LAST b with s_boff[b] <= e0 (empty workgroups share their
-        // offset with a successor and lose, which is what we want)
-        uint32_t lo = 0, hi = bin_grid;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (s_boff[mid] <= e0) lo = mid; else hi = mid;
-        }
-        uint32_t b = lo;
-        uint32_t first = b * bin_per * BIN_THREADS;                     // start of b's slice of the compacted list
-        uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
-        uint32_t boff = s_boff[b];
-        // level 2: LAST splat j of that slice with boff + coff[j] <= e0
-        uint32_t jl = 0, jh = cnt;
-        const uint32_t rel = e0 - boff;
-        while (jh - jl > 1) {
-            const uint32_t mid = (jl + jh) >> 1;
-            if (coff[first + mid] <= rel) jl = mid; else jh = mid;
-        }
-        uint32_t j = jl;
-        uint2 r16 = crect[first + j];                                   // 16-px tile rect of the splat
-        uint2 r = rect_to_bins(r16);                                    // the bins it touches
-        uint32_t idx = cidx[first + j];
-        uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
-        uint32_t n = rect_tiles(r);
-        uint32_t k = rel - coff[first + j];
-        uint32_t ty = (r.x >> 16) + k / w, tx = x0 + k % w;              // absolute bin coordinates
+        s_hist[threadIdx.x] = 0u;                                       // BIN_THREADS == RADIX_BINS
+        __syncthreads();
+        if (e0 < D) {
+            // level 1: binning workgroup b owning slot e0 = LAST b with s_boff[b] <= e0 (empty workgroups share their
+            // offset with a successor and lose, which is what we want)
+            uint32_t lo = 0, hi = bin_grid;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_boff[mid] <= e0) lo = mid; else hi = mid;
+            }
+            uint32_t b = lo;
+            uint32_t first = b * bin_per * BIN_THREADS;                     // start of b's slice of the compacted list
+            uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
+            uint32_t boff = s_boff[b];
+            // level 2: LAST splat j of that slice with boff + coff[j] <= e0
+            uint32_t jl = 0, jh = cnt;
+            const uint32_t rel = e0 - boff;
+            while (jh - jl > 1) {
+                const uint32_t mid = (jl + jh) >> 1;
+                if (coff[first + mid] <= rel) jl = mid; else jh = mid;
+            }
+            uint32_t j = jl;
+            uint2 r16 = crect[first + j];                                   // 16-px tile rect of the splat
+            uint2 r = rect_to_bins(r16);                                    // the bins it touches
+            uint32_t idx = cidx[first + j];
+            uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
+            uint32_t n = rect_tiles(r);
+            uint32_t k = rel - coff[first + j];
+            uint32_t ty = (r.x >> 16) + k / w, tx = x0 + k % w;              // absolute bin coordinates
 
-        uint32_t kk[EMIT_PER_LANE], vv[EMIT_PER_LANE];
+            uint32_t kk[EMIT_PER_LANE], vv[EMIT_PER_LANE];
 #pragma unroll
-        for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
-            kk[t] = (ty - row_begin) * tiles_x + tx;
-            vv[t] = idx | (quadrant_mask(r16, tx, ty) << 28);
-            if (e0 + t + 1 < e1) {
-                if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
-                    if (++j == cnt) {
-                        do {
-                            b++;
-                            cnt = block_sums[BIN_MAX_BLOCKS + b];
-                        } while (cnt == 0);
-                        first = b * bin_per * BIN_THREADS;
-                        j = 0;
+            for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
+                kk[t] = (ty - row_begin) * tiles_x + tx;
+                vv[t] = idx | (quadrant_mask(r16, tx, ty) << 28);
+                if (e0 + t + 1 < e1) {
+                    if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
+                        if (++j == cnt) {
+                            do {
+                                b++;
+                                cnt = block_sums[BIN_MAX_BLOCKS + b];
+                            } while (cnt == 0);
+                            first = b * bin_per * BIN_THREADS;
+                            j = 0;
+                        }
+                        r16 = crect[first + j];
+                        r = rect_to_bins(r16);
+                        idx = cidx[first + j];
+                        x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
+                        n = rect_tiles(r);
+                        k = 0;
+                        tx = x0; ty = r.x >> 16;
+                    } else if (++tx > x1) {
+                        tx = x0; ty++;
                     }
-                    r16 = crect[first + j];
-                    r = rect_to_bins(r16);
-                    idx = cidx[first + j];
-                    x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
-                    n = rect_tiles(r);
-                    k = 0;
-                    tx = x0; ty = r.x >> 16;
-                } else if (++tx > x1) {
-                    tx = x0; ty++;
                 }
             }
-        }
-        if (e1 - e0 == EMIT_PER_LANE) {
-            // whole 32-byte (keys, u16) / 64-byte (payload) sectors per lane
-            if (sizeof(KeyT) == 2) {
-                uint4 p0, p1;
-                p0.x = kk[0] | (kk[1] << 16); p0.y = kk[2] | (kk[3] << 16); p0.z = kk[4] | (kk[5] << 16); p0.w = kk[6] | (kk[7] << 16);
-                p1.x = kk[8] | (kk[9] << 16); p1.y = kk[10] | (kk[11] << 16); p1.z = kk[12] | (kk[13] << 16); p1.w = kk[14] | (kk[15] << 16);
-                uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
-                dst[0] = p0; dst[1] = p1;
+            if (e1 - e0 == EMIT_PER_LANE) {
+                // whole 32-byte (keys, u16) / 64-byte (payload) sectors per lane
+                if (sizeof(KeyT) == 2) {
+                    uint4 p0, p1;
+                    p0.x = kk[0] | (kk[1] << 16); p0.y = kk[2] | (kk[3] << 16); p0.z = kk[4] | (kk[5] << 16); p0.w = kk[6] | (kk[7] << 16);
+                    p1.x = kk[8] | (kk[9] << 16); p1.y = kk[10] | (kk[11] << 16); p1.z = kk[12] | (kk[13] << 16); p1.w = kk[14] | (kk[15] << 16);
+                    uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
+                    dst[0] = p0; dst[1] = p1;
+                } else {
+                    uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) dst[t] = make_uint4(kk[4 * t], kk[4 * t + 1], kk[4 * t + 2], kk[4 * t + 3]);
+                }
+                uint4* vd = reinterpret_cast<uint4*>(vals_out + e0);
+#pragma unroll
+                for (int t = 0; t < 4; t++) vd[t] = make_uint4(vv[4 * t], vv[4 * t + 1], vv[4 * t + 2], vv[4 * t + 3]);
             } else {
-                uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
 #pragma unroll
-                for (int t = 0; t < 4; t++) dst[t] = make_uint4(kk[4 * t], kk[4 * t + 1], kk[4 * t + 2], kk[4 * t + 3]);
+                for (uint32_t t = 0; t < EMIT_PER_LANE; t++)
+                    if (e0 + t < e1) {
+                        keys_out[e0 + t] = (KeyT)kk[t];
+                        vals_out[e0 + t] = vv[t];
+                    }
             }
-            uint4* vd = reinterpret_cast<uint4*>(vals_out + e0);
-#pragma unroll
-            for (int t = 0; t < 4; t++) vd[t] = make_uint4(vv[4 * t], vv[4 * t + 1], vv[4 * t + 2], vv[4 * t + 3]);
-        } else {
 #pragma unroll
             for (uint32_t t = 0; t < EMIT_PER_LANE; t++)
-                if (e0 + t < e1) {
-                    keys_out[e0 + t] = (KeyT)kk[t];
-                    vals_out[e0 + t] = vv[t];
-                }
+                if (e0 + t < e1) atomicAdd(&s_hist[kk[t] & 255u], 1u);
+        }   // e0 < D
+        __syncthreads();
+        {
+            const uint32_t c = s_hist[threadIdx.x], rb = win / radix_per;
+            if (c) {
+                atomicAdd(&block_hist[rb * RADIX_BINS + threadIdx.x], c);
+                atomicAdd(&group_hist[(rb / RADIX_GROUP) * RADIX_BINS + threadIdx.x], c);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -337,19 +379,19 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
-                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>());
+                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(), m->radix.block_hist.as<uint32_t>(),
+                       m->tile_ranges.as<uint2>(), tiles);
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
     }
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, m->bin_sums.as<uint32_t>(), grid, cap, frame,
-                       m->tile_ranges.as<uint2>(), tiles);
     uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, grid, m->cidx.as<uint32_t>(),
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, cap, grid, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.bins_x, pp.bin_row_begin,
-                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>());
+                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
+                       m->radix.digit_total.as<uint32_t>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
 
@@ -360,12 +402,13 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     uint32_t* vbuf[2] = {m->evalA.as<uint32_t>(), m->evalB.as<uint32_t>()};
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
+        const bool have_hist = (p == 0);           // k_bin_emit accumulated pass 0's histogram
         if (p + 1 == passes)
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ex, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
-                                                                     vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>())));
+                                                                     vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>(), have_hist)));
         else
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true, false>(ex, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1],
-                                                                     vbuf[(p + 1) & 1])));
+                                                                     vbuf[(p + 1) & 1], nullptr, have_hist)));
     }
     m->sorted_buf = (passes & 1);            // which ping-pong buffer holds the tile-sorted entries
     return GS_OK;

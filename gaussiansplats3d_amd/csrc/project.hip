@@ -38,6 +38,67 @@ __device__ __forceinline__ uint32_t unorm16(float v) { return (uint32_t)(clamp01
 constexpr float GS_K_POWER = 2.4022448f;          // sqrt(4*log2(e)): alpha = exp2(-|K*q|^2) == exp(-0.5*A)
 constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zero tiles
 
+// View-dependent colour (SplatMaterial.js:179-337): evaluated only for splats that reach the frame - the SH planes are
+// the widest read of the vertex stage (48 B/splat at SH-2), and a splat dropped by the eigenvalue floor, an empty pixel
+// rect or another rank's strip of tile rows never needs them.
+template <bool EXT>
+__device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPlanes& mp, uint32_t i, uint32_t scene, float c0,
+                                          float c1, float c2, float* col) {
+    if (pp.sh_stored >= 1 && pp.sh_degree >= 1) {
+        float cp0 = pp.cam_pos[0], cp1 = pp.cam_pos[1], cp2 = pp.cam_pos[2];
+        if (EXT && (pp.flags & GS_CAM_DYNAMIC)) {                // :179-183 camera in the scene's own frame
+            cp0 = mp.scenes->inv_cam_pos[scene][0]; cp1 = mp.scenes->inv_cam_pos[scene][1];
+            cp2 = mp.scenes->inv_cam_pos[scene][2];
+        }
+        float d0 = c0 - cp0, d1 = c1 - cp1, d2 = c2 - cp2;                                 // :185
+        const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float x = d0 * inv, y = d1 * inv, z = d2 * inv;
+        float sh[24];
+        const uint4 a = mp.sh0[i];
+        if (EXT && pp.sh_u8) {
+            // 8-bit SH (:150-154,265-269): texel = v/255 (unorm8), sh = texel*range + min; sh0 = bytes 0..15
+            const float mn = mp.scenes->sh8_min[scene], range = mp.scenes->sh8_max[scene] - mn;
+            const uint32_t w0[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) sh[k] = ((float)((w0[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
+            if (pp.sh_stored >= 2) {
+                const uint2 b = reinterpret_cast<const uint2*>(mp.sh1)[i];
+                const uint32_t w1[2] = {b.x, b.y};
+#pragma unroll
+                for (int k = 0; k < 8; k++) sh[16 + k] = ((float)((w1[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
+            }
+        } else {
+        sh[0] = h2f(a.x); sh[1] = h2f(a.x >> 16); sh[2] = h2f(a.y); sh[3] = h2f(a.y >> 16);
+        sh[4] = h2f(a.z); sh[5] = h2f(a.z >> 16); sh[6] = h2f(a.w); sh[7] = h2f(a.w >> 16);
+        if (pp.sh_stored >= 2) {
+            const uint4 b = reinterpret_cast<const uint4*>(mp.sh1)[i];
+            sh[8] = h2f(b.x); sh[9] = h2f(b.x >> 16); sh[10] = h2f(b.y); sh[11] = h2f(b.y >> 16);
+            sh[12] = h2f(b.z); sh[13] = h2f(b.z >> 16); sh[14] = h2f(b.w); sh[15] = h2f(b.w >> 16);
+        } else {
+            sh[8] = h2f(reinterpret_cast<const uint32_t*>(mp.sh1)[i]);
+        }
+        }
+        const float SH_C1 = 0.4886025119029199f;                                            // :273
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
+        if (pp.sh_stored >= 2 && pp.sh_degree >= 2) {                                       // :308-330
+            if (!(EXT && pp.sh_u8)) {
+                const uint4 cc = mp.sh2[i];
+                sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
+                sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
+            }
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            const float C0 = 1.0925484f, C1 = -1.0925484f, C2 = 0.3153916f, C3 = -1.0925484f, C4 = 0.5462742f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                col[ch] += (C0 * xy) * sh[9 + ch] + (C1 * yz) * sh[12 + ch] + (C2 * (2.0f * zz - xx - yy)) * sh[15 + ch] +
+                           (C3 * xz) * sh[18 + ch] + (C4 * (xx - yy)) * sh[21 + ch];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) col[ch] = clamp01(col[ch]);                          // :337
+    }
+}
+
 // EXT = false: the static perspective scene with fp16 SH (the benchmark path).  EXT = true adds the reference's shader
 // permutations: orthographic J, per-scene transforms (dynamicMode), per-scene opacity / visibility
 // (enableOptionalEffects), 8-bit SH, distance fade-in.
@@ -95,59 +156,6 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                             (float)((packed >> 16) & 255u) * (1.0f / 255.0f)};                 // :169
             float alpha = (float)(packed >> 24) * (1.0f / 255.0f);
 
-            if (pp.sh_stored >= 1 && pp.sh_degree >= 1) {
-                float cp0 = pp.cam_pos[0], cp1 = pp.cam_pos[1], cp2 = pp.cam_pos[2];
-                if (EXT && (pp.flags & GS_CAM_DYNAMIC)) {                // :179-183 camera in the scene's own frame
-                    cp0 = mp.scenes->inv_cam_pos[scene][0]; cp1 = mp.scenes->inv_cam_pos[scene][1];
-                    cp2 = mp.scenes->inv_cam_pos[scene][2];
-                }
-                float d0 = c0 - cp0, d1 = c1 - cp1, d2 = c2 - cp2;                                 // :185
-                const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-                const float x = d0 * inv, y = d1 * inv, z = d2 * inv;
-                float sh[24];
-                const uint4 a = mp.sh0[i];
-                if (EXT && pp.sh_u8) {
-                    // 8-bit SH (:150-154,265-269): texel = v/255 (unorm8), sh = texel*range + min; sh0 = bytes 0..15
-                    const float mn = mp.scenes->sh8_min[scene], range = mp.scenes->sh8_max[scene] - mn;
-                    const uint32_t w0[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                    for (int k = 0; k < 16; k++) sh[k] = ((float)((w0[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
-                    if (pp.sh_stored >= 2) {
-                        const uint2 b = reinterpret_cast<const uint2*>(mp.sh1)[i];
-                        const uint32_t w1[2] = {b.x, b.y};
-#pragma unroll
-                        for (int k = 0; k < 8; k++) sh[16 + k] = ((float)((w1[k >> 2] >> (8 * (k & 3))) & 255u) / 255.0f) * range + mn;
-                    }
-                } else {
-                sh[0] = h2f(a.x); sh[1] = h2f(a.x >> 16); sh[2] = h2f(a.y); sh[3] = h2f(a.y >> 16);
-                sh[4] = h2f(a.z); sh[5] = h2f(a.z >> 16); sh[6] = h2f(a.w); sh[7] = h2f(a.w >> 16);
-                if (pp.sh_stored >= 2) {
-                    const uint4 b = reinterpret_cast<const uint4*>(mp.sh1)[i];
-                    sh[8] = h2f(b.x); sh[9] = h2f(b.x >> 16); sh[10] = h2f(b.y); sh[11] = h2f(b.y >> 16);
-                    sh[12] = h2f(b.z); sh[13] = h2f(b.z >> 16); sh[14] = h2f(b.w); sh[15] = h2f(b.w >> 16);
-                } else {
-                    sh[8] = h2f(reinterpret_cast<const uint32_t*>(mp.sh1)[i]);
-                }
-                }
-                const float SH_C1 = 0.4886025119029199f;                                            // :273
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
-                if (pp.sh_stored >= 2 && pp.sh_degree >= 2) {                                       // :308-330
-                    if (!(EXT && pp.sh_u8)) {
-                        const uint4 cc = mp.sh2[i];
-                        sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
-                        sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
-                    }
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    const float C0 = 1.0925484f, C1 = -1.0925484f, C2 = 0.3153916f, C3 = -1.0925484f, C4 = 0.5462742f;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
-                        col[ch] += (C0 * xy) * sh[9 + ch] + (C1 * yz) * sh[12 + ch] + (C2 * (2.0f * zz - xx - yy)) * sh[15 + ch] +
-                                   (C3 * xz) * sh[18 + ch] + (C4 * (xx - yy)) * sh[21 + ch];
-                }
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) col[ch] = clamp01(col[ch]);                          // :337
-            }
 
             // SplatMaterial3D.js:87-109 covariance fetch
             float V00, V01, V02, V11, V12, V22;
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                     rec.cx = cx; rec.cy = cy;
                     rec.ax = GS_K_POWER * (b1x / n1); rec.ay = GS_K_POWER * (b1y / n1);
                     rec.bx = GS_K_POWER * (b2x / n2); rec.by = GS_K_POWER * (b2y / n2);
+                    sh_colour<EXT>(pp, mp, i, scene, c0, c1, c2, col);
                     rec.c0 = unorm16(col[0]) | (unorm16(col[1]) << 16);
                     rec.c1 = unorm16(col[2]) | (unorm16(alpha) << 16);
                 }

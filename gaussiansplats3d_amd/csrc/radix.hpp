@@ -203,15 +203,29 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (size
         // workgroups; two threads per digit split the rows, every load is independent of the others
         const uint32_t d = tid & 255u, half = tid >> 8;      // `half` = which of the SCATTER_PARTS row subsets
         const uint32_t g = blockIdx.x / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
-        uint32_t before = 0, all = 0;
-#pragma unroll 8
-        for (uint32_t r = half; r < groups; r += (uint32_t)SCATTER_PARTS) {
-            const uint32_t v = group_hist[r * RADIX_BINS + d];
-            all += v;
-            before += r < g ? v : 0u;
+        // fixed trip counts, fully unrolled and predicated: every load of the prologue is in flight at once (one memory
+        // round trip instead of a chain of batches: isolated C3 sort 0.182 -> 0.176 ms)
+        constexpr uint32_t GROUP_LOADS = (RADIX_MAX_GROUPS + SCATTER_PARTS - 1) / SCATTER_PARTS;
+        constexpr uint32_t ROW_LOADS = (RADIX_GROUP + SCATTER_PARTS - 1) / SCATTER_PARTS;
+        uint32_t gv[GROUP_LOADS], rv[ROW_LOADS];
+#pragma unroll
+        for (uint32_t k = 0; k < GROUP_LOADS; k++) {
+            const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
+            gv[k] = r < groups ? group_hist[r * RADIX_BINS + d] : 0u;
         }
-#pragma unroll 8
-        for (uint32_t r = g * RADIX_GROUP + half; r < blockIdx.x; r += (uint32_t)SCATTER_PARTS) before += block_hist[r * RADIX_BINS + d];
+#pragma unroll
+        for (uint32_t k = 0; k < ROW_LOADS; k++) {
+            const uint32_t r = g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS;
+            rv[k] = r < blockIdx.x ? block_hist[r * RADIX_BINS + d] : 0u;
+        }
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < GROUP_LOADS; k++) {
+            all += gv[k];
+            before += (half + k * (uint32_t)SCATTER_PARTS) < g ? gv[k] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < ROW_LOADS; k++) before += rv[k];
         uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop zeroes it
         uint32_t* s_all = &s_wave[SCATTER_PARTS][0];
         s_before[tid] = before;

@@ -60,7 +60,8 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
         }
         ctx->own_stream = true;
     }
-    ctx->serial = getenv("GSPLAT_SERIAL") != nullptr;
+    const char* serial = getenv("GSPLAT_SERIAL");               // "1" (anything but empty / "0"): one stream for everything
+    ctx->serial = serial && serial[0] != '\0' && !(serial[0] == '0' && serial[1] == '\0');
     if (!ctx->serial) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
         if (e != hipSuccess) {

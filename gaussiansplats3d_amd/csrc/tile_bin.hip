@@ -11,7 +11,9 @@
 //                 slots, finds the splat covering its first slot with two binary searches (workgroup table in LDS,
 //                 then that workgroup's per-splat offsets) and walks forward.  Work per lane is constant, so the
 //                 few near-camera splats that cover thousands of tiles cannot unbalance the grid, and every lane
-//                 stores whole 32-byte sectors.
+//                 stores whole 32-byte sectors.  Each workgroup first scans the binning workgroups' sums itself, and while it
+//                 writes a window of 4096 entries (= one radix tile) it adds the window's low-digit counts to the
+//                 first sort pass's table, so neither a scan kernel nor that pass's histogram kernel is launched.
 //   tile sort     stable LSD radix passes on the tile id (radix.hpp): stability keeps near->far order per tile; the
 //                 last pass also publishes every tile's [begin,end) (no separate range kernel)
 // Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.

@@ -74,6 +74,19 @@ def test_c3_full_size_invariants(ctx, c3):
     parts = [morton.render(tile_rows=r)[0] for r in ((0, 17), (17, 18), (18, 45), (45, 68))]
     np.testing.assert_array_equal(np.concatenate(parts, axis=0), a)
 
+    # 3b. the per-splat frustum cull fused into the sort: same pixels, and the list is the reference's minus the dropped
+    import oracle
+    w.set_frustum_cull(True)
+    culled = w.post_message({"sort": {"modelViewProj": cam.sort_mvp(), "splatRenderCount": n, "splatSortCount": n}})
+    expect, keep = oracle.culled_sort(np.arange(n, dtype=np.uint32), util.integer_centers(scene.centers), cam.sort_mvp())
+    assert culled["stats"].result_count == len(expect) < n
+    np.testing.assert_array_equal(culled["sortedIndexes"], expect)
+    w.sort_on_device(cam.sort_mvp(), n)
+    f, _ = morton.render()
+    np.testing.assert_array_equal(a, f)
+    w.set_frustum_cull(False)
+    w.sort_on_device(cam.sort_mvp(), n)
+
     # 4. statistics agree with the per-splat vertex-stage outputs (of a full-frame draw: the last draw above was a strip)
     _, sa = morton.render()
     recs, rects, vis = morton.debug_records()

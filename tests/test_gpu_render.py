@@ -262,3 +262,22 @@ def test_hand_picked_projection_cases(ctx):
     fb, q, amb, frags = oracle.render(ocam, centers, cov, rgba, None, order)
     print(helpers.compare_frames(got, fb, amb, "hand-picked"))
     mesh.dispose()
+
+
+def test_wide_entry_keys_match_the_16_bit_path(ctx):
+    """More than 65536 bins (16384 x 4352 px = 512 x 136 bins) switch the entry sort to 32-bit keys; two half-height
+    strips of the same frame stay below the limit and use 16-bit keys.  Both paths must produce the same pixels."""
+    scene = helpers.small_scene(1500, 0, seed=61, scale=0.01)
+    W, H = 16384, 4352
+    cam = camera.demo_camera("garden", W, H)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(sorted_order(scene, cam), scene.count)
+    full, stats = mesh.render()
+    assert stats.visible_splats > 300 and stats.tile_entries > stats.visible_splats
+    assert (W // 32) * (H // 32) > 65536
+    top, _ = mesh.render(tile_rows=(0, 136))
+    bottom, _ = mesh.render(tile_rows=(136, 272))
+    assert full.any()
+    np.testing.assert_array_equal(np.concatenate([top, bottom], axis=0), full)
+    mesh.dispose()

@@ -18,7 +18,7 @@ GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
 GS_TILE = 16
-GS_BIN = 32          # entry lists / blend workgroups are per 32-px bin (2x2 tiles)
+GS_BIN = 32          # blend workgroups are per 32-px bin (2x2 tiles); entry lists per list bin, see list_bin_px()
 GS_MAX_SCENES = 32
 
 
@@ -78,6 +78,8 @@ _VP = C.c_void_p
 SYMBOLS = {
     "gs_last_error": (C.c_char_p, []),
     "gs_abi_version": (C.c_int, []),
+    "gs_list_bin_px": (C.c_int, []),
+    "gs_mesh_debug_set_entry_capacity": (C.c_int, [_VP, C.c_uint32]),
     "gs_device_count": (C.c_int, []),
     "gs_context_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     "gs_context_destroy": (None, [_VP]),
@@ -138,6 +140,11 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def list_bin_px():
+    """Edge of a list bin (the unit of the entry lists) in pixels, as compiled into the library."""
+    return int(load().gs_list_bin_px())
 
 
 def check(status):

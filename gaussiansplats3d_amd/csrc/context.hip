@@ -17,6 +17,7 @@ extern "C" {
 
 const char* gs_last_error(void) { return g_err; }
 int gs_abi_version(void) { return GS_ABI_VERSION; }
+int gs_list_bin_px(void) { return (int)GS_LIST; }
 
 int gs_device_count(void) {
     int n = 0;
@@ -60,6 +61,8 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
         }
         ctx->own_stream = true;
     }
+    const char* wide = getenv("GSPLAT_WIDE_ENTRY_KEYS");
+    ctx->wide_entry_keys = wide && wide[0] == '1';
     const char* serial = getenv("GSPLAT_SERIAL");               // "1" (anything but empty / "0"): one stream for everything
     ctx->serial = serial && serial[0] != '\0' && !(serial[0] == '0' && serial[1] == '\0');
     if (!ctx->serial) {

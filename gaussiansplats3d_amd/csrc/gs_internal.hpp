@@ -72,8 +72,18 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------------------
 // radix sort geometry (radix.hpp)
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t GS_BIN_SHIFT = 1;                       // a bin is 2x2 tiles of 16 px = 32x32 px
+constexpr uint32_t GS_BIN_SHIFT = 1;                       // a blend workgroup owns a bin of 2x2 tiles of 16 px = 32x32 px
 constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
+// The entry lists are per LIST BIN of (16 << GS_LIST_SHIFT) px.  The blend reads only the head of a list before its pixels
+// saturate (C3: the first 256 of ~2900 entries per 32-px bin, tools/blend_profile.py), so emitting and sorting per-32-px
+// entries mostly produced entries nobody read.  128-px list bins cut the entries 3.7x and their sort to ONE 8-bit pass at
+// 1080p (15 x 9 = 135 lists); a blend workgroup scans its parent list and keeps what touches its own 32-px block.
+#ifndef GS_LIST_SHIFT_CFG
+#define GS_LIST_SHIFT_CFG 3
+#endif
+constexpr uint32_t GS_LIST_SHIFT = GS_LIST_SHIFT_CFG;
+constexpr uint32_t GS_LIST = GS_TILE << GS_LIST_SHIFT;
+static_assert(GS_LIST_SHIFT >= GS_BIN_SHIFT && GS_LIST_SHIFT <= 6, "a list bin is a whole number of blend bins");
 
 #ifndef RADIX_TILE_CFG
 #define RADIX_TILE_CFG 4096
@@ -109,6 +119,7 @@ struct RadixScratch {
 struct gs_mesh;
 struct gs_context {
     int device = 0;
+    bool wide_entry_keys = false;      // GSPLAT_WIDE_ENTRY_KEYS=1: 32-bit list keys even below 65536 lists (test hook)
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;
     bool own_stream = false;
@@ -228,8 +239,10 @@ struct ProjectParams {
     float ortho_zoom, fade_start;
     float scene_center[3];
     uint32_t scene_count, sh_u8;
-    uint32_t bins_x;               // 32-px bin grid: the unit of the entry lists (one 256-thread workgroup blends a bin)
+    uint32_t bins_x;               // 32-px bin grid: one 256-thread workgroup blends a bin
     uint32_t bin_row_begin, bin_row_end;
+    uint32_t lists_x;              // list-bin grid (GS_LIST px): the unit of the entry lists and of the entry sort's keys
+    uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
 };

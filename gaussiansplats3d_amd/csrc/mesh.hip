@@ -170,7 +170,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     GS_REQUIRE(ctx && out, "ctx / out == NULL");
     *out = nullptr;
     GS_REQUIRE(max_splat_count > 0, "max_splat_count == 0");
-    GS_REQUIRE(max_splat_count <= (1u << 28), "max_splat_count > 2^28 (entry payload = 28-bit record slot + 4-bit quadrant mask)");
+    GS_REQUIRE(max_splat_count <= (1u << 28), "max_splat_count > 2^28");
     GS_REQUIRE(sh_degree <= 2, "sh_degree > 2 (the reference renders degrees 0..2, src/Viewer.js:154)");
     GS_REQUIRE((flags & ~(GS_MESH_COV_HALF | GS_MESH_SH_U8 | GS_MESH_KEEP_ORDER)) == 0, "unknown mesh flags");
     ScopedDevice sd(ctx->device);
@@ -402,7 +402,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
                           uint8_t* out_dev) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
-    const uint32_t tiles = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);     // entry lists are per 32-px bin
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     GS_HIP(hipEventRecord(m->ev[0], st));
     // fork: the vertex stage only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
@@ -498,6 +498,9 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     pp.bins_x = (cam->width + GS_BIN - 1) / GS_BIN;
     pp.bin_row_begin = y0 / GS_BIN;
     pp.bin_row_end = pp.y1 > y0 ? (pp.y1 + GS_BIN - 1) / GS_BIN : pp.bin_row_begin;
+    pp.lists_x = (cam->width + GS_LIST - 1) / GS_LIST;
+    pp.list_row_begin = y0 / GS_LIST;
+    pp.list_row_end = pp.y1 > y0 ? (pp.y1 + GS_LIST - 1) / GS_LIST : pp.list_row_begin;
     const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
 
     const uint32_t* order_dev = nullptr;
@@ -549,6 +552,13 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
         if (stats) *stats = m->last;
     }
     return status;
+}
+
+int gs_mesh_debug_set_entry_capacity(gs_mesh* m, uint32_t capacity) {
+    GS_REQUIRE(m != nullptr && capacity >= 1024u && capacity <= 0x7FFFFFFFu, "mesh == NULL or capacity outside [1024, 2^31)");
+    ScopedDevice sd(m->ctx->device);
+    GS_HIP(hipStreamSynchronize(m->ctx->stream));
+    return mesh_alloc_entries(m, capacity);
 }
 
 int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats) {

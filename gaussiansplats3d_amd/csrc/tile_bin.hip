@@ -25,23 +25,15 @@ constexpr int BIN_THREADS = 256;
 #endif
 constexpr int BIN_MAX_BLOCKS = 2048;                      // 8 workgroups of 256 per CU: full wave occupancy
 
-// vertex-stage rects are in 16-px tiles; the entry lists are per 32-px bin (2x2 tiles)
+// vertex-stage rects are in 16-px tiles; the entry lists are per list bin of GS_LIST px
 __device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
     const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
     return (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1u) * (y1 - y0 + 1u) : 0u;
 }
-// which of the 2x2 tiles of bin (bx, by) the 16-px rect touches: bit (qx + 2*qy).  Carried in the top 4 bits of the
-// entry payload, so the blend takes exactly the per-16-px-tile decisions of the vertex stage (a strip of a multi-GPU
-// draw then reproduces the full frame bit for bit).
-__device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32_t by) {
-    const uint32_t x0 = r16.x & 0xFFFFu, y0 = r16.x >> 16, x1 = r16.y & 0xFFFFu, y1 = r16.y >> 16;
-    const uint32_t cx = 2u * bx, cy = 2u * by;
-    const uint32_t mx = ((cx >= x0 && cx <= x1) ? 1u : 0u) | ((cx + 1u >= x0 && cx + 1u <= x1) ? 2u : 0u);
-    const uint32_t my = ((cy >= y0 && cy <= y1) ? 1u : 0u) | ((cy + 1u >= y0 && cy + 1u <= y1) ? 2u : 0u);
-    return (mx & (my & 1u ? 3u : 0u)) | ((mx & (my & 2u ? 3u : 0u)) << 2);
-}
-__device__ __forceinline__ uint2 rect_to_bins(uint2 r) {     // per-field shift: (x|y<<16) >> 1 with the carry bit masked
-    return make_uint2((r.x >> GS_BIN_SHIFT) & 0x7FFF7FFFu, (r.y >> GS_BIN_SHIFT) & 0x7FFF7FFFu);
+// 16-px tile rect -> list-bin rect: per-field shift of (x | y << 16) with the bits that cross the field boundary masked
+__device__ __forceinline__ uint2 rect_to_bins(uint2 r) {
+    constexpr uint32_t FIELD = 0xFFFFu >> GS_LIST_SHIFT, MASK = FIELD | (FIELD << 16);
+    return make_uint2((r.x >> GS_LIST_SHIFT) & MASK, (r.y >> GS_LIST_SHIFT) & MASK);
 }
 
 struct BinChunk {
@@ -126,7 +118,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         uint32_t n[BIN_PER_LANE], cnt = 0, ent = 0;
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) {
-            n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k])) : 0u;   // entries = 32-px bins touched
+            n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k])) : 0u;   // entries = list bins touched
             cnt += keep[k] ? 1u : 0u;
             ent += n[k];
         }
@@ -304,7 +296,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
 #pragma unroll
             for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
                 kk[t] = (ty - row_begin) * tiles_x + tx;
-                vv[t] = idx | (quadrant_mask(r16, tx, ty) << 28);
+                vv[t] = idx;
                 if (e0 + t + 1 < e1) {
                     if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
                         if (++j == cnt) {
@@ -391,7 +383,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     if (egrid > 4096u) egrid = 4096u;
     if (egrid < 1u) egrid = 1u;
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, cap, grid, m->cidx.as<uint32_t>(),
-                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.bins_x, pp.bin_row_begin,
+                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
                        m->radix.digit_total.as<uint32_t>());
     GS_HIP(hipGetLastError());
@@ -405,7 +397,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
         const bool have_hist = (p == 0);           // k_bin_emit accumulated pass 0's histogram
-        if (p + 1 == passes)
+        if (passes == 1)                           // <= 256 lists: the digit is the key, ranges come from the digit totals
+            GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, false>(ex, al, al, cap, 0, 0, (KeyT*)nullptr, vbuf[1],
+                                                                      m->tile_ranges.as<uint2>(), have_hist, tiles)));
+        else if (p + 1 == passes)
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ex, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
                                                                      vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>(), have_hist)));
         else
@@ -417,7 +412,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
 }
 
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count) {
-    const uint32_t tiles = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
-    if (tiles <= 65536u) return binning_typed<uint16_t>(m, pp, order_dev, sorter, render_count, tiles);
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);
+    if (tiles <= 65536u && !m->ctx->wide_entry_keys) return binning_typed<uint16_t>(m, pp, order_dev, sorter, render_count, tiles);
     return binning_typed<uint32_t>(m, pp, order_dev, sorter, render_count, tiles);
 }

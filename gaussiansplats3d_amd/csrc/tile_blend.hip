@@ -40,6 +40,17 @@ struct __attribute__((aligned(16))) LdsSplat {
     float r, g, b, a;
 };
 
+// which of the 2x2 tiles of the 32-px bin (bx, by) the splat's 16-px tile rect touches: bit (qx + 2*qy).  The rect is the
+// vertex stage's own (k_project), so the blend takes exactly its per-tile decisions (a strip of a multi-GPU draw then
+// reproduces the full frame bit for bit).
+__device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32_t by) {
+    const uint32_t x0 = r16.x & 0xFFFFu, y0 = r16.x >> 16, x1 = r16.y & 0xFFFFu, y1 = r16.y >> 16;
+    const uint32_t cx = 2u * bx, cy = 2u * by;
+    const uint32_t mx = ((cx >= x0 && cx <= x1) ? 1u : 0u) | ((cx + 1u >= x0 && cx + 1u <= x1) ? 2u : 0u);
+    const uint32_t my = ((cy >= y0 && cy <= y1) ? 1u : 0u) | ((cy + 1u >= y0 && cy + 1u <= y1) ? 2u : 0u);
+    return (mx & (my & 1u ? 3u : 0u)) | ((mx & (my & 2u ? 3u : 0u)) << 2);
+}
+
 // expands one record
 __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi) {
     LdsSplat s;
@@ -63,9 +74,10 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #endif
 
 __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
-                                                              const uint4* __restrict__ recs, uint32_t* __restrict__ out,
-                                                              uint32_t width, uint32_t y0, uint32_t y1, uint32_t bins_x,
-                                                              uint32_t bin_row_begin) {
+                                                              const uint4* __restrict__ recs, const uint2* __restrict__ rects,
+                                                              uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
+                                                              uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
+                                                              uint32_t list_row_begin) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
@@ -80,9 +92,11 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
 
 #ifdef GS_BLEND_PROFILE
     const unsigned long long t_start = wall_clock64();
-    uint32_t walked = 0;
+    uint32_t walked = 0, batches = 0;
 #endif
-    const uint2 range = ranges[bin];
+    // the entry list of the list bin (GS_LIST px) this 32-px bin lies in
+    constexpr uint32_t PER_LIST = GS_LIST_SHIFT - GS_BIN_SHIFT;
+    const uint2 range = ranges[((by >> PER_LIST) - list_row_begin) * lists_x + (bx >> PER_LIST)];
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
 
     // a quadrant outside the viewport / this rank's strip of pixel rows has nothing to draw
@@ -93,33 +107,37 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
     v2f Cr[2] = {{0, 0}, {0, 0}}, Cg[2] = {{0, 0}, {0, 0}}, Cb[2] = {{0, 0}, {0, 0}};
     const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
 
-    // entry payload = record slot | quadrant mask << 28 (k_bin_emit)
+    // entry payload = record slot (k_bin_emit); the slot also names the splat's tile rect, which says whether and where the
+    // splat touches THIS bin - most entries of a 128-px list do not, and only the others are expanded into LDS.
     // Software pipeline over batches of 256 entries: the entry word is fetched two batches ahead and the record it names
     // one batch ahead, so a batch waits for ONE gather latency, not for two dependent ones.  Long lists whose pixels do not
     // saturate are bound by exactly that latency (tools/blend_profile.py: ~8 us per batch before, a wave only walks
     // ~10 survivors of a batch).
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-    uint32_t qm = 0, v_next = 0;
+    uint2 rect = make_uint2(0xFFFFu, 0u);              // empty
+    uint32_t v_next = 0;
     if (tid < n) {
-        const uint32_t v = vals[begin + tid];
-        const uint32_t slot = v & 0x0FFFFFFFu;
-        qm = v >> 28;
+        const uint32_t slot = vals[begin + tid];
+        rect = rects[slot];
         lo = recs[2 * (size_t)slot];
         hi = recs[2 * (size_t)slot + 1];
     }
     if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid];
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
+#ifdef GS_BLEND_PROFILE
+        batches++;
+#endif
         __syncthreads();                               // previous batch fully consumed, s_live read by everyone
-        s_qmask[tid] = tid < cnt ? qm : 0u;
-        if (tid < cnt) stage_entry(&s_batch[tid], lo, hi);
+        const uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
+        s_qmask[tid] = qm;
+        if (qm) stage_entry(&s_batch[tid], lo, hi);
         if (tid == 0) s_live = 0u;
         const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
         if (nxt < n) {
-            const uint32_t slot = v_next & 0x0FFFFFFFu;
-            qm = v_next >> 28;
-            lo = recs[2 * (size_t)slot];
-            hi = recs[2 * (size_t)slot + 1];
+            rect = rects[v_next];
+            lo = recs[2 * (size_t)v_next];
+            hi = recs[2 * (size_t)v_next + 1];
         }
         if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS];
         __syncthreads();
@@ -187,6 +205,7 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
         if (wave == 0u) {
             g_blend_prof[8 * bin + 0] = t_start;
             g_blend_prof[8 * bin + 2] = n;
+            g_blend_prof[8 * bin + 3] = batches;
         }
         g_blend_prof[8 * bin + 4 + wave] = walked;
     }
@@ -212,8 +231,8 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     if (bins == 0) return GS_OK;
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
-                       m->recs.as<uint4>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0, pp.y1, pp.bins_x,
-                       pp.bin_row_begin);
+                       m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
+                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

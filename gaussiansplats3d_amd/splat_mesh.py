@@ -189,6 +189,10 @@ class SplatMesh:
             C.byref(stats) if stats is not None else None))
         return out, stats
 
+    def debug_set_entry_capacity(self, capacity):
+        """Test hook: resize the entry buffers (the overflow -> regrow path of a draw)."""
+        L.check(self.lib.gs_mesh_debug_set_entry_capacity(self.handle, int(capacity)))
+
     def last_stats(self):
         stats = L.RenderStats()
         L.check(self.lib.gs_mesh_last_stats(self.handle, C.byref(stats)))
@@ -215,13 +219,14 @@ class SplatMesh:
         return recs, rects, vis
 
     def bin_entry_counts(self, tile_rows=None):
-        """Entries per 32-px bin of the last draw, shaped [bin_rows, bins_x] (`tile_rows`: the strip it drew)."""
+        """Entries per list bin of the last draw, shaped [list_rows, lists_x] (`tile_rows`: the strip it drew)."""
         cam = self._cam
-        bins_x = (cam.width + L.GS_BIN - 1) // L.GS_BIN
+        LB = L.list_bin_px()
+        bins_x = (cam.width + LB - 1) // LB
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
         y0, y1 = r0 * L.GS_TILE, min(r1 * L.GS_TILE, cam.height)
-        b0, b1 = y0 // L.GS_BIN, (max(y1, y0) + L.GS_BIN - 1) // L.GS_BIN if y1 > y0 else y0 // L.GS_BIN
+        b0, b1 = y0 // LB, (max(y1, y0) + LB - 1) // LB if y1 > y0 else y0 // LB
         rng = np.empty(((b1 - b0) * bins_x, 2), dtype=np.uint32)
         if rng.shape[0]:
             L.check(self.lib.gs_mesh_debug_read(self.handle, 2, rng.ctypes.data, rng.shape[0]))
@@ -230,11 +235,11 @@ class SplatMesh:
 
     def tile_row_costs(self):
         """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips): every
-        32-px bin row's entry count is split evenly between the tile rows it covers."""
+        list-bin row's entry count is split evenly between the tile rows it covers."""
         cam = self._cam
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         per_bin_row = self.bin_entry_counts().sum(axis=1).astype(np.float64)
-        ratio = L.GS_BIN // L.GS_TILE
+        ratio = L.list_bin_px() // L.GS_TILE
         return np.repeat(per_bin_row / ratio, ratio)[:rows_total]
 
     def dispose(self):

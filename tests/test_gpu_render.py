@@ -162,7 +162,8 @@ def test_empty_and_offscreen(ctx):
 
 
 def test_entry_buffer_grows_on_overflow(ctx):
-    """A few hundred near-camera splats cover the whole 1080p screen: D >> 8*N forces the regrow path."""
+    """A few hundred near-camera splats cover the whole 1080p screen: with the entry buffers shrunk to 4096 entries the
+    draw overflows and must regrow them and redraw."""
     rng = np.random.default_rng(9)
     n = 700
     cam = camera.demo_camera("garden", 1920, 1080)
@@ -174,11 +175,12 @@ def test_entry_buffer_grows_on_overflow(ctx):
     rgba = rng.integers(1, 255, (n, 4), dtype=np.uint8); rgba[:, 3] = 3
     scene = scenes.SplatScene(centers, cov, rgba, np.zeros((n, 0), np.float16), 0)
     mesh = build_mesh(ctx, scene)
+    mesh.debug_set_entry_capacity(4096)
     mesh.set_camera(cam)
     order = sorted_order(scene, cam)
     mesh.update_render_indexes(order, n)
     got, stats = mesh.render()
-    assert stats.overflowed == 1 and stats.tile_entries > 8 * n
+    assert stats.overflowed == 1 and stats.tile_entries > 8 * n and stats.entry_capacity >= stats.tile_entries
     _, (fb, q, amb, _) = oracle_frame(scene, cam, order)
     print(helpers.compare_frames(got, fb, amb, "overflow"))
     mesh.dispose()
@@ -264,20 +266,24 @@ def test_hand_picked_projection_cases(ctx):
     mesh.dispose()
 
 
-def test_wide_entry_keys_match_the_16_bit_path(ctx):
-    """More than 65536 bins (16384 x 4352 px = 512 x 136 bins) switch the entry sort to 32-bit keys; two half-height
-    strips of the same frame stay below the limit and use 16-bit keys.  Both paths must produce the same pixels."""
-    scene = helpers.small_scene(1500, 0, seed=61, scale=0.01)
-    W, H = 16384, 4352
-    cam = camera.demo_camera("garden", W, H)
+def test_wide_entry_keys_match_the_16_bit_path(ctx, monkeypatch):
+    """More than 65536 list bins switch the entry sort to 32-bit keys (a 65536 x 17408 px viewport at 128-px lists), so the
+    path is forced through the GSPLAT_WIDE_ENTRY_KEYS test hook instead; it must produce the same pixels."""
+    scene = helpers.small_scene(3000, 1, seed=61)
+    cam = camera.demo_camera("garden", 1000, 600)
+    order = sorted_order(scene, cam)
     mesh = build_mesh(ctx, scene)
     mesh.set_camera(cam)
-    mesh.update_render_indexes(sorted_order(scene, cam), scene.count)
-    full, stats = mesh.render()
-    assert stats.visible_splats > 300 and stats.tile_entries > stats.visible_splats
-    assert (W // 32) * (H // 32) > 65536
-    top, _ = mesh.render(tile_rows=(0, 136))
-    bottom, _ = mesh.render(tile_rows=(136, 272))
-    assert full.any()
-    np.testing.assert_array_equal(np.concatenate([top, bottom], axis=0), full)
+    mesh.update_render_indexes(order, scene.count)
+    narrow, s_narrow = mesh.render()
     mesh.dispose()
+    monkeypatch.setenv("GSPLAT_WIDE_ENTRY_KEYS", "1")
+    wide_ctx = Context(0)
+    mesh = build_mesh(wide_ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(order, scene.count)
+    wide, s_wide = mesh.render()
+    assert narrow.any() and s_wide.tile_entries == s_narrow.tile_entries > 0
+    np.testing.assert_array_equal(wide, narrow)
+    mesh.dispose()
+    wide_ctx.close()

@@ -26,6 +26,11 @@ lib.gs_debug_blend_prof.argtypes = [C.c_void_p, C.c_uint]
 assert lib.gs_debug_blend_prof(buf.ctypes.data, bins) == 0
 t0, t1, n = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64), buf[:, 2].astype(np.int64)
 walked = buf[:, 4:8].astype(np.int64)
+batches = buf[:, 3].astype(np.int64)
+need = (n + 255) // 256
+print("batches staged per bin: mean %.2f (of %.2f in the list), p50 %d p90 %d max %d; bins that stop early: %.1f %%; entries staged / entries in lists: %.3f" %
+      (batches.mean(), need.mean(), np.percentile(batches, 50), np.percentile(batches, 90), batches.max(),
+       100.0 * (batches < need).mean(), np.minimum(batches * 256, n).sum() / max(n.sum(), 1)))
 start = t0.min()
 dur = (t1 - t0) / 100.0          # us (100 MHz)
 rel0, rel1 = (t0 - start) / 100.0, (t1 - start) / 100.0

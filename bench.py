@@ -323,7 +323,7 @@ def main():
             # whole frame against SURVEY.md §8d's formula
             "frame": {"algorithmic_bytes": int(B), "bytes_per_splat": round(B / R, 1), "GBps": round(frame_gbs, 1),
                       "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
-                      "D_per_splat": round(D16 / R, 3), "bin_entries": D32,
+                      "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": int(st_probe.list_bin_px),
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
             "orbit": orbit,
             "cull_on": cull,

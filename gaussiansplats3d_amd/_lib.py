@@ -18,7 +18,7 @@ GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
 GS_TILE = 16
-GS_BIN = 32          # blend workgroups are per 32-px bin (2x2 tiles); entry lists per list bin, see list_bin_px()
+GS_BIN = 32          # blend workgroups are per 32-px bin (2x2 tiles); entry lists per list bin (RenderStats.list_bin_px)
 GS_MAX_SCENES = 32
 
 
@@ -53,7 +53,7 @@ class RenderStats(C.Structure):
     _fields_ = [("device_ms", C.c_float), ("project_ms", C.c_float), ("bin_ms", C.c_float),
                 ("tile_sort_ms", C.c_float), ("blend_ms", C.c_float), ("visible_splats", C.c_uint32),
                 ("tile_entries", C.c_uint64), ("entry_capacity", C.c_uint32), ("overflowed", C.c_uint32),
-                ("tiles16", C.c_uint64)]
+                ("tiles16", C.c_uint64), ("list_bin_px", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class TreeInfo(C.Structure):
@@ -78,7 +78,6 @@ _VP = C.c_void_p
 SYMBOLS = {
     "gs_last_error": (C.c_char_p, []),
     "gs_abi_version": (C.c_int, []),
-    "gs_list_bin_px": (C.c_int, []),
     "gs_mesh_debug_set_entry_capacity": (C.c_int, [_VP, C.c_uint32]),
     "gs_device_count": (C.c_int, []),
     "gs_context_create": (C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
@@ -140,11 +139,6 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
-
-
-def list_bin_px():
-    """Edge of a list bin (the unit of the entry lists) in pixels, as compiled into the library."""
-    return int(load().gs_list_bin_px())
 
 
 def check(status):

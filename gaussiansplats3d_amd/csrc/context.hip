@@ -17,7 +17,6 @@ extern "C" {
 
 const char* gs_last_error(void) { return g_err; }
 int gs_abi_version(void) { return GS_ABI_VERSION; }
-int gs_list_bin_px(void) { return (int)GS_LIST; }
 
 int gs_device_count(void) {
     int n = 0;

@@ -78,12 +78,12 @@ constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 // saturate (C3: the first 256 of ~2900 entries per 32-px bin, tools/blend_profile.py), so emitting and sorting per-32-px
 // entries mostly produced entries nobody read.  128-px list bins cut the entries 3.7x and their sort to ONE 8-bit pass at
 // 1080p (15 x 9 = 135 lists); a blend workgroup scans its parent list and keeps what touches its own 32-px block.
-#ifndef GS_LIST_SHIFT_CFG
-#define GS_LIST_SHIFT_CFG 3
-#endif
-constexpr uint32_t GS_LIST_SHIFT = GS_LIST_SHIFT_CFG;
-constexpr uint32_t GS_LIST = GS_TILE << GS_LIST_SHIFT;
-static_assert(GS_LIST_SHIFT >= GS_BIN_SHIFT && GS_LIST_SHIFT <= 6, "a list bin is a whole number of blend bins");
+// That only pays when splats are large enough to share lists: a scene of many tiny splats (C4: 16 M splats of ~1.5 tiles)
+// gains no entries and makes every blend workgroup scan 16 bins' worth of them, so the size is chosen per mesh from the
+// statistics of its last measured draw (gs_mesh::list_shift): 128 px when a visible splat covers >= 3 tiles, else 32 px.
+constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
+constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
+constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
 
 #ifndef RADIX_TILE_CFG
 #define RADIX_TILE_CFG 4096
@@ -241,7 +241,8 @@ struct ProjectParams {
     uint32_t scene_count, sh_u8;
     uint32_t bins_x;               // 32-px bin grid: one 256-thread workgroup blends a bin
     uint32_t bin_row_begin, bin_row_end;
-    uint32_t lists_x;              // list-bin grid (GS_LIST px): the unit of the entry lists and of the entry sort's keys
+    uint32_t list_shift;           // a list bin is (16 << list_shift) px
+    uint32_t lists_x;              // list-bin grid: the unit of the entry lists and of the entry sort's keys
     uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
@@ -249,6 +250,9 @@ struct ProjectParams {
 
 struct gs_mesh {
     gs_context* ctx = nullptr;
+    uint32_t list_shift = GS_LIST_SHIFT_LARGE;     // list-bin size of the next draw (mesh_collect_stats re-evaluates it)
+    uint32_t drawn_list_shift = GS_LIST_SHIFT_LARGE;   // ... of the last draw (what tile_ranges / the statistics refer to)
+    int forced_list_shift = -1;                    // GSPLAT_LIST_SHIFT (A/B and tests)
     uint32_t max_count = 0, sh_degree = 0, flags = 0, uploaded = 0;
     // SoA planes
     DevBuf px, py, pz;         // float centres

@@ -196,6 +196,8 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     }
     A(m->scene_dev, sizeof(gs_scene_params));
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
+    if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
+        if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
     if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
@@ -394,6 +396,11 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.tile_entries = ((uint64_t)f.entries_hi << 32) | f.entries_lo;
     m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;
+    m->last.list_bin_px = GS_TILE << m->drawn_list_shift;
+    // list-bin size of the following draws: large lists only pay when splats are large enough to share them
+    if (m->last.visible_splats > 0)
+        m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats ? GS_LIST_SHIFT_LARGE
+                                                                                                            : GS_LIST_SHIFT_SMALL;
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;
 }
@@ -498,9 +505,12 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     pp.bins_x = (cam->width + GS_BIN - 1) / GS_BIN;
     pp.bin_row_begin = y0 / GS_BIN;
     pp.bin_row_end = pp.y1 > y0 ? (pp.y1 + GS_BIN - 1) / GS_BIN : pp.bin_row_begin;
-    pp.lists_x = (cam->width + GS_LIST - 1) / GS_LIST;
-    pp.list_row_begin = y0 / GS_LIST;
-    pp.list_row_end = pp.y1 > y0 ? (pp.y1 + GS_LIST - 1) / GS_LIST : pp.list_row_begin;
+    pp.list_shift = m->forced_list_shift >= 0 ? (uint32_t)m->forced_list_shift : m->list_shift;
+    const uint32_t list_px = GS_TILE << pp.list_shift;
+    pp.lists_x = (cam->width + list_px - 1) / list_px;
+    pp.list_row_begin = y0 / list_px;
+    pp.list_row_end = pp.y1 > y0 ? (pp.y1 + list_px - 1) / list_px : pp.list_row_begin;
+    m->drawn_list_shift = pp.list_shift;
     const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
 
     const uint32_t* order_dev = nullptr;

@@ -25,15 +25,15 @@ constexpr int BIN_THREADS = 256;
 #endif
 constexpr int BIN_MAX_BLOCKS = 2048;                      // 8 workgroups of 256 per CU: full wave occupancy
 
-// vertex-stage rects are in 16-px tiles; the entry lists are per list bin of GS_LIST px
+// vertex-stage rects are in 16-px tiles; the entry lists are per list bin of (16 << list_shift) px
 __device__ __forceinline__ uint32_t rect_tiles(uint2 r) {
     const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, x1 = r.y & 0xFFFFu, y1 = r.y >> 16;
     return (x1 >= x0 && y1 >= y0) ? (x1 - x0 + 1u) * (y1 - y0 + 1u) : 0u;
 }
 // 16-px tile rect -> list-bin rect: per-field shift of (x | y << 16) with the bits that cross the field boundary masked
-__device__ __forceinline__ uint2 rect_to_bins(uint2 r) {
-    constexpr uint32_t FIELD = 0xFFFFu >> GS_LIST_SHIFT, MASK = FIELD | (FIELD << 16);
-    return make_uint2((r.x >> GS_LIST_SHIFT) & MASK, (r.y >> GS_LIST_SHIFT) & MASK);
+__device__ __forceinline__ uint2 rect_to_bins(uint2 r, uint32_t list_shift) {
+    const uint32_t field = 0xFFFFu >> list_shift, mask = field | (field << 16);
+    return make_uint2((r.x >> list_shift) & mask, (r.y >> list_shift) & mask);
 }
 
 struct BinChunk {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
                                                            uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ digit_total,
                                                            uint32_t* __restrict__ block_hist,
-                                                           uint2* __restrict__ tile_ranges, uint32_t tiles) {
+                                                           uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift) {
     __shared__ unsigned long long s_w[4];
     // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
     // pass and the workgroup rows of its first pass (k_bin_emit accumulates that histogram), reset the bin ranges.
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         uint32_t n[BIN_PER_LANE], cnt = 0, ent = 0;
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) {
-            n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k])) : 0u;   // entries = list bins touched
+            n[k] = keep[k] ? rect_tiles(rect_to_bins(r[k], list_shift)) : 0u;   // entries = list bins touched
             cnt += keep[k] ? 1u : 0u;
             ent += n[k];
         }
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* bins per row */,
                                                           uint32_t row_begin /* first bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, uint32_t radix_grid,
-                                                          uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist) {
+                                                          uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist,
+                                                          uint32_t list_shift) {
     static_assert(BIN_THREADS * 16 == RADIX_TILE, "an emit window must be one radix tile");
     __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
     __shared__ unsigned long long s_scan[4];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             }
             uint32_t j = jl;
             uint2 r16 = crect[first + j];                                   // 16-px tile rect of the splat
-            uint2 r = rect_to_bins(r16);                                    // the bins it touches
+            uint2 r = rect_to_bins(r16, list_shift);                                    // the bins it touches
             uint32_t idx = cidx[first + j];
             uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
             uint32_t n = rect_tiles(r);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                             j = 0;
                         }
                         r16 = crect[first + j];
-                        r = rect_to_bins(r16);
+                        r = rect_to_bins(r16, list_shift);
                         idx = cidx[first + j];
                         x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
                         n = rect_tiles(r);
@@ -374,7 +375,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(), m->radix.block_hist.as<uint32_t>(),
-                       m->tile_ranges.as<uint2>(), tiles);
+                       m->tile_ranges.as<uint2>(), tiles, pp.list_shift);
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
@@ -385,7 +386,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, cap, grid, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
-                       m->radix.digit_total.as<uint32_t>());
+                       m->radix.digit_total.as<uint32_t>(), pp.list_shift);
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
-                                                              uint32_t list_row_begin) {
+                                                              uint32_t list_row_begin, uint32_t list_shift) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
     const unsigned long long t_start = wall_clock64();
     uint32_t walked = 0, batches = 0;
 #endif
-    // the entry list of the list bin (GS_LIST px) this 32-px bin lies in
-    constexpr uint32_t PER_LIST = GS_LIST_SHIFT - GS_BIN_SHIFT;
-    const uint2 range = ranges[((by >> PER_LIST) - list_row_begin) * lists_x + (bx >> PER_LIST)];
+    // the entry list of the list bin this 32-px bin lies in
+    const uint32_t per_list = list_shift - GS_BIN_SHIFT;
+    const uint2 range = ranges[((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list)];
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
 
     // a quadrant outside the viewport / this rank's strip of pixel rows has nothing to draw
@@ -232,7 +232,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                        m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
-                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin);
+                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

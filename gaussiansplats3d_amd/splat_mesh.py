@@ -221,7 +221,7 @@ class SplatMesh:
     def bin_entry_counts(self, tile_rows=None):
         """Entries per list bin of the last draw, shaped [list_rows, lists_x] (`tile_rows`: the strip it drew)."""
         cam = self._cam
-        LB = L.list_bin_px()
+        LB = int(self.last_stats().list_bin_px)
         bins_x = (cam.width + LB - 1) // LB
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         r0, r1 = (0, rows_total) if tile_rows is None else tile_rows
@@ -239,7 +239,7 @@ class SplatMesh:
         cam = self._cam
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         per_bin_row = self.bin_entry_counts().sum(axis=1).astype(np.float64)
-        ratio = L.list_bin_px() // L.GS_TILE
+        ratio = int(self.last_stats().list_bin_px) // L.GS_TILE
         return np.repeat(per_bin_row / ratio, ratio)[:rows_total]
 
     def dispose(self):

@@ -46,9 +46,6 @@ typedef struct gs_tree gs_tree;
 /* Message of the last failing call on this thread (the reference throws JS Errors, SplatMesh.js:1518-1533). */
 const char* gs_last_error(void);
 int gs_abi_version(void);
-/* Edge of a list bin in pixels: entry lists (gs_render_stats.tile_entries, gs_mesh_debug_read what = 2) are per
- * list bin; multi-GPU strips and vertex-stage rects stay in 16-px tiles, blend workgroups in 32-px bins. */
-int gs_list_bin_px(void);
 /* Number of visible HIP devices, or a negative status. */
 int gs_device_count(void);
 
@@ -281,10 +278,13 @@ typedef struct gs_render_stats {
     float device_ms;          /* whole draw                                                                  */
     float project_ms, bin_ms, tile_sort_ms, blend_ms;
     uint32_t visible_splats;  /* splats that survive the vertex-stage rejects                                */
-    uint64_t tile_entries;    /* list entries = sum over splats of list bins (gs_list_bin_px) touched        */
+    uint64_t tile_entries;    /* list entries = sum over splats of list bins (list_bin_px) touched           */
     uint32_t entry_capacity;
     uint32_t overflowed;      /* 1 = frame was re-run after growing the entry buffer                         */
     uint64_t tiles16;         /* D of SURVEY.md 8d = sum over splats of 16x16-px tiles touched               */
+    uint32_t list_bin_px;     /* edge of a list bin of this draw (32 or 128): the unit of the entry lists and of
+                                 gs_mesh_debug_read(what = 2); chosen per mesh from the previous measured draw    */
+    uint32_t pad;
 } gs_render_stats;
 
 /* updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)

@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.Camera) == 272
     assert C.sizeof(_lib.SceneParams) == 8 + 32 * (64 + 16 + 4 + 4 + 4 + 4)
     assert C.sizeof(_lib.GatherParams) == 160 and C.sizeof(_lib.TreeInfo) == 64
-    assert C.sizeof(_lib.RenderStats) == 48
+    assert C.sizeof(_lib.RenderStats) == 56
     assert _lib.RenderStats.tile_entries.offset == 24
 
 

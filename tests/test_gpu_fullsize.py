@@ -93,7 +93,7 @@ def test_c3_full_size_invariants(ctx, c3):
     assert int(vis.sum()) == sa.visible_splats
     x0, y0, x1, y1 = rects[vis, 0] & 0xFFFF, rects[vis, 0] >> 16, rects[vis, 1] & 0xFFFF, rects[vis, 1] >> 16
     assert int(((x1 - x0 + 1).astype(np.int64) * (y1 - y0 + 1)).sum()) == sa.tiles16
-    sh = int(np.log2(L.list_bin_px() // 16))                   # 16-px tiles per list-bin edge, as a shift
+    sh = int(np.log2(sa.list_bin_px // 16))                    # 16-px tiles per list-bin edge, as a shift
     bins = ((x1 >> sh) - (x0 >> sh) + 1).astype(np.int64) * ((y1 >> sh) - (y0 >> sh) + 1)
     assert int(bins.sum()) == sa.tile_entries
     assert int(morton.bin_entry_counts().sum()) == sa.tile_entries

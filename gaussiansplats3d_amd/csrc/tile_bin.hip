@@ -1,4 +1,4 @@
-// tile_bin.hip — order-preserving duplication of splats into 16x16-pixel screen tiles.
+// tile_bin.hip — order-preserving duplication of splats into the entry lists of the screen's list bins.
 //
 // The reference has no binning: it draws one instanced quad per splat, back to front, and lets the ROPs blend
 // (/root/reference/src/splatmesh/SplatGeometry.js:11-37, SplatMaterial3D.js:65-75, src/Viewer.js:1616).  A
@@ -7,15 +7,15 @@
 //                 per 32 splats, 1.45 MB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
 //                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
 //                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
-//   k_bin_emit    ENTRY-centric expansion into (tile id, splat index) pairs: every lane owns 16 consecutive output
+//   k_bin_emit    ENTRY-centric expansion into (list bin, record slot) pairs: every lane owns 16 consecutive output
 //                 slots, finds the splat covering its first slot with two binary searches (workgroup table in LDS,
 //                 then that workgroup's per-splat offsets) and walks forward.  Work per lane is constant, so the
 //                 few near-camera splats that cover thousands of tiles cannot unbalance the grid, and every lane
 //                 stores whole 32-byte sectors.  Each workgroup first scans the binning workgroups' sums itself, and while it
 //                 writes a window of 4096 entries (= one radix tile) it adds the window's low-digit counts to the
 //                 first sort pass's table, so neither a scan kernel nor that pass's histogram kernel is launched.
-//   tile sort     stable LSD radix passes on the tile id (radix.hpp): stability keeps near->far order per tile; the
-//                 last pass also publishes every tile's [begin,end) (no separate range kernel)
+//   entry sort    stable LSD radix passes on the list-bin id (radix.hpp): stability keeps near->far order per list;
+//                 one pass for <= 256 lists (1080p at 128-px lists), and the pass publishes every list's [begin,end)
 // Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.
 #include "radix.hpp"
 

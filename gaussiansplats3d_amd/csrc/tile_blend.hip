@@ -10,15 +10,15 @@
 //   C += T*alpha*rgb ; T *= 1-alpha      =>  rgb_out = C , alpha_out = 1 - T      (identical in exact arithmetic)
 // with early termination once T < 1e-4 (bounded error 1e-4, far below 1/255).
 //
-// CDNA4 mapping.  The entry lists are per 32-px bin (2.2x fewer entries to emit and sort than per 16-px tile), the
-// pixel work stays per 16x16 quadrant: the workgroup gathers a batch of 256 records (one 32-byte record per thread),
-// expands them to fp32 in LDS next to the 4-bit "which 16-px tiles of the bin does the rect touch" mask that k_bin_emit
-// packed into the entry, and every wave
-// walks only its own survivors of the batch (4 ballots + s_ff1 per 256 entries).  Each lane owns 4 pixels
-// (x = lane&15, y = (lane>>4) + 4g); the inner loop reads a splat as three wave-uniform ds_read_b128 broadcasts,
-// and runs the four 16x4 strips of a lane as two packed, branch-free chains (v_pk_*_f32).  Every bin of a 1080p frame is
-// resident at once (8 workgroups per CU) and a wave walks only ~90 splats before its quadrant saturates, so the kernel is
-// bound by VALU issue slots per walked splat, not by the length of the lists (tools/blend_profile.py).
+// CDNA4 mapping.  The entry lists are per list bin (128 px, or 32 px for scenes of tiny splats), the pixel work is per
+// 16x16 quadrant: the workgroup scans its parent list in batches of 256 entries (one entry per thread: slot -> the
+// vertex stage's tile rect and the 32-byte record), keeps the entries whose rect touches its own 32-px bin, expands them
+// to fp32 in LDS next to the 4-bit "which quadrants" mask, and every wave walks only its own survivors of the batch
+// (4 ballots + s_ff1 per 256 entries).  Each lane owns 4 pixels (x = lane&15, y = (lane>>4) + 4g); the inner loop reads
+// a splat as three wave-uniform ds_read_b128 broadcasts and runs the four 16x4 strips of a lane as two packed,
+// branch-free chains (v_pk_*_f32).  Every bin of a 1080p frame is resident at once (8 workgroups per CU) and a wave walks
+// only ~90 splats before its quadrant saturates, so the kernel is bound by VALU issue slots per walked splat, not by the
+// length of the lists (tools/blend_profile.py).
 #include "gs_internal.hpp"
 
 constexpr float GS_POWER_CUT = 5.7707801636f;    // 4*log2(e)  <=>  A > 8

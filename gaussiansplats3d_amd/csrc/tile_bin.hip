@@ -7,13 +7,10 @@
 //                 per 32 splats, 1.45 MB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
 //                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
 //                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
-//   k_bin_emit    ENTRY-centric expansion into (list bin, record slot) pairs: every lane owns 16 consecutive output
-//                 slots, finds the splat covering its first slot with two binary searches (workgroup table in LDS,
-//                 then that workgroup's per-splat offsets) and walks forward.  Work per lane is constant, so the
-//                 few near-camera splats that cover thousands of tiles cannot unbalance the grid, and every lane
-//                 stores whole 32-byte sectors.  Each workgroup first scans the binning workgroups' sums itself, and while it
-//                 writes a window of 4096 entries (= one radix tile) it adds the window's low-digit counts to the
-//                 first sort pass's table, so neither a scan kernel nor that pass's histogram kernel is launched.
+//   k_bin_emit    splat-centric expansion into (list bin, record slot) pairs, one lane per surviving splat, runs
+//                 written at the offsets the count pass fixed; each workgroup sums the earlier workgroups' counts itself
+//                 and adds its entries' low-digit counts to the first sort pass's table, so neither a scan kernel nor that
+//                 pass's histogram kernel is launched.
 //   entry sort    stable LSD radix passes on the list-bin id (radix.hpp): stability keeps near->far order per list;
 //                 one pass for <= 256 lists (1080p at 128-px lists), and the pass publishes every list's [begin,end)
 // Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.
@@ -167,70 +164,55 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     }
 }
 
-constexpr uint32_t EMIT_PER_LANE = 16;
-constexpr uint32_t EMIT_WINDOW = BIN_THREADS * EMIT_PER_LANE;     // entries per workgroup iteration
-
+// k_bin_emit: one workgroup per binning workgroup, one lane per compacted splat.  With 128-px list bins a splat touches
+// 1.5 lists on average and at most the whole screen's 135, so a splat-centric expansion is balanced enough and needs
+// neither searches nor dependent walks: the lane reads its (slot, rect, first entry) with coalesced loads and writes its
+// run of (list bin, slot) pairs; neighbouring lanes write neighbouring runs.
 // block_sums: [0,BIN_MAX_BLOCKS) entries of every binning workgroup | [BIN_MAX_BLOCKS,..) its compacted splat count |
-// [2*BIN_MAX_BLOCKS,..) its 16-px tiles | [3*BIN_MAX_BLOCKS] batches per binning workgroup.  `bin_grid` = k_bin_count's grid.
-// Every workgroup scans the <= 2048 workgroup sums itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan kernel
-// and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
-// It also accumulates the first entry-sort pass's histogram: an emit window is exactly one 4096-key radix tile, so the
-// window's low-digit counts go straight into the row of the radix workgroup that will scatter it (`radix_grid` = that
-// pass's grid; rows and group rows were zeroed by k_bin_count) and the pass runs without its histogram kernel.
+// [2*BIN_MAX_BLOCKS,..) its 16-px tiles | [3*BIN_MAX_BLOCKS] batches per binning workgroup.
+// Every workgroup sums the sums of the workgroups before it itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan
+// kernel and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
+// It also accumulates the first entry-sort pass's histogram: entry e belongs to radix tile e / 4096, i.e. to the row of the
+// radix workgroup that will scatter that tile (`radix_grid` = that pass's grid; rows and group rows were zeroed by
+// k_bin_count), so the pass runs without its histogram kernel.
+constexpr uint32_t EMIT_ROWS = 4;      // radix rows a workgroup's entries normally span; the rest goes straight to global atomics
+
 template <class KeyT>
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restrict__ frame, uint32_t capacity, uint32_t bin_grid,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restrict__ frame, uint32_t capacity,
                                                           const uint32_t* __restrict__ cidx,
                                                           const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
-                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* bins per row */,
-                                                          uint32_t row_begin /* first bin row */, KeyT* __restrict__ keys_out,
+                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* list bins per row */,
+                                                          uint32_t row_begin /* first list-bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, uint32_t radix_grid,
                                                           uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist,
                                                           uint32_t list_shift) {
-    static_assert(BIN_THREADS * 16 == RADIX_TILE, "an emit window must be one radix tile");
-    __shared__ uint32_t s_boff[BIN_MAX_BLOCKS + 1];
-    __shared__ unsigned long long s_scan[4];
-    __shared__ uint32_t s_hist[RADIX_BINS];
-    __shared__ unsigned long long s_t16[4];
+    __shared__ unsigned long long s_sum[4], s_before[4], s_t16[4];
     __shared__ uint32_t s_vis[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;            // 8 consecutive workgroup sums per thread
-    unsigned long long D64;
-    {
-        uint32_t v[PER_T];
-        unsigned long long mine = 0;
+    __shared__ uint32_t s_hist[EMIT_ROWS][RADIX_BINS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, b = blockIdx.x, bin_grid = gridDim.x;
+    constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;            // 8 workgroup sums per thread
+    // total entries D and the entries of the workgroups before this one
+    unsigned long long all = 0, before = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PER_T; k++) {
-            const uint32_t i = threadIdx.x * PER_T + k;
-            v[k] = i < bin_grid ? block_sums[i] : 0u;
-            mine += v[k];
-        }
-        unsigned long long incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long t = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += t;
-        }
-        if (lane == 63u) s_scan[wave] = incl;
-        __syncthreads();
-        unsigned long long base = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const unsigned long long c = s_scan[w];
-            base += ((uint32_t)w < wave) ? c : 0ull;
-            total += c;
-        }
-        unsigned long long run = base + incl - mine;
-#pragma unroll
-        for (uint32_t k = 0; k < PER_T; k++) {
-            const uint32_t i = threadIdx.x * PER_T + k;
-            if (i < bin_grid) s_boff[i] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
-            run += v[k];
-        }
-        if (threadIdx.x == 0) s_boff[bin_grid] = 0xFFFFFFFFu;
-        D64 = total;
+    for (uint32_t k = 0; k < PER_T; k++) {
+        const uint32_t i = threadIdx.x + k * BIN_THREADS;               // coalesced
+        const uint32_t v = i < bin_grid ? block_sums[i] : 0u;
+        all += v;
+        before += i < b ? v : 0u;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        all += __shfl_xor(all, o, 64);
+        before += __shfl_xor(before, o, 64);
+    }
+    if (lane == 0u) { s_sum[wave] = all; s_before[wave] = before; }
+#pragma unroll
+    for (uint32_t r = 0; r < EMIT_ROWS; r++) s_hist[r][threadIdx.x] = 0u;       // BIN_THREADS == RADIX_BINS
+    __syncthreads();
+    const unsigned long long D64 = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    const unsigned long long boff64 = s_before[0] + s_before[1] + s_before[2] + s_before[3];
     const uint32_t D = D64 > capacity ? capacity : (uint32_t)D64;
-    if (blockIdx.x == 0) {                                   // the frame's scalars (read by the sort passes and the host)
+    if (b == 0) {                                            // the frame's scalars (read by the sort passes and the host)
         unsigned long long t16 = 0;
         uint32_t vis = 0;
         for (uint32_t i = threadIdx.x; i < bin_grid; i += BIN_THREADS) {
@@ -256,107 +238,58 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             frame->pad = 0;
         }
     }
+    if (boff64 >= D) return;                                 // nothing of this workgroup fits (or it has no entries)
+    const uint32_t boff = (uint32_t)boff64;
     const uint32_t bin_per = block_sums[3 * BIN_MAX_BLOCKS];             // batches per binning workgroup (k_bin_count)
-    const uint32_t radix_tiles = (D + EMIT_WINDOW - 1u) / EMIT_WINDOW;
+    const uint32_t first = b * bin_per * BIN_THREADS;                   // this workgroup's slice of the compacted list
+    const uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
+    const uint32_t radix_tiles = (D + (uint32_t)RADIX_TILE - 1u) / (uint32_t)RADIX_TILE;
     const uint32_t radix_per = max((radix_tiles + radix_grid - 1u) / radix_grid, 1u);   // = radix_chunk()'s tiles per workgroup
-    __syncthreads();
-    for (uint32_t win = blockIdx.x; (unsigned long long)win * EMIT_WINDOW < D; win += gridDim.x) {
-        const uint32_t e0 = win * EMIT_WINDOW + threadIdx.x * EMIT_PER_LANE;
-        const uint32_t e1 = min(e0 + EMIT_PER_LANE, D);
-        s_hist[threadIdx.x] = 0u;                                       // BIN_THREADS == RADIX_BINS
-        __syncthreads();
-        if (e0 < D) {
-            // level 1: binning workgroup b owning slot e0 = LAST b with s_boff[b] <= e0 (empty workgroups share their
-            // offset with a successor and lose, which is what we want)
-            uint32_t lo = 0, hi = bin_grid;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_boff[mid] <= e0) lo = mid; else hi = mid;
-            }
-            uint32_t b = lo;
-            uint32_t first = b * bin_per * BIN_THREADS;                     // start of b's slice of the compacted list
-            uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
-            uint32_t boff = s_boff[b];
-            // level 2: LAST splat j of that slice with boff + coff[j] <= e0
-            uint32_t jl = 0, jh = cnt;
-            const uint32_t rel = e0 - boff;
-            while (jh - jl > 1) {
-                const uint32_t mid = (jl + jh) >> 1;
-                if (coff[first + mid] <= rel) jl = mid; else jh = mid;
-            }
-            uint32_t j = jl;
-            uint2 r16 = crect[first + j];                                   // 16-px tile rect of the splat
-            uint2 r = rect_to_bins(r16, list_shift);                                    // the bins it touches
-            uint32_t idx = cidx[first + j];
-            uint32_t x0 = r.x & 0xFFFFu, x1 = r.y & 0xFFFFu, w = x1 - x0 + 1u;
-            uint32_t n = rect_tiles(r);
-            uint32_t k = rel - coff[first + j];
-            uint32_t ty = (r.x >> 16) + k / w, tx = x0 + k % w;              // absolute bin coordinates
-
-            uint32_t kk[EMIT_PER_LANE], vv[EMIT_PER_LANE];
-#pragma unroll
-            for (uint32_t t = 0; t < EMIT_PER_LANE; t++) {
-                kk[t] = (ty - row_begin) * tiles_x + tx;
-                vv[t] = idx;
-                if (e0 + t + 1 < e1) {
-                    if (++k == n) {                                        // next splat (possibly in the next workgroup slice)
-                        if (++j == cnt) {
-                            do {
-                                b++;
-                                cnt = block_sums[BIN_MAX_BLOCKS + b];
-                            } while (cnt == 0);
-                            first = b * bin_per * BIN_THREADS;
-                            j = 0;
-                        }
-                        r16 = crect[first + j];
-                        r = rect_to_bins(r16, list_shift);
-                        idx = cidx[first + j];
-                        x0 = r.x & 0xFFFFu; x1 = r.y & 0xFFFFu;
-                        n = rect_tiles(r);
-                        k = 0;
-                        tx = x0; ty = r.x >> 16;
-                    } else if (++tx > x1) {
-                        tx = x0; ty++;
-                    }
-                }
-            }
-            if (e1 - e0 == EMIT_PER_LANE) {
-                // whole 32-byte (keys, u16) / 64-byte (payload) sectors per lane
-                if (sizeof(KeyT) == 2) {
-                    uint4 p0, p1;
-                    p0.x = kk[0] | (kk[1] << 16); p0.y = kk[2] | (kk[3] << 16); p0.z = kk[4] | (kk[5] << 16); p0.w = kk[6] | (kk[7] << 16);
-                    p1.x = kk[8] | (kk[9] << 16); p1.y = kk[10] | (kk[11] << 16); p1.z = kk[12] | (kk[13] << 16); p1.w = kk[14] | (kk[15] << 16);
-                    uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
-                    dst[0] = p0; dst[1] = p1;
-                } else {
-                    uint4* dst = reinterpret_cast<uint4*>(keys_out + e0);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) dst[t] = make_uint4(kk[4 * t], kk[4 * t + 1], kk[4 * t + 2], kk[4 * t + 3]);
-                }
-                uint4* vd = reinterpret_cast<uint4*>(vals_out + e0);
-#pragma unroll
-                for (int t = 0; t < 4; t++) vd[t] = make_uint4(vv[4 * t], vv[4 * t + 1], vv[4 * t + 2], vv[4 * t + 3]);
-            } else {
-#pragma unroll
-                for (uint32_t t = 0; t < EMIT_PER_LANE; t++)
-                    if (e0 + t < e1) {
-                        keys_out[e0 + t] = (KeyT)kk[t];
-                        vals_out[e0 + t] = vv[t];
-                    }
-            }
-#pragma unroll
-            for (uint32_t t = 0; t < EMIT_PER_LANE; t++)
-                if (e0 + t < e1) atomicAdd(&s_hist[kk[t] & 255u], 1u);
-        }   // e0 < D
-        __syncthreads();
-        {
-            const uint32_t c = s_hist[threadIdx.x], rb = win / radix_per;
-            if (c) {
-                atomicAdd(&block_hist[rb * RADIX_BINS + threadIdx.x], c);
-                atomicAdd(&group_hist[(rb / RADIX_GROUP) * RADIX_BINS + threadIdx.x], c);
-            }
+    const uint32_t row0 = (boff / (uint32_t)RADIX_TILE) / radix_per;
+    // entry k of a splat whose first entry is e0: list bin (x0 + k % w, y0 + k / w)
+    auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
+        if (e >= D) return;                                             // dropped by an overflowing draw (it is redone)
+        keys_out[e] = (KeyT)key;
+        vals_out[e] = idx;
+        const uint32_t row = (e / (uint32_t)RADIX_TILE) / radix_per, d = key & 255u;
+        if (row - row0 < EMIT_ROWS) {
+            atomicAdd(&s_hist[row - row0][d], 1u);
+        } else {
+            atomicAdd(&block_hist[row * RADIX_BINS + d], 1u);
+            atomicAdd(&group_hist[(row / RADIX_GROUP) * RADIX_BINS + d], 1u);
         }
-        __syncthreads();
+    };
+    constexpr uint32_t OWN = 4;        // entries a lane writes for its own splat; longer runs are shared by the wave
+    for (uint32_t j0 = 0; j0 < cnt; j0 += BIN_THREADS) {
+        const uint32_t j = j0 + threadIdx.x;
+        uint2 r = make_uint2(0u, 0u);
+        uint32_t idx = 0, e0 = 0, n = 0;
+        if (j < cnt) {
+            r = rect_to_bins(crect[first + j], list_shift);             // the list bins the splat touches
+            idx = cidx[first + j];
+            e0 = boff + coff[first + j];
+            n = rect_tiles(r);
+        }
+        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, w = (r.y & 0xFFFFu) - x0 + 1u;
+        for (uint32_t k = 0; k < min(n, OWN); k++) put(e0 + k, (y0 + k / w - row_begin) * tiles_x + x0 + k % w, idx);
+        // the few near splats that cover many lists: all 64 lanes write one splat's remaining entries together
+        unsigned long long big = __ballot(n > OWN);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1ull;
+            const uint32_t bn = __shfl(n, src, 64), be0 = __shfl(e0, src, 64), bidx = __shfl(idx, src, 64);
+            const uint32_t bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64);
+            for (uint32_t k = OWN + lane; k < bn; k += 64u) put(be0 + k, (by0 + k / bw - row_begin) * tiles_x + bx0 + k % bw, bidx);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < EMIT_ROWS; r++) {
+        const uint32_t c = s_hist[r][threadIdx.x], row = row0 + r;
+        if (c) {
+            atomicAdd(&block_hist[row * RADIX_BINS + threadIdx.x], c);
+            atomicAdd(&group_hist[(row / RADIX_GROUP) * RADIX_BINS + threadIdx.x], c);
+        }
     }
 }
 
@@ -380,10 +313,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
     }
-    uint32_t egrid = (uint32_t)(((unsigned long long)cap + EMIT_WINDOW - 1) / EMIT_WINDOW);
-    if (egrid > 4096u) egrid = 4096u;
-    if (egrid < 1u) egrid = 1u;
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(egrid), dim3(BIN_THREADS), 0, st, frame, cap, grid, m->cidx.as<uint32_t>(),
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
                        m->radix.digit_total.as<uint32_t>(), pp.list_shift);

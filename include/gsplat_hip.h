@@ -299,7 +299,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
 
 /* Intermediates of the last draw (tests, strip load-balancing).  what: 0 = per splat (storage order) the
  * 32-byte vertex-stage record {cx, cy, ax, ay, bx, by, r|g<<16, b|a<<16 (unorm16)}; 1 = per splat the tile
- * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per 32-px bin of the
+ * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per list bin (gs_render_stats.list_bin_px) of the
  * drawn strip the [begin,end) range of its entry list ((~0,0) = untouched); 3 = the visibility mask, 1 bit per
  * splat packed in uint64 words (count = number of words). */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);

@@ -114,3 +114,84 @@ def test_small_frame_matches_independent_numpy_compositor():
     clear = ~amb.astype(bool)
     assert np.abs(fb - ref)[clear].max() < 2e-4
     assert frags > 100
+
+
+def numpy_permutation(cam, centers, cov6, rgba, W, H, antialiased=False, point_cloud=False, splat_scale=1.0,
+                      focal_adjustment=1.0, kernel=0.3, ortho_zoom=None):
+    """fp64 restatement of the vertex-stage permutations (SplatMaterial3D.js:112-117, 137-151, 184-186, 206-207):
+    returns (ok, b1, b2, alpha) for SH-0 splats."""
+    MV = np.asarray(cam.model_view(), np.float64).reshape(4, 4).T
+    P = np.asarray(cam.projection, np.float64).reshape(4, 4).T
+    n = centers.shape[0]
+    v = (MV @ np.c_[centers.astype(np.float64), np.ones(n)].T).T
+    q = (P @ v.T).T
+    w = q[:, 3]
+    ok = ~((q[:, 2] < -1.2 * w) | (np.abs(q[:, 0]) > 1.2 * w) | (np.abs(q[:, 1]) > 1.2 * w))
+    ok &= (q[:, 2] / w >= -1) & (q[:, 2] / w <= 1)
+    fx, fy = P[0, 0] * 0.5 * W * focal_adjustment, P[1, 1] * 0.5 * H * focal_adjustment
+    c6 = cov6.astype(np.float64)
+    Vrk = np.stack([np.stack([c6[:, 0], c6[:, 1], c6[:, 2]], 1), np.stack([c6[:, 1], c6[:, 3], c6[:, 4]], 1),
+                    np.stack([c6[:, 2], c6[:, 4], c6[:, 5]], 1)], 1)
+    J = np.zeros((n, 3, 3))
+    if ortho_zoom is None:
+        J[:, 0, 0] = fx / v[:, 2]; J[:, 2, 0] = -fx * v[:, 0] / v[:, 2] ** 2
+        J[:, 1, 1] = fy / v[:, 2]; J[:, 2, 1] = -fy * v[:, 1] / v[:, 2] ** 2
+    else:
+        J[:, 0, 0] = ortho_zoom; J[:, 1, 1] = ortho_zoom
+    T = MV[:3, :3].T[None] @ J
+    S2 = np.transpose(T, (0, 2, 1)) @ Vrk @ T
+    a, b, d = S2[:, 0, 0], S2[:, 0, 1], S2[:, 1, 1]
+    alpha = rgba[:, 3] / 255.0
+    if antialiased:
+        det0 = a * d - b * b
+        a, d = a + kernel, d + kernel
+        alpha = alpha * np.sqrt(np.maximum(det0 / (a * d - b * b), 0.0))
+        ok &= alpha >= 1.0 / 255.0
+    else:
+        a, d = a + kernel, d + kernel
+    t = 0.5 * (a + d)
+    r = np.sqrt(np.maximum(0.1, t * t - (a * d - b * b)))
+    l1, l2 = t + r, t - r
+    if point_cloud:
+        l1 = np.full(n, 0.2); l2 = np.full(n, 0.2)
+    ok &= l2 > 0
+    e1 = np.stack([b, (t + r) - a], axis=1) if not point_cloud else np.stack([b, 0.2 - a], axis=1)
+    e1 /= np.linalg.norm(e1, axis=1, keepdims=True)
+    e2 = np.stack([e1[:, 1], -e1[:, 0]], axis=1)
+    k = splat_scale / focal_adjustment
+    h1 = np.minimum(np.sqrt(8 * l1), 1024.0) * k
+    h2 = np.minimum(np.sqrt(8 * np.maximum(l2, 1e-300)), 1024.0) * k
+    return ok, e1 * h1[:, None], e2 * h2[:, None], alpha
+
+
+@pytest.mark.parametrize("opts", [dict(antialiased=True), dict(point_cloud=True), dict(splat_scale=0.6, focal_adjustment=1.7),
+                                  dict(antialiased=True, kernel=0.1), dict(ortho=True)])
+def test_vertex_stage_permutations_match_independent_numpy_restatement(opts):
+    opts = dict(opts)
+    ortho = opts.pop("ortho", False)
+    scene = helpers.small_scene(3000, 0, seed=330)
+    W, H = 640, 360
+    if ortho:
+        up, pos, look = camera.DEMO_POSES["garden"]
+        cam = camera.OrthographicCamera(W, H, pos, look, up, zoom=45.0)
+    else:
+        cam = camera.demo_camera("garden", W, H)
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    kernel = opts.get("kernel", 0.3)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0, splat_scale=opts.get("splat_scale", 1.0),
+                              kernel2d=kernel, focal_adjustment=opts.get("focal_adjustment", 1.0),
+                              antialiased=opts.get("antialiased", False), point_cloud=opts.get("point_cloud", False))
+    if ortho:
+        ocam.orthographic = 1
+        ocam.ortho_zoom = cam.zoom
+    got = oracle.project(ocam, c, cov, rgba, None)
+    ok, b1, b2, alpha = numpy_permutation(cam, c, cov, rgba, W, H, ortho_zoom=cam.zoom if ortho else None, **opts)
+    vis = got["visible"].astype(bool)
+    assert (vis != ok).sum() <= 3                      # threshold cases only
+    both = vis & ok
+    assert both.sum() > 800
+    for gx, gy, ref in ((got["b1x"], got["b1y"], b1), (got["b2x"], got["b2y"], b2)):
+        np.testing.assert_allclose(np.hypot(gx[both], gy[both]), np.linalg.norm(ref[both], axis=1), rtol=3e-3, atol=2e-3)
+    np.testing.assert_allclose(got["a"][both], alpha[both], rtol=2e-4, atol=2e-6)
+    if opts.get("point_cloud"):
+        np.testing.assert_allclose(np.hypot(got["b1x"][both], got["b1y"][both]), np.sqrt(8 * 0.2), rtol=1e-5)

@@ -195,3 +195,98 @@ def test_vertex_stage_permutations_match_independent_numpy_restatement(opts):
     np.testing.assert_allclose(got["a"][both], alpha[both], rtol=2e-4, atol=2e-6)
     if opts.get("point_cloud"):
         np.testing.assert_allclose(np.hypot(got["b1x"][both], got["b1y"][both]), np.sqrt(8 * 0.2), rtol=1e-5)
+
+
+def _sh_colour(rgba, sh, d, sh_degree):
+    """fp64 SH-1/2 colour (SplatMaterial.js:185-337) for unit directions d and coefficient-major RGB triples."""
+    col = rgba[:, :3].astype(np.float64) / 255.0
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    s = sh.astype(np.float64).reshape(sh.shape[0], -1, 3)
+    col = col + 0.4886025119029199 * (-s[:, 0] * y + s[:, 1] * z - s[:, 2] * x)
+    if sh_degree >= 2:
+        col = col + (1.0925484 * x * y) * s[:, 3] - (1.0925484 * y * z) * s[:, 4] + (0.3153916 * (2 * z * z - x * x - y * y)) * s[:, 5] \
+            - (1.0925484 * x * z) * s[:, 6] + (0.5462742 * (x * x - y * y)) * s[:, 7]
+    return np.clip(col, 0, 1)
+
+
+def test_fade_in_and_scene_effects_match_numpy():
+    """alpha *= sceneOpacity, hidden / transparent scenes dropped (SplatMaterial.js:129-137, SplatMaterial3D.js:199-203);
+    fade-in factor (SplatMaterial.js:347-363)."""
+    scene = helpers.small_scene(3000, 0, seed=340)
+    W, H = 320, 180
+    cam = camera.demo_camera("garden", W, H)
+    c, cov, rgba, _ = helpers.oracle_inputs(scene)
+    sidx = (np.arange(scene.count) % 3).astype(np.uint32)
+    opacity, visible = [1.0, 0.4, 0.005], [1, 1, 1]
+    base = oracle.project(oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0), c, cov, rgba, None)
+    ocam = oracle.set_scenes(oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0), opacity=opacity,
+                             visible=visible, effects=True)
+    got = oracle.project(ocam, c, cov, rgba, None, scene_indexes=sidx)
+    vis0 = base["visible"].astype(bool)
+    exp_vis = vis0 & (sidx != 2)                                       # opacity <= 0.01 hides the scene
+    np.testing.assert_array_equal(got["visible"].astype(bool), exp_vis)
+    np.testing.assert_allclose(got["a"][exp_vis], (base["a"] * np.array(opacity)[sidx])[exp_vis], rtol=1e-6)
+    ocam = oracle.set_scenes(oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0), opacity=[1, 1, 1],
+                             visible=[1, 0, 1], effects=True)
+    got = oracle.project(ocam, c, cov, rgba, None, scene_indexes=sidx)
+    np.testing.assert_array_equal(got["visible"].astype(bool), vis0 & (sidx != 1))
+    # fade-in
+    center = scene.centers.mean(axis=0)
+    dist = np.linalg.norm(scene.centers.astype(np.float64) - center, axis=1)
+    radius = float(np.median(dist))
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, 0, 0)
+    ocam.fade_in, ocam.fade_start = 1, radius
+    ocam.scene_center[:] = center.tolist()
+    got = oracle.project(ocam, c, cov, rgba, None)
+    step = (dist >= radius).astype(np.float64)
+    fade = (1.0 - step) + (1.0 - np.clip((dist - radius) / 0.75, 0, 1)) * step
+    np.testing.assert_allclose(got["a"][vis0], (base["a"] * fade)[vis0], rtol=2e-5, atol=2e-6)
+    assert 0.2 < (fade[vis0] < 1).mean() < 0.8
+
+
+@pytest.mark.parametrize("sh_degree", [1, 2])
+def test_8bit_sh_and_dynamic_view_direction_match_numpy(sh_degree):
+    """u8 SH dequantisation v/255*(max-min)+min (SplatMaterial.js:265-269) and, in dynamic mode, the view direction from
+    inverse(transform)*cameraPosition with modelView = viewMatrix*transform (:140-144, 179-183)."""
+    scene = helpers.small_scene(2500, sh_degree, seed=350 + sh_degree)
+    W, H = 320, 180
+    cam = camera.demo_camera("garden", W, H)
+    c, cov, rgba, sh = helpers.oracle_inputs(scene)
+    n = scene.count
+    rng = np.random.default_rng(7)
+    ncoef = 9 if sh_degree == 1 else 24
+    sh8 = rng.integers(0, 256, size=(n, ncoef), dtype=np.uint8)
+    lo, hi = -1.5, 1.5
+    ocam = oracle.set_scenes(oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, sh_degree, sh_degree),
+                             sh8_range=[(lo, hi)])
+    ocam.sh8 = 1
+    got = oracle.project(ocam, c, cov, rgba, sh8.astype(np.float32))
+    d = c.astype(np.float64) - np.asarray(cam.position, np.float64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    col = _sh_colour(rgba, sh8.astype(np.float64) / 255.0 * (hi - lo) + lo, d, sh_degree)
+    vis = got["visible"].astype(bool)
+    np.testing.assert_allclose(np.c_[got["r"], got["g"], got["b"]][vis], col[vis], atol=3e-5)
+
+    # dynamic mode: one scene rotated and shifted
+    a = np.deg2rad(17.0)
+    Tm = np.eye(4)
+    Tm[0, 0] = Tm[2, 2] = np.cos(a); Tm[0, 2] = np.sin(a); Tm[2, 0] = -np.sin(a); Tm[:3, 3] = (0.2, -0.1, 0.3)
+    transforms = [np.eye(4).T.reshape(16), Tm.T.reshape(16)]
+    sidx = (np.arange(n) % 2).astype(np.uint32)
+    ocam = oracle.set_scenes(oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, sh_degree, sh_degree),
+                             view_matrix=cam.view, transforms=transforms, camera_position=cam.position, dynamic=True)
+    got = oracle.project(ocam, c, cov, rgba, sh, scene_indexes=sidx)
+    cams = [np.asarray(cam.position, np.float64), (np.linalg.inv(Tm) @ np.r_[np.asarray(cam.position, np.float64), 1.0])[:3]]
+    d = c.astype(np.float64) - np.stack(cams)[sidx]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    col = _sh_colour(rgba, sh, d, sh_degree)
+    vis = got["visible"].astype(bool)
+    assert vis.sum() > 800
+    np.testing.assert_allclose(np.c_[got["r"], got["g"], got["b"]][vis], col[vis], atol=3e-5)
+    # and the centres follow viewMatrix * transform
+    V = np.asarray(cam.view, np.float64).reshape(4, 4).T
+    P = np.asarray(cam.projection, np.float64).reshape(4, 4).T
+    world = np.where(sidx[:, None] == 1, (Tm @ np.c_[c.astype(np.float64), np.ones(n)].T).T[:, :3], c.astype(np.float64))
+    q = (P @ V @ np.c_[world, np.ones(n)].T).T
+    px = (q[:, 0] / q[:, 3] * 0.5 + 0.5) * W
+    np.testing.assert_allclose(got["cx"][vis], px[vis], atol=2e-2)

@@ -188,6 +188,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         proj_ms_sum, proj_launches = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
+        st_timed = mesh.last_stats()                          # the list-bin size the timed frames used, and their entries
+        list_px_timed, D32 = int(st_timed.list_bin_px), int(st_timed.tile_entries)
 
         # per-stage device times (HIP events recorded by the library), one synchronised frame at a time; also the
         # latency of an isolated frame
@@ -290,7 +292,6 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     D16 = int(st_probe.tiles16)
-    D32 = int(st_probe.tile_entries)
     visible = int(st_probe.visible_splats)
     if rank == 0:
         R = Rs = N
@@ -323,7 +324,7 @@ def main():
             # whole frame against SURVEY.md §8d's formula
             "frame": {"algorithmic_bytes": int(B), "bytes_per_splat": round(B / R, 1), "GBps": round(frame_gbs, 1),
                       "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
-                      "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": int(st_probe.list_bin_px),
+                      "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": list_px_timed,
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
             "orbit": orbit,
             "cull_on": cull,

@@ -310,7 +310,8 @@ def main():
             "fps": round(1e3 / ms_per_step, 2), "frame_latency_ms": round(float(np.median(latency)), 4),
             "host_enqueue_ms_per_frame": round(t_enqueued / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "int32 keys / f32 raster", "data": "synthetic",
+            "dtype": "int32 keys / f32 raster",
+            "data": "synthetic" if scene.name == args.config else f"file:{scene.name}",
             "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",

@@ -5,6 +5,7 @@ gets a seeded generator producing the arrays the reference hands its GPU path
 (src/splatmesh/SplatMesh.js:637-898): fp32 centres, fp32 (or fp16) covariances R*S^2*R^T
 (src/loaders/SplatBuffer.js:440-486), RGBA8 colour and fp16 SH as coefficient-major RGB triples.
 """
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -102,7 +103,35 @@ CONFIGS = {
 }
 
 
+# Real captures, when the caller supplies them: $GS_DATA_DIR/<file>; none ship with this repository.
+REAL_FILES = {"C1": "bonsai.ksplat", "C2": "truck.ply", "C3": "garden.ply", "C5": "garden.ply"}
+
+
+def load_real_scene(cfg):
+    """The config's real capture from $GS_DATA_DIR through the native asset reader, or None if it is not there.
+    .ksplat files with 8-bit SH are not supported here (the bench draws fp16 SH)."""
+    root = os.environ.get("GS_DATA_DIR")
+    name = REAL_FILES.get(cfg)
+    if not root or not name:
+        return None
+    path = os.path.join(root, name)
+    if not os.path.isfile(path):
+        return None
+    from . import assets
+    want = CONFIGS[cfg]["sh"]
+    arr = assets.load(path, spherical_harmonics_degree=want)
+    deg = int(arr["sh_degree"])
+    if deg and arr["sh_f16"] is None:
+        raise ValueError(f"{path}: 8-bit spherical harmonics are not supported by the benchmark scene loader")
+    sh = arr["sh_f16"].view(np.float16) if deg else np.zeros((arr["centers"].shape[0], 0), np.float16)
+    return SplatScene(arr["centers"], arr["cov"], arr["rgba"], sh, deg, False, name)
+
+
 def make_config_scene(cfg, n_override=None):
+    if not n_override:
+        real = load_real_scene(cfg)
+        if real is not None:
+            return real
     c = CONFIGS[cfg]
     n = int(n_override) if n_override else c["n"]
     num = int(cfg[1:])

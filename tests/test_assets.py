@@ -159,3 +159,22 @@ def test_ply_file_renders_like_its_arrays():
     print(helpers.compare_frames(got, fb, amb, "ply end-to-end"))
     mesh.dispose()
     ctx.close()
+
+
+def test_real_capture_from_data_dir_replaces_the_stand_in(tmp_path, monkeypatch):
+    """$GS_DATA_DIR/garden.ply is read through the native asset reader instead of the synthetic scene."""
+    from gaussiansplats3d_amd import scenes
+    rng = np.random.default_rng(11)
+    n = 500
+    centers = rng.normal(size=(n, 3)).astype(np.float32)
+    data = assets.write_ply(centers, rng.normal(-3, 0.3, (n, 3)).astype(np.float32), rng.normal(size=(n, 4)).astype(np.float32),
+                            rng.normal(size=(n, 3)).astype(np.float32), rng.normal(1, 2, n).astype(np.float32),
+                            rng.normal(0, 0.2, (n, 24)).astype(np.float32))
+    (tmp_path / "garden.ply").write_bytes(data)
+    monkeypatch.setenv("GS_DATA_DIR", str(tmp_path))
+    scene = scenes.make_config_scene("C3")
+    assert scene.name == "garden.ply" and scene.count == n and scene.sh_degree == 2 and scene.sh.shape == (n, 24)
+    np.testing.assert_array_equal(scene.centers, centers)
+    assert scenes.make_config_scene("C2").name == "C2"          # truck.ply is not there: synthetic stand-in
+    monkeypatch.delenv("GS_DATA_DIR")
+    assert scenes.load_real_scene("C3") is None

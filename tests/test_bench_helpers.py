@@ -1,0 +1,44 @@
+"""CPU tier: the arithmetic behind bench.py's JSON line (SURVEY.md 8d formulas), the PMC look-up and the CPU baseline leg."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_frame_formula_matches_the_survey():
+    # B = 56 Rs + (84 + S) R + 40 D + 4 P, S = 48 for SH-2 (C3 numbers)
+    R = Rs = 5_800_000
+    D, P = 14_551_988, 1920 * 1080
+    assert bench.frame_algorithmic_bytes(R, Rs, D, P, 2, False) == 56 * Rs + (84 + 48) * R + 40 * D + 4 * P == 1_680_773_920
+    # fp16 covariances (C4) and a third radix pass (precision 20)
+    assert bench.frame_algorithmic_bytes(10, 10, 0, 0, 0, True) == 56 * 10 + 72 * 10
+    assert bench.frame_algorithmic_bytes(10, 10, 0, 0, 0, False, precision=20) == (56 + 16) * 10 + 84 * 10
+
+
+def test_project_bytes():
+    assert bench.project_algorithmic_bytes(5_800_000, 1_444_147, 2, False) == 12 * 5_800_000 + (24 + 4 + 48 + 40) * 1_444_147 + 725_000
+    assert bench.project_algorithmic_bytes(1000, 0, 0, True) == 12_000 + 125
+
+
+def test_pmc_lookup_reads_the_committed_summary():
+    traffic, src = bench.pmc_traffic("k_project")
+    assert src is not None and src.endswith("pmc_traffic.json")
+    d = json.load(open(os.path.join(ROOT, "profiles", src)))
+    name = next(k for k in d["kernels"] if k.split("<")[0] == "k_project")
+    assert traffic == d["kernels"][name]["hbm_bytes_per_launch"] > 100e6
+    assert bench.pmc_traffic("no_such_kernel")[0] is None
+
+
+def test_cpu_baseline_leg_times_the_reference_sorter():
+    from gaussiansplats3d_amd import camera, scenes
+    scene = scenes.scene_like(20000, 0, 5, name="t")
+    cam = camera.demo_camera("garden", 320, 180)
+    r = bench.cpu_baseline(scene, cam.sort_mvp(), 0.2)
+    assert r["cores"] == 1 and r["kind"] in ("reference", "port") and r["value"] > 1.0 and r["ms_per_sort"] > 0
+    assert "sorts" in r["sample"]

@@ -14,7 +14,8 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'gsplat_addon.node'));
 
 const Constants = { DefaultSplatSortDistanceMapPrecision: 16, BytesPerInt: 4, BytesPerFloat: 4, MaxScenes: 32 };
-const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2;
+const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_MESH_SH_U8 = 2;
+const GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2, GS_CAM_ORTHOGRAPHIC = 4, GS_CAM_FADE_IN = 8, GS_CAM_SCENE_EFFECTS = 16, GS_CAM_DYNAMIC = 32;
 
 let sharedContext = null;
 function getContext(device) {
@@ -135,14 +136,21 @@ class SplatMeshHIP {
     this.maxScreenSpaceSplatSize = options.maxScreenSpaceSplatSize || 1024;
     this.splatScale = 1.0;
     this.pointCloudModeEnabled = false;
-    this.handle = addon.meshCreate(this.ctx.handle, maxSplatCount, this.shDegree, this.halfPrecisionCovariancesOnGPU ? GS_MESH_COV_HALF : 0);
+    this.dynamicMode = !!options.dynamicMode;                               // per-scene transforms (SplatMesh dynamicMode)
+    this.enableOptionalEffects = !!options.enableOptionalEffects;           // per-scene opacity / visibility
+    this.sphericalHarmonics8Bit = !!options.sphericalHarmonics8Bit;         // .ksplat compression level 2 SH
+    this.orthographicMode = false;
+    this.fadeIn = false;
+    this.handle = addon.meshCreate(this.ctx.handle, maxSplatCount, this.shDegree,
+      (this.halfPrecisionCovariancesOnGPU ? GS_MESH_COV_HALF : 0) | (this.sphericalHarmonics8Bit ? GS_MESH_SH_U8 : 0));
     this.splatCount = 0;
     this.renderCount = 0;
     this.indexes = null;
     this.sortWorker = null;
     this.cam = { view: new Float32Array(16), proj: new Float32Array(16), camPos: new Float32Array(3), focal: new Float32Array(2),
       width: 0, height: 0, splatScale: 1, kernel2d: this.kernel2DSize, maxSplatPx: this.maxScreenSpaceSplatSize, invFocalAdj: 1,
-      shDegree: this.shDegree, flags: 0, tileRowBegin: 0, tileRowEnd: 0 };
+      shDegree: this.shDegree, flags: 0, tileRowBegin: 0, tileRowEnd: 0, orthoZoom: 1, fadeStartRadius: 0,
+      sceneCenter: new Float32Array(3), viewMatrix: new Float32Array(16) };
   }
   // fillSplatDataArrays output (SplatMesh.js:1853-1902): centers F32[3n], covariances F32[6n], colors U8[4n], sh Uint16 half bits
   build(centers, covariances, colors, sphericalHarmonics, start = 0) {
@@ -152,27 +160,44 @@ class SplatMeshHIP {
       cov16 = new Uint16Array(covariances.length);
       for (let i = 0; i < covariances.length; i++) cov16[i] = toHalfFloat(covariances[i]);
     }
-    addon.meshUpload(this.handle, start, n, centers, cov16 ? null : covariances, cov16, colors, this.shDegree ? sphericalHarmonics : null);
+    const sh16 = this.shDegree && !this.sphericalHarmonics8Bit ? sphericalHarmonics : null;
+    addon.meshUpload(this.handle, start, n, centers, cov16 ? null : covariances, cov16, colors, sh16);
+    if (this.shDegree && this.sphericalHarmonics8Bit) addon.meshUploadShU8(this.handle, start, n, sphericalHarmonics);   // Uint8Array
     this.splatCount = Math.max(this.splatCount, start + n);
+  }
+  // sceneIndexes texture (SplatMesh.js:881-897) and the per-scene uniforms of updateUniforms (:1263-1276):
+  // {sceneCount, transforms F32(16n), invCamPos F32(4n) = inverse(transform) * cameraPosition, opacity F32(n), visible U32(n),
+  //  sh8Min F32(n), sh8Max F32(n)}
+  setSceneIndexes(sceneIndexes, start = 0) { addon.meshUploadSceneIndexes(this.handle, start, sceneIndexes.length, sceneIndexes); }
+  setScenes(params) { addon.meshSetScenes(this.handle, params); this.hasScenes = true; }
+  // the fade-in of SplatMesh.updateVisibleRegionFadeDistance: visibleRegionFadeStartRadius + sceneCenter; null switches it off
+  setFadeIn(sceneCenter, fadeStartRadius) {
+    this.fadeIn = sceneCenter !== null && sceneCenter !== undefined;
+    if (this.fadeIn) { this.cam.sceneCenter.set(sceneCenter); this.cam.fadeStartRadius = fadeStartRadius; }
   }
   getSplatCount() { return this.splatCount; }
   updateRenderIndexes(globalIndexes, renderSplatCount) { this.indexes = globalIndexes; this.sortWorker = null; this.renderCount = renderSplatCount; }
   useSortWorkerResult(worker, renderSplatCount) { this.sortWorker = worker; this.indexes = null; this.renderCount = renderSplatCount; }
   updateUniforms(renderDimensions, cameraFocalLengthX, cameraFocalLengthY, orthographicMode, orthographicZoom, inverseFocalAdjustment) {
-    if (orthographicMode) throw new Error('orthographic cameras are not supported by the HIP engine yet');
+    this.orthographicMode = !!orthographicMode;
+    this.cam.orthoZoom = orthographicZoom === undefined ? 1 : orthographicZoom;
     this.cam.width = renderDimensions.x; this.cam.height = renderDimensions.y;
     this.cam.focal[0] = cameraFocalLengthX; this.cam.focal[1] = cameraFocalLengthY;
     this.cam.invFocalAdj = inverseFocalAdjustment;
   }
-  setCameraMatrices(modelViewElements, projectionElements, cameraPosition) {  // three's built-in uniforms
+  // three's built-in uniforms; viewMatrixElements (camera.matrixWorldInverse) is only needed in dynamic mode
+  setCameraMatrices(modelViewElements, projectionElements, cameraPosition, viewMatrixElements) {
     this.cam.view.set(modelViewElements); this.cam.proj.set(projectionElements); this.cam.camPos.set(cameraPosition);
+    this.cam.viewMatrix.set(viewMatrixElements || modelViewElements);
   }
   setSplatScale(s = 1) { this.splatScale = s; }
   setPointCloudModeEnabled(e) { this.pointCloudModeEnabled = !!e; }
   render(out) {
     const c = this.cam;
     c.splatScale = this.splatScale;
-    c.flags = (this.antialiased ? GS_CAM_ANTIALIASED : 0) | (this.pointCloudModeEnabled ? GS_CAM_POINT_CLOUD : 0);
+    c.flags = (this.antialiased ? GS_CAM_ANTIALIASED : 0) | (this.pointCloudModeEnabled ? GS_CAM_POINT_CLOUD : 0) |
+      (this.orthographicMode ? GS_CAM_ORTHOGRAPHIC : 0) | (this.fadeIn ? GS_CAM_FADE_IN : 0) |
+      (this.enableOptionalEffects ? GS_CAM_SCENE_EFFECTS : 0) | (this.dynamicMode ? GS_CAM_DYNAMIC : 0);
     const pixels = out || new Uint8Array(c.width * c.height * 4);
     const stats = addon.meshRender(this.handle, c, this.indexes, this.sortWorker ? this.sortWorker.handle : null, this.renderCount, pixels);
     return { pixels, stats };

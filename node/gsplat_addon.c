@@ -222,6 +222,14 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     NUM("flags", cam.flags, uint32_t)
     NUM("tileRowBegin", cam.tile_row_begin, uint32_t)
     NUM("tileRowEnd", cam.tile_row_end, uint32_t)
+    /* optional: the uniforms of the orthographic / fade-in / dynamic permutations (absent = zero) */
+    {
+        bool has = false;
+        if (napi_has_named_property(env, argv[1], "orthoZoom", &has) == napi_ok && has) { NUM("orthoZoom", cam.ortho_zoom, float) }
+        if (napi_has_named_property(env, argv[1], "fadeStartRadius", &has) == napi_ok && has) { NUM("fadeStartRadius", cam.fade_start_radius, float) }
+        if (napi_has_named_property(env, argv[1], "sceneCenter", &has) == napi_ok && has) { F32ARR("sceneCenter", cam.scene_center, 3) }
+        if (napi_has_named_property(env, argv[1], "viewMatrix", &has) == napi_ok && has) { F32ARR("viewMatrix", cam.view_matrix, 16) }
+    }
     void *idx, *out;
     size_t ib, ob;
     if (!get_bytes(env, argv[2], &idx, &ib) || !get_bytes(env, argv[5], &out, &ob)) { napi_throw_type_error(env, NULL, "meshRender: bad buffer"); return NULL; }
@@ -241,6 +249,8 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     set(env, r, "blendMs", stats.blend_ms);
     set(env, r, "visibleSplats", stats.visible_splats);
     set(env, r, "tileEntries", (double)stats.tile_entries);
+    set(env, r, "tiles16", (double)stats.tiles16);
+    set(env, r, "listBinPx", stats.list_bin_px);
     set(env, r, "overflowed", stats.overflowed);
     return r;
 }

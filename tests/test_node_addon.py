@@ -147,3 +147,54 @@ def test_tree_gather_through_node_matches_oracle(tmp_path):
     info = json.loads(res.stdout.strip().splitlines()[-1])
     assert info["renderCount"] == len(expect)
     np.testing.assert_array_equal(np.fromfile(opath, dtype=np.uint32), expect)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ortho,fade,effects", [(False, False, False), (True, False, False), (False, True, True)])
+def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho, fade, effects):
+    """SplatMeshHIP (node/gsplat.js -> N-API -> C ABI) and SplatMesh (ctypes -> C ABI) must draw the same pixels,
+    including the orthographic, fade-in and per-scene opacity / visibility uniforms."""
+    import helpers
+    import oracle
+    from gaussiansplats3d_amd import Context, SplatMesh, camera, util
+    _built()
+    scene = helpers.small_scene(2500, 1, seed=88)
+    n, W, H = scene.count, 320, 180
+    up, pos, look = camera.DEMO_POSES["garden"]
+    cam = camera.OrthographicCamera(W, H, pos, look, up, zoom=40.0) if ortho else camera.demo_camera("garden", W, H)
+    order = oracle.sort_indexes(np.arange(n, dtype=np.uint32), util.integer_centers(scene.centers), cam.sort_mvp())
+    sidx = (np.arange(n) % 3).astype(np.uint32)
+    opacity, visible = np.array([1.0, 0.5, 1.0], np.float32), np.array([1, 1, 0], np.uint32)
+    center = scene.centers.mean(axis=0).astype(np.float32)
+    radius = float(np.median(np.linalg.norm(scene.centers - center, axis=1)))
+    # the Python mirror
+    ctx = Context(0)
+    mesh = SplatMesh(ctx, n, 1, enable_optional_effects=effects)
+    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh, scene_indexes=sidx if effects else None)
+    if effects:
+        mesh.set_scenes(opacity=opacity.tolist(), visible=visible.tolist())
+    if fade:
+        mesh.set_fade_in(center, radius)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(order, n)
+    expect, _ = mesh.render()
+    mesh.dispose()
+    ctx.close()
+    # the same draw through Node
+    fx, fy = cam.focal()
+    flags = (1 if ortho else 0) | (2 if fade else 0) | (4 if effects else 0)
+    nsc = 3 if effects else 1
+    hdr = np.array([n, 1, W, H, flags, nsc, 0, 0], np.uint32)
+    parts = [hdr, scene.centers.astype(np.float32), scene.cov.astype(np.float32), scene.rgba, scene.sh.view(np.uint16), order, sidx,
+             np.asarray(cam.model_view(), np.float64).astype(np.float32), np.asarray(cam.projection, np.float64).astype(np.float32),
+             np.asarray(cam.position, np.float32), np.array([fx, fy], np.float32), np.array([getattr(cam, "zoom", 1.0)], np.float32),
+             center, np.array([radius], np.float32), opacity[:nsc], visible[:nsc]]
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as f:
+        for p in parts:
+            f.write(np.ascontiguousarray(p).tobytes())
+    res = subprocess.run(["node", "render_via_js.js", inp, outp], cwd=NODE_DIR, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(outp, dtype=np.uint8).reshape(H, W, 4)
+    assert got.any()
+    np.testing.assert_array_equal(got, expect)

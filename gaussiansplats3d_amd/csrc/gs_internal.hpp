@@ -219,6 +219,8 @@ struct RenderFrame {          // device-resident per-draw scalars
     uint32_t tiles16_lo;      // sum over visible splats of 16x16 tiles touched (the D of SURVEY.md section 8d)
     uint32_t tiles16_hi;
     uint32_t pad;
+    unsigned long long scanned;   // list entries the blend staged (read, rect-tested) before its pixels saturated
+    unsigned long long walked;    // (splat, 16-px tile) pairs the blend evaluated: one per wave per walked splat
 };
 
 struct ProjectParams {

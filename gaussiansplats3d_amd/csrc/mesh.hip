@@ -397,6 +397,8 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;
     m->last.list_bin_px = GS_TILE << m->drawn_list_shift;
+    m->last.entries_scanned = f.scanned;
+    m->last.splats_walked = f.walked;
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them
     if (m->last.visible_splats > 0)
         m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats ? GS_LIST_SHIFT_LARGE

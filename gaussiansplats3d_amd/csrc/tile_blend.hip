@@ -51,6 +51,42 @@ __device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32
     return (mx & (my & 1u ? 3u : 0u)) | ((mx & (my & 2u ? 3u : 0u)) << 2);
 }
 
+// Exact refinement of the rect's quadrant mask.  A splat reaches a pixel only where power = (a.d)^2 + (b.d)^2 <= 4*log2(e)
+// (d = pixel centre - splat centre), a convex quadratic d^T M d with M = a a^T + b b^T.  Its minimum over the box of a
+// quadrant's pixel centres is 0 when the centre lies inside, and otherwise lies on an edge facing the centre (moving from
+// the minimiser towards the centre lowers the form, so that direction must leave the box): at most two 1-D minimisations.
+// The bounding rect of a long diagonal ellipse covers many tiles the ellipse never enters; a wave that skips them saves
+// ~150 VALU cycles per splat, and a skipped splat would have been discarded at every pixel, so the frame does not change
+// (strips of a multi-GPU draw stay bit-exact).  The 1e-4 margin covers the fp32 rounding of the per-pixel evaluation.
+#ifndef GS_BLEND_EXACT
+#define GS_BLEND_EXACT 1
+#endif
+__device__ __forceinline__ uint32_t exact_quadrants(uint32_t qm, const uint4 lo, const uint4 hi, uint32_t bx, uint32_t by) {
+    const float cx = __uint_as_float(lo.x), cy = __uint_as_float(lo.y);
+    const float ax = __uint_as_float(lo.z), ay = __uint_as_float(lo.w), ex = __uint_as_float(hi.x), ey = __uint_as_float(hi.y);
+    const float m00 = ax * ax + ex * ex, m01 = ax * ay + ex * ey, m11 = ay * ay + ey * ey;
+    const float r00 = __builtin_amdgcn_rcpf(m00), r11 = __builtin_amdgcn_rcpf(m11);
+    const float limit = GS_POWER_CUT * 1.0001f + 1e-6f;
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) {
+        const float X0 = (float)(bx * GS_BIN + (q & 1u) * GS_TILE) + 0.5f - cx, X1 = X0 + (float)(GS_TILE - 1u);
+        const float Y0 = (float)(by * GS_BIN + (q >> 1) * GS_TILE) + 0.5f - cy, Y1 = Y0 + (float)(GS_TILE - 1u);
+        const float xb = X0 > 0.0f ? X0 : (X1 < 0.0f ? X1 : 0.0f);       // bound between the box and the centre, 0 = none
+        const float yb = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);
+        float qmin = 0.0f;
+        if (xb != 0.0f || yb != 0.0f) {
+            const float dy = fminf(fmaxf(-(m01 * xb) * r11, Y0), Y1);     // along the edge x = xb
+            const float q1 = xb != 0.0f ? (m00 * xb) * xb + ((2.0f * m01) * xb + m11 * dy) * dy : GS_HUGE;
+            const float dx = fminf(fmaxf(-(m01 * yb) * r00, X0), X1);     // along the edge y = yb
+            const float q2 = yb != 0.0f ? (m11 * yb) * yb + ((2.0f * m01) * yb + m00 * dx) * dx : GS_HUGE;
+            qmin = fminf(q1, q2);
+        }
+        if (!(qmin > limit)) out |= 1u << q;                              // NaN keeps the quadrant
+    }
+    return qm & out;
+}
+
 // expands one record
 __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi) {
     LdsSplat s;
@@ -73,11 +109,15 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 }
 #endif
 
-__global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
+#ifndef BLEND_OCC
+#define BLEND_OCC 8
+#endif
+__global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
-                                                              uint32_t list_row_begin, uint32_t list_shift) {
+                                                              uint32_t list_row_begin, uint32_t list_shift,
+                                                              RenderFrame* __restrict__ frame) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
@@ -92,8 +132,9 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
 
 #ifdef GS_BLEND_PROFILE
     const unsigned long long t_start = wall_clock64();
-    uint32_t walked = 0, batches = 0;
+    uint32_t batches = 0;
 #endif
+    uint32_t walked = 0, scanned = 0;                  // statistics: wave-uniform, kept in scalar registers
     // the entry list of the list bin this 32-px bin lies in
     const uint32_t per_list = list_shift - GS_BIN_SHIFT;
     const uint2 range = ranges[((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list)];
@@ -128,8 +169,10 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
 #ifdef GS_BLEND_PROFILE
         batches++;
 #endif
+        scanned += cnt;
         __syncthreads();                               // previous batch fully consumed, s_live read by everyone
-        const uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
+        uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
+        if (GS_BLEND_EXACT && qm) qm = exact_quadrants(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi);
         if (tid == 0) s_live = 0u;
@@ -149,9 +192,7 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
                 while (m) {
                     const uint32_t j = g0 + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1ull;
-#ifdef GS_BLEND_PROFILE
                     walked++;
-#endif
                     const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].cx);
                     const float4 q1 = *reinterpret_cast<const float4*>(&s_batch[j].bx);
                     const float4 q2 = *reinterpret_cast<const float4*>(&s_batch[j].r);
@@ -212,6 +253,10 @@ __global__ __launch_bounds__(BLEND_THREADS, 8) void k_tile_blend(const uint2* __
     __syncthreads();
     if (bin < 8192u && tid == 0u) g_blend_prof[8 * bin + 1] = wall_clock64();
 #endif
+    if (lane == 0u) {
+        if (walked) atomicAdd(&frame->walked, (unsigned long long)walked);
+        if (wave == 0u && scanned) atomicAdd(&frame->scanned, (unsigned long long)scanned);
+    }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
@@ -232,7 +277,8 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                        m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
-                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift);
+                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
+                       m->frame.as<RenderFrame>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

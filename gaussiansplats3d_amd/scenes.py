@@ -100,6 +100,10 @@ CONFIGS = {
     "C4": dict(n=16_000_000, sh=0, pose="synthetic16m", width=3840, height=2160,
                label="16M uniform-random Gaussians, SH0, 3840x2160"),
     "C5": dict(n=5_800_000, sh=2, pose="garden", width=7680, height=4320, label="garden.ply stand-in, SH2, 7680x4320"),
+    # not a BASELINE.json config: the C3 geometry with translucent splats (opacity ~ sigmoid(N(-2, 1)) instead of
+    # sigmoid(N(0.5, 4))), so that pixels do not saturate after a few splats and the blend really walks its lists
+    "C3T": dict(n=5_800_000, sh=2, pose="garden", width=1920, height=1080,
+                label="garden.ply stand-in with translucent splats, SH2, 1920x1080"),
 }
 
 
@@ -134,8 +138,12 @@ def make_config_scene(cfg, n_override=None):
             return real
     c = CONFIGS[cfg]
     n = int(n_override) if n_override else c["n"]
-    num = int(cfg[1:])
-    seed = SEED_BASE + (3 if cfg == "C5" else num)     # C5 is the C3 scene at 8K
+    num = 3 if cfg in ("C5", "C3T") else int(cfg[1:])  # C5 is the C3 scene at 8K, C3T the C3 scene made translucent
+    seed = SEED_BASE + num
     if cfg == "C4":
         return uniform_box(n, seed, name=cfg)
-    return scene_like(n, c["sh"], seed, name=cfg)
+    scene = scene_like(n, c["sh"], seed, name=cfg)
+    if cfg == "C3T":
+        rng = np.random.default_rng(seed + 1000)
+        scene.rgba[:, 3] = np.clip(np.round(255.0 / (1.0 + np.exp(-rng.normal(-2.0, 1.0, size=n)))), 1, 255).astype(np.uint8)
+    return scene

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 1
+#define GS_ABI_VERSION 2
 
 /* status codes (negative = error, positive = warning, result still defined) */
 #define GS_OK 0
@@ -285,6 +285,9 @@ typedef struct gs_render_stats {
     uint32_t list_bin_px;     /* edge of a list bin of this draw (32 or 128): the unit of the entry lists and of
                                  gs_mesh_debug_read(what = 2); chosen per mesh from the previous measured draw    */
     uint32_t pad;
+    uint64_t entries_scanned; /* list entries the blend read before its pixels saturated (<= tile_entries per 32-px
+                                 bin of a list)                                                                  */
+    uint64_t splats_walked;   /* (splat, 16x16-px tile) pairs the blend evaluated                                */
 } gs_render_stats;
 
 /* updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)

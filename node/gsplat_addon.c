@@ -252,6 +252,8 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     set(env, r, "tiles16", (double)stats.tiles16);
     set(env, r, "listBinPx", stats.list_bin_px);
     set(env, r, "overflowed", stats.overflowed);
+    set(env, r, "entriesScanned", (double)stats.entries_scanned);
+    set(env, r, "splatsWalked", (double)stats.splats_walked);
     return r;
 }
 

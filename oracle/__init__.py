@@ -331,3 +331,39 @@ def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-
     q = np.empty((H, W, 4), dtype=np.uint8)
     _lib().gro_quantize(_p(fb, _f32p), C.c_uint64(fb.size), _p(q, _u8p))
     return fb, q, amb, int(frags)
+
+
+def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop8=False, amb_eps=1e-3, scene_indexes=None):
+    """Crops of the full frame: `windows` = [(x0, y0, w, h)] in GL window coordinates (row 0 = bottom).  Every splat of
+    `order` is projected once and composited into the windows it reaches; window k's pixels equal pixels
+    [y0:y0+h, x0:x0+w] of :func:`render`.  `sh` may be float32 [n, 9|24] or IEEE-half bits / float16 (kept as stored:
+    the full-size scenes need no fp32 copy).  Returns [(fb float32[h,w,4], ambig uint8[h,w])] and the fragment count."""
+    centers = np.ascontiguousarray(centers, dtype=np.float32).reshape(-1, 3)
+    cov = np.ascontiguousarray(cov, dtype=np.float32).reshape(-1, 6)
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8).reshape(-1, 4)
+    sh_f16 = 0
+    if sh is not None:
+        sh = np.ascontiguousarray(sh)
+        if sh.dtype in (np.float16, np.uint16):
+            sh = sh.view(np.uint16)
+            sh_f16 = 1
+        else:
+            sh = np.ascontiguousarray(sh, dtype=np.float32)
+        sh = sh.reshape(centers.shape[0], -1)
+    _keep = _set_scene_idx(scene_indexes)  # noqa: F841
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+    count = centers.shape[0] if order is None else order.shape[0]
+    wins = np.ascontiguousarray(np.asarray(windows, dtype=np.int32).reshape(-1, 4))
+    n = wins.shape[0]
+    fbs = [np.zeros((int(h), int(w), 4), dtype=np.float32) for _, _, w, h in wins]
+    ambs = [np.zeros((int(h), int(w)), dtype=np.uint8) for _, _, w, h in wins]
+    fb_ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fbs])
+    amb_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ambs])
+    lib = _lib()
+    lib.gro_render_windows.restype = C.c_uint64
+    frags = lib.gro_render_windows(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p),
+                                   sh.ctypes.data_as(C.c_void_p) if sh is not None else None, C.c_int(sh_f16),
+                                   _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)), C.c_float(amb_eps),
+                                   C.c_uint32(n), wins.ctypes.data_as(C.POINTER(C.c_int32)), fb_ptrs, amb_ptrs)
+    return list(zip(fbs, ambs)), int(frags)

@@ -235,6 +235,48 @@ void gro_project(const gro_camera* cam, const float* centers, const float* cov, 
     }
 }
 
+/* Composites one projected splat over the window [wx0, wx0+ww) x [wy0, wy0+wh) of the W x H frame; fb / ambig are the
+ * window's own [wh][ww] arrays. */
+static uint64_t blend_one(const gro_splat2d* s, int W, int H, int wx0, int wy0, int ww, int wh, int rop8, float amb_eps,
+                          float* fb, uint8_t* ambig) {
+    uint64_t frags = 0;
+    /* bounding box of the quad centre +- b1 +- b2 */
+    const float ext_x = fabsf(s->b1x) + fabsf(s->b2x), ext_y = fabsf(s->b1y) + fabsf(s->b2y);
+    float fx0 = floorf(s->cx - ext_x - 1.0f), fx1 = ceilf(s->cx + ext_x + 1.0f);
+    float fy0 = floorf(s->cy - ext_y - 1.0f), fy1 = ceilf(s->cy + ext_y + 1.0f);
+    const int xe = (wx0 + ww < W ? wx0 + ww : W) - 1, ye = (wy0 + wh < H ? wy0 + wh : H) - 1;
+    if (fx0 < (float)wx0) fx0 = (float)wx0;
+    if (fy0 < (float)wy0) fy0 = (float)wy0;
+    if (fx1 > (float)xe) fx1 = (float)xe;
+    if (fy1 > (float)ye) fy1 = (float)ye;
+    if (!(fx0 <= fx1) || !(fy0 <= fy1)) return 0;
+    const float n1 = s->b1x * s->b1x + s->b1y * s->b1y, n2 = s->b2x * s->b2x + s->b2y * s->b2y;
+    for (int py = (int)fy0; py <= (int)fy1; py++) {
+        for (int px = (int)fx0; px <= (int)fx1; px++) {
+            const float dx = ((float)px + 0.5f) - s->cx, dy = ((float)py + 0.5f) - s->cy;
+            /* quad-local coordinates q in [-1,1]^2 (b1 is orthogonal to b2) */
+            const float qx = (dx * s->b1x + dy * s->b1y) / n1;
+            const float qy = (dx * s->b2x + dy * s->b2y) / n2;
+            /* vPosition = q*sqrt8 (SplatMaterial3D.js:213); A = dot(vPosition,vPosition) (:237) */
+            const float A = 8.0f * (qx * qx + qy * qy);
+            const size_t at = (size_t)(py - wy0) * ww + (px - wx0);
+            if (ambig && fabsf(A - 8.0f) <= amb_eps) ambig[at] = 1;
+            if (!(A <= 8.0f)) continue;                    /* :242 `if (A > 8.0) discard` */
+            const float al = expf(-0.5f * A) * s->a;       /* :249 */
+            float* dst = fb + 4 * at;
+            const float om = 1.0f - al;
+            dst[0] = al * s->r + om * dst[0];
+            dst[1] = al * s->g + om * dst[1];
+            dst[2] = al * s->b + om * dst[2];
+            dst[3] = al + om * dst[3];
+            if (rop8)
+                for (int ch = 0; ch < 4; ch++) dst[ch] = floorf(clamp01(dst[ch]) * 255.0f + 0.5f) * (1.0f / 255.0f);
+            frags++;
+        }
+    }
+    return frags;
+}
+
 /*
  * Full frame.  fb = float RGBA [H][W][4], row 0 = bottom, must be zeroed by the caller (clear colour
  * (0,0,0,0), Viewer.js:358-359).  rop8 != 0 emulates the RGBA8 render target by rounding dst to unorm8
@@ -255,38 +297,59 @@ uint64_t gro_render(const gro_camera* cam, const float* centers, const float* co
         project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL,
                     g_scene_idx ? g_scene_idx[g] : 0u, &s);
         if (!s.visible) continue;
-        /* bounding box of the quad centre +- b1 +- b2 */
-        const float ext_x = fabsf(s.b1x) + fabsf(s.b2x), ext_y = fabsf(s.b1y) + fabsf(s.b2y);
-        float fx0 = floorf(s.cx - ext_x - 1.0f), fx1 = ceilf(s.cx + ext_x + 1.0f);
-        float fy0 = floorf(s.cy - ext_y - 1.0f), fy1 = ceilf(s.cy + ext_y + 1.0f);
-        if (fx0 < 0.0f) fx0 = 0.0f;
-        if (fy0 < 0.0f) fy0 = 0.0f;
-        if (fx1 > (float)(W - 1)) fx1 = (float)(W - 1);
-        if (fy1 > (float)(H - 1)) fy1 = (float)(H - 1);
-        if (!(fx0 <= fx1) || !(fy0 <= fy1)) continue;
-        const float n1 = s.b1x * s.b1x + s.b1y * s.b1y, n2 = s.b2x * s.b2x + s.b2y * s.b2y;
-        for (int py = (int)fy0; py <= (int)fy1; py++) {
-            for (int px = (int)fx0; px <= (int)fx1; px++) {
-                const float dx = ((float)px + 0.5f) - s.cx, dy = ((float)py + 0.5f) - s.cy;
-                /* quad-local coordinates q in [-1,1]^2 (b1 is orthogonal to b2) */
-                const float qx = (dx * s.b1x + dy * s.b1y) / n1;
-                const float qy = (dx * s.b2x + dy * s.b2y) / n2;
-                /* vPosition = q*sqrt8 (SplatMaterial3D.js:213); A = dot(vPosition,vPosition) (:237) */
-                const float A = 8.0f * (qx * qx + qy * qy);
-                if (ambig && fabsf(A - 8.0f) <= amb_eps) ambig[(size_t)py * W + px] = 1;
-                if (!(A <= 8.0f)) continue;                    /* :242 `if (A > 8.0) discard` */
-                const float al = expf(-0.5f * A) * s.a;        /* :249 */
-                float* dst = fb + 4 * ((size_t)py * W + px);
-                const float om = 1.0f - al;
-                dst[0] = al * s.r + om * dst[0];
-                dst[1] = al * s.g + om * dst[1];
-                dst[2] = al * s.b + om * dst[2];
-                dst[3] = al + om * dst[3];
-                if (rop8)
-                    for (int ch = 0; ch < 4; ch++) dst[ch] = floorf(clamp01(dst[ch]) * 255.0f + 0.5f) * (1.0f / 255.0f);
-                frags++;
-            }
+        frags += blend_one(&s, W, H, 0, 0, W, H, rop8, amb_eps, fb, ambig);
+    }
+    return frags;
+}
+
+/*
+ * The same composite restricted to `nwin` windows of the frame (wins = {x0, y0, w, h} per window, GL window
+ * coordinates; fbs[k] / ambigs[k] = that window's zeroed [h][w][4] floats / [h][w] bytes): every splat of the list is
+ * projected once and composited into the windows it reaches, so crops of a full-size frame (5.8 M splats at 1080p ... 8K)
+ * cost one projection pass instead of a full rasterisation.  A window's pixels equal the same pixels of gro_render.
+ * sh_f16 != 0: `sh` holds IEEE half bits (uint16), widened here - the full-size scenes keep their SH as stored.
+ */
+static float half_bits_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u;
+    uint32_t bits;
+    if (e == 0) {
+        if (m == 0) bits = sign;
+        else {
+            int sh_ = 0;
+            uint32_t mm = m;
+            while (!(mm & 1024u)) { mm <<= 1; sh_++; }
+            bits = sign | ((uint32_t)(113 - sh_) << 23) | ((mm & 1023u) << 13);
         }
+    } else if (e == 31) bits = sign | 0x7F800000u | (m << 13);
+    else bits = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+uint64_t gro_render_windows(const gro_camera* cam, const float* centers, const float* cov, const uint8_t* rgba,
+                            const void* sh, int sh_f16, const uint32_t* order, uint32_t count, int rop8, float amb_eps,
+                            uint32_t nwin, const int32_t* wins, float** fbs, uint8_t** ambigs) {
+    const int W = (int)cam->viewport[0], H = (int)cam->viewport[1];
+    const int shn = cam->sh_stored == 0 ? 0 : (cam->sh_stored == 1 ? 9 : 24);
+    uint64_t frags = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const size_t g = order ? order[i] : i;
+        gro_splat2d s;
+        float shf[24];
+        const float* shp = NULL;
+        if (sh && shn) {
+            if (sh_f16) {
+                const uint16_t* h = (const uint16_t*)sh + (size_t)shn * g;
+                for (int k = 0; k < shn; k++) shf[k] = half_bits_to_float(h[k]);
+                shp = shf;
+            } else shp = (const float*)sh + (size_t)shn * g;
+        }
+        project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, shp, g_scene_idx ? g_scene_idx[g] : 0u, &s);
+        if (!s.visible) continue;
+        for (uint32_t k = 0; k < nwin; k++)
+            frags += blend_one(&s, W, H, wins[4 * k], wins[4 * k + 1], wins[4 * k + 2], wins[4 * k + 3], rop8, amb_eps,
+                               fbs[k], ambigs ? ambigs[k] : NULL);
     }
     return frags;
 }

@@ -1,24 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — headline benchmark: Msplats/s sorted + rasterized (BASELINE.json metric).
+"""bench.py — headline benchmark: Msplats/s sorted + rasterized (BASELINE.json metric, SURVEY.md §8d).
 
 One "step" = one frame of the hot path on the garden.ply stand-in (configs[2]: 5.8 M splats, SH-2, 1920x1080):
 depth-key + device-wide stable radix sort of ALL splats (cull off, R = N, the reference's own no-tree path,
-src/Viewer.js:2061-2073), then project -> bin -> entry sort -> blend into an RGBA8 framebuffer.  Inputs are
-resident in HBM before the timed region.  With --gpus N every rank sorts + projects the replicated scene and
-rasterises a strip of tile rows; strips are gathered to rank 0 over RCCL inside the timed region (strong scaling).
+src/Viewer.js:2061-2073), then project -> bin -> entry sort -> blend into an RGBA8 framebuffer.  Inputs are resident in
+HBM before the timed region.
 
-Like the reference (sort in a Web Worker, draw on the main thread) the sorter owns a HIP stream of its own: the
-sort of frame k+1 may overlap the tail of frame k's draw.  Every frame still waits for ITS OWN sort before it
-bins (use_sorter_result joins the streams), so `value` is whole frames per second times R; `frame_latency_ms`
-is one isolated frame (sort -> draw, synchronised on both sides).
+`value` is the §8d metric: R / (t_sort + t_raster) with the whole frame on ONE stream (a single-stream context:
+sort -> draw, nothing overlaps).  The engine's default shape — the sort on a stream of its own, like the reference's Web
+Worker, so that the sort of frame k+1 overlaps the tail of frame k's draw — is reported next to it as `pipelined`.
 
-Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline` objects.
+--gpus N: every rank holds the scene, rasterises a strip of tile rows (and sorts only what can reach it); strips are
+gathered to rank 0 over RCCL inside the timed region (strong scaling).  Launched by torch.distributed.run, or — when
+WORLD_SIZE is not set — bench.py starts the N ranks itself.
+
+--config C1: configs[0], the reference's own CPU-runnable case: the bonsai stand-in through createSortWorker under Node,
+the reference's WASM sorter on the host beside the HIP sorter, outputs compared bit for bit.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline`, `blend`, `frame` and `cpu_baseline` objects.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,7 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy ceiling)
+FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector peak (same guide)
 SH_BYTES = {0: 0, 1: 18, 2: 48}
+# fp32 operations the blend spends per (pixel, walked splat): dy, two projected offsets (2 fma), power (mul + fma), exp2,
+# discard mask (fma), alpha (2 mul), weight, three colour fma, transmittance update (sub, fma, mul); fma = 2
+BLEND_FLOPS_PER_PIXEL_SPLAT = 24
 
 
 def frame_algorithmic_bytes(R, Rs, D16, P, sh_degree, cov_half, precision=16):
@@ -47,26 +59,54 @@ def project_algorithmic_bytes(N, visible, sh_degree, cov_half):
     return 12 * N + per_visible * visible + N // 8
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*pmc_traffic.json,
-    written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
+def _newest_profile(pattern, config):
+    """Newest committed profiles/<pattern> summary that was recorded on `config` (files carry a "config" key; older
+    files without one were all recorded on C3)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("config", "C3") == config:
+            return d, os.path.basename(path)
+    return None, None
+
+
+def pmc_traffic(kernel, config="C3"):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of THIS config
+    (profiles/*pmc_traffic.json, written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes);
+    (None, None) when no summary of this config is committed."""
+    d, src = _newest_profile("*pmc_traffic.json", config)
+    if d is None:
         return None, None
-    try:
-        d = json.load(open(files[-1]))
-        k = d["kernels"].get(kernel)
-        if k is None:                                           # template instances: "k_project<false>"
-            k = next((v for name, v in sorted(d["kernels"].items()) if name.split("<")[0] == kernel), None)
-        return (int(k["hbm_bytes_per_launch"]) if k else None), os.path.basename(files[-1])
-    except Exception:
+    k = d["kernels"].get(kernel)
+    if k is None:                                           # template instances: "k_project<false>"
+        k = next((v for name, v in sorted(d["kernels"].items()) if name.split("<")[0] == kernel), None)
+    return (int(k["hbm_bytes_per_launch"]) if k else None), src
+
+
+def pmc_frame_traffic(config="C3"):
+    """Counter-measured HBM bytes of one whole frame (sum over the frame's kernels, tools/pmc_traffic.py), or None."""
+    d, src = _newest_profile("*pmc_traffic.json", config)
+    if d is None or "frame_hbm_bytes" not in d:
         return None, None
+    return int(d["frame_hbm_bytes"]), src
+
+
+def pmc_valu(kernel, config="C3"):
+    """VALU-busy fraction of `kernel` from the newest committed SQ counter pass (profiles/*pmc_valu.json)."""
+    d, src = _newest_profile("*pmc_valu.json", config)
+    if d is None:
+        return None, None
+    k = next((v for name, v in sorted(d["kernels"].items()) if name.split("<")[0] == kernel), None)
+    return k, src
 
 
 def cpu_baseline(scene, mvp, budget_s):
-    """Time the reference's own sorter (oracle/_ref, compiled from the reference's sorter_no_simd.cpp) on this
-    host: 1 thread, the faithful configuration (one Web Worker).  The reference has no CPU rasteriser, so the
-    baseline covers the sort half of the frame only."""
+    """The reference's own sorter timed on this host, 1 thread (one Web Worker in the reference): (1) its prebuilt
+    sorter_no_simd_non_shared.wasm under Node, timed as src/worker/SortWorker.js:53-60 runs it, and (2)
+    sorter_no_simd.cpp compiled natively -O2 (oracle/_ref).  The reference has no CPU rasteriser, so the baseline covers
+    the sort half of the frame only."""
     import oracle
     from gaussiansplats3d_amd import util
     n = scene.count
@@ -82,40 +122,170 @@ def cpu_baseline(scene, mvp, budget_s):
         t_total += time.perf_counter() - t0
         reps += 1
     per = t_total / reps
-    return {"value": round(n / per / 1e6, 2), "unit": "Msplats/s (sort only)", "cores": 1, "kind": kind,
-            "ms_per_sort": round(per * 1e3, 2), "host_cpus": os.cpu_count(),
-            "sample": f"{reps} full sorts ({t_total:.1f} s) of the same {n} splats / same MVP, precision 16, integer "
-                      "static path, sorter_no_simd.cpp built -O2; the reference has no CPU rasteriser, so raster has "
-                      "no CPU leg"}
+    out = {"value": round(n / per / 1e6, 2), "unit": "Msplats/s (sort only)", "cores": 1, "kind": kind,
+           "ms_per_sort": round(per * 1e3, 2), "host_cpus": os.cpu_count(),
+           "sample": f"{reps} full sorts ({t_total:.1f} s) of the same {n} splats / same MVP, precision 16, integer "
+                     "static path, sorter_no_simd.cpp built -O2; the reference has no CPU rasteriser, so raster has "
+                     "no CPU leg"}
+    wasm = oracle.wasm_sort_timing(idx, ci, mvp, repeat=max(3, min(40, int(budget_s / max(per * 1.6, 1e-3)))))
+    if wasm is not None:
+        out["wasm"] = {"value": round(n / (wasm["ms_mean"] * 1e-3) / 1e6, 2), "unit": "Msplats/s (sort only)",
+                       "ms_per_sort": round(wasm["ms_mean"], 2), "ms_per_sort_min": round(wasm["ms_min"], 2), "cores": 1,
+                       "kind": "reference", "node": wasm["node"],
+                       "sample": f"{wasm['repeat']} sorts of the same input by the reference's prebuilt "
+                                 "sorter_no_simd_non_shared.wasm under Node, frequencies zeroed and process.hrtime "
+                                 "around exports.sortIndexes as src/worker/SortWorker.js:53-60 does"}
+    return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------------
+# launching
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C3T"])
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-cull", action="store_true", help="skip the secondary cull-on measurement (octree build + gather)")
-    args = ap.parse_args()
+    ap.add_argument("--no-cull", action="store_true",
+                    help="skip the secondary columns (orbit, octree cull, fused frustum cull, translucent scene)")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="probe + warm-up + the timed frames and nothing else (profiler runs: every frame is a headline frame)")
+    return ap.parse_args()
+
+
+class Rig:
+    """Scene resident on one context: sort worker + mesh + the frame function."""
+
+    def __init__(self, ctx, scene, cam, device, torch):
+        from gaussiansplats3d_amd import SplatMesh, create_sort_worker, util
+        self.ctx, self.scene, self.cam, self.torch = ctx, scene, cam, torch
+        self.N = scene.count
+        self.mvp = cam.sort_mvp()
+        self.worker = create_sort_worker(ctx, self.N)             # integerBasedSort, precision 16: Viewer defaults
+        self.worker.post_message({"centers": util.integer_centers(scene.centers),
+                                  "range": {"from": 0, "to": self.N - 1, "count": self.N}})
+        self.mesh = SplatMesh(ctx, self.N, scene.sh_degree, scene.cov_half)
+        self.mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+        self.mesh.set_camera(cam)
+        self.frames = 0
+
+    def probe(self, out_ptr):
+        """Untimed full-frame draws: grow the entry buffer if needed, settle the list-bin size, return the statistics."""
+        st = None
+        for _ in range(2):
+            self.worker.sort_on_device(self.mvp, self.N)
+            self.mesh.use_sorter_result(self.worker, self.N)
+            _, st = self.mesh.render(out_device_ptr=out_ptr, to_host=False, want_stats=True)
+            self.frames += 1
+        return st
+
+    def frame(self, out_ptr, tile_rows=None):
+        self.worker.sort_on_device(self.mvp, self.N)
+        self.mesh.render(tile_rows=tile_rows, out_device_ptr=out_ptr, to_host=False, want_stats=False)
+        self.frames += 1
+
+    def timed(self, steps, out_ptr, tile_rows=None, after=None):
+        torch = self.torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.frame(out_ptr, tile_rows)
+            if after:
+                after()
+        enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, enq
+
+    def close(self):
+        self.worker.terminate()
+        self.mesh.dispose()
+
+
+def bench_c1(args):
+    """configs[0]: bonsai stand-in (1.2 M splats, SH-0), sort only: the reference's WASM sorter on the host and the HIP
+    sorter behind the same createSortWorker message protocol, both driven from Node, outputs compared bit for bit."""
+    from gaussiansplats3d_amd import camera, scenes, util
+    cfg = scenes.CONFIGS["C1"]
+    scene = scenes.make_config_scene("C1", args.splats or None)
+    cam = camera.demo_camera(cfg["pose"], cfg["width"], cfg["height"])
+    n = scene.count
+    ci = util.integer_centers(scene.centers)
+    mvp = np.asarray(cam.sort_mvp(), dtype=np.float64)
+    import oracle
+    wasm = oracle.wasm_path()
+    with tempfile.TemporaryDirectory() as d:
+        ci.tofile(os.path.join(d, "centers.bin"))
+        mvp.tofile(os.path.join(d, "mvp.bin"))
+        cmd = ["node", os.path.join(ROOT, "node", "bench_c1.js"), os.path.join(d, "centers.bin"), os.path.join(d, "mvp.bin"),
+               str(n), str(args.steps), str(args.warmup), wasm or "-"]
+        line = subprocess.check_output(cmd, cwd=os.path.join(ROOT, "node"), text=True).strip().splitlines()[-1]
+    r = json.loads(line)
+    out = {"metric": "Msplats/s sorted (configs[0]: bonsai stand-in, integer sort through createSortWorker)",
+           "value": round(n / (r["hip_ms"] * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(r["hip_ms"], 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "int32 keys", "data": "synthetic" if scene.name == "C1" else f"file:{scene.name}",
+           "config": {"workload": f"C1: {cfg['label']}, sort only (the reference's CPU-runnable configuration)",
+                      "splats": n, "sort_precision_bits": 16, "path": "node/gsplat.js createSortWorker -> N-API -> gs_sorter_sort",
+                      "includes": "PCIe both ways: the sorted indexes return to a JS Uint32Array like the reference's sortDone"},
+           "device_sort_ms": round(r["hip_device_ms"], 4),
+           "cpu_baseline": None if r.get("wasm_ms") is None else
+           {"value": round(n / (r["wasm_ms"] * 1e-3) / 1e6, 2), "unit": "Msplats/s (sort only)", "cores": 1, "kind": "reference",
+            "ms_per_sort": round(r["wasm_ms"], 3), "host_cpus": os.cpu_count(),
+            "sample": f"{r['wasm_reps']} sorts by the reference's sorter_no_simd_non_shared.wasm in the same Node process"},
+           "identical_to_reference": r.get("identical")}
+    print(json.dumps(out), flush=True)
+    return 0 if r.get("identical") in (True, None) else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if args.config == "C1":
+        sys.exit(bench_c1(args))
 
     import torch
     import torch.distributed as dist
 
-    from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util
+    from gaussiansplats3d_amd import Context, camera, scenes
     from gaussiansplats3d_amd import dist as gdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    # GS_BENCH_BACKEND=gloo + fewer GPUs than ranks: dry run of the N > 1 path on a 1-GPU box (ranks share the device)
-    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: WORLD_SIZE={world} overrides --gpus {args.gpus}", file=sys.stderr)
+    # fewer GPUs than ranks (a 1-GPU box): dry run of the N > 1 path, the ranks share the device and talk over gloo
+    n_dev = max(torch.cuda.device_count(), 1)
+    dry_run = world > n_dev
+    backend = os.environ.get("GS_BENCH_BACKEND", "gloo" if dry_run else "nccl")
+    local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -130,89 +300,86 @@ def main():
     t_gen = time.perf_counter()
     scene = scenes.make_config_scene(args.config, args.splats or None)
     cam = camera.demo_camera(cfg["pose"], W, H)
-    mvp = cam.sort_mvp()
     N = scene.count
     t_gen = time.perf_counter() - t_gen
+    extras = world == 1 and not args.no_cull and not args.only_headline
 
     stream = torch.cuda.Stream(device=device)
-    ctx = Context(local_rank, stream.cuda_stream)
-    worker = create_sort_worker(ctx, N)                       # integerBasedSort, precision 16: Viewer defaults
-    worker.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
-    mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half)
-    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
-    mesh.set_camera(cam)
-
+    ctx = Context(local_rank, stream.cuda_stream, single_stream=True)     # §8d: the whole frame on one stream
+    rig = Rig(ctx, scene, cam, device, torch)
+    worker, mesh, mvp = rig.worker, rig.mesh, rig.mvp
     rows_total = (H + 15) // 16
     with torch.cuda.stream(stream):
         full = torch.zeros((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None
-
-        # probe frame (untimed): full-frame draw gives per-tile-row entry counts to balance the strips, and grows
-        # the entry buffer if the first guess was too small
-        worker.sort_on_device(mvp, N)
-        mesh.use_sorter_result(worker, N)
         probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
-        _, st_probe = mesh.render(out_device_ptr=probe.data_ptr(), to_host=False, want_stats=True)
+        st_probe = rig.probe(probe.data_ptr())
         row_cost = mesh.tile_row_costs()
         strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
         my = strips[rank]
         y0, y1 = gdist.strip_pixel_rows(my, H)
         strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
         del probe
-
-        def frame():
-            worker.sort_on_device(mvp, N)
-            mesh.render(tile_rows=my if world > 1 else None, out_device_ptr=strip.data_ptr(), to_host=False,
-                        want_stats=False)
-            if world > 1:
-                gdist.gather_strips(strip, strips, full, rank, world, dist)
+        tile_rows = my if world > 1 else None
+        gather = (lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)) if world > 1 else None
 
         for _ in range(args.warmup):
-            frame()
+            rig.frame(strip.data_ptr(), tile_rows)
+            if gather:
+                gather()
         stream.synchronize()
         torch.cuda.synchronize()
         mesh.kernel_time(0, reset=True)                       # start the per-launch k_project clock
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            frame()
-        t_enqueued = time.perf_counter() - t0                # host time to enqueue the K frames (no device wait in it)
-        stream.synchronize()
-        torch.cuda.synchronize()
+        elapsed, t_enqueued = rig.timed(args.steps, strip.data_ptr(), tile_rows, gather)
         if world > 1:
             dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        if os.environ.get("GS_BENCH_DUMP") and rank == 0:      # tests: the frame the timed steps left on rank 0
+            np.save(os.environ["GS_BENCH_DUMP"], full.cpu().numpy())
         proj_ms_sum, proj_launches = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
         st_timed = mesh.last_stats()                          # the list-bin size the timed frames used, and their entries
         list_px_timed, D32 = int(st_timed.list_bin_px), int(st_timed.tile_entries)
+        frames_headline = rig.frames
 
-        # per-stage device times (HIP events recorded by the library), one synchronised frame at a time; also the
-        # latency of an isolated frame
-        stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
-        latency = []
-        for _ in range(min(args.steps, 10)):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            worker.sort_on_device(mvp, N)
-            mesh.render(tile_rows=my if world > 1 else None, out_device_ptr=strip.data_ptr(), to_host=False,
-                        want_stats=False)
-            torch.cuda.synchronize()
-            latency.append((time.perf_counter() - t1) * 1e3)
-            rs = mesh.last_stats()
-            ss, _ = worker.last_stats()
-            stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
-            stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
-        stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
+        stage_ms, latency, orbit, cull, fused, translucent, pipelined = {}, [], None, None, None, None, None
+        if not args.only_headline:
+            # per-stage device times (HIP events recorded by the library), one synchronised frame at a time
+            stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
+            for _ in range(min(args.steps, 10)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rig.frame(strip.data_ptr(), tile_rows)
+                torch.cuda.synchronize()
+                latency.append((time.perf_counter() - t1) * 1e3)
+                rs = mesh.last_stats()
+                ss, _ = worker.last_stats()
+                stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
+                stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
+            stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
 
-        # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the
-        # headline stays the fixed demo pose so rounds remain comparable)
-        orbit = None
-        if world == 1 and not args.no_cull:
+        if world == 1 and not args.only_headline:
+            # the engine's default shape: sorter and vertex stage on streams of their own (the reference sorts in a Web
+            # Worker concurrently with drawing); every frame still waits for ITS OWN sort before it bins
+            ctx2 = Context(local_rank, stream.cuda_stream, single_stream=False)
+            rig2 = Rig(ctx2, scene, cam, device, torch)
+            rig2.probe(strip.data_ptr())
+            for _ in range(args.warmup):
+                rig2.frame(strip.data_ptr())
+            p_el, p_enq = rig2.timed(args.steps, strip.data_ptr())
+            pipelined = {"ms_per_step": round(p_el / args.steps * 1e3, 4),
+                         "Msplats_per_s": round(N / (p_el / args.steps) / 1e6, 1),
+                         "host_enqueue_ms_per_frame": round(p_enq / args.steps * 1e3, 4),
+                         "note": "sorter + vertex stage on their own HIP streams: the sort of frame k+1 overlaps the tail "
+                                 "of frame k's draw (same camera); throughput of whole frames, not the §8d metric"}
+            rig2.close()
+            ctx2.close()
+
+        if extras:
+            # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the
+            # headline stays the fixed demo pose so rounds remain comparable)
             ms, vis = [], []
             for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
                 mesh.set_camera(oc)
@@ -232,9 +399,7 @@ def main():
                      "visible_splats_median": int(np.median(vis)), "visible_splats_max": int(np.max(vis)),
                      "note": "isolated (synchronised) frames, so compare with frame_latency_ms, not ms_per_step"}
 
-        # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
-        cull = None
-        if world == 1 and not args.no_cull:
+            # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
             from gaussiansplats3d_amd import SplatTree
             t_tree = time.perf_counter()
             tree = SplatTree(ctx, 8, 1000).process_splat_mesh(scene.centers, alphas=scene.rgba[:, 3])
@@ -263,32 +428,47 @@ def main():
             tree.dispose()
             mesh.use_sorter_result(worker, N)
 
-        # third column: the per-splat frustum cull fused into pass 0 of the sort (gs_sorter_set_frustum_cull).  Keys,
-        # range and buckets still span all N splats, so the frame must be bit-identical to the headline path's
-        fused = None
-        if world == 1 and not args.no_cull:
-            frame()
+            # third column: the per-splat frustum cull fused into pass 0 of the sort (gs_sorter_set_frustum_cull).  Keys,
+            # range and buckets still span all N splats, so the frame must be bit-identical to the headline path's
+            rig.frame(strip.data_ptr())
             torch.cuda.synchronize()
             ref_img = strip.clone()
             worker.set_frustum_cull(True)
             for _ in range(3):
-                frame()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                frame()
-            f_enq = (time.perf_counter() - t1) / args.steps * 1e3
-            torch.cuda.synchronize()
-            f_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                rig.frame(strip.data_ptr())
+            f_el, f_enq = rig.timed(args.steps, strip.data_ptr())
+            f_ms = f_el / args.steps * 1e3
             fs, _ = worker.last_stats()
             fused = {"kept": int(fs.result_count), "ms_per_frame": round(f_ms, 4),
                      "Msplats_per_s_scene": round(N / (f_ms * 1e-3) / 1e6, 1),
-                     "host_enqueue_ms_per_frame": round(f_enq, 4), "sort_ms_last": round(float(fs.device_ms), 4),
+                     "host_enqueue_ms_per_frame": round(f_enq / args.steps * 1e3, 4), "sort_ms_last": round(float(fs.device_ms), 4),
                      "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
                      "note": "keys + min/max over all N, then pass 0 of the radix sort drops the splats whose centre is "
                              "outside 1.25x the clip volume; the list is the full sort's list minus those splats"}
             worker.set_frustum_cull(False)
             del ref_img
+
+        if extras and args.config == "C3":
+            # fourth column: the same geometry with translucent splats.  The stand-in's pixels saturate after ~90 splats
+            # (the blend reads ~2 % of its lists); here they do not, so the blend walks its lists
+            rig.close()
+            t_scene = scenes.make_config_scene("C3T")
+            rig_t = Rig(ctx, t_scene, cam, device, torch)
+            st_t = rig_t.probe(strip.data_ptr())
+            for _ in range(3):
+                rig_t.frame(strip.data_ptr())
+            t_el, _ = rig_t.timed(min(args.steps, 20), strip.data_ptr())
+            t_ms = t_el / min(args.steps, 20) * 1e3
+            _, st_t = rig_t.mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
+            translucent = {"workload": scenes.CONFIGS["C3T"]["label"], "ms_per_frame": round(t_ms, 4),
+                           "Msplats_per_s": round(N / (t_ms * 1e-3) / 1e6, 1), "blend_ms": round(float(st_t.blend_ms), 4),
+                           "list_entries": int(st_t.tile_entries), "list_bin_px": int(st_t.list_bin_px),
+                           "entries_scanned": int(st_t.entries_scanned), "splats_walked": int(st_t.splats_walked),
+                           "visible_splats": int(st_t.visible_splats),
+                           "note": "opacity ~ sigmoid(N(-2,1)): pixels do not saturate early, the blend scans and walks "
+                                   "its entry lists (compare entries_scanned / splats_walked with the `blend` object)"}
+            rig_t.close()
+            rig = None
 
     ms_per_step = elapsed / args.steps * 1e3
     D16 = int(st_probe.tiles16)
@@ -301,46 +481,70 @@ def main():
         kb = project_algorithmic_bytes(N, visible, scene.sh_degree, scene.cov_half)
         k_ms = proj_ms_sum / max(proj_launches, 1)
         k_gbs = kb / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("k_project")
+        traffic, traffic_src = pmc_traffic("k_project", args.config)
+        frame_traffic, frame_traffic_src = pmc_frame_traffic(args.config) if world == 1 else (None, None)
+        walked, scanned = int(st_probe.splats_walked), int(st_probe.entries_scanned)
+        blend_ms = stage_ms.get("blend")
+        blend_tflops = (walked * 256 * BLEND_FLOPS_PER_PIXEL_SPLAT / (blend_ms * 1e-3) / 1e12) if blend_ms else None
+        valu, valu_src = pmc_valu("k_tile_blend", args.config)
         out = {
             "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if args.config == "C3"
                       else f"Msplats/s sorted+rasterized ({cfg['label']})",
             "value": round(N / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "fps": round(1e3 / ms_per_step, 2), "frame_latency_ms": round(float(np.median(latency)), 4),
+            "fps": round(1e3 / ms_per_step, 2),
+            "frame_latency_ms": round(float(np.median(latency)), 4) if latency else None,
             "host_enqueue_ms_per_frame": round(t_enqueued / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 keys / f32 raster",
             "data": "synthetic" if scene.name == args.config else f"file:{scene.name}",
             "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
+                       "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
-                       "strips": strips if world > 1 else None},
-            # dominant kernel (largest single kernel of the frame): the vertex stage
+                       "strips": strips if world > 1 else None, "backend": backend if world > 1 else None,
+                       "dry_run_shared_gpu": dry_run if world > 1 else None},
+            # the largest HBM-bound kernel: the vertex stage (the largest kernel overall is the blend, which is VALU-bound:
+            # see `blend`)
             "roofline": {"bound": "hbm", "kernel": "k_project", "achieved": round(k_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(kb),
                          "avg_launch_ms": round(k_ms, 5), "launches_timed": proj_launches,
                          "visible_splats": visible},
-            # whole frame against SURVEY.md §8d's formula
+            # the largest kernel of the frame
+            "blend": {"kernel": "k_tile_blend", "bound": "valu", "ms": round(blend_ms, 4) if blend_ms else None,
+                      "splats_walked": walked, "entries_scanned": scanned, "list_entries": D32,
+                      "flops_per_pixel_splat": BLEND_FLOPS_PER_PIXEL_SPLAT,
+                      "tflops": round(blend_tflops, 2) if blend_tflops else None,
+                      "frac_of_157TF": round(blend_tflops / FP32_PEAK_TFLOPS, 4) if blend_tflops else None,
+                      "valu_busy_frac": valu.get("valu_busy_frac") if valu else None,
+                      "valu_insts_per_launch": valu.get("SQ_INSTS_VALU") if valu else None, "counter_source": valu_src},
+            # whole frame: SURVEY.md §8d's formula, and what the counters say the engine really moves
             "frame": {"algorithmic_bytes": int(B), "bytes_per_splat": round(B / R, 1), "GBps": round(frame_gbs, 1),
-                      "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4), "tiles16_D": D16,
-                      "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": list_px_timed,
+                      "frac_of_hbm_peak": round(frame_gbs / HBM_PEAK_GBS, 4),
+                      "counter_bytes": frame_traffic, "counter_source": frame_traffic_src,
+                      "counter_GBps": round(frame_traffic / (ms_per_step * 1e-3) / 1e9, 1) if frame_traffic else None,
+                      "counter_frac_of_hbm_peak": round(frame_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                      if frame_traffic else None,
+                      "tiles16_D": D16, "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": list_px_timed,
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "pipelined": pipelined,
             "orbit": orbit,
             "cull_on": cull,
             "frustum_cull_fused": fused,
+            "translucent": translucent,
             "cpu_baseline": None,
+            "frames_drawn_before_timing_ended": frames_headline,
             "scene_gen_s": round(t_gen, 1),
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.only_headline:
             out["cpu_baseline"] = cpu_baseline(scene, mvp, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    worker.terminate()
-    mesh.dispose()
+    if rig is not None:
+        rig.close()
     ctx.close()
 
 

@@ -29,7 +29,14 @@ int gs_device_count(void) {
 }
 
 int gs_context_create(int device, void* hip_stream, gs_context** out) {
+    const char* serial = getenv("GSPLAT_SERIAL");               // "1" (anything but empty / "0"): one stream for everything
+    const bool single = serial && serial[0] != '\0' && !(serial[0] == '0' && serial[1] == '\0');
+    return gs_context_create_ex(device, hip_stream, single ? GS_CTX_SINGLE_STREAM : 0u, out);
+}
+
+int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out) {
     GS_REQUIRE(out != nullptr, "out == NULL");
+    GS_REQUIRE((flags & ~GS_CTX_SINGLE_STREAM) == 0, "unknown context flags");
     *out = nullptr;
     int n = gs_device_count();
     if (n < 0) return n;
@@ -62,8 +69,7 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
     }
     const char* wide = getenv("GSPLAT_WIDE_ENTRY_KEYS");
     ctx->wide_entry_keys = wide && wide[0] == '1';
-    const char* serial = getenv("GSPLAT_SERIAL");               // "1" (anything but empty / "0"): one stream for everything
-    ctx->serial = serial && serial[0] != '\0' && !(serial[0] == '0' && serial[1] == '\0');
+    ctx->serial = (flags & GS_CTX_SINGLE_STREAM) != 0;
     if (!ctx->serial) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
         if (e != hipSuccess) {

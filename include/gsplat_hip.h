@@ -52,6 +52,12 @@ int gs_device_count(void);
 /* One context per GPU.  hip_stream: an existing hipStream_t to enqueue on (e.g. PyTorch's current
  * stream) or NULL to let the library create its own. */
 int gs_context_create(int device, void* hip_stream, gs_context** out);
+/* The same with explicit flags.  GS_CTX_SINGLE_STREAM: sorts, the vertex stage and the rest of a draw all run on the one
+ * stream (no worker / aux streams), i.e. a frame is strictly sort -> draw.  gs_context_create takes this flag from the
+ * environment (GSPLAT_SERIAL=1); the default is the reference's shape: the sort runs concurrently with drawing, like its
+ * Web Worker (src/worker/SortWorker.js). */
+#define GS_CTX_SINGLE_STREAM 1u
+int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out);
 void gs_context_destroy(gs_context* ctx);
 int gs_context_synchronize(gs_context* ctx);
 

@@ -38,7 +38,8 @@ def build(force=False):
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libsorter_ref.so")
-    if (force or not os.path.exists(ref_so)) and os.path.exists("/root/reference/src/worker/sorter_no_simd.cpp"):
+    ref_wasm = os.path.join(_HERE, "_ref", "sorter_no_simd_non_shared.wasm")
+    if (force or not os.path.exists(ref_so) or not os.path.exists(ref_wasm)) and os.path.exists("/root/reference/src/worker/sorter_no_simd.cpp"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -63,6 +64,41 @@ def _ref():
         _REF = C.CDLL(os.path.join(_HERE, "_ref", "libsorter_ref.so"))
         _REF.sortIndexes.restype = None
     return _REF
+
+
+def wasm_path():
+    """The reference's prebuilt scalar, non-shared-memory WASM sorter: in place under /root/reference, or the copy
+    oracle/Makefile leaves in oracle/_ref/ (what the GPU box sees); None when neither exists."""
+    for p in ("/root/reference/src/worker/sorter_no_simd_non_shared.wasm",
+              os.path.join(_HERE, "_ref", "sorter_no_simd_non_shared.wasm")):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def wasm_sort_timing(indexes, centers4, mvp, repeat=5, precision=16):
+    """Times the reference's WASM sorter under Node on a static integer full sort (oracle/wasm_ref.js: frequencies zeroed,
+    process.hrtime around exports.sortIndexes, as src/worker/SortWorker.js:53-60).  Returns {ms_min, ms_mean, repeat, node}
+    or None when the module or Node is missing."""
+    import shutil
+    import tempfile
+    wasm = wasm_path()
+    if wasm is None or shutil.which("node") is None:
+        return None
+    indexes = np.ascontiguousarray(indexes, dtype=np.uint32)
+    centers4 = np.ascontiguousarray(centers4, dtype=np.int32)
+    n, r = centers4.shape[0], indexes.shape[0]
+    hdr = np.array([n, r, r, 1 << precision, 1, 0, 0, 0], dtype=np.uint32)
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "in.bin"), "wb") as f:
+            f.write(hdr.tobytes())
+            f.write(indexes.tobytes())
+            f.write(centers4.tobytes())
+            f.write(np.asarray(mvp, dtype=np.float64).astype(np.float32).tobytes())
+        out = subprocess.check_output(["node", os.path.join(_HERE, "wasm_ref.js"), wasm, os.path.join(d, "in.bin"),
+                                       os.path.join(d, "out.bin"), str(int(repeat))], text=True)
+    j = __import__("json").loads(out.strip().splitlines()[-1])
+    return {"ms_min": float(j["ms"]), "ms_mean": float(j["ms_mean"]), "repeat": int(j["repeat"]), "node": j.get("node", "")}
 
 
 def _p(a, t):

@@ -33,6 +33,9 @@ def test_pmc_lookup_reads_the_committed_summary():
     name = next(k for k in d["kernels"] if k.split("<")[0] == "k_project")
     assert traffic == d["kernels"][name]["hbm_bytes_per_launch"] > 100e6
     assert bench.pmc_traffic("no_such_kernel")[0] is None
+    # a summary recorded on one config is never quoted for another
+    d4, _ = bench._newest_profile("*pmc_traffic.json", "no-such-config")
+    assert d4 is None
 
 
 def test_cpu_baseline_leg_times_the_reference_sorter():
@@ -42,3 +45,25 @@ def test_cpu_baseline_leg_times_the_reference_sorter():
     r = bench.cpu_baseline(scene, cam.sort_mvp(), 0.2)
     assert r["cores"] == 1 and r["kind"] in ("reference", "port") and r["value"] > 1.0 and r["ms_per_sort"] > 0
     assert "sorts" in r["sample"]
+    if r.get("wasm"):                      # the reference's prebuilt WASM sorter under Node, timed beside the native build
+        assert r["wasm"]["kind"] == "reference" and r["wasm"]["ms_per_sort"] > 0 and r["wasm"]["cores"] == 1
+
+
+def test_self_spawn_sets_up_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks with the torch.distributed environment."""
+    started = []
+
+    class P:
+        def __init__(self, cmd, env):
+            started.append((cmd, env))
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None: P(cmd, env))
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    assert bench.spawn_ranks(4) == 0
+    assert [e["RANK"] for _, e in started] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["LOCAL_RANK"] == e["RANK"] for _, e in started)
+    assert len({e["MASTER_PORT"] for _, e in started}) == 1
+    assert all(c[-4:] == ["--gpus", "4", "--steps", "2"] for c, _ in started)

@@ -1,0 +1,34 @@
+"""-m gpu: `python bench.py --gpus 2` as the driver runs it (no launcher: bench.py starts the ranks itself).  On a 1-GPU box
+the two ranks share the device and exchange their strips over gloo; the gathered frame must equal the N = 1 frame."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, gpus):
+    dump = str(tmp_path / f"frame_{gpus}.npy")
+    env = dict(os.environ, GS_BENCH_DUMP=dump)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3",
+                                   "--warmup", "1", "--no-cpu", "--no-cull", "--splats", "300000"], env=env, text=True,
+                                  timeout=600)
+    line = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(line) == 1, out
+    return json.loads(line[0]), np.load(dump)
+
+
+def test_two_ranks_gather_the_single_gpu_frame(tmp_path):
+    one, frame1 = _run(tmp_path, 1)
+    two, frame2 = _run(tmp_path, 2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["config"]["parallelism"] == "tile-row strips x2"
+    assert len(two["config"]["strips"]) == 2 and two["config"]["strips"][0][1] == two["config"]["strips"][1][0]
+    assert frame1.shape == frame2.shape == (1080, 1920, 4) and frame1.any()
+    np.testing.assert_array_equal(frame1, frame2)
+    assert two["value"] > 0 and two["ms_per_step"] > 0

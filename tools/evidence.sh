@@ -7,7 +7,7 @@ cd /root/repo; mkdir -p gpurun_out/$TAG
 (timeout 400 python bench.py 2>/dev/null | tail -1) > gpurun_out/$TAG/bench.json
 bash tools/prof.sh ${TAG}_pipe --no-cull > gpurun_out/$TAG/kstats.txt 2>&1
 GSPLAT_SERIAL=1 bash tools/prof.sh ${TAG}_serial --no-cull > gpurun_out/$TAG/serial_kstats.txt 2>&1
-bash tools/pmc.sh $TAG hbm --no-cull
+bash tools/pmc.sh $TAG hbm; bash tools/pmc.sh $TAG valu
 cd /root/repo
 python tools/pmc_traffic.py gpurun_out/pmc_$TAG gpurun_out/$TAG/pmc_traffic.json > gpurun_out/$TAG/pmc_traffic.txt 2>&1
 for C in C2 C4 C5; do (timeout 300 python bench.py --config $C --no-cpu --no-cull --steps 30 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_$C.json; done

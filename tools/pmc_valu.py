@@ -1,0 +1,48 @@
+"""VALU utilisation per kernel from the SQ counter pass of tools/pmc.sh <tag> valu.
+
+SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's VALU is executing, summed over the chip's 1024 SIMDs
+(MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles), GRBM_GUI_ACTIVE the kernel's
+duration in shader clocks, so   valu_busy_frac = 4 * SQ_ACTIVE_INST_VALU / (1024 * GRBM_GUI_ACTIVE).
+SQ_INSTS_VALU is wave-level VALU instructions issued; cycles_per_valu_inst = 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU.
+
+usage: python tools/pmc_valu.py gpurun_out/pmc_<tag> profiles/<tag>_pmc_valu.json
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/valu_*/**/*counter_collection.csv", recursive=True) + glob.glob(root + "/all_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+bench = None
+for log in sorted(glob.glob(root + "/*.log")):
+    for line in open(log, errors="replace"):
+        if line.startswith('{"metric"'):
+            bench = json.loads(line)
+config = bench["config"]["workload"].split(":")[0] if bench else "C3"
+kernels = {}
+for name, cs in sorted(acc.items()):
+    if name.startswith(("__amd", "at::", "k_split", "k_aos4", "k_morton", "k_perm_from", "k_scatter_u32", "k_selftest")):
+        continue
+    if "SQ_ACTIVE_INST_VALU" not in cs:
+        continue
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    clocks = m.get("GRBM_GUI_ACTIVE") or (m.get("SQ_BUSY_CYCLES", 0.0) / 32.0)
+    k = {c: round(v, 1) for c, v in sorted(m.items())}
+    k["dispatches"] = len(cs["SQ_ACTIVE_INST_VALU"])
+    if clocks:
+        k["valu_busy_frac"] = round(4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * clocks), 4)
+    if m.get("SQ_INSTS_VALU"):
+        k["cycles_per_valu_inst"] = round(4.0 * m["SQ_ACTIVE_INST_VALU"] / m["SQ_INSTS_VALU"], 3)
+    kernels[name] = k
+json.dump({"source": root, "config": config,
+           "formula": "valu_busy_frac = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE)", "kernels": kernels},
+          open(out, "w"), indent=1)
+for n, k in kernels.items():
+    print(f"{k.get('valu_busy_frac', float('nan')):7.3f} busy  {k.get('cycles_per_valu_inst', float('nan')):6.2f} cyc/inst  {n[:90]}")

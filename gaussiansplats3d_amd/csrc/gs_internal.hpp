@@ -219,8 +219,6 @@ struct RenderFrame {          // device-resident per-draw scalars
     uint32_t tiles16_lo;      // sum over visible splats of 16x16 tiles touched (the D of SURVEY.md section 8d)
     uint32_t tiles16_hi;
     uint32_t pad;
-    unsigned long long scanned;   // list entries the blend staged (read, rect-tested) before its pixels saturated
-    unsigned long long walked;    // (splat, 16-px tile) pairs the blend evaluated: one per wave per walked splat
 };
 
 struct ProjectParams {
@@ -285,6 +283,8 @@ struct gs_mesh {
     DevBuf tile_ranges;        // uint2 [bins]
     DevBuf frame;              // RenderFrame
     DevBuf fb;                 // internal RGBA8 framebuffer
+    DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, (splat, tile) pairs walked}
+    uint32_t blend_bins = 0;
     RadixScratch radix;
     uint32_t entry_capacity = 0;
     uint32_t sorted_buf = 0;   // ping-pong buffer index holding the tile-sorted entries of the last draw

@@ -397,8 +397,17 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;
     m->last.list_bin_px = GS_TILE << m->drawn_list_shift;
-    m->last.entries_scanned = f.scanned;
-    m->last.splats_walked = f.walked;
+    m->last.entries_scanned = 0;
+    m->last.splats_walked = 0;
+    if (m->blend_bins) {                                   // per-workgroup counters of the blend, summed here
+        std::vector<uint2> bs(m->blend_bins);
+        GS_HIP(hipMemcpyAsync(bs.data(), m->blend_stats.p, (size_t)m->blend_bins * 8, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        for (const uint2& b : bs) {
+            m->last.entries_scanned += b.x;
+            m->last.splats_walked += b.y;
+        }
+    }
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them
     if (m->last.visible_splats > 0)
         m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats ? GS_LIST_SHIFT_LARGE

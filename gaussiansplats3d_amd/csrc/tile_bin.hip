@@ -236,8 +236,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             frame->overflow = D64 > capacity ? 1u : 0u;
             frame->entry_count = D;
             frame->pad = 0;
-            frame->scanned = 0ull;                           // accumulated by this draw's k_tile_blend
-            frame->walked = 0ull;
         }
     }
     if (boff64 >= D) return;                                 // nothing of this workgroup fits (or it has no entries)

@@ -117,10 +117,11 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
                                                               uint32_t list_row_begin, uint32_t list_shift,
-                                                              RenderFrame* __restrict__ frame) {
+                                                              uint2* __restrict__ bin_stats) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
+    __shared__ uint32_t s_walked[4];
     const uint32_t bin = blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
@@ -253,10 +254,11 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     __syncthreads();
     if (bin < 8192u && tid == 0u) g_blend_prof[8 * bin + 1] = wall_clock64();
 #endif
-    if (lane == 0u) {
-        if (walked) atomicAdd(&frame->walked, (unsigned long long)walked);
-        if (wave == 0u && scanned) atomicAdd(&frame->scanned, (unsigned long long)scanned);
-    }
+    // statistics: one plain 8-byte store per workgroup, summed by the host when somebody asks (8160 same-address atomics
+    // at the end of the kernel cost 60 us: a device-scope counter retires ~88 atomics per microsecond)
+    if (lane == 0u) s_walked[wave] = walked;
+    __syncthreads();
+    if (tid == 0u) bin_stats[bin] = make_uint2(scanned, s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3]);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
@@ -275,10 +277,12 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
     if (bins == 0) return GS_OK;
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
+    GS_TRY(m->blend_stats.ensure((size_t)bins * 8));
+    m->blend_bins = bins;
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                        m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
                        pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                       m->frame.as<RenderFrame>());
+                       m->blend_stats.as<uint2>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

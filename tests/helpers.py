@@ -40,12 +40,14 @@ def oracle_inputs(scene):
     return scene.centers, cov, scene.rgba, sh
 
 
-def compare_frames(got_u8, fb_f32, ambig, label=""):
+def compare_frames(got_u8, fb_f32, ambig, label="", strict=False):
     """The stated framebuffer tolerance:
        * >= 99.9 % of channel values within 1/255 of the fp32 oracle,
        * every pixel within 2/255, except pixels the oracle flags as discard-ambiguous (some splat had
          |A - 8| <= 1e-3 there: the hard `A > 8 -> discard` edge may flip under fp32 reassociation and jump
-         by up to exp(-4)*alpha = 4.67/255), which must stay within 6/255."""
+         by up to exp(-4)*alpha = 4.67/255), which must stay within 6/255.
+    The message reports how many pixels actually needed that carve-out (error above 2/255 on an ambiguous pixel).
+    strict=True (the full-size crop tests): every channel of every pixel within 1/255, ambiguous or not."""
     ref = np.clip(fb_f32, 0.0, 1.0) * 255.0
     err = np.abs(got_u8.astype(np.float32) - ref)           # in 1/255 units, vs the unquantised oracle
     frac_1 = float((err <= 1.0 + 0.5).mean())                # +0.5: our own final rounding to unorm8
@@ -54,7 +56,11 @@ def compare_frames(got_u8, fb_f32, ambig, label=""):
     worst_amb = float(np.where(amb, err, 0.0).max())
     mse = float(((got_u8.astype(np.float64) - ref) ** 2).mean())
     psnr = 10.0 * np.log10(255.0 ** 2 / max(mse, 1e-12))
-    msg = f"{label}: within1={frac_1:.5f} worst_clear={worst_clear:.3f} worst_amb={worst_amb:.3f} psnr={psnr:.1f}"
+    carve = int((np.where(amb, err, 0.0).max(axis=-1) > 2.0 + 0.5).sum())    # pixels that NEED the ambiguity carve-out
+    msg = (f"{label}: within1={frac_1:.5f} worst_clear={worst_clear:.3f} worst_amb={worst_amb:.3f} psnr={psnr:.1f} "
+           f"carve_out_pixels={carve}")
+    if strict:       # what the full-size crops actually achieve: every channel within 1/255 (+ our final rounding), no carve-out
+        assert max(worst_clear, worst_amb) <= 1.0 + 0.5 and carve == 0, msg
     assert frac_1 >= 0.999, msg
     assert worst_clear <= 2.0 + 0.5, msg
     assert worst_amb <= 6.0 + 0.5, msg

@@ -29,6 +29,10 @@ def ctx():
     c.close()
 
 
+def mesh_frame_reaches_corners(counts):
+    return bool(counts[0, 0] and counts[0, -1] and counts[-1, 0] and counts[-1, -1])
+
+
 def _windows(W, H, mesh, cut_row, n_max):
     """[(label, x0, y0, w, h)] in GL window coordinates."""
     counts = mesh.bin_entry_counts()
@@ -43,6 +47,9 @@ def _windows(W, H, mesh, cut_row, n_max):
             ("list-bin-boundary", clampx(lx - WIN // 2), clampy(ly - WIN // 2)),
             ("strip-cut", clampx(W // 3), clampy(cut_row * 16 - WIN // 2)),
             ("corner-bl", 0, 0), ("corner-tr", W - WIN, H - WIN), ("corner-br", W - WIN, 0), ("corner-tl", 0, H - WIN)]
+    if not mesh_frame_reaches_corners(counts):          # C4's cube does not fill the frame: quarter points instead
+        wins[4:] = [("quarter-bl", W // 4, H // 4), ("quarter-tr", 3 * W // 4 - WIN, 3 * H // 4 - WIN),
+                    ("quarter-br", 3 * W // 4 - WIN, H // 4), ("quarter-tl", W // 4, 3 * H // 4 - WIN)]
     return [(name, x, y, WIN, WIN) for name, x, y in wins[:n_max]]
 
 
@@ -88,7 +95,8 @@ def _crop_parity(ctx, cfg_name, n_windows):
     amb_pixels = 0
     for (name, x0, y0, w, h), (fb, amb), (fb8, _) in zip(wins, crops, crops8):
         got = frame[y0:y0 + h, x0:x0 + w]
-        msg = helpers.compare_frames(got, fb, amb, f"{cfg_name} {name} @({x0},{y0})")
+        msg = helpers.compare_frames(got, fb, amb, f"{cfg_name} {name} @({x0},{y0})", strict=True)
+        assert got[..., 3].any(), f"{cfg_name} {name}: the window is empty, it checks nothing"
         ref = np.clip(fb, 0, 1) * 255.0
         ref8 = np.clip(fb8, 0, 1) * 255.0
         gap = np.abs(ref - ref8)                     # fp32 composite vs per-splat RGBA8 rounding, both by the oracle

@@ -12,6 +12,7 @@
 //                     max(1, buffer level) (SplatMesh.js:1064-1066)
 // A PLY is first laid out as the level-0 section the reference would build from it (file order, i.e. the reference's
 // `optimizeSplatData: false`), so every fill routine reads one format.
+#include <algorithm>
 #include <math.h>
 #include <string>
 
@@ -47,12 +48,16 @@ double from_half(uint16_t h) {                         // exact
     return sign ? -v : v;
 }
 
-double clampd(double v, double lo, double hi) { return fmax(fmin(v, hi), lo); }     // Util.js clamp
+// Util.js clamp = Math.max(Math.min(v, hi), lo): JS min / max PROPAGATE NaN (C's fmin / fmax drop it)
+double clampd(double v, double lo, double hi) {
+    if (v != v) return v;
+    return v > hi ? hi : (v < lo ? lo : v);
+}
 
 uint8_t to_uint8_range(double v, double lo, double hi) {                            // SplatBuffer.js:22-26
     v = clampd(v, lo, hi);
     const double r = clampd(floor((v - lo) / (hi - lo) * 255.0), 0.0, 255.0);
-    return (uint8_t)r;
+    return r == r ? (uint8_t)r : (uint8_t)0;                                        // a NaN stored into a Uint8Array is 0
 }
 
 uint8_t clamped_u8(double v) {                         // Uint8ClampedArray store: NaN -> 0, round half to even
@@ -68,6 +73,8 @@ struct Section {
     double half_block, scale_factor;
     size_t base, buckets_base, data_base;
     uint32_t count_offset;
+    uint32_t bucket_storage;
+    std::vector<uint32_t> partial_end;     // cumulative end (in section-local splats) of every partial bucket
 };
 
 constexpr size_t KS_HEADER = 4096, KS_SECTION_HEADER = 1024;
@@ -118,6 +125,7 @@ int parse_ksplat(gs_asset* a) {
         const float block = a->rd<float>(h + 16);
         sec.half_block = (double)block / 2.0;
         const uint32_t bucket_storage = a->rd<uint16_t>(h + 20);
+        sec.bucket_storage = bucket_storage;
         const uint32_t range = a->rd<uint32_t>(h + 24);
         sec.scale_range = range ? range : (a->level == 0 ? 1u : 32767u);
         sec.scale_factor = sec.half_block / (double)sec.scale_range;
@@ -134,6 +142,22 @@ int parse_ksplat(gs_asset* a) {
         sec.count_offset = count_offset;
         const size_t end = sec.data_base + (size_t)sec.bytes_per_splat * sec.max_splat_count;
         GS_REQUIRE(end <= n, ".ksplat: section data exceeds the file");
+        if (a->level > 0 && sec.max_splat_count > 0) {
+            // Bucket tables are only read for compressed centres (SplatBuffer.js:199-246).  The reference is memory-safe
+            // JavaScript; here every index into the tables is proven in range before gs_asset_fill reads through them.
+            GS_REQUIRE(bucket_storage >= 12, ".ksplat: bucket storage below the 12 bytes of a bucket centre");
+            GS_REQUIRE(sec.bucket_size > 0, ".ksplat: bucket size 0 in a compressed section");
+            GS_REQUIRE((uint64_t)sec.full_buckets + sec.partial_buckets <= sec.bucket_count,
+                       ".ksplat: more full + partial buckets than the section stores");
+            uint64_t covered = (uint64_t)sec.full_buckets * sec.bucket_size;
+            sec.partial_end.reserve(sec.partial_buckets);
+            for (uint32_t p = 0; p < sec.partial_buckets; p++) {
+                covered += a->rd<uint32_t>(sec.base + 4 * (size_t)p);
+                GS_REQUIRE(covered <= 0xFFFFFFFFull, ".ksplat: partial bucket lengths overflow");
+                sec.partial_end.push_back((uint32_t)covered);
+            }
+            GS_REQUIRE(covered >= sec.max_splat_count, ".ksplat: the buckets do not cover every splat of the section");
+        }
         base = end;
         count_offset += sec.max_splat_count;
         if (s == 0 || sec.sh_degree < min_degree) min_degree = sec.sh_degree;   // getMinSphericalHarmonicsDegree
@@ -302,7 +326,7 @@ int parse_ply(gs_asset* a, const uint8_t* data, size_t bytes, uint32_t want_degr
     for (uint32_t i = 0; i < vertex_count; i++) {
         const uint8_t* row = rows + (size_t)i * bytes_per_vertex;
         const size_t o = KS_HEADER + KS_SECTION_HEADER + (size_t)i * bps;
-        double v, s3[3], r4[4] = {NAN, NAN, NAN, NAN}, c3[3] = {NAN, NAN, NAN}, col[3], op = NAN;
+        double v, s3[3], r4[4] = {NAN, NAN, NAN, NAN}, c3[3] = {NAN, NAN, NAN}, col[3], op = 0.0;   // createSplat() starts every field at 0
         // INRIAV1PlyParser.js:148-156
         if (read_field(row, F_scale[0], &v)) {
             for (int k = 0; k < 3; k++) { s3[k] = NAN; if (read_field(row, F_scale[k], &v)) s3[k] = exp(v); }
@@ -333,7 +357,7 @@ int parse_ply(gs_asset* a, const uint8_t* data, size_t bytes, uint32_t want_degr
         for (int k = 0; k < 3; k++) WF(o + 12 + 4 * k, (float)(s3[k] == s3[k] ? s3[k] : 0.0));   // `|| 0`
         for (int k = 0; k < 4; k++) WF(o + 24 + 4 * k, (float)r4[k]);
         B[o + 40] = clamped_u8(col[0]); B[o + 41] = clamped_u8(col[1]); B[o + 42] = clamped_u8(col[2]);
-        B[o + 43] = clamped_u8(op == op ? op : 0.0);
+        B[o + 43] = clamped_u8(op);
         if (out_degree >= 1) {                                                         // :183-194
             const bool have = read_field(row, F_rest0, &v);
             for (int s = 0; s < 9; s++) {
@@ -352,18 +376,13 @@ int parse_ply(gs_asset* a, const uint8_t* data, size_t bytes, uint32_t want_degr
     return parse_ksplat(a);
 }
 
-uint32_t bucket_index(const gs_asset* a, const Section& sec, uint32_t local) {          // SplatBuffer.js:199-219
+// SplatBuffer.js:199-219: full buckets first, then the partial ones by their stored lengths.  parse_ksplat proved that the
+// tables cover every splat, so the result is always < bucket_count.
+uint32_t bucket_index(const gs_asset*, const Section& sec, uint32_t local) {
     const uint32_t full_span = sec.full_buckets * sec.bucket_size;
     if (local < full_span) return local / sec.bucket_size;
-    uint32_t bucket_splat = full_span, index = sec.full_buckets, p = 0;
-    while (bucket_splat < sec.splat_count) {
-        const uint32_t len = a->rd<uint32_t>(sec.base + 4 * (size_t)p);
-        if (local >= bucket_splat && local < bucket_splat + len) break;
-        bucket_splat += len;
-        index++;
-        p++;
-    }
-    return index;
+    const auto it = std::upper_bound(sec.partial_end.begin(), sec.partial_end.end(), local);
+    return sec.full_buckets + (uint32_t)(it - sec.partial_end.begin());
 }
 
 double comp(const gs_asset* a, size_t row, uint32_t index, bool sh) {                   // dataViewFloatForCompressionLevel + toUncompressedFloat
@@ -437,7 +456,7 @@ int gs_asset_fill(gs_asset* a, uint32_t min_alpha, float* centers, float* cov_f3
                 const uint32_t b = bucket_index(a, sec, local);
                 for (int k = 0; k < 3; k++) {
                     const double x = a->rd<uint16_t>(row + 2 * k);
-                    const double bc = a->rd<float>(sec.buckets_base + 12 * (size_t)b + 4 * k);
+                    const double bc = a->rd<float>(sec.buckets_base + (size_t)sec.bucket_storage * b + 4 * k);
                     centers[3 * (size_t)i + k] = (float)((x - (double)sec.scale_range) * sec.scale_factor + bc);
                 }
             }

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/gsplat_hip.h"
@@ -262,6 +263,7 @@ struct gs_mesh {
                                // u8  : sh0 = uint4 (bytes 0..15), sh1 = uint2 (bytes 16..23, SH2 only)
     DevBuf perm;               // uint32 [n]: original splat index -> internal (Morton-ordered) position
     DevBuf inv_perm;           // uint32 [n]: internal position -> original splat index
+    std::vector<std::pair<uint32_t, uint32_t>> slotted;   // [begin, end) ranges of splats that own storage slots (disjoint, sorted)
     bool reorder = true;
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)

@@ -5,6 +5,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <utility>
+
 #include "radix.hpp"
 
 void gs_set_error(const char* fmt, ...);
@@ -255,17 +258,21 @@ void gs_mesh_destroy(gs_mesh* m) {
     delete m;
 }
 
-int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
-                   const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16) {
-    GS_REQUIRE(m && centers && rgba, "mesh / centers / rgba == NULL");
-    GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+// true when every splat of [from, from + count) already owns a storage slot (gs_mesh_upload has seen it)
+static bool mesh_range_slotted(const gs_mesh* m, uint32_t from, uint32_t count) {
+    if (!m->reorder || count == 0) return true;
+    for (const auto& r : m->slotted)
+        if (r.first <= from && from + count <= r.second) return true;      // ranges are merged, so one must cover it
+    return false;
+}
+
+// One segment of an upload.  fresh: these splats have no storage slots yet - they get the Morton order of the segment;
+// otherwise they keep the slots an earlier upload gave them (perm stays a bijection, planes uploaded through the other
+// entry points and a bound sorter's resident result stay valid).
+static int mesh_upload_segment(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
+                               const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16, bool fresh) {
     const bool half = (m->flags & GS_MESH_COV_HALF) != 0;
-    GS_REQUIRE(half ? (cov_f16 && !cov_f32) : (cov_f32 && !cov_f16), "covariance format does not match the mesh (GS_MESH_COV_HALF)");
     const bool sh_u8 = (m->flags & GS_MESH_SH_U8) != 0;
-    GS_REQUIRE(m->sh_degree == 0 || sh_u8 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
-    GS_REQUIRE(!(sh_u8 && sh_f16), "GS_MESH_SH_U8 mesh: upload SH with gs_mesh_upload_sh_u8");
-    if (count == 0) return GS_OK;
-    ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     const uint32_t ncoef = (m->sh_degree == 0 || sh_u8) ? 0 : (m->sh_degree == 1 ? 9 : 24);
     const size_t b_c = (size_t)count * 12, b_cov = (size_t)count * (half ? 12 : 24), b_sh = (size_t)count * ncoef * 2;
@@ -276,9 +283,9 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     GS_HIP(hipMemcpyAsync(stg + off_cov, half ? (const void*)cov_f16 : (const void*)cov_f32, b_cov, hipMemcpyHostToDevice, st));
     if (ncoef) GS_HIP(hipMemcpyAsync(stg + off_sh, sh_f16, b_sh, hipMemcpyHostToDevice, st));
     const dim3 g(up_grid(count)), b(256);
-    const uint32_t* perm = nullptr;
-    if (m->reorder) {
-        // Morton order of this upload: bounds on the host (the centres are host memory anyway), 30-bit codes, 4 stable
+    const uint32_t* perm = m->reorder ? m->perm.as<uint32_t>() : nullptr;
+    if (m->reorder && fresh) {
+        // Morton order of this segment: bounds on the host (the centres are host memory anyway), 30-bit codes, 4 stable
         // radix passes with the entry ping-pong buffers as scratch, then perm[original] = internal
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (uint32_t i = 0; i < count; i++)
@@ -303,7 +310,6 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
                                                                      vbuf[(pass + 1) & 1])));
         }
         hipLaunchKernelGGL(k_perm_from_sorted, g, b, 0, st, vbuf[0], count, from, m->perm.as<uint32_t>(), m->inv_perm.as<uint32_t>());
-        perm = m->perm.as<uint32_t>();
     }
     const size_t off_rgba = (off_sh + b_sh + 255) & ~(size_t)255;
     GS_HIP(hipMemcpyAsync(stg + off_rgba, rgba, (size_t)count * 4, hipMemcpyHostToDevice, st));
@@ -321,7 +327,57 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
                            m->sh1.p, m->sh2.as<uint4>());
     GS_HIP(hipGetLastError());
     GS_HIP(hipStreamSynchronize(st));
-    if (from + count > m->uploaded) m->uploaded = from + count;
+    return GS_OK;
+}
+
+// SplatMesh.updateDataTexturesFromBaseData(fromSplat, toSplat) accepts any range, any number of times
+// (/root/reference/src/splatmesh/SplatMesh.js:900-1062).  Splats seen for the first time are stored along the Morton curve
+// of their own contiguous run; splats uploaded before keep their slots and only have their data replaced.
+int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* centers, const float* cov_f32,
+                   const uint16_t* cov_f16, const uint8_t* rgba, const uint16_t* sh_f16) {
+    GS_REQUIRE(m && centers && rgba, "mesh / centers / rgba == NULL");
+    GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    const bool half = (m->flags & GS_MESH_COV_HALF) != 0;
+    GS_REQUIRE(half ? (cov_f16 && !cov_f32) : (cov_f32 && !cov_f16), "covariance format does not match the mesh (GS_MESH_COV_HALF)");
+    const bool sh_u8 = (m->flags & GS_MESH_SH_U8) != 0;
+    GS_REQUIRE(m->sh_degree == 0 || sh_u8 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
+    GS_REQUIRE(!(sh_u8 && sh_f16), "GS_MESH_SH_U8 mesh: upload SH with gs_mesh_upload_sh_u8");
+    if (count == 0) return GS_OK;
+    ScopedDevice sd(m->ctx->device);
+    // earlier draws may still read the planes / the permutation on either stream
+    GS_HIP(hipStreamSynchronize(m->ctx->stream));
+    if (m->ctx->aux != m->ctx->stream) GS_HIP(hipStreamSynchronize(m->ctx->aux));
+    const uint32_t ncoef = (m->sh_degree == 0 || sh_u8) ? 0 : (m->sh_degree == 1 ? 9 : 24);
+    const uint32_t end = from + count;
+    // cut [from, end) at the borders of the ranges that already own storage slots (disjoint, sorted by begin)
+    std::vector<std::pair<uint32_t, bool>> cuts;          // (segment begin, fresh)
+    uint32_t pos = from;
+    for (const auto& r : m->slotted) {
+        if (r.second <= pos) continue;
+        if (r.first >= end) break;
+        if (r.first > pos) { cuts.push_back({pos, true}); pos = r.first; }
+        cuts.push_back({pos, false});
+        pos = r.second < end ? r.second : end;
+        if (pos == end) break;
+    }
+    if (pos < end) cuts.push_back({pos, true});
+    for (size_t k = 0; k < cuts.size(); k++) {
+        const uint32_t b = cuts[k].first, e = k + 1 < cuts.size() ? cuts[k + 1].first : end, o = b - from;
+        GS_TRY(mesh_upload_segment(m, b, e - b, centers + 3 * (size_t)o, cov_f32 ? cov_f32 + 6 * (size_t)o : nullptr,
+                                   cov_f16 ? cov_f16 + 6 * (size_t)o : nullptr, rgba + 4 * (size_t)o,
+                                   sh_f16 ? sh_f16 + (size_t)ncoef * o : nullptr, cuts[k].second || !m->reorder));
+    }
+    // merge [from, end) into the slotted ranges
+    std::vector<std::pair<uint32_t, uint32_t>> merged;
+    std::pair<uint32_t, uint32_t> cur(from, end);
+    for (const auto& r : m->slotted) {
+        if (r.second < cur.first || r.first > cur.second) merged.push_back(r);
+        else { cur.first = r.first < cur.first ? r.first : cur.first; cur.second = r.second > cur.second ? r.second : cur.second; }
+    }
+    merged.push_back(cur);
+    std::sort(merged.begin(), merged.end());
+    m->slotted.swap(merged);
+    if (end > m->uploaded) m->uploaded = end;
     return GS_OK;
 }
 
@@ -329,6 +385,7 @@ int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_
     GS_REQUIRE(m && sh_u8, "mesh / sh_u8 == NULL");
     GS_REQUIRE((m->flags & GS_MESH_SH_U8) && m->sh_degree >= 1, "mesh was not created with GS_MESH_SH_U8 and sh_degree >= 1");
     GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    GS_REQUIRE(mesh_range_slotted(m, from, count), "upload the splats with gs_mesh_upload before their 8-bit SH");
     if (count == 0) return GS_OK;
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
@@ -345,6 +402,7 @@ int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_
 int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, const uint32_t* scene_indexes) {
     GS_REQUIRE(m && scene_indexes, "mesh / scene_indexes == NULL");
     GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
+    GS_REQUIRE(mesh_range_slotted(m, from, count), "upload the splats with gs_mesh_upload before their scene indexes");
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     if (!m->scene_idx.p) {

@@ -74,8 +74,28 @@ struct ArrayLoader {
     __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (uint32_t)keys[j]; }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return vals[j]; }
+    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const { k = (uint32_t)keys[j]; v = vals[j]; }
     __device__ __forceinline__ bool valid(uint32_t) const { return true; }
     __device__ __forceinline__ void note_clamp(bool) const {}
+};
+
+// Second (last) pass of a 16-bit sort whose first pass left ONE word per element: the remaining digit in the payload's
+// spare top byte, (digit << 24) | payload, payload < 2^24.  A scatter pass is bound by its store instructions (runs of ~16
+// elements per digit), so not writing - and not re-reading - a separate key array is worth a third of the pass.
+struct PackedLoader {
+    const uint32_t* __restrict__ packed;
+    const uint32_t* __restrict__ n_dev;   // device-resident count (nullable)
+    uint32_t n_host;
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
+    __device__ __forceinline__ uint32_t key(uint32_t j) const { return packed[j] >> 24; }
+    __device__ __forceinline__ uint32_t val(uint32_t j) const { return packed[j] & 0x00FFFFFFu; }
+    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const {
+        const uint32_t w = packed[j];
+        k = w >> 24;
+        v = w & 0x00FFFFFFu;
+    }
+    __device__ __forceinline__ bool valid(uint32_t) const { return true; }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -118,6 +138,17 @@ __device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint
                 atomicAdd(&hist[(w[c] >> shift) & 255u], 1u);
             }
         }
+    }
+}
+__device__ __forceinline__ void hist_full_tile(const PackedLoader& ld, uint32_t base, int shift, uint32_t* hist) {
+    const uint4* src = reinterpret_cast<const uint4*>(ld.packed + base);
+#pragma unroll
+    for (uint32_t l = threadIdx.x; l < (uint32_t)RADIX_TILE / 4u; l += HIST_THREADS) {
+        const uint4 v = src[l];
+        atomicAdd(&hist[((v.x >> 24) >> shift) & 255u], 1u);
+        atomicAdd(&hist[((v.y >> 24) >> shift) & 255u], 1u);
+        atomicAdd(&hist[((v.z >> 24) >> shift) & 255u], 1u);
+        atomicAdd(&hist[((v.w >> 24) >> shift) & 255u], 1u);
     }
 }
 template <class Loader>
@@ -260,8 +291,9 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (size
         for (int r = 0; r < SCATTER_ITEMS; r++) {
             const uint32_t j = wbase + r * 64;
             ok[r] = j < ch.n && ld.valid(j);      // a loader that drops elements turns the pass into a stable compaction
-            key[r] = ok[r] ? ld.key(j) : 0xFFFFFFFFu;
-            val[r] = ok[r] ? ld.val(j) : 0u;
+            key[r] = 0xFFFFFFFFu;
+            val[r] = 0u;
+            if (ok[r]) ld.load(j, key[r], val[r]);
         }
 #pragma unroll
         for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;

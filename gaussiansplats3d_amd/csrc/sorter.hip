@@ -8,6 +8,7 @@
 // Arithmetic that decides the order is spelled with non-contracting intrinsics (__fmul_rn ...) so hipcc's
 // default fp-contract=fast cannot fuse it; this file is also built with -ffp-contract=off.
 #include <math.h>
+#include <stdlib.h>
 
 #include "radix.hpp"
 
@@ -36,6 +37,8 @@ struct KeyParams {
     SortFrame* next_frame;                   // the other buffer: reset here for the next sort (no separate init kernel)
     uint32_t* digit_total;                   // radix digit totals of this sort's passes: zeroed here, before any histogram
     uint32_t sort_start, render_count, mode;
+    uint32_t last_splat;                     // uploaded - 1: list entries are clamped to it (the reference reads whatever
+                                             // WASM memory a stale index points at; here that would be a GPU page fault)
     int32_t im0, im1, im2;                   // static path: (int)(mvp[k]*1000.0), k = 2,6,10
     float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
     float mvp[16];                           // frustum-cull variant only: the whole modelViewProj, fp32 column-major
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
         }
     } else {
         for (uint32_t i = p.sort_start + t; i < p.render_count; i += stride) {
-            const uint32_t g = p.idx_in ? p.idx_in[i] : i;
+            const uint32_t g = p.idx_in ? min(p.idx_in[i], p.last_splat) : i;
             const int32_t k = depth_key_one(p, g);
             p.keys_out[i] = k;
             lo = min(lo, k);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
             for (int k = 0; k < 4; k++) {
                 const uint32_t i = base + 64u * k + lane;
                 in[k] = i < R;
-                g[k] = in[k] ? (p.idx_in ? p.idx_in[i] : i) : 0u;
+                g[k] = in[k] ? (p.idx_in ? min(p.idx_in[i], p.last_splat) : i) : 0u;
             }
             uint4 c[4];
 #pragma unroll
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
 
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
-template <bool CULL>
+// PACK (16-bit sorts of at most 2^24 splats): the payload carries the key's high byte, (key' >> 8) << 24 | payload, and the
+// pass writes no key array (radix.hpp, PackedLoader).
+template <bool CULL, bool PACK>
 struct DepthLoaderT {
     const int32_t* __restrict__ keys;
     const unsigned long long* __restrict__ keep;   // CULL: 1 bit per list position (k_depth_key_cull)
@@ -326,6 +331,7 @@ struct DepthLoaderT {
     const uint32_t* __restrict__ map;      // nullable: payload = map[splat index] (a bound mesh's internal position)
     SortFrame* frame;
     uint32_t sort_start, render_count, range;
+    uint32_t last_splat;                   // list entries are clamped to it
     uint32_t count_clamps;                 // only the histogram launch counts, so each element counts once
     int32_t lo;
     float range_map;
@@ -354,10 +360,19 @@ struct DepthLoaderT {
         return (uint32_t)b;
     }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (range - 1) - bucket(render_count - 1 - j); }
-    __device__ __forceinline__ uint32_t val(uint32_t j) const {
-        const uint32_t i = render_count - 1 - j;
-        const uint32_t o = idx ? idx[i] : i;
+    __device__ __forceinline__ uint32_t payload(uint32_t i) const {
+        const uint32_t o = idx ? min(idx[i], last_splat) : i;
         return map ? map[o] : o;
+    }
+    __device__ __forceinline__ uint32_t val(uint32_t j) const {
+        const uint32_t v = payload(render_count - 1 - j);
+        return PACK ? (((key(j) >> 8) << 24) | v) : v;
+    }
+    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const {
+        const uint32_t i = render_count - 1 - j;
+        k = (range - 1) - bucket(i);
+        v = payload(i);
+        if (PACK) v |= (k >> 8) << 24;
     }
     __device__ __forceinline__ bool valid(uint32_t j) const {
         if (!CULL) return true;
@@ -365,13 +380,15 @@ struct DepthLoaderT {
         return (keep[i >> 6] >> (i & 63u)) & 1ull;
     }
 };
-typedef DepthLoaderT<false> DepthLoader;
-typedef DepthLoaderT<true> DepthLoaderCull;
+typedef DepthLoaderT<false, false> DepthLoader;
+typedef DepthLoaderT<true, false> DepthLoaderCull;
+typedef DepthLoaderT<false, true> DepthLoaderPacked;
+typedef DepthLoaderT<true, true> DepthLoaderCullPacked;
 
 __global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ map, uint32_t* __restrict__ out,
-                            uint32_t n) {
+                            uint32_t n, uint32_t last_splat) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t o = idx ? idx[i] : i;
+        const uint32_t o = idx ? min(idx[i], last_splat) : i;
         out[i] = map ? map[o] : o;
     }
 }
@@ -578,6 +595,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     kp.digit_total = s->radix.digit_total.as<uint32_t>();
     kp.sort_start = sort_start;
     kp.render_count = R;
+    kp.last_splat = s->uploaded ? s->uploaded - 1u : 0u;
     kp.im0 = trunc_f64_i32((double)mvp[2] * 1000.0);     // sorter.cpp:64
     kp.im1 = trunc_f64_i32((double)mvp[6] * 1000.0);
     kp.im2 = trunc_f64_i32((double)mvp[10] * 1000.0);
@@ -593,12 +611,13 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
+        static const uint32_t key_grid = getenv("GSPLAT_KEY_GRID") ? (uint32_t)atoi(getenv("GSPLAT_KEY_GRID")) : 2u;   // A/B
         if (cull && vec4)
             hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else if (cull)
             hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (vec4)
-            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * key_grid)), dim3(256), 0, st, kp);
         else
             hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         GS_HIP(hipGetLastError());
@@ -610,9 +629,13 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         dl.sort_start = sort_start;
         dl.render_count = R;
         dl.range = 1u << s->precision;
+        dl.last_splat = kp.last_splat;
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
         const bool wide = s->precision > 16;
+        // two passes and every payload below 2^24: one word per element between the passes (radix.hpp, PackedLoader)
+        const bool packed = passes == 2 && s->uploaded <= (1u << 24) && (!map || s->bound_mesh->uploaded <= (1u << 24)) &&
+                            !getenv("GSPLAT_NO_PACKED_SORT");
         void* kbuf[2] = {s->keyA.p, s->keyB.p};
         uint32_t* vbuf[2] = {s->valA.as<uint32_t>(), s->valB.as<uint32_t>()};
         for (uint32_t p = 0; p < passes; p++) {
@@ -621,10 +644,29 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
             const uint32_t* n_dev = cull ? &kp.frame->kept : nullptr;
-            if (p == 0 && cull) {
+            if (packed) {
+                if (p == 0 && cull) {
+                    DepthLoaderCullPacked dc = {};
+                    dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
+                    dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;
+                    DepthLoaderCullPacked h = dc;
+                    h.count_clamps = 1;
+                    GS_TRY((radix_pass<DepthLoaderCullPacked, uint16_t, false>(ex, h, dc, Rs, 0, 0, (uint16_t*)nullptr, vbuf[0])));
+                } else if (p == 0) {
+                    DepthLoaderPacked dp = {};
+                    dp.keys = dl.keys; dp.idx = dl.idx; dp.map = dl.map; dp.frame = dl.frame;
+                    dp.sort_start = dl.sort_start; dp.render_count = dl.render_count; dp.range = dl.range; dp.last_splat = dl.last_splat;
+                    DepthLoaderPacked h = dp;    // only the histogram launch counts clamped buckets (once per element)
+                    h.count_clamps = 1;
+                    GS_TRY((radix_pass<DepthLoaderPacked, uint16_t, false>(ex, h, dp, Rs, 0, 0, (uint16_t*)nullptr, vbuf[0])));
+                } else {
+                    PackedLoader pl = {vbuf[0], n_dev, Rs};
+                    GS_TRY((radix_pass<PackedLoader, uint16_t, false>(ex, pl, pl, Rs, 0, 1, (uint16_t*)nullptr, out_tail)));
+                }
+            } else if (p == 0 && cull) {
                 DepthLoaderCull dc = {};
                 dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
-                dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range;
+                dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;
                 DepthLoaderCull h = dc;
                 h.count_clamps = 1;
                 if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
@@ -647,7 +689,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     }
     if (sort_start > 0) {
         hipLaunchKernelGGL(k_copy_head, dim3(grid_for(sort_start, 1024, 2048)), dim3(256), 0, st, idx_dev, map,
-                           s->sorted.as<uint32_t>(), sort_start);
+                           s->sorted.as<uint32_t>(), sort_start, s->uploaded - 1u);
     }
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(s->ev1, st));

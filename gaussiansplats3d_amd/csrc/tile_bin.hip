@@ -59,7 +59,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
                                                            uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ digit_total,
                                                            uint32_t* __restrict__ block_hist,
-                                                           uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift) {
+                                                           uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift,
+                                                           uint32_t splat_count) {
     __shared__ unsigned long long s_w[4];
     // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
     // pass and the workgroup rows of its first pass (k_bin_emit accumulates that histogram), reset the bin ranges.
@@ -93,6 +94,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
             keep[k] = q < pos_end;
             const uint32_t p = R - 1u - min(q, R - 1u);    // draw order is back-to-front; we go front-to-back
             idx[k] = order ? order[p] : p;
+            // a stale or wrong caller list must not fault the GPU (WebGL's texelFetch out of range is harmless too):
+            // entries beyond the uploaded splats draw nothing
+            keep[k] = keep[k] && idx[k] < splat_count;
+            idx[k] = min(idx[k], splat_count - 1u);
         }
         if (perm) {                                        // caller's splat index -> internal (Morton) position
 #pragma unroll
@@ -308,7 +313,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(), m->radix.block_hist.as<uint32_t>(),
-                       m->tile_ranges.as<uint2>(), tiles, pp.list_shift);
+                       m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count);
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;

@@ -78,10 +78,14 @@ class SortWorker:
         idx = s.get("indexesToSort")
         if idx is not None:
             idx = np.ascontiguousarray(idx, dtype=np.uint32)
+            if idx.size < render:                    # the C side copies splatRenderCount entries
+                raise ValueError(f"indexesToSort holds {idx.size} entries, splatRenderCount is {render}")
         pre = None
         if s.get("usePrecomputedDistances"):
             pre = np.ascontiguousarray(s["precomputedDistances"],
                                        dtype=np.int32 if self.integer_based_sort else np.float32)
+            if pre.size < self.uploaded_splat_count:  # one distance per uploaded splat (SortWorker.js:125-178)
+                raise ValueError(f"precomputedDistances holds {pre.size} values for {self.uploaded_splat_count} splats")
         tr = None
         if self.dynamic_mode:
             tr = np.zeros(16 * L.GS_MAX_SCENES, dtype=np.float32)

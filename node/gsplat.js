@@ -31,6 +31,10 @@ class HipSortWorker {
     this.integerBasedSort = !!integerBasedSort;
     this.dynamicMode = !!dynamicMode;
     this.uploadedSplatCount = 0;
+    this._busy = false;
+    this._queue = [];
+    this._terminated = false;
+    this.synchronous = false;
     this.ctx = getContext(device);
     const flags = (this.integerBasedSort ? GS_SORT_INTEGER : 0) | (this.dynamicMode ? GS_SORT_DYNAMIC : 0);
     this.handle = addon.sorterCreate(this.ctx.handle, splatCount, flags, precision);
@@ -52,7 +56,21 @@ class HipSortWorker {
 
   _emit(data) { if (this.onmessage) this.onmessage({ data }); }
 
+  // The reference's worker handles one message at a time, in posting order, on its own thread: postMessage returns at once
+  // and sortDone arrives later (SortWorker.js:62-80, Viewer.js:1243-1264).  Same here: a sort runs on a libuv pool thread
+  // (addon.sorterSortAsync); messages posted while it is in flight wait in a queue.
   postMessage(msg) {
+    if (this._busy) { this._queue.push(msg); return; }
+    this._handle(msg);
+  }
+
+  _drain() {
+    this._busy = false;
+    if (this._terminated) { this._destroy(); return; }
+    while (!this._busy && this._queue.length) this._handle(this._queue.shift());
+  }
+
+  _handle(msg) {
     if (msg.centers) {                                                    // SortWorker.js:84-98
       const count = msg.range.count;
       const centers = this.integerBasedSort ? new Int32Array(msg.centers) : new Float32Array(msg.centers);
@@ -75,15 +93,29 @@ class HipSortWorker {
         if (transforms) transforms.set(s.transforms);
         if (s.usePrecomputedDistances) pre = s.precomputedDistances;
       }
+      if (pre && pre.length < this.uploadedSplatCount) throw new RangeError('precomputedDistances shorter than the uploaded splat count');
       if (this.dynamicMode && !transforms) transforms = new Float32Array(Constants.MaxScenes * 16);
       const out = this.useSharedMemory ? new Uint32Array(this.sortedIndexesBuffer, 0, renderCount) : new Uint32Array(renderCount);
-      const r = addon.sorterSort(this.handle, mvp, indexes, sortCount, renderCount, pre, this.dynamicMode ? transforms : null, out);
-      // under setFrustumCull the list holds only the kept splats: the Viewer draws `splatRenderCount` of them
-      // (Viewer.js:1251-1262 passes e.data.splatRenderCount to updateRenderIndexes)
-      const drawCount = this.frustumCull ? r.resultCount : renderCount;
-      const reply = { sortDone: true, splatSortCount: Math.min(sortCount, drawCount), splatRenderCount: drawCount, sortTime: r.sortTime, status: r.status };
-      if (!this.useSharedMemory) reply.sortedIndexes = this.frustumCull ? out.subarray(0, drawCount) : out;
-      setImmediate(() => this._emit(reply));
+      const culled = this.frustumCull;
+      const done = (r) => {
+        // under setFrustumCull the list holds only the kept splats: the Viewer draws `splatRenderCount` of them
+        // (Viewer.js:1251-1262 passes e.data.splatRenderCount to updateRenderIndexes)
+        const drawCount = culled ? r.resultCount : renderCount;
+        const reply = { sortDone: true, splatSortCount: Math.min(sortCount, drawCount), splatRenderCount: drawCount, sortTime: r.sortTime, status: r.status };
+        if (!this.useSharedMemory) reply.sortedIndexes = culled ? out.subarray(0, drawCount) : out;
+        return reply;
+      };
+      if (this.synchronous) {                                             // test hook: the round-1 behaviour
+        const reply = done(addon.sorterSort(this.handle, mvp, indexes, sortCount, renderCount, pre, this.dynamicMode ? transforms : null, out));
+        setImmediate(() => this._emit(reply));
+        return;
+      }
+      this._busy = true;
+      addon.sorterSortAsync(this.handle, mvp, indexes, sortCount, renderCount, pre, this.dynamicMode ? transforms : null, out, (err, r) => {
+        if (err) { this._drain(); throw err; }
+        this._emit(done(r));
+        this._drain();
+      });
     } else if (msg.init) {
       // the reference ships its WASM bytes through an init message (SortWorker.js:116-199); nothing to do here
     }
@@ -95,7 +127,12 @@ class HipSortWorker {
     this.frustumCull = !!enable;
   }
 
-  terminate() {
+  terminate() {                                                           // Viewer.js:1311
+    this._terminated = true;
+    if (!this._busy) this._destroy();                                     // else: once the sort in flight has landed
+  }
+
+  _destroy() {
     if (this.handle) { addon.sorterDestroy(this.handle); this.handle = null; }
   }
 }

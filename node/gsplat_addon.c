@@ -10,7 +10,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+
 #include "../include/gsplat_hip.h"
+
+/* The C ABI wants calls on one context serialised by the caller.  JavaScript is single-threaded, but sorterSortAsync runs
+ * gs_sorter_sort on a libuv pool thread (the reference's sort runs in a Web Worker, src/worker/SortWorker.js), so every
+ * library call of this addon takes one lock: a draw issued while a sort is in flight waits for it (~1 ms), never races it. */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+#define LOCKED(stmt) do { pthread_mutex_lock(&g_lock); stmt; pthread_mutex_unlock(&g_lock); } while (0)
 
 #define NAPI_OK(call)                                                        \
     do {                                                                     \
@@ -89,7 +97,9 @@ static napi_value DeviceCount(napi_env env, napi_callback_info info) {
 static napi_value ContextCreate(napi_env env, napi_callback_info info) {
     ARGS(1)
     gs_context* ctx = NULL;
-    int st = gs_context_create((int)get_u32(env, argv[0]), NULL, &ctx);
+    int st;
+
+    LOCKED(st = gs_context_create((int)get_u32(env, argv[0]), NULL, &ctx));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_external(env, ctx, NULL, NULL, &r));
@@ -97,7 +107,7 @@ static napi_value ContextCreate(napi_env env, napi_callback_info info) {
 }
 static napi_value ContextDestroy(napi_env env, napi_callback_info info) {
     ARGS(1)
-    gs_context_destroy((gs_context*)get_external(env, argv[0]));
+    LOCKED(gs_context_destroy((gs_context*)get_external(env, argv[0])));
     return NULL;
 }
 
@@ -105,8 +115,10 @@ static napi_value ContextDestroy(napi_env env, napi_callback_info info) {
 static napi_value SorterCreate(napi_env env, napi_callback_info info) {
     ARGS(4)
     gs_sorter* s = NULL;
-    int st = gs_sorter_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]),
-                              get_u32(env, argv[3]), &s);
+    int st;
+
+    LOCKED(st = gs_sorter_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]),
+                              get_u32(env, argv[3]), &s));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_external(env, s, NULL, NULL, &r));
@@ -114,7 +126,7 @@ static napi_value SorterCreate(napi_env env, napi_callback_info info) {
 }
 static napi_value SorterDestroy(napi_env env, napi_callback_info info) {
     ARGS(1)
-    gs_sorter_destroy((gs_sorter*)get_external(env, argv[0]));
+    LOCKED(gs_sorter_destroy((gs_sorter*)get_external(env, argv[0])));
     return NULL;
 }
 /* sorterUploadCenters(sorter, from, count, centers(Int32Array|Float32Array|ArrayBuffer), sceneIndexes|null) */
@@ -125,7 +137,9 @@ static napi_value SorterUploadCenters(napi_env env, napi_callback_info info) {
     if (!get_bytes(env, argv[3], &c, &cb) || !get_bytes(env, argv[4], &sc, &sb)) { napi_throw_type_error(env, NULL, "centers / sceneIndexes"); return NULL; }
     const uint32_t count = get_u32(env, argv[2]);
     if (cb < (size_t)count * 16 || (sc && sb < (size_t)count * 4)) { napi_throw_range_error(env, NULL, "buffer shorter than count"); return NULL; }
-    int st = gs_sorter_upload_centers((gs_sorter*)get_external(env, argv[0]), get_u32(env, argv[1]), count, c, (const uint32_t*)sc);
+    int st;
+
+    LOCKED(st = gs_sorter_upload_centers((gs_sorter*)get_external(env, argv[0]), get_u32(env, argv[1]), count, c, (const uint32_t*)sc));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -147,8 +161,10 @@ static napi_value SorterSort(napi_env env, napi_callback_info info) {
     }
     gs_sort_stats stats;
     memset(&stats, 0, sizeof stats);
-    int st = gs_sorter_sort((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, (const uint32_t*)idx, sortc, renderc,
-                            pre, (const float*)tr, (uint32_t*)out, out ? &stats : NULL);
+    int st;
+
+    LOCKED(st = gs_sorter_sort((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, (const uint32_t*)idx, sortc, renderc,
+                            pre, (const float*)tr, (uint32_t*)out, out ? &stats : NULL));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_object(env, &r));
@@ -162,11 +178,117 @@ static napi_value SorterSort(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* sorterSortAsync(sorter, mvp, indexes|null, sortCount, renderCount, precomputed|null, transforms|null, out|null, callback)
+ * The same sort on a libuv pool thread: returns at once, callback(error|null, {status, sortTime, ...}) runs on the main
+ * thread when the result is in `out` - the shape of the reference's worker: postMessage returns immediately, sortDone
+ * arrives later (src/worker/SortWorker.js:62-80 -> src/Viewer.js:1243-1264).  The typed arrays are referenced until then. */
+typedef struct {
+    napi_async_work work;
+    napi_ref cb, keep[3];
+    gs_sorter* sorter;
+    float mvp[16];
+    float transforms[16 * GS_MAX_SCENES];
+    int has_tr;
+    const uint32_t* idx;
+    const void* pre;
+    uint32_t* out;
+    uint32_t sortc, renderc;
+    gs_sort_stats stats;
+    int status;
+    char err[512];
+} sort_job;
+
+static void sort_execute(napi_env env, void* data) {
+    (void)env;
+    sort_job* j = (sort_job*)data;
+    pthread_mutex_lock(&g_lock);
+    j->status = gs_sorter_sort(j->sorter, j->mvp, j->idx, j->sortc, j->renderc, j->pre, j->has_tr ? j->transforms : NULL, j->out,
+                               j->out ? &j->stats : NULL);
+    if (j->status < 0) snprintf(j->err, sizeof j->err, "libgsplat_hip status %d: %s", j->status, gs_last_error());   /* thread-local */
+    pthread_mutex_unlock(&g_lock);
+}
+
+static void sort_complete(napi_env env, napi_status status, void* data) {
+    sort_job* j = (sort_job*)data;
+    napi_value cb, undef, args[2], r;
+    napi_get_undefined(env, &undef);
+    napi_get_reference_value(env, j->cb, &cb);
+    if (status != napi_ok || j->status < 0) {
+        napi_value msg;
+        napi_create_string_utf8(env, status != napi_ok ? "sorterSortAsync: the work item was cancelled" : j->err, NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &args[0]);
+        args[1] = undef;
+    } else {
+        napi_get_null(env, &args[0]);
+        napi_create_object(env, &r);
+        set(env, r, "status", j->status);
+        set(env, r, "sortTime", j->stats.device_ms);
+        set(env, r, "keyMin", j->stats.key_min);
+        set(env, r, "keyMax", j->stats.key_max);
+        set(env, r, "clamped", j->stats.clamped);
+        set(env, r, "passes", j->stats.passes);
+        set(env, r, "resultCount", j->stats.result_count);
+        args[1] = r;
+    }
+    napi_delete_reference(env, j->cb);
+    for (int k = 0; k < 3; k++)
+        if (j->keep[k]) napi_delete_reference(env, j->keep[k]);
+    napi_delete_async_work(env, j->work);
+    free(j);
+    napi_value ignored;
+    napi_call_function(env, undef, cb, 2, args, &ignored);
+}
+
+static napi_value SorterSortAsync(napi_env env, napi_callback_info info) {
+    ARGS(9)
+    void *mvp, *idx, *pre, *tr, *out;
+    size_t mb, ib, pb, tb, ob;
+    if (!get_bytes(env, argv[1], &mvp, &mb) || mb < 64 || !get_bytes(env, argv[2], &idx, &ib) ||
+        !get_bytes(env, argv[5], &pre, &pb) || !get_bytes(env, argv[6], &tr, &tb) || !get_bytes(env, argv[7], &out, &ob)) {
+        napi_throw_type_error(env, NULL, "sorterSortAsync: bad buffer argument");
+        return NULL;
+    }
+    const uint32_t sortc = get_u32(env, argv[3]), renderc = get_u32(env, argv[4]);
+    if ((idx && ib < (size_t)renderc * 4) || (out && ob < (size_t)renderc * 4) || (tr && tb < 16 * 4 * GS_MAX_SCENES)) {
+        napi_throw_range_error(env, NULL, "sorterSortAsync: buffer shorter than renderCount");
+        return NULL;
+    }
+    napi_valuetype ft;
+    if (napi_typeof(env, argv[8], &ft) != napi_ok || ft != napi_function) {
+        napi_throw_type_error(env, NULL, "sorterSortAsync: callback");
+        return NULL;
+    }
+    sort_job* j = (sort_job*)calloc(1, sizeof *j);
+    if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    j->sorter = (gs_sorter*)get_external(env, argv[0]);
+    memcpy(j->mvp, mvp, 64);
+    if (tr) { memcpy(j->transforms, tr, sizeof j->transforms); j->has_tr = 1; }
+    j->idx = (const uint32_t*)idx; j->pre = pre; j->out = (uint32_t*)out;
+    j->sortc = sortc; j->renderc = renderc;
+    napi_create_reference(env, argv[8], 1, &j->cb);
+    const int held[3] = {2, 5, 7};                         /* indexes, precomputed, out: alive until the callback */
+    for (int k = 0; k < 3; k++) {
+        napi_valuetype t;
+        napi_typeof(env, argv[held[k]], &t);
+        if (t == napi_object) napi_create_reference(env, argv[held[k]], 1, &j->keep[k]);
+    }
+    napi_value name;
+    napi_create_string_utf8(env, "gsplat.sorterSort", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, sort_execute, sort_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        napi_throw_error(env, NULL, "sorterSortAsync: could not queue the work item");
+        return NULL;
+    }
+    return NULL;
+}
+
 /* meshCreate(ctx, maxSplatCount, shDegree, flags) */
 static napi_value MeshCreate(napi_env env, napi_callback_info info) {
     ARGS(4)
     gs_mesh* m = NULL;
-    int st = gs_mesh_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3]), &m);
+    int st;
+
+    LOCKED(st = gs_mesh_create((gs_context*)get_external(env, argv[0]), get_u32(env, argv[1]), get_u32(env, argv[2]), get_u32(env, argv[3]), &m));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_external(env, m, NULL, NULL, &r));
@@ -174,7 +296,7 @@ static napi_value MeshCreate(napi_env env, napi_callback_info info) {
 }
 static napi_value MeshDestroy(napi_env env, napi_callback_info info) {
     ARGS(1)
-    gs_mesh_destroy((gs_mesh*)get_external(env, argv[0]));
+    LOCKED(gs_mesh_destroy((gs_mesh*)get_external(env, argv[0])));
     return NULL;
 }
 /* meshUpload(mesh, from, count, centers F32, covF32|null, covF16(Uint16)|null, rgba U8, shF16(Uint16)|null) */
@@ -189,8 +311,10 @@ static napi_value MeshUpload(napi_env env, napi_callback_info info) {
         napi_throw_range_error(env, NULL, "meshUpload: buffer shorter than count");
         return NULL;
     }
-    int st = gs_mesh_upload((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const float*)p[0], (const float*)p[1],
-                            (const uint16_t*)p[2], (const uint8_t*)p[3], (const uint16_t*)p[4]);
+    int st;
+
+    LOCKED(st = gs_mesh_upload((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const float*)p[0], (const float*)p[1],
+                            (const uint16_t*)p[2], (const uint8_t*)p[3], (const uint16_t*)p[4]));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -237,8 +361,10 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     if (idx && ib < (size_t)renderc * 4) { napi_throw_range_error(env, NULL, "sortedIndexes shorter than renderCount"); return NULL; }
     gs_render_stats stats;
     memset(&stats, 0, sizeof stats);
-    int st = gs_mesh_render((gs_mesh*)get_external(env, argv[0]), &cam, (const uint32_t*)idx, (gs_sorter*)get_external(env, argv[3]),
-                            renderc, (uint8_t*)out, NULL, &stats);
+    int st;
+
+    LOCKED(st = gs_mesh_render((gs_mesh*)get_external(env, argv[0]), &cam, (const uint32_t*)idx, (gs_sorter*)get_external(env, argv[3]),
+                            renderc, (uint8_t*)out, NULL, &stats));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_object(env, &r));
@@ -277,7 +403,9 @@ static napi_value MeshUploadSceneIndexes(napi_env env, napi_callback_info info) 
     if (!get_bytes(env, argv[3], &p, &b) || !p) { napi_throw_type_error(env, NULL, "meshUploadSceneIndexes: bad buffer"); return NULL; }
     const uint32_t count = get_u32(env, argv[2]);
     if (b < (size_t)count * 4) { napi_throw_range_error(env, NULL, "meshUploadSceneIndexes: buffer shorter than count"); return NULL; }
-    int st = gs_mesh_upload_scene_indexes((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint32_t*)p);
+    int st;
+
+    LOCKED(st = gs_mesh_upload_scene_indexes((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint32_t*)p));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -310,7 +438,9 @@ static napi_value MeshSetScenes(napi_env env, napi_callback_info info) {
         if (nb < want) { napi_throw_range_error(env, NULL, "meshSetScenes: array shorter than sceneCount"); return NULL; }
         memcpy(fields[f].dst, d, want);
     }
-    int st = gs_mesh_set_scenes((gs_mesh*)get_external(env, argv[0]), &sp);
+    int st;
+
+    LOCKED(st = gs_mesh_set_scenes((gs_mesh*)get_external(env, argv[0]), &sp));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -318,14 +448,18 @@ static napi_value MeshSetScenes(napi_env env, napi_callback_info info) {
 /* sorterBindMesh(sorter, mesh|null) */
 static napi_value SorterBindMesh(napi_env env, napi_callback_info info) {
     ARGS(2)
-    int st = gs_sorter_bind_mesh((gs_sorter*)get_external(env, argv[0]), (gs_mesh*)get_external(env, argv[1]));
+    int st;
+
+    LOCKED(st = gs_sorter_bind_mesh((gs_sorter*)get_external(env, argv[0]), (gs_mesh*)get_external(env, argv[1])));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
 /* sorterSetFrustumCull(sorter, enable) */
 static napi_value SorterSetFrustumCull(napi_env env, napi_callback_info info) {
     ARGS(2)
-    int st = gs_sorter_set_frustum_cull((gs_sorter*)get_external(env, argv[0]), (int)get_u32(env, argv[1]));
+    int st;
+
+    LOCKED(st = gs_sorter_set_frustum_cull((gs_sorter*)get_external(env, argv[0]), (int)get_u32(env, argv[1])));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -340,8 +474,10 @@ static napi_value SorterSortGathered(napi_env env, napi_callback_info info) {
     }
     gs_sort_stats stats;
     memset(&stats, 0, sizeof stats);
-    int st = gs_sorter_sort_gathered((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, get_u32(env, argv[2]), NULL, NULL,
-                                     (uint32_t*)out, out ? &stats : NULL);
+    int st;
+
+    LOCKED(st = gs_sorter_sort_gathered((gs_sorter*)get_external(env, argv[0]), (const float*)mvp, get_u32(env, argv[2]), NULL, NULL,
+                                     (uint32_t*)out, out ? &stats : NULL));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_object(env, &r));
@@ -360,8 +496,10 @@ static napi_value TreeCreate(napi_env env, napi_callback_info info) {
     const uint32_t count = get_u32(env, argv[3]);
     if (cb < (size_t)count * 12 || (k && kb < count)) { napi_throw_range_error(env, NULL, "treeCreate: buffer shorter than count"); return NULL; }
     gs_tree* t = NULL;
-    int st = gs_tree_create((gs_context*)get_external(env, argv[0]), (const float*)c, (const uint8_t*)k, count, get_u32(env, argv[4]),
-                            get_u32(env, argv[5]), get_u32(env, argv[6]), &t);
+    int st;
+
+    LOCKED(st = gs_tree_create((gs_context*)get_external(env, argv[0]), (const float*)c, (const uint8_t*)k, count, get_u32(env, argv[4]),
+                            get_u32(env, argv[5]), get_u32(env, argv[6]), &t));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_external(env, t, NULL, NULL, &r));
@@ -369,14 +507,16 @@ static napi_value TreeCreate(napi_env env, napi_callback_info info) {
 }
 static napi_value TreeDestroy(napi_env env, napi_callback_info info) {
     ARGS(1)
-    gs_tree_destroy((gs_tree*)get_external(env, argv[0]));
+    LOCKED(gs_tree_destroy((gs_tree*)get_external(env, argv[0])));
     return NULL;
 }
 /* treeInfo(tree) -> {leaves, allLeaves, nodes, splats} */
 static napi_value TreeInfo(napi_env env, napi_callback_info info) {
     ARGS(1)
     gs_tree_info ti;
-    int st = gs_tree_get_info((gs_tree*)get_external(env, argv[0]), &ti);
+    int st;
+
+    LOCKED(st = gs_tree_get_info((gs_tree*)get_external(env, argv[0]), &ti));
     if (st < 0) return throw_gs(env, st);
     napi_value r;
     NAPI_OK(napi_create_object(env, &r));
@@ -408,7 +548,9 @@ static napi_value TreeGather(napi_env env, napi_callback_info info) {
     if (gs_tree_get_info(t, &ti) < 0) return throw_gs(env, GS_ERR_INVALID);
     if (out && ob < (size_t)ti.splats * 4) { napi_throw_range_error(env, NULL, "treeGather: out shorter than the tree's splat count"); return NULL; }
     uint32_t render_count = 0;
-    int st = gs_tree_gather(t, &gp, (gs_sorter*)get_external(env, argv[6]), &render_count, (uint32_t*)out);
+    int st;
+
+    LOCKED(st = gs_tree_gather(t, &gp, (gs_sorter*)get_external(env, argv[6]), &render_count, (uint32_t*)out));
     if (st < 0) return throw_gs(env, st);
     return num(env, render_count);
 }
@@ -421,7 +563,9 @@ static napi_value AssetLoad(napi_env env, napi_callback_info info) {
     size_t nb;
     if (!get_bytes(env, argv[0], &data, &nb) || !data) { napi_throw_type_error(env, NULL, "assetLoad: bytes"); return NULL; }
     gs_asset* a = NULL;
-    int st = gs_asset_open(data, nb, get_u32(env, argv[1]), get_u32(env, argv[2]), &a);
+    int st;
+
+    LOCKED(st = gs_asset_open(data, nb, get_u32(env, argv[1]), get_u32(env, argv[2]), &a));
     if (st < 0) return throw_gs(env, st);
     gs_asset_info ai;
     gs_asset_get_info(a, &ai);
@@ -437,9 +581,9 @@ static napi_value AssetLoad(napi_env env, napi_callback_info info) {
     if (ncoef) {
         if (ai.sh_level == 2) { NEWARR("sh", napi_uint8_array, (size_t)n * ncoef, 1, sh) } else { NEWARR("sh", napi_uint16_array, (size_t)n * ncoef, 2, sh) }
     }
-    st = gs_asset_fill(a, get_u32(env, argv[3]), (float*)centers, half ? NULL : (float*)cov, half ? (uint16_t*)cov : NULL, (uint8_t*)rgba,
-                       (ncoef && ai.sh_level != 2) ? (uint16_t*)sh : NULL, (ncoef && ai.sh_level == 2) ? (uint8_t*)sh : NULL, NULL, NULL);
-    gs_asset_close(a);
+    LOCKED(st = gs_asset_fill(a, get_u32(env, argv[3]), (float*)centers, half ? NULL : (float*)cov, half ? (uint16_t*)cov : NULL, (uint8_t*)rgba,
+                       (ncoef && ai.sh_level != 2) ? (uint16_t*)sh : NULL, (ncoef && ai.sh_level == 2) ? (uint8_t*)sh : NULL, NULL, NULL));
+    LOCKED(gs_asset_close(a));
     if (st < 0) return throw_gs(env, st);
     set(env, r, "splatCount", n);
     set(env, r, "shDegree", ai.sh_degree);
@@ -454,7 +598,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount},       {"contextCreate", ContextCreate}, {"contextDestroy", ContextDestroy},
         {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},
-        {"sorterSort", SorterSort},         {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
+        {"sorterSort", SorterSort},         {"sorterSortAsync", SorterSortAsync}, {"meshCreate", MeshCreate},       {"meshDestroy", MeshDestroy},
         {"meshUpload", MeshUpload},         {"meshRender", MeshRender},       {"meshUploadShU8", MeshUploadShU8},
         {"meshUploadSceneIndexes", MeshUploadSceneIndexes},                   {"meshSetScenes", MeshSetScenes},
         {"sorterBindMesh", SorterBindMesh}, {"sorterSetFrustumCull", SorterSetFrustumCull}, {"sorterSortGathered", SorterSortGathered},

@@ -79,6 +79,28 @@ def test_sort_through_the_js_protocol_is_bit_exact(tmp_path, name, mode):
 
 
 @pytest.mark.gpu
+def test_sort_seam_is_asynchronous_like_the_reference_worker(tmp_path):
+    """postMessage returns before sortDone fires (src/worker/SortWorker.js:62-80 replies from a worker thread), messages are
+    handled in posting order, and both results are the reference's."""
+    _built()
+    import oracle
+    case = [c for c in kat_cases.CASES if c["name"] == "permuted_partial"][0]
+    args = kat_cases.make_case(case)
+    inp, out_a, out_b = str(tmp_path / "in.bin"), str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    _write_case(inp, args)
+    res = subprocess.run(["node", "async_via_js.js", inp, out_a, out_b], cwd=NODE_DIR, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["repliesAtReturn"] == 0, "a sortDone fired before postMessage returned"
+    assert info["events"] == ["posted", "sortDone1", "sortDone2"]
+    kw = dict(sort_count=args["sort_count"], render_count=args["render_count"], precision=args["precision"])
+    np.testing.assert_array_equal(np.fromfile(out_a, dtype=np.uint32),
+                                  oracle.sort_indexes(args["indexes"], args["centers4"], args["mvp"], **kw))
+    np.testing.assert_array_equal(np.fromfile(out_b, dtype=np.uint32),
+                                  oracle.sort_indexes(args["indexes"], args["centers4"], info["mvpB"], **kw))
+
+
+@pytest.mark.gpu
 def test_frustum_culled_sort_through_the_js_protocol(tmp_path):
     """worker.setFrustumCull(true): the sortDone reply carries the kept list and its length as splatRenderCount."""
     import oracle

@@ -468,8 +468,13 @@ int gs_asset_fill(gs_asset* a, uint32_t min_alpha, float* centers, float* cov_f3
             const double w = comp(a, srow, 3, false), x = comp(a, srow, 4, false), y = comp(a, srow, 5, false), z = comp(a, srow, 6, false);
             if (scales) { scales[3 * (size_t)i] = (float)sx; scales[3 * (size_t)i + 1] = (float)sy; scales[3 * (size_t)i + 2] = (float)sz; }
             if (rotations) {
-                rotations[4 * (size_t)i] = (float)x; rotations[4 * (size_t)i + 1] = (float)y;
-                rotations[4 * (size_t)i + 2] = (float)z; rotations[4 * (size_t)i + 3] = (float)w;
+                // fillSplatScaleRotationArray (SplatBuffer.js:407-424): Quaternion.normalize, then ensurePositiveW
+                double q[4] = {x, y, z, w};
+                double l = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                if (l == 0) { q[0] = q[1] = q[2] = 0; q[3] = 1; }
+                else { l = 1 / l; for (int k = 0; k < 4; k++) q[k] = q[k] * l; }
+                const double flip = q[3] < 0 ? -1 : 1;
+                for (int k = 0; k < 4; k++) rotations[4 * (size_t)i + k] = (float)(q[k] * flip);
             }
             if (cov_f32 || cov_f16) {
                 // Matrix4.makeRotationFromQuaternion = compose(zero, q, one) (three r160)

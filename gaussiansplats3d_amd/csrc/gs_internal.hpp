@@ -152,9 +152,20 @@ struct ScopedDevice {
 // ---------------------------------------------------------------------------------------------------
 // sorter object (sorter.hip)
 // ---------------------------------------------------------------------------------------------------
+constexpr uint32_t SORT_SHARDS = 32;   // min / max words per sort: workgroup b reduces into shard b % 32
 struct SortFrame {            // device-resident per-sort scalars
-    int32_t key_min;          // atomicMin target, initialised to +2147483640 (sorter.cpp:25)
-    int32_t key_max;          // atomicMax target, initialised to -2147483640 (sorter.cpp:24)
+    int32_t key_min[SORT_SHARDS];   // atomicMin targets, initialised to +2147483640 (sorter.cpp:25)
+    int32_t key_max[SORT_SHARDS];   // atomicMax targets, initialised to -2147483640 (sorter.cpp:24)
+    __host__ __device__ int32_t lo() const {
+        int32_t v = key_min[0];
+        for (uint32_t k = 1; k < SORT_SHARDS; k++) v = key_min[k] < v ? key_min[k] : v;
+        return v;
+    }
+    __host__ __device__ int32_t hi() const {
+        int32_t v = key_max[0];
+        for (uint32_t k = 1; k < SORT_SHARDS; k++) v = key_max[k] > v ? key_max[k] : v;
+        return v;
+    }
     uint32_t clamped;
     uint32_t kept;            // frustum-cull variant: list positions that survive = length of the sorted result
 };

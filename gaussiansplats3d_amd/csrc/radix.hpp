@@ -74,42 +74,47 @@ struct ArrayLoader {
     __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (uint32_t)keys[j]; }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return vals[j]; }
-    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const { k = (uint32_t)keys[j]; v = vals[j]; }
+    // fetch = the memory reads of element j, decode = the arithmetic on them (none here)
+    struct Raw { uint32_t key, val; };
+    __device__ __forceinline__ Raw fetch(uint32_t j) const { return Raw{(uint32_t)keys[j], vals[j]}; }
+    __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const { k = r.key; v = r.val; }
     __device__ __forceinline__ bool valid(uint32_t) const { return true; }
     __device__ __forceinline__ void note_clamp(bool) const {}
-};
-
-// Second (last) pass of a 16-bit sort whose first pass left ONE word per element: the remaining digit in the payload's
-// spare top byte, (digit << 24) | payload, payload < 2^24.  A scatter pass is bound by its store instructions (runs of ~16
-// elements per digit), so not writing - and not re-reading - a separate key array is worth a third of the pass.
-struct PackedLoader {
-    const uint32_t* __restrict__ packed;
-    const uint32_t* __restrict__ n_dev;   // device-resident count (nullable)
-    uint32_t n_host;
-    __device__ __forceinline__ void prepare() {}
-    __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
-    __device__ __forceinline__ uint32_t key(uint32_t j) const { return packed[j] >> 24; }
-    __device__ __forceinline__ uint32_t val(uint32_t j) const { return packed[j] & 0x00FFFFFFu; }
-    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const {
-        const uint32_t w = packed[j];
-        k = w >> 24;
-        v = w & 0x00FFFFFFu;
-    }
-    __device__ __forceinline__ bool valid(uint32_t) const { return true; }
 };
 
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// XCD-aware chunk order for walks over the depth-sorted list (the binner, tile_bin.hip).  Workgroup b runs on XCD b % 8
+// (observed dispatch rule, used for speed only) and each XCD has an L2 of its own.  Giving one XCD RUNS of neighbouring
+// chunks makes the 8-byte rect gathers of Morton neighbours (similar depth, so close in the sorted list) find the line a
+// neighbour fetched into that L2.  Runs, not one contiguous eighth per XCD: the near end of the list holds most of the
+// visible splats, and an XCD that owned it alone finished last (C3 binning 74 -> 92 us; with runs it keeps the balance).
+// The radix passes gain nothing from either order (measured) and keep chunk = workgroup.
+#ifndef GS_XCD_RUN
+#define GS_XCD_RUN 16
+#endif
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t grid) {
+#if GS_XCD_RUN
+    if (grid % (8u * GS_XCD_RUN)) return b;                       // only grids that split evenly (the binner's 2048)
+    const uint32_t x = b % 8u, k = b / 8u;                       // the k-th workgroup of XCD x
+    return ((k / GS_XCD_RUN) * 8u + x) * GS_XCD_RUN + k % GS_XCD_RUN;
+#else
+    (void)grid;
+    return b;
+#endif
+}
+
 struct RadixChunk {
-    uint32_t n, tile_begin, tile_end;
+    uint32_t n, tile_begin, tile_end, id;
 };
 __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
     const uint32_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
     RadixChunk c;
     c.n = n;
-    c.tile_begin = min(blockIdx.x * per, tiles);
+    c.id = blockIdx.x;
+    c.tile_begin = min(c.id * per, tiles);
     c.tile_end = min(c.tile_begin + per, tiles);
     return c;
 }
@@ -138,17 +143,6 @@ __device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint
                 atomicAdd(&hist[(w[c] >> shift) & 255u], 1u);
             }
         }
-    }
-}
-__device__ __forceinline__ void hist_full_tile(const PackedLoader& ld, uint32_t base, int shift, uint32_t* hist) {
-    const uint4* src = reinterpret_cast<const uint4*>(ld.packed + base);
-#pragma unroll
-    for (uint32_t l = threadIdx.x; l < (uint32_t)RADIX_TILE / 4u; l += HIST_THREADS) {
-        const uint4 v = src[l];
-        atomicAdd(&hist[((v.x >> 24) >> shift) & 255u], 1u);
-        atomicAdd(&hist[((v.y >> 24) >> shift) & 255u], 1u);
-        atomicAdd(&hist[((v.z >> 24) >> shift) & 255u], 1u);
-        atomicAdd(&hist[((v.w >> 24) >> shift) & 255u], 1u);
     }
 }
 template <class Loader>
@@ -184,10 +178,10 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
     __syncthreads();
     if (tid >= RADIX_BINS) return;
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
-    block_hist[blockIdx.x * RADIX_BINS + tid] = total;           // one coalesced 1 KiB row per workgroup
+    block_hist[ch.id * RADIX_BINS + tid] = total;                // one coalesced 1 KiB row per workgroup
     // Group rows.  Same-address atomics serialise in the fabric (~12 ns each, MI355X_MICROARCH.md row "fanin"): with 32
     // adders per word they stay < 1 us, where one word per digit for the whole grid cost 10-15 us per pass (A/B r01b).
-    if (total) atomicAdd(&digit_total[(blockIdx.x / RADIX_GROUP) * RADIX_BINS + tid], total);
+    if (total) atomicAdd(&digit_total[(ch.id / RADIX_GROUP) * RADIX_BINS + tid], total);
 }
 
 
@@ -211,7 +205,7 @@ constexpr int SCATTER_PARTS = SCATTER_THREADS / RADIX_BINS;     // threads per d
 static_assert(SCATTER_THREADS % RADIX_BINS == 0 && 2 * SCATTER_PARTS <= SCATTER_WAVES, "offset prologue layout");
 
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
-__global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (sizeof(KeyOutT) == 2 ? 8 : 6))) void k_radix_scatter(Loader ld, int shift,
+__global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld, int shift,
                                                                       const uint32_t* __restrict__ block_hist,
                                                                       const uint32_t* __restrict__ group_hist,
                                                                       KeyOutT* __restrict__ keys_out,
@@ -234,7 +228,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (size
     {   // this workgroup's first output slot per digit = keys with a smaller digit + keys of this digit in earlier
         // workgroups; two threads per digit split the rows, every load is independent of the others
         const uint32_t d = tid & 255u, half = tid >> 8;      // `half` = which of the SCATTER_PARTS row subsets
-        const uint32_t g = blockIdx.x / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
+        const uint32_t g = ch.id / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
         // fixed trip counts, fully unrolled and predicated: every load of the prologue is in flight at once (one memory
         // round trip instead of a chain of batches: isolated C3 sort 0.182 -> 0.176 ms)
         constexpr uint32_t GROUP_LOADS = (RADIX_MAX_GROUPS + SCATTER_PARTS - 1) / SCATTER_PARTS;
@@ -248,7 +242,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (size
 #pragma unroll
         for (uint32_t k = 0; k < ROW_LOADS; k++) {
             const uint32_t r = g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS;
-            rv[k] = r < blockIdx.x ? block_hist[r * RADIX_BINS + d] : 0u;
+            rv[k] = r < ch.id ? block_hist[r * RADIX_BINS + d] : 0u;
         }
         uint32_t before = 0, all = 0;
 #pragma unroll
@@ -282,18 +276,23 @@ __global__ __launch_bounds__(SCATTER_THREADS, (SCATTER_THREADS > 512 ? 4 : (size
     }
 
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
-        const uint32_t tile_base = tile * RADIX_TILE;
         uint32_t key[SCATTER_ITEMS], val[SCATTER_ITEMS], rank[SCATTER_ITEMS];
         bool ok[SCATTER_ITEMS];
-        // wave-striped load: the stable order inside a tile is (wave, r, lane)
-        const uint32_t wbase = tile_base + wave * (64 * SCATTER_ITEMS) + lane;
+        typename Loader::Raw raw[SCATTER_ITEMS];
+        // wave-striped load: the stable order inside a tile is (wave, r, lane).  All memory reads first, then the arithmetic
+        // on them.  (Issuing the next tile's reads before ranking this one changed nothing: 0.100 vs 0.100 ms per C3 sort.)
+        const uint32_t wbase = tile * RADIX_TILE + wave * (64 * SCATTER_ITEMS) + lane;
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
             const uint32_t j = wbase + r * 64;
             ok[r] = j < ch.n && ld.valid(j);      // a loader that drops elements turns the pass into a stable compaction
+            if (ok[r]) raw[r] = ld.fetch(j);
+        }
+#pragma unroll
+        for (int r = 0; r < SCATTER_ITEMS; r++) {
             key[r] = 0xFFFFFFFFu;
             val[r] = 0u;
-            if (ok[r]) ld.load(j, key[r], val[r]);
+            if (ok[r]) ld.decode(raw[r], key[r], val[r]);
         }
 #pragma unroll
         for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;

@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     // housekeeping folded into the first kernel of a sort (two launches and their boundaries saved per sort)
     for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;   // sorter.cpp:25
+        p.next_frame->key_max[t] = -2147483640;  // sorter.cpp:24
+    }
     if (t == 0) {
-        p.next_frame->key_min = 2147483640;      // sorter.cpp:25
-        p.next_frame->key_max = -2147483640;     // sorter.cpp:24
         p.next_frame->clamped = 0;
         p.next_frame->kept = 0;
     }
@@ -163,8 +165,10 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     if (threadIdx.x == 0) {
         lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
         hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-        atomicMin(&p.frame->key_min, lo);
-        atomicMax(&p.frame->key_max, hi);
+        // one device-scope word retires ~88 atomics per microsecond: 2 x 512 workgroups on one pair of words were ~10 us of
+        // this kernel's tail.  SORT_SHARDS pairs, reduced by whoever reads them (SortFrame::lo() / hi()).
+        atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
+        atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
     }
 }
 
@@ -204,9 +208,11 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
     const uint32_t stride = gridDim.x * blockDim.x;               // a multiple of 64
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;
+        p.next_frame->key_max[t] = -2147483640;
+    }
     if (t == 0) {
-        p.next_frame->key_min = 2147483640;
-        p.next_frame->key_max = -2147483640;
         p.next_frame->clamped = 0;
         p.next_frame->kept = 0;
     }
@@ -313,17 +319,15 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
     if (threadIdx.x == 0) {
         lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
         hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-        atomicMin(&p.frame->key_min, lo);
-        atomicMax(&p.frame->key_max, hi);
+        atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
+        atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
         atomicAdd(&p.frame->kept, s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3]);
     }
 }
 
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
-// PACK (16-bit sorts of at most 2^24 splats): the payload carries the key's high byte, (key' >> 8) << 24 | payload, and the
-// pass writes no key array (radix.hpp, PackedLoader).
-template <bool CULL, bool PACK>
+template <bool CULL>
 struct DepthLoaderT {
     const int32_t* __restrict__ keys;
     const unsigned long long* __restrict__ keep;   // CULL: 1 bit per list position (k_depth_key_cull)
@@ -337,15 +341,16 @@ struct DepthLoaderT {
     float range_map;
 
     __device__ __forceinline__ void prepare() {
-        lo = frame->key_min;
-        const int32_t hi = frame->key_max;
+        lo = frame->lo();
+        const int32_t hi = frame->hi();
         // sorter.cpp:142-143: (float)(range-1) / ((float)max - (float)min), fp32, correctly rounded
         range_map = __fdiv_rn((float)(range - 1), __fsub_rn((float)hi, (float)lo));
     }
     __device__ __forceinline__ uint32_t count() const { return render_count - sort_start; }
-    __device__ __forceinline__ uint32_t bucket(uint32_t i) const {
+    __device__ __forceinline__ uint32_t bucket(uint32_t i) const { return bucket_of(keys[i]); }
+    __device__ __forceinline__ uint32_t bucket_of(int32_t depth) const {
         // sorter.cpp:146: (int)((float)(mapped - min) * rangeMap): int32 wrap, one fp32 multiply, truncation
-        const int32_t diff = (int32_t)((uint32_t)keys[i] - (uint32_t)lo);
+        const int32_t diff = (int32_t)((uint32_t)depth - (uint32_t)lo);
         const float f = __fmul_rn((float)diff, range_map);
         if (!(f >= -2147483648.0f && f < 2147483648.0f)) return 0u;   // NaN (hi==lo) / overflow: WASM -> bucket 0
         const int32_t b = (int32_t)f;
@@ -364,15 +369,20 @@ struct DepthLoaderT {
         const uint32_t o = idx ? min(idx[i], last_splat) : i;
         return map ? map[o] : o;
     }
-    __device__ __forceinline__ uint32_t val(uint32_t j) const {
-        const uint32_t v = payload(render_count - 1 - j);
-        return PACK ? (((key(j) >> 8) << 24) | v) : v;
-    }
-    __device__ __forceinline__ void load(uint32_t j, uint32_t& k, uint32_t& v) const {
+    __device__ __forceinline__ uint32_t val(uint32_t j) const { return payload(render_count - 1 - j); }
+    // fetch = the memory reads of element j, decode = the arithmetic on them: the scatter issues the fetches of its next
+    // tile before it ranks the current one (radix.hpp)
+    struct Raw { int32_t depth; uint32_t payload; };
+    __device__ __forceinline__ Raw fetch(uint32_t j) const {
         const uint32_t i = render_count - 1 - j;
-        k = (range - 1) - bucket(i);
-        v = payload(i);
-        if (PACK) v |= (k >> 8) << 24;
+        Raw r;
+        r.depth = keys[i];
+        r.payload = payload(i);
+        return r;
+    }
+    __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const {
+        k = (range - 1) - bucket_of(r.depth);
+        v = r.payload;
     }
     __device__ __forceinline__ bool valid(uint32_t j) const {
         if (!CULL) return true;
@@ -380,10 +390,8 @@ struct DepthLoaderT {
         return (keep[i >> 6] >> (i & 63u)) & 1ull;
     }
 };
-typedef DepthLoaderT<false, false> DepthLoader;
-typedef DepthLoaderT<true, false> DepthLoaderCull;
-typedef DepthLoaderT<false, true> DepthLoaderPacked;
-typedef DepthLoaderT<true, true> DepthLoaderCullPacked;
+typedef DepthLoaderT<false> DepthLoader;
+typedef DepthLoaderT<true> DepthLoaderCull;
 
 __global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ map, uint32_t* __restrict__ out,
                             uint32_t n, uint32_t last_splat) {
@@ -442,7 +450,11 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
         st = GS_ERR_HIP;
     }
     if (st == GS_OK) {
-        const SortFrame init[2] = {{2147483640, -2147483640, 0, 0}, {2147483640, -2147483640, 0, 0}};
+        SortFrame init[2];
+        for (SortFrame& f : init) {
+            for (uint32_t k = 0; k < SORT_SHARDS; k++) { f.key_min[k] = 2147483640; f.key_max[k] = -2147483640; }
+            f.clamped = f.kept = 0;
+        }
         if (hipMemcpy(s->frame.p, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemset(s->radix.digit_total.p, 0, sizeof(uint32_t) * RADIX_TOTAL_WORDS) != hipSuccess) {
             gs_set_error("initialising the sorter scratch failed");
@@ -506,14 +518,15 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     GS_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
     GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    int32_t key_lo = f.lo(), key_hi = f.hi();
     if (s->last_sort == 0) {                       // nothing was keyed: the frame belongs to an earlier sort
-        f.key_min = 2147483640;
-        f.key_max = -2147483640;
+        key_lo = 2147483640;
+        key_hi = -2147483640;
         f.clamped = 0;
     }
     stats->device_ms = ms;
-    stats->key_min = f.key_min;
-    stats->key_max = f.key_max;
+    stats->key_min = key_lo;
+    stats->key_max = key_hi;
     stats->clamped = f.clamped;
     stats->passes = s->last_passes;
     stats->result_count = s->last_culled ? f.kept : s->last_render;
@@ -611,13 +624,12 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
-        static const uint32_t key_grid = getenv("GSPLAT_KEY_GRID") ? (uint32_t)atoi(getenv("GSPLAT_KEY_GRID")) : 2u;   // A/B
         if (cull && vec4)
             hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else if (cull)
             hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (vec4)
-            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * key_grid)), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else
             hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         GS_HIP(hipGetLastError());
@@ -633,9 +645,6 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
         const bool wide = s->precision > 16;
-        // two passes and every payload below 2^24: one word per element between the passes (radix.hpp, PackedLoader)
-        const bool packed = passes == 2 && s->uploaded <= (1u << 24) && (!map || s->bound_mesh->uploaded <= (1u << 24)) &&
-                            !getenv("GSPLAT_NO_PACKED_SORT");
         void* kbuf[2] = {s->keyA.p, s->keyB.p};
         uint32_t* vbuf[2] = {s->valA.as<uint32_t>(), s->valB.as<uint32_t>()};
         for (uint32_t p = 0; p < passes; p++) {
@@ -644,26 +653,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
             const uint32_t* n_dev = cull ? &kp.frame->kept : nullptr;
-            if (packed) {
-                if (p == 0 && cull) {
-                    DepthLoaderCullPacked dc = {};
-                    dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
-                    dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;
-                    DepthLoaderCullPacked h = dc;
-                    h.count_clamps = 1;
-                    GS_TRY((radix_pass<DepthLoaderCullPacked, uint16_t, false>(ex, h, dc, Rs, 0, 0, (uint16_t*)nullptr, vbuf[0])));
-                } else if (p == 0) {
-                    DepthLoaderPacked dp = {};
-                    dp.keys = dl.keys; dp.idx = dl.idx; dp.map = dl.map; dp.frame = dl.frame;
-                    dp.sort_start = dl.sort_start; dp.render_count = dl.render_count; dp.range = dl.range; dp.last_splat = dl.last_splat;
-                    DepthLoaderPacked h = dp;    // only the histogram launch counts clamped buckets (once per element)
-                    h.count_clamps = 1;
-                    GS_TRY((radix_pass<DepthLoaderPacked, uint16_t, false>(ex, h, dp, Rs, 0, 0, (uint16_t*)nullptr, vbuf[0])));
-                } else {
-                    PackedLoader pl = {vbuf[0], n_dev, Rs};
-                    GS_TRY((radix_pass<PackedLoader, uint16_t, false>(ex, pl, pl, Rs, 0, 1, (uint16_t*)nullptr, out_tail)));
-                }
-            } else if (p == 0 && cull) {
+            if (p == 0 && cull) {
                 DepthLoaderCull dc = {};
                 dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
                 dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;

@@ -35,12 +35,14 @@ __device__ __forceinline__ uint2 rect_to_bins(uint2 r, uint32_t list_shift) {
 
 struct BinChunk {
     uint32_t begin, end;   // batch indices (256 list positions per batch)
+    uint32_t id;           // chunk index: workgroups of one XCD walk neighbouring chunks of the sorted list (radix.hpp, xcd_chunk)
 };
 __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
     const uint32_t batches = (n + BIN_THREADS - 1) / BIN_THREADS;
     const uint32_t per = (batches + gridDim.x - 1) / gridDim.x;
     BinChunk c;
-    c.begin = min(blockIdx.x * per, batches);
+    c.id = xcd_chunk(blockIdx.x, gridDim.x);
+    c.begin = min(c.id * per, batches);
     c.end = min(c.begin + per, batches);
     return c;
 }
@@ -163,9 +165,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     if (lane == 0) s_w[wave] = t16;                        // the loop's trailing barrier makes s_w reusable
     __syncthreads();
     if (threadIdx.x == 0) {
-        block_sums[blockIdx.x] = sum;
-        block_sums[BIN_MAX_BLOCKS + blockIdx.x] = out - pos_begin;
-        block_sums[2 * BIN_MAX_BLOCKS + blockIdx.x] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+        block_sums[ch.id] = sum;
+        block_sums[BIN_MAX_BLOCKS + ch.id] = out - pos_begin;
+        block_sums[2 * BIN_MAX_BLOCKS + ch.id] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
     }
 }
 
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     __shared__ unsigned long long s_sum[4], s_before[4], s_t16[4];
     __shared__ uint32_t s_vis[4];
     __shared__ uint32_t s_hist[EMIT_ROWS][RADIX_BINS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, b = blockIdx.x, bin_grid = gridDim.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, bin_grid = gridDim.x;
+    const uint32_t b = xcd_chunk(blockIdx.x, bin_grid);       // the binning chunk this workgroup expands (same map as k_bin_count)
     constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;            // 8 workgroup sums per thread
     // total entries D and the entries of the workgroups before this one
     unsigned long long all = 0, before = 0;

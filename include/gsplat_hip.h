@@ -195,7 +195,8 @@ int gs_asset_get_info(gs_asset* a, gs_asset_info* info);
 /* SplatMesh.fillSplatDataArrays (src/splatmesh/SplatMesh.js:1853-1902) without a scene transform; any pointer may
  * be NULL.  centers float[3n]; cov_f32 float[6n] / cov_f16 half bits[6n] (covariance compression level 0 / 1);
  * rgba uint8[4n] with alpha zeroed below min_alpha; sh_f16 half bits[ncoef*n] (sh_level 1) or sh_u8 uint8[ncoef*n]
- * (sh_level 2), coefficient-major RGB triples; scales float[3n], rotations float[4n] (x,y,z,w) as stored. */
+ * (sh_level 2), coefficient-major RGB triples; scales float[3n], rotations float[4n] (x,y,z,w) normalised with
+ * w >= 0, as fillSplatScaleRotationArray returns them (SplatBuffer.js:349-437). */
 int gs_asset_fill(gs_asset* a, uint32_t min_alpha, float* centers, float* cov_f32, uint16_t* cov_f16, uint8_t* rgba,
                   uint16_t* sh_f16, uint8_t* sh_u8, float* scales, float* rotations);
 

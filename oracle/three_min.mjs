@@ -1,0 +1,332 @@
+// oracle/three_min.mjs — TEST INFRASTRUCTURE.  The handful of three.js r0.160.0 primitives that the reference's loader /
+// cull code calls (package-lock.json pins three 0.160.0; the package is a peer dependency and is not installed here, no
+// network).  Each method is restated from the r160 sources' semantics — same formula, same operation order — so that the
+// reference's OWN function text (src/loaders/SplatBuffer.js, src/loaders/ply/INRIAV1PlyParser.js,
+// Viewer.gatherSceneNodesForSort ...) can be executed under Node through oracle/three_loader.mjs to record goldens.
+// Nothing here is a copy of reference code; tests/test_three_min.py checks every primitive against independent arithmetic.
+
+export class Vector3 {
+  constructor(x = 0, y = 0, z = 0) { this.x = x; this.y = y; this.z = z; }
+  set(x, y, z) { if (z === undefined) z = this.z; this.x = x; this.y = y; this.z = z; return this; }
+  setScalar(s) { this.x = s; this.y = s; this.z = s; return this; }
+  clone() { return new Vector3(this.x, this.y, this.z); }
+  copy(v) { this.x = v.x; this.y = v.y; this.z = v.z; return this; }
+  add(v) { this.x += v.x; this.y += v.y; this.z += v.z; return this; }
+  sub(v) { this.x -= v.x; this.y -= v.y; this.z -= v.z; return this; }
+  addVectors(a, b) { this.x = a.x + b.x; this.y = a.y + b.y; this.z = a.z + b.z; return this; }
+  subVectors(a, b) { this.x = a.x - b.x; this.y = a.y - b.y; this.z = a.z - b.z; return this; }
+  multiplyScalar(s) { this.x *= s; this.y *= s; this.z *= s; return this; }
+  divideScalar(s) { return this.multiplyScalar(1 / s); }
+  min(v) { this.x = Math.min(this.x, v.x); this.y = Math.min(this.y, v.y); this.z = Math.min(this.z, v.z); return this; }
+  max(v) { this.x = Math.max(this.x, v.x); this.y = Math.max(this.y, v.y); this.z = Math.max(this.z, v.z); return this; }
+  dot(v) { return this.x * v.x + this.y * v.y + this.z * v.z; }
+  lengthSq() { return this.x * this.x + this.y * this.y + this.z * this.z; }
+  length() { return Math.sqrt(this.x * this.x + this.y * this.y + this.z * this.z); }
+  normalize() { return this.divideScalar(this.length() || 1); }
+  distanceTo(v) { return Math.sqrt(this.distanceToSquared(v)); }
+  distanceToSquared(v) { const dx = this.x - v.x, dy = this.y - v.y, dz = this.z - v.z; return dx * dx + dy * dy + dz * dz; }
+  crossVectors(a, b) {
+    const ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    this.x = ay * bz - az * by; this.y = az * bx - ax * bz; this.z = ax * by - ay * bx;
+    return this;
+  }
+  cross(v) { return this.crossVectors(this, v); }
+  // Vector3.applyMatrix4: perspective divide by the fourth row
+  applyMatrix4(m) {
+    const x = this.x, y = this.y, z = this.z, e = m.elements;
+    const w = 1 / (e[3] * x + e[7] * y + e[11] * z + e[15]);
+    this.x = (e[0] * x + e[4] * y + e[8] * z + e[12]) * w;
+    this.y = (e[1] * x + e[5] * y + e[9] * z + e[13]) * w;
+    this.z = (e[2] * x + e[6] * y + e[10] * z + e[14]) * w;
+    return this;
+  }
+  applyQuaternion(q) {
+    // r160: t = 2 * cross(q.xyz, v); v + q.w * t + cross(q.xyz, t)
+    const vx = this.x, vy = this.y, vz = this.z, qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+    const tx = 2 * (qy * vz - qz * vy), ty = 2 * (qz * vx - qx * vz), tz = 2 * (qx * vy - qy * vx);
+    this.x = vx + qw * tx + qy * tz - qz * ty;
+    this.y = vy + qw * ty + qz * tx - qx * tz;
+    this.z = vz + qw * tz + qx * ty - qy * tx;
+    return this;
+  }
+  setFromMatrixPosition(m) { const e = m.elements; this.x = e[12]; this.y = e[13]; this.z = e[14]; return this; }
+  equals(v) { return v.x === this.x && v.y === this.y && v.z === this.z; }
+  fromArray(array, offset = 0) { this.x = array[offset]; this.y = array[offset + 1]; this.z = array[offset + 2]; return this; }
+  toArray(array = [], offset = 0) { array[offset] = this.x; array[offset + 1] = this.y; array[offset + 2] = this.z; return array; }
+}
+
+export class Vector2 {
+  constructor(x = 0, y = 0) { this.x = x; this.y = y; }
+  set(x, y) { this.x = x; this.y = y; return this; }
+  copy(v) { this.x = v.x; this.y = v.y; return this; }
+  clone() { return new Vector2(this.x, this.y); }
+}
+
+export class Vector4 {
+  constructor(x = 0, y = 0, z = 0, w = 1) { this.x = x; this.y = y; this.z = z; this.w = w; }
+  set(x, y, z, w) { this.x = x; this.y = y; this.z = z; this.w = w; return this; }
+  copy(v) { this.x = v.x; this.y = v.y; this.z = v.z; this.w = (v.w !== undefined) ? v.w : 1; return this; }
+  clone() { return new Vector4(this.x, this.y, this.z, this.w); }
+}
+
+export class Quaternion {
+  constructor(x = 0, y = 0, z = 0, w = 1) { this._x = x; this._y = y; this._z = z; this._w = w; }
+  get x() { return this._x; } set x(v) { this._x = v; }
+  get y() { return this._y; } set y(v) { this._y = v; }
+  get z() { return this._z; } set z(v) { this._z = v; }
+  get w() { return this._w; } set w(v) { this._w = v; }
+  set(x, y, z, w) { this._x = x; this._y = y; this._z = z; this._w = w; return this; }
+  clone() { return new Quaternion(this._x, this._y, this._z, this._w); }
+  copy(q) { this._x = q.x; this._y = q.y; this._z = q.z; this._w = q.w; return this; }
+  length() { return Math.sqrt(this._x * this._x + this._y * this._y + this._z * this._z + this._w * this._w); }
+  normalize() {
+    let l = this.length();
+    if (l === 0) { this._x = 0; this._y = 0; this._z = 0; this._w = 1; } else {
+      l = 1 / l;
+      this._x = this._x * l; this._y = this._y * l; this._z = this._z * l; this._w = this._w * l;
+    }
+    return this;
+  }
+  // Quaternion.setFromRotationMatrix (m's upper 3x3 is a pure rotation): the r160 branch structure and formulas
+  setFromRotationMatrix(m) {
+    const te = m.elements, m11 = te[0], m12 = te[4], m13 = te[8], m21 = te[1], m22 = te[5], m23 = te[9],
+      m31 = te[2], m32 = te[6], m33 = te[10], trace = m11 + m22 + m33;
+    if (trace > 0) {
+      const s = 0.5 / Math.sqrt(trace + 1.0);
+      this._w = 0.25 / s; this._x = (m32 - m23) * s; this._y = (m13 - m31) * s; this._z = (m21 - m12) * s;
+    } else if (m11 > m22 && m11 > m33) {
+      const s = 2.0 * Math.sqrt(1.0 + m11 - m22 - m33);
+      this._w = (m32 - m23) / s; this._x = 0.25 * s; this._y = (m12 + m21) / s; this._z = (m13 + m31) / s;
+    } else if (m22 > m33) {
+      const s = 2.0 * Math.sqrt(1.0 + m22 - m11 - m33);
+      this._w = (m13 - m31) / s; this._x = (m12 + m21) / s; this._y = 0.25 * s; this._z = (m23 + m32) / s;
+    } else {
+      const s = 2.0 * Math.sqrt(1.0 + m33 - m11 - m22);
+      this._w = (m21 - m12) / s; this._x = (m13 + m31) / s; this._y = (m23 + m32) / s; this._z = 0.25 * s;
+    }
+    return this;
+  }
+}
+
+const _zero = new Vector3(0, 0, 0), _one = new Vector3(1, 1, 1), _v1 = new Vector3();
+
+export class Matrix4 {
+  constructor() { this.elements = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]; }
+  // arguments in row-major order, stored column-major
+  set(n11, n12, n13, n14, n21, n22, n23, n24, n31, n32, n33, n34, n41, n42, n43, n44) {
+    const te = this.elements;
+    te[0] = n11; te[4] = n12; te[8] = n13; te[12] = n14;
+    te[1] = n21; te[5] = n22; te[9] = n23; te[13] = n24;
+    te[2] = n31; te[6] = n32; te[10] = n33; te[14] = n34;
+    te[3] = n41; te[7] = n42; te[11] = n43; te[15] = n44;
+    return this;
+  }
+  identity() { return this.set(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1); }
+  clone() { return new Matrix4().fromArray(this.elements); }
+  copy(m) { const te = this.elements, me = m.elements; for (let i = 0; i < 16; i++) te[i] = me[i]; return this; }
+  fromArray(array, offset = 0) { for (let i = 0; i < 16; i++) this.elements[i] = array[i + offset]; return this; }
+  toArray(array = [], offset = 0) { for (let i = 0; i < 16; i++) array[offset + i] = this.elements[i]; return array; }
+  multiply(m) { return this.multiplyMatrices(this, m); }
+  premultiply(m) { return this.multiplyMatrices(m, this); }
+  multiplyMatrices(a, b) {
+    const ae = a.elements, be = b.elements, te = this.elements;
+    const a11 = ae[0], a12 = ae[4], a13 = ae[8], a14 = ae[12], a21 = ae[1], a22 = ae[5], a23 = ae[9], a24 = ae[13];
+    const a31 = ae[2], a32 = ae[6], a33 = ae[10], a34 = ae[14], a41 = ae[3], a42 = ae[7], a43 = ae[11], a44 = ae[15];
+    const b11 = be[0], b12 = be[4], b13 = be[8], b14 = be[12], b21 = be[1], b22 = be[5], b23 = be[9], b24 = be[13];
+    const b31 = be[2], b32 = be[6], b33 = be[10], b34 = be[14], b41 = be[3], b42 = be[7], b43 = be[11], b44 = be[15];
+    te[0] = a11 * b11 + a12 * b21 + a13 * b31 + a14 * b41;
+    te[4] = a11 * b12 + a12 * b22 + a13 * b32 + a14 * b42;
+    te[8] = a11 * b13 + a12 * b23 + a13 * b33 + a14 * b43;
+    te[12] = a11 * b14 + a12 * b24 + a13 * b34 + a14 * b44;
+    te[1] = a21 * b11 + a22 * b21 + a23 * b31 + a24 * b41;
+    te[5] = a21 * b12 + a22 * b22 + a23 * b32 + a24 * b42;
+    te[9] = a21 * b13 + a22 * b23 + a23 * b33 + a24 * b43;
+    te[13] = a21 * b14 + a22 * b24 + a23 * b34 + a24 * b44;
+    te[2] = a31 * b11 + a32 * b21 + a33 * b31 + a34 * b41;
+    te[6] = a31 * b12 + a32 * b22 + a33 * b32 + a34 * b42;
+    te[10] = a31 * b13 + a32 * b23 + a33 * b33 + a34 * b43;
+    te[14] = a31 * b14 + a32 * b24 + a33 * b34 + a34 * b44;
+    te[3] = a41 * b11 + a42 * b21 + a43 * b31 + a44 * b41;
+    te[7] = a41 * b12 + a42 * b22 + a43 * b32 + a44 * b42;
+    te[11] = a41 * b13 + a42 * b23 + a43 * b33 + a44 * b43;
+    te[15] = a41 * b14 + a42 * b24 + a43 * b34 + a44 * b44;
+    return this;
+  }
+  determinant() {
+    const te = this.elements;
+    const n11 = te[0], n12 = te[4], n13 = te[8], n14 = te[12], n21 = te[1], n22 = te[5], n23 = te[9], n24 = te[13];
+    const n31 = te[2], n32 = te[6], n33 = te[10], n34 = te[14], n41 = te[3], n42 = te[7], n43 = te[11], n44 = te[15];
+    return (
+      n41 * (+n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34) +
+      n42 * (+n11 * n23 * n34 - n11 * n24 * n33 + n14 * n21 * n33 - n13 * n21 * n34 + n13 * n24 * n31 - n14 * n23 * n31) +
+      n43 * (+n11 * n24 * n32 - n11 * n22 * n34 - n14 * n21 * n32 + n12 * n21 * n34 + n14 * n22 * n31 - n12 * n24 * n31) +
+      n44 * (-n13 * n22 * n31 - n11 * n23 * n32 + n11 * n22 * n33 + n13 * n21 * n32 - n12 * n21 * n33 + n12 * n23 * n31));
+  }
+  transpose() {
+    const te = this.elements; let t;
+    t = te[1]; te[1] = te[4]; te[4] = t; t = te[2]; te[2] = te[8]; te[8] = t; t = te[6]; te[6] = te[9]; te[9] = t;
+    t = te[3]; te[3] = te[12]; te[12] = t; t = te[7]; te[7] = te[13]; te[13] = t; t = te[11]; te[11] = te[14]; te[14] = t;
+    return this;
+  }
+  // Matrix4.invert: cofactor expansion in the r160 term order (euclideanspace.com formula)
+  invert() {
+    const te = this.elements,
+      n11 = te[0], n21 = te[1], n31 = te[2], n41 = te[3], n12 = te[4], n22 = te[5], n32 = te[6], n42 = te[7],
+      n13 = te[8], n23 = te[9], n33 = te[10], n43 = te[11], n14 = te[12], n24 = te[13], n34 = te[14], n44 = te[15],
+      t11 = n23 * n34 * n42 - n24 * n33 * n42 + n24 * n32 * n43 - n22 * n34 * n43 - n23 * n32 * n44 + n22 * n33 * n44,
+      t12 = n14 * n33 * n42 - n13 * n34 * n42 - n14 * n32 * n43 + n12 * n34 * n43 + n13 * n32 * n44 - n12 * n33 * n44,
+      t13 = n13 * n24 * n42 - n14 * n23 * n42 + n14 * n22 * n43 - n12 * n24 * n43 - n13 * n22 * n44 + n12 * n23 * n44,
+      t14 = n14 * n23 * n32 - n13 * n24 * n32 - n14 * n22 * n33 + n12 * n24 * n33 + n13 * n22 * n34 - n12 * n23 * n34;
+    const det = n11 * t11 + n21 * t12 + n31 * t13 + n41 * t14;
+    if (det === 0) return this.set(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const detInv = 1 / det;
+    te[0] = t11 * detInv;
+    te[1] = (n24 * n33 * n41 - n23 * n34 * n41 - n24 * n31 * n43 + n21 * n34 * n43 + n23 * n31 * n44 - n21 * n33 * n44) * detInv;
+    te[2] = (n22 * n34 * n41 - n24 * n32 * n41 + n24 * n31 * n42 - n21 * n34 * n42 - n22 * n31 * n44 + n21 * n32 * n44) * detInv;
+    te[3] = (n23 * n32 * n41 - n22 * n33 * n41 - n23 * n31 * n42 + n21 * n33 * n42 + n22 * n31 * n43 - n21 * n32 * n43) * detInv;
+    te[4] = t12 * detInv;
+    te[5] = (n13 * n34 * n41 - n14 * n33 * n41 + n14 * n31 * n43 - n11 * n34 * n43 - n13 * n31 * n44 + n11 * n33 * n44) * detInv;
+    te[6] = (n14 * n32 * n41 - n12 * n34 * n41 - n14 * n31 * n42 + n11 * n34 * n42 + n12 * n31 * n44 - n11 * n32 * n44) * detInv;
+    te[7] = (n12 * n33 * n41 - n13 * n32 * n41 + n13 * n31 * n42 - n11 * n33 * n42 - n12 * n31 * n43 + n11 * n32 * n43) * detInv;
+    te[8] = t13 * detInv;
+    te[9] = (n14 * n23 * n41 - n13 * n24 * n41 - n14 * n21 * n43 + n11 * n24 * n43 + n13 * n21 * n44 - n11 * n23 * n44) * detInv;
+    te[10] = (n12 * n24 * n41 - n14 * n22 * n41 + n14 * n21 * n42 - n11 * n24 * n42 - n12 * n21 * n44 + n11 * n22 * n44) * detInv;
+    te[11] = (n13 * n22 * n41 - n12 * n23 * n41 - n13 * n21 * n42 + n11 * n23 * n42 + n12 * n21 * n43 - n11 * n22 * n43) * detInv;
+    te[12] = t14 * detInv;
+    te[13] = (n13 * n24 * n31 - n14 * n23 * n31 + n14 * n21 * n33 - n11 * n24 * n33 - n13 * n21 * n34 + n11 * n23 * n34) * detInv;
+    te[14] = (n14 * n22 * n31 - n12 * n24 * n31 - n14 * n21 * n32 + n11 * n24 * n32 + n12 * n21 * n34 - n11 * n22 * n34) * detInv;
+    te[15] = (n12 * n23 * n31 - n13 * n22 * n31 + n13 * n21 * n32 - n11 * n23 * n32 - n12 * n21 * n33 + n11 * n22 * n33) * detInv;
+    return this;
+  }
+  makeScale(x, y, z) { return this.set(x, 0, 0, 0, 0, y, 0, 0, 0, 0, z, 0, 0, 0, 0, 1); }
+  makeTranslation(x, y, z) { return this.set(1, 0, 0, x, 0, 1, 0, y, 0, 0, 1, z, 0, 0, 0, 1); }
+  makeRotationFromQuaternion(q) { return this.compose(_zero, q, _one); }
+  compose(position, quaternion, scale) {
+    const te = this.elements;
+    const x = quaternion._x, y = quaternion._y, z = quaternion._z, w = quaternion._w;
+    const x2 = x + x, y2 = y + y, z2 = z + z;
+    const xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2;
+    const wx = w * x2, wy = w * y2, wz = w * z2;
+    const sx = scale.x, sy = scale.y, sz = scale.z;
+    te[0] = (1 - (yy + zz)) * sx; te[1] = (xy + wz) * sx; te[2] = (xz - wy) * sx; te[3] = 0;
+    te[4] = (xy - wz) * sy; te[5] = (1 - (xx + zz)) * sy; te[6] = (yz + wx) * sy; te[7] = 0;
+    te[8] = (xz + wy) * sz; te[9] = (yz - wx) * sz; te[10] = (1 - (xx + yy)) * sz; te[11] = 0;
+    te[12] = position.x; te[13] = position.y; te[14] = position.z; te[15] = 1;
+    return this;
+  }
+  decompose(position, quaternion, scale) {
+    const te = this.elements;
+    let sx = _v1.set(te[0], te[1], te[2]).length();
+    const sy = _v1.set(te[4], te[5], te[6]).length();
+    const sz = _v1.set(te[8], te[9], te[10]).length();
+    const det = this.determinant();                       // a negative determinant flips one scale
+    if (det < 0) sx = -sx;
+    position.x = te[12]; position.y = te[13]; position.z = te[14];
+    const m1 = new Matrix4().copy(this), invSX = 1 / sx, invSY = 1 / sy, invSZ = 1 / sz, e = m1.elements;
+    e[0] *= invSX; e[1] *= invSX; e[2] *= invSX;
+    e[4] *= invSY; e[5] *= invSY; e[6] *= invSY;
+    e[8] *= invSZ; e[9] *= invSZ; e[10] *= invSZ;
+    quaternion.setFromRotationMatrix(m1);
+    scale.x = sx; scale.y = sy; scale.z = sz;
+    return this;
+  }
+  // PerspectiveCamera.updateProjectionMatrix -> makePerspective(left, right, top, bottom, near, far), WebGL depth range
+  makePerspective(left, right, top, bottom, near, far) {
+    const te = this.elements;
+    const x = 2 * near / (right - left), y = 2 * near / (top - bottom);
+    const a = (right + left) / (right - left), b = (top + bottom) / (top - bottom);
+    const c = -(far + near) / (far - near), d = (-2 * far * near) / (far - near);
+    te[0] = x; te[4] = 0; te[8] = a; te[12] = 0;
+    te[1] = 0; te[5] = y; te[9] = b; te[13] = 0;
+    te[2] = 0; te[6] = 0; te[10] = c; te[14] = d;
+    te[3] = 0; te[7] = 0; te[11] = -1; te[15] = 0;
+    return this;
+  }
+}
+
+export class Matrix3 {
+  constructor() { this.elements = [1, 0, 0, 0, 1, 0, 0, 0, 1]; }
+  set(n11, n12, n13, n21, n22, n23, n31, n32, n33) {
+    const te = this.elements;
+    te[0] = n11; te[1] = n21; te[2] = n31; te[3] = n12; te[4] = n22; te[5] = n32; te[6] = n13; te[7] = n23; te[8] = n33;
+    return this;
+  }
+  identity() { return this.set(1, 0, 0, 0, 1, 0, 0, 0, 1); }
+  copy(m) { const te = this.elements, me = m.elements; for (let i = 0; i < 9; i++) te[i] = me[i]; return this; }
+  setFromMatrix4(m) { const me = m.elements; return this.set(me[0], me[4], me[8], me[1], me[5], me[9], me[2], me[6], me[10]); }
+  multiply(m) { return this.multiplyMatrices(this, m); }
+  premultiply(m) { return this.multiplyMatrices(m, this); }
+  multiplyMatrices(a, b) {
+    const ae = a.elements, be = b.elements, te = this.elements;
+    const a11 = ae[0], a12 = ae[3], a13 = ae[6], a21 = ae[1], a22 = ae[4], a23 = ae[7], a31 = ae[2], a32 = ae[5], a33 = ae[8];
+    const b11 = be[0], b12 = be[3], b13 = be[6], b21 = be[1], b22 = be[4], b23 = be[7], b31 = be[2], b32 = be[5], b33 = be[8];
+    te[0] = a11 * b11 + a12 * b21 + a13 * b31;
+    te[3] = a11 * b12 + a12 * b22 + a13 * b32;
+    te[6] = a11 * b13 + a12 * b23 + a13 * b33;
+    te[1] = a21 * b11 + a22 * b21 + a23 * b31;
+    te[4] = a21 * b12 + a22 * b22 + a23 * b32;
+    te[7] = a21 * b13 + a22 * b23 + a23 * b33;
+    te[2] = a31 * b11 + a32 * b21 + a33 * b31;
+    te[5] = a31 * b12 + a32 * b22 + a33 * b32;
+    te[8] = a31 * b13 + a32 * b23 + a33 * b33;
+    return this;
+  }
+  transpose() {
+    let tmp; const m = this.elements;
+    tmp = m[1]; m[1] = m[3]; m[3] = tmp; tmp = m[2]; m[2] = m[6]; m[6] = tmp; tmp = m[5]; m[5] = m[7]; m[7] = tmp;
+    return this;
+  }
+}
+
+// MathUtils.clamp
+const clamp = (value, min, max) => Math.max(min, Math.min(max, value));
+export const MathUtils = { clamp, DEG2RAD: Math.PI / 180, RAD2DEG: 180 / Math.PI };
+
+// DataUtils.toHalfFloat / fromHalfFloat: the r160 table construction (van der Zijp's "Fast Half Float Conversions");
+// toHalfFloat clamps to +-65504 and TRUNCATES the mantissa (it does not round to nearest)
+const _tables = (() => {
+  const buffer = new ArrayBuffer(4), floatView = new Float32Array(buffer), uint32View = new Uint32Array(buffer);
+  const baseTable = new Uint32Array(512), shiftTable = new Uint32Array(512);
+  for (let i = 0; i < 256; ++i) {
+    const e = i - 127;
+    if (e < -27) { baseTable[i] = 0x0000; baseTable[i | 0x100] = 0x8000; shiftTable[i] = 24; shiftTable[i | 0x100] = 24; }
+    else if (e < -14) { baseTable[i] = 0x0400 >> (-e - 14); baseTable[i | 0x100] = (0x0400 >> (-e - 14)) | 0x8000; shiftTable[i] = -e - 1; shiftTable[i | 0x100] = -e - 1; }
+    else if (e <= 15) { baseTable[i] = (e + 15) << 10; baseTable[i | 0x100] = ((e + 15) << 10) | 0x8000; shiftTable[i] = 13; shiftTable[i | 0x100] = 13; }
+    else if (e < 128) { baseTable[i] = 0x7c00; baseTable[i | 0x100] = 0xfc00; shiftTable[i] = 24; shiftTable[i | 0x100] = 24; }
+    else { baseTable[i] = 0x7c00; baseTable[i | 0x100] = 0xfc00; shiftTable[i] = 13; shiftTable[i | 0x100] = 13; }
+  }
+  const mantissaTable = new Uint32Array(2048), exponentTable = new Uint32Array(64), offsetTable = new Uint32Array(64);
+  for (let i = 1; i < 1024; ++i) {
+    let m = i << 13, e = 0;
+    while ((m & 0x00800000) === 0) { m <<= 1; e -= 0x00800000; }
+    m &= ~0x00800000; e += 0x38800000;
+    mantissaTable[i] = m | e;
+  }
+  for (let i = 1024; i < 2048; ++i) mantissaTable[i] = 0x38000000 + ((i - 1024) << 13);
+  for (let i = 1; i < 31; ++i) exponentTable[i] = i << 23;
+  exponentTable[31] = 0x47800000; exponentTable[32] = 0x80000000;
+  for (let i = 33; i < 63; ++i) exponentTable[i] = 0x80000000 + ((i - 32) << 23);
+  exponentTable[63] = 0xc7800000;
+  for (let i = 1; i < 64; ++i) if (i !== 32) offsetTable[i] = 1024;
+  return { floatView, uint32View, baseTable, shiftTable, mantissaTable, exponentTable, offsetTable };
+})();
+
+export const DataUtils = {
+  toHalfFloat(val) {
+    val = clamp(val, -65504, 65504);
+    _tables.floatView[0] = val;
+    const f = _tables.uint32View[0], e = (f >> 23) & 0x1ff;
+    return _tables.baseTable[e] + ((f & 0x007fffff) >> _tables.shiftTable[e]);
+  },
+  fromHalfFloat(val) {
+    const m = val >> 10;
+    _tables.uint32View[0] = _tables.mantissaTable[_tables.offsetTable[m] + (val & 0x3ff)] + _tables.exponentTable[m];
+    return _tables.floatView[0];
+  },
+};
+
+// Box3 as far as the loaders use it
+export class Box3 {
+  constructor(min = new Vector3(+Infinity, +Infinity, +Infinity), max = new Vector3(-Infinity, -Infinity, -Infinity)) { this.min = min; this.max = max; }
+  containsPoint(p) { return !(p.x < this.min.x || p.x > this.max.x || p.y < this.min.y || p.y > this.max.y || p.z < this.min.z || p.z > this.max.z); }
+}

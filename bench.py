@@ -206,6 +206,8 @@ class Rig:
         return st
 
     def frame(self, out_ptr, tile_rows=None):
+        if self.worker.visibility_cull:            # vertex stage first: its mask (this rank's strip) is the sort's keep test
+            self.mesh.project(tile_rows)
         self.worker.sort_on_device(self.mvp, self.N)
         self.mesh.render(tile_rows=tile_rows, out_device_ptr=out_ptr, to_host=False, want_stats=False)
         self.frames += 1
@@ -320,7 +322,21 @@ def main():
         strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
         del probe
         tile_rows = my if world > 1 else None
-        gather = (lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)) if world > 1 else None
+        gather, gather_kind, group = None, None, None
+        if world > 1:
+            # every rank keys all splats but sorts / bins / blends only what reaches its strip
+            worker.set_visibility_cull(True)
+            if backend == "nccl" and os.environ.get("GS_BENCH_GATHER", "capi") == "capi":
+                try:
+                    group = gdist.StripGroup(ctx, rank, world, dist)          # RCCL behind the C ABI (gs_group_*)
+                    gather_kind = "gs_group_gather_strips (RCCL grouped send/recv behind the C ABI)"
+                    full_ptr = full.data_ptr() if rank == 0 else 0
+                    gather = lambda: group.gather_strips(strip.data_ptr(), full_ptr, W, strips, H)      # noqa: E731
+                except Exception as e:                                       # fall back to torch.distributed P2P
+                    print(f"bench.py rank {rank}: gs_group unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
+            if gather is None:
+                gather_kind = f"torch.distributed batch_isend_irecv ({backend})"
+                gather = lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)            # noqa: E731
 
         for _ in range(args.warmup):
             rig.frame(strip.data_ptr(), tile_rows)
@@ -344,7 +360,7 @@ def main():
         list_px_timed, D32 = int(st_timed.list_bin_px), int(st_timed.tile_entries)
         frames_headline = rig.frames
 
-        stage_ms, latency, orbit, cull, fused, translucent, pipelined = {}, [], None, None, None, None, None
+        stage_ms, latency, orbit, cull, fused, translucent, pipelined, vis_fused = {}, [], None, None, None, None, None, None
         if not args.only_headline:
             # per-stage device times (HIP events recorded by the library), one synchronised frame at a time
             stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
@@ -446,6 +462,21 @@ def main():
                      "note": "keys + min/max over all N, then pass 0 of the radix sort drops the splats whose centre is "
                              "outside 1.25x the clip volume; the list is the full sort's list minus those splats"}
             worker.set_frustum_cull(False)
+
+            # the exact version, and what every rank of a multi-GPU run does with its strip: vertex stage first, then the
+            # sort keeps only the splats that survived it (gs_sorter_set_visibility_cull)
+            worker.set_visibility_cull(True)
+            for _ in range(3):
+                rig.frame(strip.data_ptr())
+            v_el, v_enq = rig.timed(args.steps, strip.data_ptr())
+            v_ms = v_el / args.steps * 1e3
+            vs, _ = worker.last_stats()
+            vis_fused = {"kept": int(vs.result_count), "ms_per_frame": round(v_ms, 4),
+                         "Msplats_per_s_scene": round(N / (v_ms * 1e-3) / 1e6, 1), "sort_ms_last": round(float(vs.device_ms), 4),
+                         "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
+                         "note": "project -> sort (keys + min/max over all N, radix passes over the visible splats only) -> "
+                                 "bin -> blend: the per-rank frame of a multi-GPU run, here with the whole screen as the strip"}
+            worker.set_visibility_cull(False)
             del ref_img
 
         if extras and args.config == "C3":
@@ -503,6 +534,9 @@ def main():
                        "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
                        "strips": strips if world > 1 else None, "backend": backend if world > 1 else None,
+                       "sort": "full list (R = N)" if world == 1 else "per rank: keys over all N, radix passes over the splats "
+                               "its strip draws (gs_sorter_set_visibility_cull)",
+                       "gather": gather_kind,
                        "dry_run_shared_gpu": dry_run if world > 1 else None},
             # the largest HBM-bound kernel: the vertex stage (the largest kernel overall is the blend, which is VALU-bound:
             # see `blend`)
@@ -532,6 +566,7 @@ def main():
             "orbit": orbit,
             "cull_on": cull,
             "frustum_cull_fused": fused,
+            "visibility_cull_fused": vis_fused,
             "translucent": translucent,
             "cpu_baseline": None,
             "frames_drawn_before_timing_ended": frames_headline,
@@ -540,6 +575,8 @@ def main():
         if world == 1 and not args.no_cpu and not args.only_headline:
             out["cpu_baseline"] = cpu_baseline(scene, mvp, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if group is not None:
+        group.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -93,6 +93,7 @@ SYMBOLS = {
     "gs_sorter_sort_gathered": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP, C.POINTER(SortStats)]),
     "gs_sorter_bind_mesh": (C.c_int, [_VP, _VP]),
     "gs_sorter_set_frustum_cull": (C.c_int, [_VP, C.c_int]),
+    "gs_sorter_set_visibility_cull": (C.c_int, [_VP, C.c_int]),
     "gs_sorter_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_asset_open": (C.c_int, [_VP, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_asset_close": (None, [_VP]),
@@ -110,6 +111,11 @@ SYMBOLS = {
     "gs_mesh_upload_sh_u8": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
     "gs_mesh_upload_scene_indexes": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
     "gs_mesh_set_scenes": (C.c_int, [_VP, C.POINTER(SceneParams)]),
+    "gs_mesh_project": (C.c_int, [_VP, C.POINTER(Camera)]),
+    "gs_group_unique_id": (C.c_int, [_VP]),
+    "gs_group_create": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
+    "gs_group_destroy": (None, [_VP]),
+    "gs_group_gather_strips": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP, _VP, C.c_uint32]),
     "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),

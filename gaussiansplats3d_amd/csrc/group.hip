@@ -1,0 +1,163 @@
+// group.hip — the one exchange step of a multi-GPU draw: row strips of the framebuffer gathered to one rank over RCCL
+// (xGMI inside a node).  The reference has no counterpart (one WebGL context, /root/reference/src/Viewer.js:1616).
+//
+// One rank per GPU (a process or a thread, each with its own gs_context).  Every rank keys all splats but sorts, bins and
+// blends only what reaches its strip of 16-px tile rows (gs_sorter_set_visibility_cull + gs_camera.tile_row_begin/end), so the
+// only bytes that cross GPUs per frame are the RGBA8 strips: W*H*4 in total, received by the root over up to 7 distinct
+// point-to-point links at once - one grouped ncclSend / ncclRecv (a gatherv), enqueued on the context's stream like any
+// kernel.  librccl is loaded on first use, so single-GPU users never need it.
+#include <dlfcn.h>
+
+#include "gs_internal.hpp"
+
+namespace {
+
+typedef void* comm_t;
+struct unique_id { char internal[128]; };
+static_assert(sizeof(unique_id) == GS_GROUP_ID_BYTES, "ncclUniqueId is 128 bytes");
+constexpr int kUint8 = 1;                                 // ncclUint8
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(unique_id*) = nullptr;
+    int (*CommInitRank)(comm_t*, int, unique_id, int) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+            r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+            r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+            r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+            r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+            r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+            r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+            r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv) {
+                dlclose(r.lib);
+                r.lib = nullptr;
+            }
+        }
+    }
+    return r.lib ? &r : nullptr;
+}
+
+}  // namespace
+
+struct gs_group {
+    gs_context* ctx = nullptr;
+    comm_t comm = nullptr;
+    uint32_t world = 1, rank = 0;
+};
+
+#define GS_NCCL(expr)                                                                              \
+    do {                                                                                           \
+        const int _r = (expr);                                                                     \
+        if (_r != 0) {                                                                             \
+            gs_set_error("%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(_r) : "RCCL error"); \
+            return GS_ERR_HIP;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+extern "C" {
+
+int gs_group_unique_id(uint8_t* id_out) {
+    GS_REQUIRE(id_out != nullptr, "id_out == NULL");
+    Rccl* R = rccl();
+    if (!R) {
+        gs_set_error("librccl.so could not be loaded: %s", dlerror());
+        return GS_ERR_UNSUPPORTED;
+    }
+    unique_id id;
+    GS_NCCL(R->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return GS_OK;
+}
+
+int gs_group_create(gs_context* ctx, const uint8_t* id_bytes, uint32_t world_size, uint32_t rank, gs_group** out) {
+    GS_REQUIRE(ctx && out, "ctx / out == NULL");
+    *out = nullptr;
+    GS_REQUIRE(world_size >= 1 && rank < world_size, "rank outside [0, world_size)");
+    GS_REQUIRE(world_size == 1 || id_bytes, "a group of more than one rank needs the id from gs_group_unique_id");
+    gs_group* g = new (std::nothrow) gs_group();
+    if (!g) return GS_ERR_NOMEM;
+    g->ctx = ctx;
+    g->world = world_size;
+    g->rank = rank;
+    if (world_size > 1) {                                  // a group of one never touches RCCL
+        Rccl* R = rccl();
+        if (!R) {
+            gs_set_error("librccl.so could not be loaded: %s", dlerror());
+            delete g;
+            return GS_ERR_UNSUPPORTED;
+        }
+        ScopedDevice sd(ctx->device);
+        unique_id id;
+        memcpy(&id, id_bytes, sizeof(id));
+        const int r = R->CommInitRank(&g->comm, (int)world_size, id, (int)rank);
+        if (r != 0) {
+            gs_set_error("ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+            delete g;
+            return GS_ERR_HIP;
+        }
+    }
+    *out = g;
+    return GS_OK;
+}
+
+void gs_group_destroy(gs_group* g) {
+    if (!g) return;
+    if (g->comm) {
+        ScopedDevice sd(g->ctx->device);
+        (void)hipStreamSynchronize(g->ctx->stream);
+        if (Rccl* R = rccl()) (void)R->CommDestroy(g->comm);
+    }
+    delete g;
+}
+
+int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, uint32_t width, const uint32_t* row_begin,
+                           const uint32_t* row_end, uint32_t root) {
+    GS_REQUIRE(g && row_begin && row_end, "group / row tables == NULL");
+    GS_REQUIRE(root < g->world && width > 0, "root outside the group or width == 0");
+    for (uint32_t r = 0; r < g->world; r++) GS_REQUIRE(row_begin[r] <= row_end[r], "strip rows: begin > end");
+    GS_REQUIRE(g->rank != root || full_dev, "the root needs full_dev");
+    const size_t row_bytes = (size_t)width * 4;
+    const size_t mine = (size_t)(row_end[g->rank] - row_begin[g->rank]) * row_bytes;
+    GS_REQUIRE(mine == 0 || strip_dev, "strip_dev == NULL");
+    ScopedDevice sd(g->ctx->device);
+    hipStream_t st = g->ctx->stream;
+    if (g->rank == root && mine)
+        GS_HIP(hipMemcpyAsync(static_cast<char*>(full_dev) + (size_t)row_begin[root] * row_bytes, strip_dev, mine, hipMemcpyDeviceToDevice, st));
+    if (g->world == 1) return GS_OK;
+    Rccl* R = rccl();
+    GS_REQUIRE(R != nullptr, "RCCL is gone");
+    GS_NCCL(R->GroupStart());
+    if (g->rank == root) {
+        for (uint32_t r = 0; r < g->world; r++) {
+            const size_t bytes = (size_t)(row_end[r] - row_begin[r]) * row_bytes;
+            if (r == root || bytes == 0) continue;
+            GS_NCCL(R->Recv(static_cast<char*>(full_dev) + (size_t)row_begin[r] * row_bytes, bytes, kUint8, (int)r, g->comm, st));
+        }
+    } else if (mine) {
+        GS_NCCL(R->Send(strip_dev, mine, kUint8, (int)root, g->comm, st));
+    }
+    GS_NCCL(R->GroupEnd());
+    return GS_OK;
+}
+
+}  // extern "C"

@@ -201,6 +201,7 @@ struct gs_sorter {
     bool last_identity = true;
     bool has_result = false;
     bool frustum_cull = false;         // gs_sorter_set_frustum_cull
+    bool visibility_cull = false;      // gs_sorter_set_visibility_cull
     bool last_culled = false;          // the resident result holds only the kept splats; its length lives in result_frame
     const SortFrame* result_frame = nullptr;
     DevBuf keep_mask;                  // 1 bit per list position (frustum-cull variant)
@@ -314,6 +315,8 @@ struct gs_mesh {
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;
+    bool projection_pending = false;   // gs_mesh_project ran; the next gs_mesh_render with the same camera consumes it
+    gs_camera projected_cam = {};
 };
 
 int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);

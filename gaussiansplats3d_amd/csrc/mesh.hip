@@ -474,16 +474,13 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     return f.overflow ? 1 : 0;
 }
 
-static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R,
-                          uint8_t* out_dev) {
+// The vertex stage of a draw.  It only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
+// caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed the records /
+// rects / mask it is about to overwrite.
+static int mesh_project(gs_mesh* m, const ProjectParams& pp) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
-    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
-    GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     GS_HIP(hipEventRecord(m->ev[0], st));
-    // fork: the vertex stage only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
-    // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed
-    // the records / rects / mask it is about to overwrite
     if (aux != st && m->has_draw) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
     {   // next slot of the timing ring; a slot about to be reused is harvested first (skipped if still in flight)
         const uint32_t slot = m->ring_next++ % gs_mesh::TIMING_RING;
@@ -503,6 +500,16 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     GS_HIP(hipEventRecord(m->ev_p0, aux));
     GS_TRY(gs_launch_project(m, pp));
     GS_HIP(hipEventRecord(m->ev_p1, aux));
+    return GS_OK;
+}
+
+static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R,
+                          uint8_t* out_dev, bool projected) {
+    gs_context* ctx = m->ctx;
+    hipStream_t st = ctx->stream, aux = ctx->aux;
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
+    GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
+    if (!projected) GS_TRY(mesh_project(m, pp));           // else gs_mesh_project already ran it for this camera
     // join: projection and (if a sorter feeds this draw) the sort result
     if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
     if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
@@ -519,21 +526,12 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     return GS_OK;
 }
 
-int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
-                   uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats) {
-    GS_REQUIRE(m && cam, "mesh / camera == NULL");
+// gs_camera -> the kernels' parameter block (shared by gs_mesh_project and gs_mesh_render)
+static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     GS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 65535u * GS_TILE && cam->height <= 65535u * GS_TILE,
                "viewport size");
-    GS_REQUIRE(render_count <= m->uploaded, "render_count exceeds the uploaded splat count");
     GS_REQUIRE(cam->sh_degree <= 2, "sphericalHarmonicsDegree > 2");
-    GS_REQUIRE(!(sorted_host && sorter), "pass either host indexes or a sorter, not both");
-    GS_REQUIRE(!sorter || (sorter->ctx == m->ctx && sorter->has_result && sorter->last_render >= render_count),
-               "sorter has no device-resident result covering render_count (or lives on another context)");
-    gs_context* ctx = m->ctx;
-    ScopedDevice sd(ctx->device);
-    hipStream_t st = ctx->stream;
-
-    ProjectParams pp = {};
+    memset(&pp, 0, sizeof(pp));
     memcpy(pp.view, cam->view, sizeof(pp.view));
     memcpy(pp.proj, cam->proj, sizeof(pp.proj));
     memcpy(pp.cam_pos, cam->cam_pos, sizeof(pp.cam_pos));
@@ -579,6 +577,37 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     pp.lists_x = (cam->width + list_px - 1) / list_px;
     pp.list_row_begin = y0 / list_px;
     pp.list_row_end = pp.y1 > y0 ? (pp.y1 + list_px - 1) / list_px : pp.list_row_begin;
+    return GS_OK;
+}
+
+int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
+    GS_REQUIRE(m && cam, "mesh / camera == NULL");
+    ProjectParams pp;
+    GS_TRY(mesh_params(m, cam, pp));
+    ScopedDevice sd(m->ctx->device);
+    GS_TRY(mesh_project(m, pp));
+    m->projection_pending = true;
+    m->projected_cam = *cam;
+    return GS_OK;
+}
+
+int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
+                   uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats) {
+    GS_REQUIRE(m && cam, "mesh / camera == NULL");
+    GS_REQUIRE(render_count <= m->uploaded, "render_count exceeds the uploaded splat count");
+    GS_REQUIRE(!(sorted_host && sorter), "pass either host indexes or a sorter, not both");
+    GS_REQUIRE(!sorter || (sorter->ctx == m->ctx && sorter->has_result && sorter->last_render >= render_count),
+               "sorter has no device-resident result covering render_count (or lives on another context)");
+    gs_context* ctx = m->ctx;
+    ScopedDevice sd(ctx->device);
+    hipStream_t st = ctx->stream;
+
+    ProjectParams pp;
+    GS_TRY(mesh_params(m, cam, pp));
+    // a gs_mesh_project of exactly this camera is consumed by exactly one draw (the vertex stage runs once per frame)
+    bool projected = m->projection_pending && memcmp(cam, &m->projected_cam, sizeof(*cam)) == 0;
+    m->projection_pending = false;
+    const uint32_t y0 = pp.y0, y1 = pp.y1;
     m->drawn_list_shift = pp.list_shift;
     const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
 
@@ -597,7 +626,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     }
 
     m->last = gs_render_stats();
-    GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev));
+    GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, projected));
     m->has_draw = true;
     m->last_count = pp.count;
 
@@ -615,7 +644,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
                 return GS_ERR_CAPACITY;
             }
             GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
-            GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev));
+            GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, true));   // the records are still valid
             ov = mesh_collect_stats(m, nullptr);
             if (ov < 0) return ov;
             m->last.overflowed = 1;

@@ -42,7 +42,9 @@ struct KeyParams {
     int32_t im0, im1, im2;                   // static path: (int)(mvp[k]*1000.0), k = 2,6,10
     float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
     float mvp[16];                           // frustum-cull variant only: the whole modelViewProj, fp32 column-major
-    unsigned long long* keep;                // frustum-cull variant only: 1 bit per list position
+    unsigned long long* keep;                // cull variants only: 1 bit per list position
+    const uint2* vis32;                      // visibility-cull variant: the bound mesh's {mask, slot} table per 32 storage positions
+    const uint32_t* perm;                    // ... and its splat index -> storage position map (nullable: identity)
 };
 
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
@@ -195,11 +197,19 @@ __device__ __forceinline__ bool frustum_keep_int(const float* m, uint32_t x, uin
                             __fmul_rn((float)(int32_t)z, 0.001f));
 }
 
+// Keep test of the VISIBILITY cull (gs_sorter_set_visibility_cull): the splat survived the bound mesh's vertex stage for this
+// camera (and this rank's strip of tile rows) - exactly the splats that reach the frame, whatever the camera model.
+__device__ __forceinline__ bool visible_keep(const KeyParams& p, uint32_t splat) {
+    const uint32_t pos = p.perm ? p.perm[splat] : splat;
+    return (p.vis32[pos >> 5].x >> (pos & 31u)) & 1u;
+}
+
 // VEC4 (identity list, static integer mode): lane l of a wave owns positions 4*(v0 + l) .. +3 of a 256-position window,
 // read as three 16-byte plane loads; the 4 keep bits of 16 neighbouring lanes are OR-combined into one mask word.
 // Otherwise: 4 positions per lane, 64 apart, so 4 index loads and then 4 centre gathers are in flight per lane and
 // every ballot is one mask word.
-template <bool VEC4>
+// VIS: keep = visible_keep (the mesh's mask) instead of the frustum test on the sorter's own centres.
+template <bool VEC4, bool VIS>
 __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
     __shared__ int32_t s_lo[4], s_hi[4];
     __shared__ uint32_t s_kept[4];
@@ -237,8 +247,16 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                 o4[v] = k;
                 lo = min(min(lo, k.x), min(min(k.y, k.z), k.w));
                 hi = max(max(hi, k.x), max(max(k.y, k.z), k.w));
-                nib = (frustum_keep_int(p.mvp, x.x, y.x, z.x) ? 1u : 0u) | (frustum_keep_int(p.mvp, x.y, y.y, z.y) ? 2u : 0u) |
-                      (frustum_keep_int(p.mvp, x.z, y.z, z.z) ? 4u : 0u) | (frustum_keep_int(p.mvp, x.w, y.w, z.w) ? 8u : 0u);
+                if (VIS) {
+                    uint4 pos = make_uint4(4u * v, 4u * v + 1u, 4u * v + 2u, 4u * v + 3u);
+                    if (p.perm) pos = reinterpret_cast<const uint4*>(p.perm)[v];
+                    const uint2 m0v = p.vis32[pos.x >> 5], m1v = p.vis32[pos.y >> 5], m2v = p.vis32[pos.z >> 5], m3v = p.vis32[pos.w >> 5];
+                    nib = ((m0v.x >> (pos.x & 31u)) & 1u) | (((m1v.x >> (pos.y & 31u)) & 1u) << 1) |
+                          (((m2v.x >> (pos.z & 31u)) & 1u) << 2) | (((m3v.x >> (pos.w & 31u)) & 1u) << 3);
+                } else {
+                    nib = (frustum_keep_int(p.mvp, x.x, y.x, z.x) ? 1u : 0u) | (frustum_keep_int(p.mvp, x.y, y.y, z.y) ? 2u : 0u) |
+                          (frustum_keep_int(p.mvp, x.z, y.z, z.z) ? 4u : 0u) | (frustum_keep_int(p.mvp, x.w, y.w, z.w) ? 8u : 0u);
+                }
             } else if (v < nvec) {                                 // the ragged last vector
                 for (uint32_t c = 0; c < 4u; c++) {
                     const uint32_t i = 4u * v + c;
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                         const uint32_t x = p.cx[i], y = p.cy[i], z = p.cz[i];
                         const int32_t k = (int32_t)(x * m0 + y * m1 + z * m2);
                         p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
-                        nib |= frustum_keep_int(p.mvp, x, y, z) ? (1u << c) : 0u;
+                        nib |= (VIS ? visible_keep(p, i) : frustum_keep_int(p.mvp, x, y, z)) ? (1u << c) : 0u;
                     }
                 }
             }
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                     p.keys_out[i] = key;
                     lo = min(lo, key);
                     hi = max(hi, key);
-                    keep[k] = frustum_keep_one(p.mvp, x, y, z);
+                    keep[k] = VIS ? visible_keep(p, g[k]) : frustum_keep_one(p.mvp, x, y, z);
                 }
             }
 #pragma unroll
@@ -543,9 +561,10 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     GS_REQUIRE(sort_count <= render_count, "splatSortCount > splatRenderCount");
     const bool dynamic = (s->flags & GS_SORT_DYNAMIC) != 0;
     GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
-    const bool cull = s->frustum_cull;
+    const bool vis_cull = s->visibility_cull;
+    const bool cull = s->frustum_cull || vis_cull;
     GS_REQUIRE(!cull || (sort_count == render_count && !dynamic && !precomputed),
-               "the per-splat frustum cull needs a full sort (splatSortCount == splatRenderCount) of a static scene without precomputed distances");
+               "a per-splat cull needs a full sort (splatSortCount == splatRenderCount) of a static scene without precomputed distances");
     gs_context* ctx = s->ctx;
     ScopedDevice sd(ctx->device);
     hipStream_t st = s->stream;
@@ -558,6 +577,11 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         if (!alive) s->bound_mesh = nullptr;
     }
     const uint32_t* map = s->bound_mesh ? gs_mesh_payload_map(s->bound_mesh, s->uploaded) : nullptr;
+    if (vis_cull) {
+        GS_REQUIRE(s->bound_mesh && s->bound_mesh->projection_pending && s->bound_mesh->uploaded >= s->uploaded,
+                   "the visibility cull needs gs_sorter_bind_mesh and a gs_mesh_project of this frame's camera before the sort");
+        if (s->bound_mesh->ev_p1 && ctx->aux != st) GS_HIP(hipStreamWaitEvent(st, s->bound_mesh->ev_p1, 0));   // the mask it reads
+    }
     const uint32_t* unmap = map ? gs_mesh_payload_unmap(s->bound_mesh) : nullptr;
     if (s->consumer_pending) {           // a draw enqueued on ctx->stream still reads the previous result
         GS_HIP(hipStreamWaitEvent(st, s->ev_consumed, 0));
@@ -618,16 +642,24 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         GS_TRY(s->keep_mask.ensure((((size_t)s->max_count + 63) / 64 + 8) * 8));   // the key kernel writes whole 256-position windows
         kp.keep = s->keep_mask.as<unsigned long long>();
         memcpy(kp.mvp, mvp, sizeof(kp.mvp));
+        if (vis_cull) {
+            kp.vis32 = s->bound_mesh->vis32.as<uint2>();
+            kp.perm = map;                                 // nullptr for a mesh that keeps upload order
+        }
     }
 
     GS_HIP(hipEventRecord(s->ev0, st));
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
-        if (cull && vec4)
-            hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        if (cull && vec4 && vis_cull)
+            hipLaunchKernelGGL((k_depth_key_cull<true, true>), dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        else if (cull && vec4)
+            hipLaunchKernelGGL((k_depth_key_cull<true, false>), dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        else if (cull && vis_cull)
+            hipLaunchKernelGGL((k_depth_key_cull<false, true>), dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (cull)
-            hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL((k_depth_key_cull<false, false>), dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (vec4)
             hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else
@@ -743,6 +775,13 @@ int gs_sorter_set_frustum_cull(gs_sorter* s, int enable) {
     GS_REQUIRE(s != nullptr, "sorter == NULL");
     GS_REQUIRE(!enable || !(s->flags & GS_SORT_DYNAMIC), "the per-splat frustum cull is not available to a dynamic-mode sorter");
     s->frustum_cull = enable != 0;
+    return GS_OK;
+}
+
+int gs_sorter_set_visibility_cull(gs_sorter* s, int enable) {
+    GS_REQUIRE(s != nullptr, "sorter == NULL");
+    GS_REQUIRE(!enable || !(s->flags & GS_SORT_DYNAMIC), "the visibility cull is not available to a dynamic-mode sorter");
+    s->visibility_cull = enable != 0;
     return GS_OK;
 }
 

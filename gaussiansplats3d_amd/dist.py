@@ -59,3 +59,47 @@ def gather_strips(local_strip, strips, full, rank, world_size, dist, dst=0):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return full if rank == dst else None
+
+
+class StripGroup:
+    """The strip gather behind the C ABI (gs_group_*): one grouped ncclSend / ncclRecv per frame on the context's stream,
+    no Python per strip.  `dist` is only the side channel that carries rank 0's ncclUniqueId to the other ranks."""
+
+    def __init__(self, context, rank, world_size, dist=None):
+        import ctypes as C
+
+        from . import _lib as L
+        self.lib, self.rank, self.world = context.lib, int(rank), int(world_size)
+        self.handle = C.c_void_p()
+        ident = np.zeros(128, dtype=np.uint8)
+        if self.world > 1:
+            import torch
+            if self.rank == 0:
+                L.check(self.lib.gs_group_unique_id(ident.ctypes.data))
+            t = torch.from_numpy(ident)
+            dev = None
+            if dist.get_backend() == "nccl":
+                dev = torch.device("cuda", torch.cuda.current_device())
+                t = t.to(dev)
+            dist.broadcast(t, src=0)
+            ident = t.cpu().numpy().copy()
+        L.check(self.lib.gs_group_create(context.handle, ident.ctypes.data, self.world, self.rank, C.byref(self.handle)))
+        context._adopt(self)
+
+    def gather_strips(self, local_strip_ptr, full_ptr, width, strips, height, dst=0):
+        """Every rank sends its strip (device pointer) to `dst`, which receives strip r at its rows of the full frame."""
+        import ctypes as C
+
+        from . import _lib as L
+        rows = np.array([strip_pixel_rows(s, height) for s in strips], dtype=np.uint32)
+        b, e = np.ascontiguousarray(rows[:, 0]), np.ascontiguousarray(rows[:, 1])
+        L.check(self.lib.gs_group_gather_strips(self.handle, C.c_void_p(local_strip_ptr or None), C.c_void_p(full_ptr or None),
+                                                int(width), b.ctypes.data, e.ctypes.data, int(dst)))
+
+    def close(self):
+        if self.handle:
+            self.lib.gs_group_destroy(self.handle)
+            import ctypes as C
+            self.handle = C.c_void_p()
+
+    dispose = terminate = close

@@ -31,6 +31,7 @@ class SortWorker:
         self.uploaded_splat_count = 0
         self.gathered_count = 0
         self.frustum_cull = False
+        self.visibility_cull = False
         flags = (L.GS_SORT_INTEGER if integer_based_sort else 0) | (L.GS_SORT_DYNAMIC if dynamic_mode else 0)
         self.handle = C.c_void_p()
         L.check(self.lib.gs_sorter_create(context.handle, self.max_splat_count, flags, self.precision,
@@ -102,7 +103,7 @@ class SortWorker:
                  "sortTime": float(stats.device_ms), "status": st}
         if out is not None:
             # under the per-splat frustum cull the list holds only the kept splats (stats.result_count of them)
-            reply["sortedIndexes"] = out[:stats.result_count] if self.frustum_cull else out
+            reply["sortedIndexes"] = out[:stats.result_count] if (self.frustum_cull or self.visibility_cull) else out
             reply["stats"] = stats
         return self._reply(reply)
 
@@ -127,7 +128,7 @@ class SortWorker:
                                                       tr.ctypes.data if tr is not None else None,
                                                       out.ctypes.data if out is not None else None,
                                                       None if keep_on_device else C.byref(stats)))
-        if out is not None and self.frustum_cull:
+        if out is not None and (self.frustum_cull or self.visibility_cull):
             out = out[:stats.result_count]
         return {"sortDone": True, "status": st, "sortTime": float(stats.device_ms), "sortedIndexes": out, "stats": stats,
                 "splatRenderCount": self.gathered_count}
@@ -137,6 +138,13 @@ class SortWorker:
         sorted list restricted to the splats that can reach the frame for this modelViewProj."""
         L.check(self.lib.gs_sorter_set_frustum_cull(self.handle, 1 if enable else 0))
         self.frustum_cull = bool(enable)
+
+    def set_visibility_cull(self, enable=True):
+        """Exact per-splat cull (gs_sorter_set_visibility_cull): a full sort keeps the list positions whose splat survived
+        ``SplatMesh.project`` of this frame's camera (and strip).  Needs ``mesh.use_sorter_result(self, ...)`` (the bind)
+        and, every frame, ``mesh.project()`` before the sort."""
+        L.check(self.lib.gs_sorter_set_visibility_cull(self.handle, 1 if enable else 0))
+        self.visibility_cull = bool(enable)
 
     def keep_bits(self, count):
         """Test hook: the cull's keep flag per list position of the last sort."""

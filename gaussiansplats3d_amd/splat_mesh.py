@@ -173,6 +173,13 @@ class SplatMesh:
         y0, y1 = r0 * L.GS_TILE, min(r1 * L.GS_TILE, cam.height)
         return max(y1 - y0, 0), cam.width
 
+    def project(self, tile_rows=None):
+        """The vertex stage on its own (gs_mesh_project) for the camera set by ``set_camera`` / ``update_uniforms`` and the
+        strip `tile_rows`; the next ``render`` with the same camera and strip consumes it instead of projecting again."""
+        cam = self._cam
+        cam.tile_row_begin, cam.tile_row_end = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        L.check(self.lib.gs_mesh_project(self.handle, C.byref(cam)))
+
     def render(self, tile_rows=None, out_device_ptr=None, want_stats=True, to_host=True):
         """renderer.render(splatMesh, camera).  Returns (uint8[h,w,4] or None, RenderStats or None).
         tile_rows=(begin,end): render only those 16-px tile rows (multi-GPU strips)."""

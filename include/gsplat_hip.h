@@ -125,6 +125,16 @@ int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m);
  * pass the sort's render_count as usual. */
 int gs_sorter_set_frustum_cull(gs_sorter* s, int enable);
 
+/* Visibility cull: the exact version of the above, for a sorter bound to a mesh (gs_sorter_bind_mesh).  After
+ * gs_mesh_project(m, cam) a full sort keeps exactly the list positions whose splat survived the mesh's vertex stage for
+ * `cam` - every reject of the shaders (SplatMaterial.js:160-164, SplatMaterial3D.js:188), an empty pixel footprint, and the
+ * camera's strip of tile rows (gs_camera.tile_row_begin / end).  Keys, min / max and buckets are still taken over every
+ * list position, so the result is the reference's sorted list restricted to the splats this frame (this rank's strip)
+ * draws, and the frame is bit-identical.  This is how the tile-row strips of a multi-GPU draw shard the sort: each rank
+ * keys all splats (12 bytes each) but radix-sorts and bins only its own.  Order per frame:
+ *     gs_mesh_project(m, cam) -> gs_sorter_sort(s, mvp of the same camera, ...) -> gs_mesh_render(m, cam, sorter = s). */
+int gs_sorter_set_visibility_cull(gs_sorter* s, int enable);
+
 /* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
  * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted,
  *       3 = keep bits of the frustum cull, bit (i & 31) of uint32 word i >> 5 per list position i. */
@@ -307,6 +317,12 @@ typedef struct gs_render_stats {
 int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
                    uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats);
 
+/* The vertex stage of a draw on its own (the GLSL vertex shader, SplatMaterial.js:112-341 + SplatMaterial3D.js:81-217):
+ * projects every uploaded splat for `cam` and leaves records, tile rects and the visibility mask on the device.  The next
+ * gs_mesh_render with an identical gs_camera consumes them instead of projecting again (once: the vertex stage runs exactly
+ * one time per frame either way); any other camera simply projects afresh.  Needed before a visibility-culled sort. */
+int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
+
 /* Intermediates of the last draw (tests, strip load-balancing).  what: 0 = per splat (storage order) the
  * 32-byte vertex-stage record {cx, cy, ax, ay, bx, by, r|g<<16, b|a<<16 (unorm16)}; 1 = per splat the tile
  * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per list bin (gs_render_stats.list_bin_px) of the
@@ -317,6 +333,23 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of
  * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams. */
 int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * MULTI-GPU: tile-row strips, one rank per GPU, strips gathered over RCCL (no counterpart in the reference)
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct gs_group gs_group;
+#define GS_GROUP_ID_BYTES 128
+/* ncclGetUniqueId: call on ONE rank and hand the 128 bytes to every rank (any side channel: MPI, a file, a pipe). */
+int gs_group_unique_id(uint8_t* id_out);
+/* ncclCommInitRank on the context's device.  Collective: every rank of the group calls it with the same id.
+ * world_size 1 needs no id and never loads RCCL. */
+int gs_group_create(gs_context* ctx, const uint8_t* id, uint32_t world_size, uint32_t rank, gs_group** out);
+void gs_group_destroy(gs_group* g);
+/* Gatherv of framebuffer strips, enqueued on the context's stream (returns without waiting).  Rank r owns pixel rows
+ * [row_begin[r], row_end[r]) of a `width`-pixel RGBA8 frame (GL row order, as gs_mesh_render writes a strip: its first row
+ * is row_begin[r]); strip_dev = this rank's rows, full_dev = the whole frame on `root` (ignored elsewhere).  Collective. */
+int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, uint32_t width, const uint32_t* row_begin,
+                           const uint32_t* row_end, uint32_t root);
 
 /* Statistics of the last draw (synchronises the stream). */
 int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats);

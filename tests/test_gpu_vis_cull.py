@@ -1,0 +1,106 @@
+"""-m gpu: the visibility cull (gs_mesh_project -> gs_sorter_set_visibility_cull sort -> gs_mesh_render) - how the tile-row
+strips of a multi-GPU draw shard the sort - and the strip gather behind the C ABI (gs_group_*, a group of one here)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import oracle
+from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, util
+from gaussiansplats3d_amd import dist as gdist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _setup(ctx, n=60000, sh=2, seed=21, w=640, h=360):
+    scene = helpers.small_scene(n, sh, seed=seed)
+    cam = camera.demo_camera("garden", w, h)
+    worker = create_sort_worker(ctx, n)
+    ci = util.integer_centers(scene.centers)
+    worker.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+    mesh = SplatMesh(ctx, n, sh)
+    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(cam)
+    return scene, cam, ci, worker, mesh
+
+
+def test_visibility_culled_sort_is_the_reference_list_restricted_to_what_the_frame_draws(ctx):
+    scene, cam, ci, worker, mesh = _setup(ctx)
+    n, mvp = scene.count, cam.sort_mvp()
+    worker.sort_on_device(mvp, n)
+    mesh.use_sorter_result(worker, n)                    # binds the sorter to the mesh
+    worker.sort_on_device(mvp, n)
+    full, _ = mesh.render()
+    _, _, vis = mesh.debug_records()                     # vertex-stage survivors, original splat numbering
+    assert 1000 < vis.sum() < n
+    order = oracle.sort_indexes(np.arange(n, dtype=np.uint32), ci, mvp)
+
+    worker.set_visibility_cull(True)
+    with pytest.raises(Exception):                       # no projection of this frame yet
+        worker.post_message({"sort": {"modelViewProj": mvp, "splatRenderCount": n, "splatSortCount": n}})
+    mesh.project()
+    reply = worker.post_message({"sort": {"modelViewProj": mvp, "splatRenderCount": n, "splatSortCount": n}})
+    np.testing.assert_array_equal(reply["sortedIndexes"], order[vis[order]])
+    assert reply["stats"].result_count == int(vis.sum())
+    np.testing.assert_array_equal(worker.keep_bits(n), vis)
+    got, st = mesh.render()                              # consumes the projection
+    np.testing.assert_array_equal(got, full)
+    assert st.visible_splats == int(vis.sum())
+
+    # strips: every "rank" projects, sorts and draws only its strip; together they are the full frame
+    rows = (cam.height + 15) // 16
+    parts, kept = [], []
+    for strip in ((0, 7), (7, 8), (8, 15), (15, rows)):
+        mesh.project(strip)
+        worker.sort_on_device(mvp, n)
+        img, s = mesh.render(tile_rows=strip)
+        parts.append(img)
+        kept.append(worker.last_stats()[0].result_count)
+        assert s.visible_splats == kept[-1]
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), full)
+    assert max(kept) < int(vis.sum())                    # a strip really sorts less than the frame
+    worker.set_visibility_cull(False)
+    worker.terminate()
+    mesh.dispose()
+
+
+def test_a_projection_is_consumed_once_and_only_by_its_own_camera(ctx):
+    scene, cam, ci, worker, mesh = _setup(ctx, n=20000, seed=5, w=320, h=200)
+    n = scene.count
+    order = oracle.sort_indexes(np.arange(n, dtype=np.uint32), ci, cam.sort_mvp())
+    mesh.update_render_indexes(order, n)
+    want, _ = mesh.render()
+    other = camera.orbit_cameras("garden", 320, 200, 8)[3]
+    mesh.set_camera(other)
+    mesh.project()                                       # projected for `other` ...
+    mesh.set_camera(cam)
+    got, _ = mesh.render()                               # ... drawn with `cam`: the stale projection must not be used
+    np.testing.assert_array_equal(got, want)
+    mesh.project()
+    a, _ = mesh.render()
+    b, _ = mesh.render()                                 # second draw projects again itself
+    np.testing.assert_array_equal(a, want)
+    np.testing.assert_array_equal(b, want)
+    worker.terminate()
+    mesh.dispose()
+
+
+def test_group_of_one_gathers_its_strip_into_the_frame(ctx):
+    """gs_group_* with world_size 1 (no RCCL involved): the root's own strip lands at its rows of the full frame."""
+    group = gdist.StripGroup(ctx, 0, 1)
+    h, w = 96, 64
+    strips = [(2, 5)]                                    # tile rows -> pixel rows [32, 80)
+    strip = torch.randint(0, 255, (48, w, 4), dtype=torch.uint8, device="cuda")
+    full = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    group.gather_strips(strip.data_ptr(), full.data_ptr(), w, strips, h)
+    ctx.synchronize()
+    assert torch.equal(full[32:80], strip) and not full[:32].any() and not full[80:].any()
+    group.close()

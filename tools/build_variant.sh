@@ -9,11 +9,11 @@ OUT=$ROOT/gpurun_ab; OBJ=/tmp/gsvar_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $*"
 pids=()
-for f in context selftest sorter mesh project tile_bin tile_blend tree assets; do
+for f in context selftest sorter mesh project tile_bin tile_blend tree assets group; do
   extra=""; [ $f = sorter -o $f = project -o $f = tree -o $f = assets ] && extra="-ffp-contract=off"
   ( /opt/rocm/bin/hipcc $FLAGS $extra -c $SRC/$f.hip -o $OBJ/$f.o ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJ/*.o -o $OUT/lib_$NAME.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $OBJ/*.o -ldl -o $OUT/lib_$NAME.so
 echo built $OUT/lib_$NAME.so

@@ -1,7 +1,7 @@
-"""What one rank of an N-GPU strip-sharded draw costs, measured on ONE GPU: for every N the ranks' strips (balanced from
-the probe frame's per-row entry counts, as bench.py does) are drawn one after the other, each as `steps` pipelined
-frames of full sort + strip draw; the slowest rank bounds the N-GPU frame (the RGBA8 gather over xGMI is not included).
-usage: python tools/strip_scaling.py [C3|C5] [steps]"""
+"""Per-rank cost of the strip-sharded frame for N = 1, 2, 4, 8, measured on ONE GPU: every rank's frame (vertex stage with
+its strip -> visibility-culled sort -> bin -> blend of the strip) is run in turn on a single-stream context and the slowest
+rank is reported, i.e. what bench.py --gpus N would take without the framebuffer gather.
+usage: python tools/strip_scaling.py [C3|C5|...] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,30 +14,45 @@ W, H = cfg["width"], cfg["height"]
 scene = scenes.make_config_scene(name)
 cam = camera.demo_camera(cfg["pose"], W, H)
 N = scene.count
-ctx = Context(0)
+ctx = Context(0, single_stream=True)
 w = create_sort_worker(ctx, N)
 w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
 mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half).build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
 mesh.set_camera(cam)
 mvp = cam.sort_mvp()
-w.sort_on_device(mvp, N)
-mesh.use_sorter_result(w, N)
-mesh.render(to_host=False, want_stats=True)
+for _ in range(2):
+    w.sort_on_device(mvp, N)
+    mesh.use_sorter_result(w, N)
+    mesh.render(to_host=False, want_stats=True)
 row_cost = mesh.tile_row_costs()
-base = None
-for world in (1, 2, 4, 8):
-    strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, (H + 15) // 16)]
-    per_rank = []
-    for s in strips:
-        for _ in range(3):
-            w.sort_on_device(mvp, N); mesh.render(tile_rows=s if world > 1 else None, to_host=False, want_stats=False)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            w.sort_on_device(mvp, N); mesh.render(tile_rows=s if world > 1 else None, to_host=False, want_stats=False)
-        ctx.synchronize()
-        per_rank.append((time.perf_counter() - t0) / steps * 1e3)
-    worst = max(per_rank)
-    base = base or worst
-    print(f"{name} N={world}: slowest rank {worst:.4f} ms (ranks {', '.join('%.3f' % t for t in per_rank)}) -> "
-          f"{N / worst / 1e3:.0f} Msplats/s, speed-up {base / worst:.2f}x without the gather")
+
+
+def timed(strip, culled):
+    w.set_visibility_cull(culled)
+    def frame():
+        if culled:
+            mesh.project(strip)
+        w.sort_on_device(mvp, N)
+        mesh.render(tile_rows=strip, to_host=False, want_stats=False)
+    for _ in range(3):
+        frame()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+base = timed(None, False)
+print(f"{name} full sort, 1 GPU (the headline path): {base:.4f} ms/frame")
+one = None
+for n in (1, 2, 4, 8):
+    strips = gdist.balanced_row_strips(row_cost, n) if n > 1 else [None]
+    ms = [timed(s, True) for s in strips]
+    kept = []
+    slow = max(ms)
+    one = one or slow
+    print(f"{name} N={n}: slowest rank {slow:.4f} ms (ranks {', '.join('%.3f' % v for v in ms)}) -> "
+          f"{N / (slow * 1e-3) / 1e6:.0f} Msplats/s, speed-up {one / slow:.2f}x over N=1 of the same path, "
+          f"{base / slow:.2f}x over the full-sort frame, without the gather")

@@ -58,11 +58,14 @@ class SplatTree:
         return bounds, centers, depths, offsets, indexes
 
     def gather_scene_nodes_for_sort(self, camera, sort_worker=None, gather_all_nodes=False, mesh_world=None,
-                                    fov_deg=cam_math.THREE_FOV_DEG, to_host=True):
+                                    fov_deg=cam_math.THREE_FOV_DEG, to_host=True, model_view=None):
         """Viewer.gatherSceneNodesForSort: returns {'splatRenderCount', 'shouldSortAll', 'indexesToSort'}.  With a
         sort worker the list is written into its device buffer (``sort_worker.sort_gathered`` consumes it)."""
         gp = L.GatherParams()
-        mv = np.asarray(camera.view if mesh_world is None else cam_math.multiply(camera.view, mesh_world), np.float64)
+        if model_view is not None:        # inverse(camera.matrixWorld) * splatMesh.matrixWorld, already multiplied (fp64)
+            mv = np.asarray(model_view, np.float64)
+        else:
+            mv = np.asarray(camera.view if mesh_world is None else cam_math.multiply(camera.view, mesh_world), np.float64)
         gp.model_view[:] = mv.reshape(16).tolist()
         gp.fov_y_deg = float(fov_deg)
         gp.render_width, gp.render_height = float(camera.width), float(camera.height)

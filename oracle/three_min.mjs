@@ -9,6 +9,9 @@ export class Vector3 {
   constructor(x = 0, y = 0, z = 0) { this.x = x; this.y = y; this.z = z; }
   set(x, y, z) { if (z === undefined) z = this.z; this.x = x; this.y = y; this.z = z; return this; }
   setScalar(s) { this.x = s; this.y = s; this.z = s; return this; }
+  setX(x) { this.x = x; return this; }
+  setY(y) { this.y = y; return this; }
+  setZ(z) { this.z = z; return this; }
   clone() { return new Vector3(this.x, this.y, this.z); }
   copy(v) { this.x = v.x; this.y = v.y; this.z = v.z; return this; }
   add(v) { this.x += v.x; this.y += v.y; this.z += v.z; return this; }

@@ -112,6 +112,53 @@ def test_scheduler_follows_run_splat_sort():
     assert s.next_sort(moved, n, True) is None and s.next_sort(moved, n, True, force=True) == n   # shouldSortAll
 
 
+# ------------------------------------------------------------------------------------------------ cull, pinned
+GATHER = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gather_kat.json")))
+
+
+def _gather_cases():
+    return [(name, k) for name in GATHER for k in range(len(GATHER[name]["cameras"]))]
+
+
+def _model_view(cam):
+    return np.array([struct.unpack("<d", bytes.fromhex(h))[0] for h in cam["modelView"]])
+
+
+class _Dims:
+    def __init__(self, cam):
+        self.width, self.height = cam["width"], cam["height"]
+
+
+@pytest.mark.parametrize("name,k", _gather_cases())
+def test_cull_oracle_matches_the_reference_gather(name, k):
+    """Pins oracle/tree_oracle.py::gather: same splatRenderCount and the same index list as the reference's own
+    Viewer.gatherSceneNodesForSort text produced under Node (oracle/gather_ref.mjs, tests/golden/gather_kat.json)."""
+    from oracle import tree_oracle
+    case = tree_cases.make_case(name)
+    cam = GATHER[name]["cameras"][k]
+    leaves, _ = tree_oracle.build_tree(case["centers"], None, case["max_depth"], case["max_centers"])
+    assert len(leaves) == GATHER[name]["leaves"]
+    got = tree_oracle.gather(leaves, _model_view(cam), cam["fov"], cam["width"], cam["height"], cam["gatherAll"])
+    assert len(got) == cam["splatRenderCount"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == cam["sha256"]
+    if cam["indexes"] is not None:
+        np.testing.assert_array_equal(got, np.array(cam["indexes"], np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,k", _gather_cases())
+def test_device_gather_matches_the_reference_gather(ctx, name, k):
+    """The device cull (gs_tree_gather) against the same reference-recorded lists."""
+    case = tree_cases.make_case(name)
+    cam = GATHER[name]["cameras"][k]
+    tree = SplatTree(ctx, case["max_depth"], case["max_centers"]).process_splat_mesh(case["centers"])
+    got = tree.gather_scene_nodes_for_sort(_Dims(cam), gather_all_nodes=cam["gatherAll"], fov_deg=cam["fov"],
+                                           model_view=_model_view(cam))
+    assert got["splatRenderCount"] == cam["splatRenderCount"]
+    assert hashlib.sha256(got["indexesToSort"].tobytes()).hexdigest() == cam["sha256"]
+    tree.dispose()
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("pose,gather_all", [("garden", False), ("truck", False), ("bonsai", False), ("garden", True)])

@@ -205,6 +205,8 @@ struct gs_sorter {
     bool last_culled = false;          // the resident result holds only the kept splats; its length lives in result_frame
     const SortFrame* result_frame = nullptr;
     DevBuf keep_mask;                  // 1 bit per list position (frustum-cull variant)
+    DevBuf chunk_counts;               // survivors per chunk of the identity list (visibility-cull variant)
+    bool last_vis_culled = false;
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -288,6 +290,8 @@ struct gs_mesh {
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
     DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
+    DevBuf vis_orig;           // uint32 [ceil(n/32)]     the mask by ORIGINAL splat index (gs_mesh_project only: feeds the
+                               //                         visibility-culled sort)
     DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)
     DevBuf order;              // uint32 [render_count] when the caller supplies host indexes
     DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx
@@ -326,6 +330,6 @@ const uint32_t* gs_mesh_payload_map(gs_mesh* m, uint32_t splats);
 const uint32_t* gs_mesh_payload_unmap(gs_mesh* m);
 
 // kernels' host launchers ---------------------------------------------------------------------------
-int gs_launch_project(gs_mesh* m, const ProjectParams& pp);
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask);
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count);
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);

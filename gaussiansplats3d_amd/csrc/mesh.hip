@@ -343,6 +343,7 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     GS_REQUIRE(m->sh_degree == 0 || sh_u8 || sh_f16, "mesh stores spherical harmonics but sh_f16 == NULL");
     GS_REQUIRE(!(sh_u8 && sh_f16), "GS_MESH_SH_U8 mesh: upload SH with gs_mesh_upload_sh_u8");
     if (count == 0) return GS_OK;
+    m->projection_pending = false;                        // the scene changed under a pending gs_mesh_project
     ScopedDevice sd(m->ctx->device);
     // earlier draws may still read the planes / the permutation on either stream
     GS_HIP(hipStreamSynchronize(m->ctx->stream));
@@ -387,6 +388,7 @@ int gs_mesh_upload_sh_u8(gs_mesh* m, uint32_t from, uint32_t count, const uint8_
     GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
     GS_REQUIRE(mesh_range_slotted(m, from, count), "upload the splats with gs_mesh_upload before their 8-bit SH");
     if (count == 0) return GS_OK;
+    m->projection_pending = false;                        // the scene changed under a pending gs_mesh_project
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     const uint32_t ncoef = m->sh_degree == 1 ? 9 : 24;
@@ -403,6 +405,7 @@ int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, cons
     GS_REQUIRE(m && scene_indexes, "mesh / scene_indexes == NULL");
     GS_REQUIRE((uint64_t)from + count <= m->max_count, "range exceeds max_splat_count");
     GS_REQUIRE(mesh_range_slotted(m, from, count), "upload the splats with gs_mesh_upload before their scene indexes");
+    m->projection_pending = false;                        // the scene changed under a pending gs_mesh_project
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     if (!m->scene_idx.p) {
@@ -424,6 +427,7 @@ int gs_mesh_upload_scene_indexes(gs_mesh* m, uint32_t from, uint32_t count, cons
 int gs_mesh_set_scenes(gs_mesh* m, const gs_scene_params* params) {
     GS_REQUIRE(m && params, "mesh / params == NULL");
     GS_REQUIRE(params->scene_count >= 1 && params->scene_count <= GS_MAX_SCENES, "scene_count outside 1..GS_MAX_SCENES");
+    m->projection_pending = false;                        // the scene changed under a pending gs_mesh_project
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     // the vertex stage of an earlier draw may still read the previous values on ctx->aux
@@ -477,7 +481,7 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
 // The vertex stage of a draw.  It only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
 // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed the records /
 // rects / mask it is about to overwrite.
-static int mesh_project(gs_mesh* m, const ProjectParams& pp) {
+static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
     GS_HIP(hipEventRecord(m->ev[0], st));
@@ -498,7 +502,7 @@ static int mesh_project(gs_mesh* m, const ProjectParams& pp) {
         m->ev_p1 = m->ring1[slot];
     }
     GS_HIP(hipEventRecord(m->ev_p0, aux));
-    GS_TRY(gs_launch_project(m, pp));
+    GS_TRY(gs_launch_project(m, pp, orig_mask));
     GS_HIP(hipEventRecord(m->ev_p1, aux));
     return GS_OK;
 }
@@ -509,7 +513,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     hipStream_t st = ctx->stream, aux = ctx->aux;
     const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
-    if (!projected) GS_TRY(mesh_project(m, pp));           // else gs_mesh_project already ran it for this camera
+    if (!projected) GS_TRY(mesh_project(m, pp, false));    // else gs_mesh_project already ran it for this camera
     // join: projection and (if a sorter feeds this draw) the sort result
     if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
     if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
@@ -585,7 +589,7 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
     ProjectParams pp;
     GS_TRY(mesh_params(m, cam, pp));
     ScopedDevice sd(m->ctx->device);
-    GS_TRY(mesh_project(m, pp));
+    GS_TRY(mesh_project(m, pp, true));                     // + the per-splat mask a visibility-culled sort reads
     m->projection_pending = true;
     m->projected_cam = *cam;
     return GS_OK;

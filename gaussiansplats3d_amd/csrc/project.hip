@@ -105,7 +105,8 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
 template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
-                                                 uint2* __restrict__ vis32) {
+                                                 uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
+                                                 const uint32_t* __restrict__ inv_perm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     SplatRec rec;
@@ -288,10 +289,16 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         const uint32_t slot = wave_base + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
         recs[slot] = rec;
         rects[slot] = rect;
+        // gs_mesh_project: the same bit by ORIGINAL splat index, for a sort that keeps only what this frame draws (the mask
+        // was zeroed before the launch; only survivors pay the atomic)
+        if (vis_orig) {
+            const uint32_t orig = inv_perm ? inv_perm[i] : i;
+            atomicOr(&vis_orig[orig >> 5], 1u << (orig & 31u));
+        }
     }
 }
 
-int gs_launch_project(gs_mesh* m, const ProjectParams& pp) {
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     MeshPlanes mp;
     mp.px = m->px.as<float>(); mp.py = m->py.as<float>(); mp.pz = m->pz.as<float>();
     mp.covA = m->covA.p; mp.covB = m->covB.p;
@@ -300,14 +307,23 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp) {
     mp.scene_idx = m->scene_idx.as<uint32_t>();
     mp.scenes = m->scene_dev.as<gs_scene_params>();
     if (pp.count == 0) return GS_OK;
+    uint32_t* vis_orig = nullptr;
+    if (orig_mask) {
+        GS_TRY(m->vis_orig.ensure(((size_t)m->max_count + 31) / 32 * 4 + 64));
+        GS_HIP(hipMemsetAsync(m->vis_orig.p, 0, ((size_t)pp.count + 31) / 32 * 4, m->ctx->aux));
+        vis_orig = m->vis_orig.as<uint32_t>();
+    }
+    const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;
     const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
-                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>());
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
+                           vis_orig, inv_perm);
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
-                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>());
+                           m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
+                           vis_orig, inv_perm);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -43,8 +43,8 @@ struct KeyParams {
     float fm0, fm1, fm2;                     // static float path: mvp[2], mvp[6], mvp[10]
     float mvp[16];                           // frustum-cull variant only: the whole modelViewProj, fp32 column-major
     unsigned long long* keep;                // cull variants only: 1 bit per list position
-    const uint2* vis32;                      // visibility-cull variant: the bound mesh's {mask, slot} table per 32 storage positions
-    const uint32_t* perm;                    // ... and its splat index -> storage position map (nullable: identity)
+    const uint32_t* count_dev;               // visibility-cull variant: the list length lives on the device (SortFrame::kept)
+    uint32_t ext_minmax;                     // ... and min / max (over EVERY splat) were taken by k_minmax_count: leave them alone
 };
 
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.ext_minmax) {
+        // visibility-culled sort: k_minmax_count did the housekeeping and took min / max over EVERY splat; this launch only
+        // keys the compacted list, whose length lives on the device
+        const uint32_t R = *p.count_dev;
+        for (uint32_t i = t; i < R; i += stride) p.keys_out[i] = depth_key_one(p, min(p.idx_in[i], p.last_splat));
+        return;
+    }
     // housekeeping folded into the first kernel of a sort (two launches and their boundaries saved per sort)
     for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
     if (t < SORT_SHARDS) {
@@ -197,19 +204,11 @@ __device__ __forceinline__ bool frustum_keep_int(const float* m, uint32_t x, uin
                             __fmul_rn((float)(int32_t)z, 0.001f));
 }
 
-// Keep test of the VISIBILITY cull (gs_sorter_set_visibility_cull): the splat survived the bound mesh's vertex stage for this
-// camera (and this rank's strip of tile rows) - exactly the splats that reach the frame, whatever the camera model.
-__device__ __forceinline__ bool visible_keep(const KeyParams& p, uint32_t splat) {
-    const uint32_t pos = p.perm ? p.perm[splat] : splat;
-    return (p.vis32[pos >> 5].x >> (pos & 31u)) & 1u;
-}
-
 // VEC4 (identity list, static integer mode): lane l of a wave owns positions 4*(v0 + l) .. +3 of a 256-position window,
 // read as three 16-byte plane loads; the 4 keep bits of 16 neighbouring lanes are OR-combined into one mask word.
 // Otherwise: 4 positions per lane, 64 apart, so 4 index loads and then 4 centre gathers are in flight per lane and
 // every ballot is one mask word.
-// VIS: keep = visible_keep (the mesh's mask) instead of the frustum test on the sorter's own centres.
-template <bool VEC4, bool VIS>
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
     __shared__ int32_t s_lo[4], s_hi[4];
     __shared__ uint32_t s_kept[4];
@@ -247,16 +246,8 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                 o4[v] = k;
                 lo = min(min(lo, k.x), min(min(k.y, k.z), k.w));
                 hi = max(max(hi, k.x), max(max(k.y, k.z), k.w));
-                if (VIS) {
-                    uint4 pos = make_uint4(4u * v, 4u * v + 1u, 4u * v + 2u, 4u * v + 3u);
-                    if (p.perm) pos = reinterpret_cast<const uint4*>(p.perm)[v];
-                    const uint2 m0v = p.vis32[pos.x >> 5], m1v = p.vis32[pos.y >> 5], m2v = p.vis32[pos.z >> 5], m3v = p.vis32[pos.w >> 5];
-                    nib = ((m0v.x >> (pos.x & 31u)) & 1u) | (((m1v.x >> (pos.y & 31u)) & 1u) << 1) |
-                          (((m2v.x >> (pos.z & 31u)) & 1u) << 2) | (((m3v.x >> (pos.w & 31u)) & 1u) << 3);
-                } else {
-                    nib = (frustum_keep_int(p.mvp, x.x, y.x, z.x) ? 1u : 0u) | (frustum_keep_int(p.mvp, x.y, y.y, z.y) ? 2u : 0u) |
-                          (frustum_keep_int(p.mvp, x.z, y.z, z.z) ? 4u : 0u) | (frustum_keep_int(p.mvp, x.w, y.w, z.w) ? 8u : 0u);
-                }
+                nib = (frustum_keep_int(p.mvp, x.x, y.x, z.x) ? 1u : 0u) | (frustum_keep_int(p.mvp, x.y, y.y, z.y) ? 2u : 0u) |
+                      (frustum_keep_int(p.mvp, x.z, y.z, z.z) ? 4u : 0u) | (frustum_keep_int(p.mvp, x.w, y.w, z.w) ? 8u : 0u);
             } else if (v < nvec) {                                 // the ragged last vector
                 for (uint32_t c = 0; c < 4u; c++) {
                     const uint32_t i = 4u * v + c;
@@ -264,7 +255,7 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                         const uint32_t x = p.cx[i], y = p.cy[i], z = p.cz[i];
                         const int32_t k = (int32_t)(x * m0 + y * m1 + z * m2);
                         p.keys_out[i] = k; lo = min(lo, k); hi = max(hi, k);
-                        nib |= (VIS ? visible_keep(p, i) : frustum_keep_int(p.mvp, x, y, z)) ? (1u << c) : 0u;
+                        nib |= frustum_keep_int(p.mvp, x, y, z) ? (1u << c) : 0u;
                     }
                 }
             }
@@ -309,7 +300,7 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
                     p.keys_out[i] = key;
                     lo = min(lo, key);
                     hi = max(hi, key);
-                    keep[k] = VIS ? visible_keep(p, g[k]) : frustum_keep_one(p.mvp, x, y, z);
+                    keep[k] = frustum_keep_one(p.mvp, x, y, z);
                 }
             }
 #pragma unroll
@@ -343,6 +334,115 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Visibility-culled sort (gs_sorter_set_visibility_cull): compact, then sort the survivors.
+// The bound mesh's vertex stage left one bit per ORIGINAL splat index (gs_mesh::vis_orig) for this camera and strip.  The
+// reference's buckets depend on min / max over every sorted position, so every splat is still keyed once - but nothing is
+// stored for the ones that draw nothing:
+//   k_minmax_count   one streaming pass over the centres (12 bytes per splat): min / max, and the number of set mask bits of
+//                    every workgroup's contiguous chunk of positions;
+//   k_mask_compact   mask -> ascending list of the surviving splat indexes (a subsequence of the identity list, so the stable
+//                    sort keeps the reference's tie order), its length -> SortFrame::kept;
+//   then the ordinary index-list sort runs on that list with the min / max above (k_depth_key ext_minmax, DepthLoader n_dev).
+// A rank of a multi-GPU draw therefore streams 12 bytes per splat and radix-sorts only what its strip draws.
+constexpr uint32_t VC_THREADS = 256, VC_SPAN = 1024;       // positions per workgroup iteration (4 per lane; 32 mask words)
+
+__device__ __forceinline__ int32_t depth_key_planes(const KeyParams& p, uint32_t i) {
+    if (p.mode & MODE_INT) return (int32_t)(p.cx[i] * (uint32_t)p.im0 + p.cy[i] * (uint32_t)p.im1 + p.cz[i] * (uint32_t)p.im2);
+    float s = __fmul_rn(p.fm0, __uint_as_float(p.cx[i]));
+    s = __fadd_rn(s, __fmul_rn(p.fm1, __uint_as_float(p.cy[i])));
+    s = __fadd_rn(s, __fmul_rn(p.fm2, __uint_as_float(p.cz[i])));
+    return trunc_f64_i32((double)s * 4096.0);
+}
+
+__global__ __launch_bounds__(VC_THREADS) void k_minmax_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t chunk_len,
+                                                             uint32_t* __restrict__ chunk_counts) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;
+        p.next_frame->key_max[t] = -2147483640;
+    }
+    if (t == 0) {
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+    }
+    const uint32_t N = p.render_count;
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);     // chunk_len % VC_SPAN == 0
+    int32_t lo = 2147483640, hi = -2147483640;
+    uint32_t cnt = 0;
+    const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
+    for (uint32_t base = begin; base < end; base += VC_SPAN) {
+        const uint32_t i0 = base + 4u * threadIdx.x;
+        if ((p.mode & MODE_INT) && i0 + 4u <= end) {               // 16-byte plane loads
+            const uint4 x = reinterpret_cast<const uint4*>(p.cx)[i0 >> 2], y = reinterpret_cast<const uint4*>(p.cy)[i0 >> 2],
+                        z = reinterpret_cast<const uint4*>(p.cz)[i0 >> 2];
+            const int32_t k0 = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2), k1 = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
+            const int32_t k2 = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2), k3 = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
+            lo = min(min(lo, k0), min(min(k1, k2), k3));
+            hi = max(max(hi, k0), max(max(k1, k2), k3));
+        } else {
+            for (uint32_t i = i0; i < min(i0 + 4u, end); i++) {
+                const int32_t k = depth_key_planes(p, i);
+                lo = min(lo, k);
+                hi = max(hi, k);
+            }
+        }
+        const uint32_t w = (base >> 5) + threadIdx.x;              // the 32 mask words of this span
+        if (threadIdx.x < VC_SPAN / 32u && (w << 5) < end) cnt += (uint32_t)__popc(mask[w]);   // bits beyond N are never set
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u) { s_lo[wave] = lo; s_hi[wave] = hi; s_cnt[wave] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])));
+        atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
+        chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    }
+}
+
+__global__ __launch_bounds__(VC_THREADS) void k_mask_compact(const uint32_t* __restrict__ mask, const uint32_t* __restrict__ chunk_counts,
+                                                             uint32_t N, uint32_t chunk_len, uint32_t* __restrict__ idx_out,
+                                                             SortFrame* __restrict__ frame) {
+    __shared__ uint32_t s_tmp[4], s_before[4], s_all[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t before = 0, all = 0;                                   // survivors of the chunks before this one / of all chunks
+    for (uint32_t c = threadIdx.x; c < gridDim.x; c += VC_THREADS) {
+        const uint32_t v = chunk_counts[c];
+        all += v;
+        before += c < blockIdx.x ? v : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o, 64);
+        all += __shfl_xor(all, o, 64);
+    }
+    if (lane == 0u) { s_before[wave] = before; s_all[wave] = all; }
+    __syncthreads();
+    uint32_t out = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);
+    for (uint32_t base = begin; base < end; base += 32u * VC_THREADS) {        // one mask word (32 positions) per thread
+        const uint32_t first = base + 32u * threadIdx.x;
+        uint32_t w = first < end ? mask[first >> 5] : 0u;
+        uint32_t total;
+        uint32_t o = out + block_excl_scan<4>((uint32_t)__popc(w), s_tmp, &total);
+        while (w) {
+            idx_out[o++] = first + (uint32_t)__builtin_ctz(w);
+            w &= w - 1u;
+        }
+        out += total;
+    }
+}
+
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
 template <bool CULL>
@@ -352,6 +452,7 @@ struct DepthLoaderT {
     const uint32_t* __restrict__ idx;      // nullable: identity
     const uint32_t* __restrict__ map;      // nullable: payload = map[splat index] (a bound mesh's internal position)
     SortFrame* frame;
+    const uint32_t* n_dev;                 // nullable: the list length lives on the device (visibility-culled sort)
     uint32_t sort_start, render_count, range;
     uint32_t last_splat;                   // list entries are clamped to it
     uint32_t count_clamps;                 // only the histogram launch counts, so each element counts once
@@ -359,8 +460,17 @@ struct DepthLoaderT {
     float range_map;
 
     __device__ __forceinline__ void prepare() {
-        lo = frame->lo();
-        const int32_t hi = frame->hi();
+        if (n_dev) render_count = *n_dev;                       // sort_start is 0 in that variant
+        // the sort's min / max live in SORT_SHARDS words each: lane l reads shard l, five xor-shuffles reduce them
+        // (every thread reading all 64 words cost the histogram kernel 5 us)
+        const uint32_t l = threadIdx.x & (SORT_SHARDS - 1u);
+        lo = frame->key_min[l];
+        int32_t hi = frame->key_max[l];
+#pragma unroll
+        for (int o = SORT_SHARDS / 2; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
         // sorter.cpp:142-143: (float)(range-1) / ((float)max - (float)min), fp32, correctly rounded
         range_map = __fdiv_rn((float)(range - 1), __fsub_rn((float)hi, (float)lo));
     }
@@ -562,8 +672,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     const bool dynamic = (s->flags & GS_SORT_DYNAMIC) != 0;
     GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
     const bool vis_cull = s->visibility_cull;
-    const bool cull = s->frustum_cull || vis_cull;
-    GS_REQUIRE(!cull || (sort_count == render_count && !dynamic && !precomputed),
+    const bool cull = s->frustum_cull && !vis_cull;        // the frustum cull's keep-mask path; the visibility cull compacts instead
+    GS_REQUIRE(!(cull || vis_cull) || (sort_count == render_count && !dynamic && !precomputed),
                "a per-splat cull needs a full sort (splatSortCount == splatRenderCount) of a static scene without precomputed distances");
     gs_context* ctx = s->ctx;
     ScopedDevice sd(ctx->device);
@@ -580,6 +690,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     if (vis_cull) {
         GS_REQUIRE(s->bound_mesh && s->bound_mesh->projection_pending && s->bound_mesh->uploaded >= s->uploaded,
                    "the visibility cull needs gs_sorter_bind_mesh and a gs_mesh_project of this frame's camera before the sort");
+        GS_REQUIRE(!indexes_to_sort && !device_list, "the visibility cull sorts the identity list (pass indexes_to_sort = NULL)");
         if (s->bound_mesh->ev_p1 && ctx->aux != st) GS_HIP(hipStreamWaitEvent(st, s->bound_mesh->ev_p1, 0));   // the mask it reads
     }
     const uint32_t* unmap = map ? gs_mesh_payload_unmap(s->bound_mesh) : nullptr;
@@ -642,24 +753,32 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         GS_TRY(s->keep_mask.ensure((((size_t)s->max_count + 63) / 64 + 8) * 8));   // the key kernel writes whole 256-position windows
         kp.keep = s->keep_mask.as<unsigned long long>();
         memcpy(kp.mvp, mvp, sizeof(kp.mvp));
-        if (vis_cull) {
-            kp.vis32 = s->bound_mesh->vis32.as<uint2>();
-            kp.perm = map;                                 // nullptr for a mesh that keeps upload order
-        }
     }
 
     GS_HIP(hipEventRecord(s->ev0, st));
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
-        if (cull && vec4 && vis_cull)
-            hipLaunchKernelGGL((k_depth_key_cull<true, true>), dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
-        else if (cull && vec4)
-            hipLaunchKernelGGL((k_depth_key_cull<true, false>), dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
-        else if (cull && vis_cull)
-            hipLaunchKernelGGL((k_depth_key_cull<false, true>), dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
+        if (vis_cull) {
+            // compact, then sort the survivors (see k_minmax_count): the list is what the bound mesh's vertex stage kept
+            const uint32_t spans = (R + VC_SPAN - 1u) / VC_SPAN;
+            const uint32_t grid = spans < (uint32_t)ctx->cu_count * 2u ? spans : (uint32_t)ctx->cu_count * 2u;
+            const uint32_t chunk_len = ((spans + grid - 1u) / grid) * VC_SPAN;
+            GS_TRY(s->chunk_counts.ensure((size_t)grid * 4));
+            GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
+            const uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
+            hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
+            hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->chunk_counts.as<uint32_t>(), R, chunk_len,
+                               s->idx_in.as<uint32_t>(), kp.frame);
+            idx_dev = s->idx_in.as<uint32_t>();
+            kp.idx_in = idx_dev;
+            kp.count_dev = &kp.frame->kept;
+            kp.ext_minmax = 1u;
+            hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+        } else if (cull && vec4)
+            hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else if (cull)
-            hipLaunchKernelGGL((k_depth_key_cull<false, false>), dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (vec4)
             hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else
@@ -674,6 +793,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         dl.render_count = R;
         dl.range = 1u << s->precision;
         dl.last_splat = kp.last_splat;
+        dl.n_dev = vis_cull ? &kp.frame->kept : nullptr;
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
         const bool wide = s->precision > 16;
@@ -684,7 +804,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             const int shift = 8 * (int)p;
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
-            const uint32_t* n_dev = cull ? &kp.frame->kept : nullptr;
+            const uint32_t* n_dev = (cull || vis_cull) ? &kp.frame->kept : nullptr;
             if (p == 0 && cull) {
                 DepthLoaderCull dc = {};
                 dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
@@ -719,7 +839,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     s->last_sort = Rs;
     s->last_passes = passes;
     s->last_identity = (idx_dev == nullptr);
-    s->last_culled = cull && Rs > 0;
+    s->last_culled = (cull || vis_cull) && Rs > 0;
+    s->last_vis_culled = vis_cull && Rs > 0;
     s->result_frame = kp.frame;
     s->result_mesh = map ? s->bound_mesh : nullptr;
     s->result_unmap = unmap;
@@ -827,8 +948,15 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
         src = s->debug.p;
     } else if (what == 3) {
         GS_REQUIRE(s->last_culled, "the last sort did not cull");
-        GS_REQUIRE((size_t)count * 4 <= s->keep_mask.bytes, "count exceeds the mask length");
-        src = s->keep_mask.p;
+        if (s->last_vis_culled) {                  // the bound mesh's per-splat mask (original splat numbering)
+            bool alive = false;
+            for (gs_mesh* m : s->ctx->live_meshes) alive = alive || (m == s->bound_mesh);
+            GS_REQUIRE(alive && (size_t)count * 4 <= s->bound_mesh->vis_orig.bytes, "the mesh is gone or count exceeds the mask length");
+            src = s->bound_mesh->vis_orig.p;
+        } else {
+            GS_REQUIRE((size_t)count * 4 <= s->keep_mask.bytes, "count exceeds the mask length");
+            src = s->keep_mask.p;
+        }
     } else {
         GS_REQUIRE(false, "unknown debug selector");
     }

@@ -333,3 +333,8 @@ export class Box3 {
   constructor(min = new Vector3(+Infinity, +Infinity, +Infinity), max = new Vector3(-Infinity, -Infinity, -Infinity)) { this.min = min; this.max = max; }
   containsPoint(p) { return !(p.x < this.min.x || p.x > this.max.x || p.y < this.min.y || p.y > this.max.y || p.z < this.min.z || p.z > this.max.z); }
 }
+
+// what SplatMaterial3D.build touches besides the math types (the material is only a bag of its parameters here)
+export class ShaderMaterial { constructor(params) { Object.assign(this, params); } }
+export class Color { constructor(r = 1, g = 1, b = 1) { this.r = r; this.g = g; this.b = b; } }
+export const NormalBlending = 1, DoubleSide = 2, FrontSide = 0;

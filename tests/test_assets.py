@@ -64,7 +64,13 @@ def test_ply_reader_against_reference_header_and_oracle(name):
     got = a.fill(minimum_alpha=1, want_scale_rotation=True)
     np.testing.assert_array_equal(got["centers"], c)
     np.testing.assert_array_equal(got["scales"].view(np.uint32), s.view(np.uint32))
-    np.testing.assert_array_equal(got["rotations"].view(np.uint32), rot[:, [1, 2, 3, 0]].view(np.uint32))   # (x,y,z,w)
+    # (x,y,z,w) as fillSplatScaleRotationArray returns them: normalised once more and flipped to w >= 0 (pinned against the
+    # reference's own code in tests/test_assets_ref.py)
+    q = rot[:, [1, 2, 3, 0]].astype(np.float64)
+    ln = np.sqrt(q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1] + q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])
+    q = np.where(ln[:, None] == 0, [[0.0, 0.0, 0.0, 1.0]], q * (1.0 / np.where(ln == 0, 1.0, ln))[:, None])
+    q = q * np.where(q[:, 3:4] < 0, -1.0, 1.0)
+    np.testing.assert_array_equal(got["rotations"].view(np.uint32), q.astype(np.float32).view(np.uint32))
     np.testing.assert_array_equal(got["rgba"], rgba_f)
     np.testing.assert_array_equal(got["cov"].view(np.uint32), cov.view(np.uint32))
     if deg:

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(CSRC, "libgsplat_hip.so")   # override: A/B of builds
 
-GS_OK, GS_WARN_KEY_CLAMPED = 0, 1
+GS_OK, GS_WARN_KEY_CLAMPED, GS_WARN_FRAME_TRUNCATED = 0, 1, 2
 GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
 GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4

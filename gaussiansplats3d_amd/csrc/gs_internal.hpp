@@ -319,6 +319,10 @@ struct gs_mesh {
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;
+    uint32_t* mirror_host = nullptr;   // mapped pinned {serial, overflow, entries lo, hi} written by every draw's k_bin_emit
+    uint32_t* mirror_dev = nullptr;
+    uint32_t draw_serial = 0, healed_serial = 0;
+    uint32_t truncated_draws = 0;      // asynchronous draws that overflowed the entry buffer (noticed after the fact)
     bool projection_pending = false;   // gs_mesh_project ran; the next gs_mesh_render with the same camera consumes it
     gs_camera projected_cam = {};
 };

@@ -229,6 +229,15 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
             gs_set_error("hipEventCreate failed");
             st = GS_ERR_HIP;
         }
+    if (st == GS_OK) {
+        if (hipHostMalloc((void**)&m->mirror_host, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&m->mirror_dev, m->mirror_host, 0) != hipSuccess) {
+            gs_set_error("hipHostMalloc(mapped) failed");
+            st = GS_ERR_HIP;
+        } else {
+            memset(m->mirror_host, 0, 64);
+        }
+    }
     if (st != GS_OK) {
         gs_mesh_destroy(m);
         return st;
@@ -255,6 +264,7 @@ void gs_mesh_destroy(gs_mesh* m) {
         if (m->ring1[i]) (void)hipEventDestroy(m->ring1[i]);
     }
     if (m->ev_done) (void)hipEventDestroy(m->ev_done);
+    if (m->mirror_host) (void)hipHostFree(m->mirror_host);
     delete m;
 }
 
@@ -584,6 +594,28 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     return GS_OK;
 }
 
+// An asynchronous draw (no stats, no host output) cannot know whether its entry buffer overflowed; the frame it produced is
+// then missing its farthest list entries.  Every draw leaves its verdict in mapped host memory (k_bin_emit), and the next
+// draw reads it here - no synchronisation when everything fitted.  After an overflow the buffers are grown to what that
+// draw needed (this waits for the stream once) and the caller is told with GS_WARN_FRAME_TRUNCATED.
+static int mesh_heal_overflow(gs_mesh* m, bool* healed) {
+    *healed = false;
+    volatile uint32_t* mir = m->mirror_host;
+    const uint32_t serial = mir[0];
+    if (serial == m->healed_serial || !mir[1]) return GS_OK;
+    const uint64_t need = ((uint64_t)mir[3] << 32) | mir[2];
+    if (mir[0] != serial) return GS_OK;                     // a newer draw is writing: look again next time
+    m->healed_serial = serial;
+    if (need <= m->entry_capacity) return GS_OK;            // already grown (by a synchronous draw or gs_mesh_last_stats)
+    uint64_t want = need + need / 8 + 1024;
+    if (want > 0x7FFFFFFFull) want = 0x7FFFFFFFull;
+    GS_HIP(hipStreamSynchronize(m->ctx->stream));           // draws in flight still use the old buffers
+    GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
+    m->truncated_draws++;
+    *healed = true;
+    return GS_OK;
+}
+
 int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
     GS_REQUIRE(m && cam, "mesh / camera == NULL");
     ProjectParams pp;
@@ -608,6 +640,8 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
 
     ProjectParams pp;
     GS_TRY(mesh_params(m, cam, pp));
+    bool healed = false;
+    GS_TRY(mesh_heal_overflow(m, &healed));
     // a gs_mesh_project of exactly this camera is consumed by exactly one draw (the vertex stage runs once per frame)
     bool projected = m->projection_pending && memcmp(cam, &m->projected_cam, sizeof(*cam)) == 0;
     m->projection_pending = false;
@@ -634,7 +668,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     m->has_draw = true;
     m->last_count = pp.count;
 
-    int status = GS_OK;
+    int status = healed ? GS_WARN_FRAME_TRUNCATED : GS_OK;
     const bool need_sync = rgba_out_host || stats;
     if (need_sync) {
         // overflow check: the only host<->device round trip of a draw, and only when the caller syncs anyway
@@ -737,6 +771,9 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     } else if (what == 2) {   // [begin,end) of every tile of the last draw's strip; count = number of tiles
         GS_REQUIRE((size_t)count * 8 <= m->tile_ranges.bytes, "count exceeds the tile count of the last draw");
         GS_HIP(hipMemcpyAsync(dst, m->tile_ranges.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    } else if (what == 4) {   // per 32-px blend bin of the last draw: {entries staged, (splat, tile) pairs walked}
+        GS_REQUIRE(count <= m->blend_bins, "count exceeds the blend bins of the last draw");
+        if (count) GS_HIP(hipMemcpyAsync(dst, m->blend_stats.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           uint32_t row_begin /* first list-bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, uint32_t radix_grid,
                                                           uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist,
-                                                          uint32_t list_shift) {
+                                                          uint32_t list_shift, volatile uint32_t* __restrict__ mirror, uint32_t serial) {
     __shared__ unsigned long long s_sum[4], s_before[4], s_t16[4];
     __shared__ uint32_t s_vis[4];
     __shared__ uint32_t s_hist[EMIT_ROWS][RADIX_BINS];
@@ -244,6 +244,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             frame->overflow = D64 > capacity ? 1u : 0u;
             frame->entry_count = D;
             frame->pad = 0;
+            // host-visible copy of the overflow verdict (mapped pinned memory): an asynchronous draw that ran out of entry
+            // slots is noticed by the NEXT gs_mesh_render without a synchronisation (mesh.hip, mesh_heal_overflow)
+            if (mirror) {
+                mirror[1] = D64 > capacity ? 1u : 0u;
+                mirror[2] = (uint32_t)D64;
+                mirror[3] = (uint32_t)(D64 >> 32);
+                __threadfence_system();
+                mirror[0] = serial;
+            }
         }
     }
     if (boff64 >= D) return;                                 // nothing of this workgroup fits (or it has no entries)
@@ -324,7 +333,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
-                       m->radix.digit_total.as<uint32_t>(), pp.list_shift);
+                       m->radix.digit_total.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial);
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
 

@@ -39,6 +39,7 @@ class SplatMesh:
         self._indexes = None          # host indexes from updateRenderIndexes
         self._sorter = None           # or a SortWorker whose result is device resident
         self._cam = L.Camera()
+        self.last_status = 0
         self.handle = C.c_void_p()
         L.check(self.lib.gs_mesh_create(context.handle, self.max_splat_count, self.sh_degree,
                                         (L.GS_MESH_COV_HALF if self.half_cov else 0) |
@@ -189,7 +190,8 @@ class SplatMesh:
         out = np.empty((h, w, 4), dtype=np.uint8) if to_host else None
         stats = L.RenderStats() if want_stats else None
         idx = self._indexes
-        L.check(self.lib.gs_mesh_render(
+        # GS_WARN_FRAME_TRUNCATED: an earlier asynchronous draw overflowed its entry buffer (buffers grown since)
+        self.last_status = L.check(self.lib.gs_mesh_render(
             self.handle, C.byref(cam), idx.ctypes.data if idx is not None else None,
             self._sorter.handle if self._sorter is not None else None, self.render_count,
             out.ctypes.data if out is not None else None, C.c_void_p(out_device_ptr) if out_device_ptr else None,
@@ -240,14 +242,28 @@ class SplatMesh:
         cnt = np.where(rng[:, 1] > rng[:, 0], rng[:, 1] - rng[:, 0], 0).astype(np.uint32)   # untouched: (~0, 0)
         return cnt.reshape(b1 - b0, bins_x)
 
+    def blend_bin_stats(self):
+        """Per 32-px blend bin of the last FULL-frame draw: (entries staged, (splat, tile) pairs walked), [bin_rows, bins_x, 2]."""
+        cam = self._cam
+        bx, by = (cam.width + L.GS_BIN - 1) // L.GS_BIN, (cam.height + L.GS_BIN - 1) // L.GS_BIN
+        out = np.zeros((by * bx, 2), dtype=np.uint32)
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 4, out.ctypes.data, by * bx))
+        return out.reshape(by, bx, 2)
+
     def tile_row_costs(self):
-        """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips): every
-        list-bin row's entry count is split evenly between the tile rows it covers."""
+        """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips).  The blend is
+        what a strip mostly pays for and its cost is what it WALKS before its pixels saturate, not the length of its lists:
+        per 32-px bin row, walked (splat, tile) pairs + an eighth of the entries it staged; binning / entry sorting add the
+        list entries of the row (a quarter each).  Rows inherit an even share of the bin / list-bin row they lie in."""
         cam = self._cam
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
-        per_bin_row = self.bin_entry_counts().sum(axis=1).astype(np.float64)
         ratio = int(self.last_stats().list_bin_px) // L.GS_TILE
-        return np.repeat(per_bin_row / ratio, ratio)[:rows_total]
+        entries = np.repeat(self.bin_entry_counts().sum(axis=1).astype(np.float64) / ratio, ratio)[:rows_total]
+        st = self.blend_bin_stats().astype(np.float64).sum(axis=1)          # [bin_rows, 2]
+        blend = np.repeat((st[:, 1] + st[:, 0] / 8.0) / 2.0, 2)[:rows_total]
+        if blend.shape[0] < rows_total:
+            blend = np.pad(blend, (0, rows_total - blend.shape[0]))
+        return blend + 0.25 * entries
 
     def dispose(self):
         if self.handle:

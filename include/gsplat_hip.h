@@ -32,6 +32,9 @@ extern "C" {
 /* status codes (negative = error, positive = warning, result still defined) */
 #define GS_OK 0
 #define GS_WARN_KEY_CLAMPED 1   /* a depth bucket fell outside [0,range): the reference corrupts memory here  */
+#define GS_WARN_FRAME_TRUNCATED 2 /* gs_mesh_render: an EARLIER asynchronous draw overflowed its entry buffer (its frame
+                                     lacks the farthest entries of some lists); the buffers have been grown, this draw and
+                                     the following ones are complete                                                   */
 #define GS_ERR_INVALID (-1)     /* bad argument                                                               */
 #define GS_ERR_HIP (-2)         /* HIP runtime / device failure (see gs_last_error)                            */
 #define GS_ERR_NOMEM (-3)
@@ -307,7 +310,11 @@ typedef struct gs_render_stats {
     uint64_t splats_walked;   /* (splat, 16x16-px tile) pairs the blend evaluated                                */
 } gs_render_stats;
 
-/* updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)
+/* Entry-buffer overflow: a draw that returns statistics or pixels to the host checks and re-runs itself after growing the
+ * buffers (gs_render_stats.overflowed).  A draw that returns nothing cannot; the following gs_mesh_render notices it without
+ * synchronising, grows the buffers and returns GS_WARN_FRAME_TRUNCATED once.
+ *
+ * updateRenderIndexes(globalIndexes, renderSplatCount) + renderer.render(splatMesh, camera)
  * (SplatMesh.js:1228-1235, src/Viewer.js:1616).  Draw order = index order = back-to-front.
  *   sorted_host   uint32[render_count] host, or NULL
  *   sorter        take the device-resident result of the last gs_sorter_sort (when sorted_host == NULL)
@@ -327,7 +334,9 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
  * 32-byte vertex-stage record {cx, cy, ax, ay, bx, by, r|g<<16, b|a<<16 (unorm16)}; 1 = per splat the tile
  * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per list bin (gs_render_stats.list_bin_px) of the
  * drawn strip the [begin,end) range of its entry list ((~0,0) = untouched); 3 = the visibility mask, 1 bit per
- * splat packed in uint64 words (count = number of words). */
+ * splat packed in uint64 words (count = number of words); 4 = per 32x32-px blend bin of the drawn strip (row-major,
+ * bins_x = ceil(width / 32)) the pair {list entries staged, (splat, 16-px tile) pairs evaluated}: the blend's real cost,
+ * used to balance multi-GPU strips. */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of

@@ -311,3 +311,36 @@ def test_every_list_bin_size_gives_the_same_pixels(ctx, monkeypatch):
         np.testing.assert_array_equal(frames[shift], frames[3])
     _, (fb, q, amb, frags) = oracle_frame(scene, cam, order)
     print(helpers.compare_frames(frames[3], fb, amb, "list bins"))
+
+
+def test_asynchronous_draws_heal_an_overflowing_entry_buffer(ctx):
+    """A draw that returns nothing to the host cannot re-run itself when its entry buffer overflows; the next draw notices
+    (mapped host mirror, no synchronisation), grows the buffer and says so once.  Moving camera: every pose needs a
+    different number of entries."""
+    import torch
+    from gaussiansplats3d_amd import _lib as L
+    scene = helpers.small_scene(6000, 0, seed=77, scale=0.12)
+    mesh = build_mesh(ctx, scene)
+    cams = camera.orbit_cameras("garden", 320, 200, 12)
+    orders = [sorted_order(scene, c) for c in cams]
+    want = []
+    for c, o in zip(cams, orders):                           # synchronous draws: the frames to expect
+        mesh.set_camera(c)
+        mesh.update_render_indexes(o, scene.count)
+        want.append(mesh.render()[0])
+    mesh.debug_set_entry_capacity(1024)                      # far too small for any pose
+    out = torch.zeros((200, 320, 4), dtype=torch.uint8, device="cuda")
+    warnings, frames = 0, []
+    for rounds in range(3):
+        for c, o in zip(cams, orders):
+            mesh.set_camera(c)
+            mesh.update_render_indexes(o, scene.count)
+            mesh.render(out_device_ptr=out.data_ptr(), to_host=False, want_stats=False)      # asynchronous
+            warnings += mesh.last_status == L.GS_WARN_FRAME_TRUNCATED
+            ctx.synchronize()
+            frames.append(out.cpu().numpy().copy())
+    assert warnings >= 1, "the overflow was never reported"
+    assert not np.array_equal(frames[0], want[0]), "the first draw cannot have fitted 1024 entries"
+    for k in range(len(cams)):                               # the last orbit is complete: buffers have grown to the largest need
+        np.testing.assert_array_equal(frames[2 * len(cams) + k], want[k])
+    mesh.dispose()

@@ -302,7 +302,9 @@ struct gs_mesh {
     DevBuf frame;              // RenderFrame
     DevBuf fb;                 // internal RGBA8 framebuffer
     DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, (splat, tile) pairs walked}
-    uint32_t blend_bins = 0;
+    uint32_t blend_bins = 0, blend_row_begin = 0, blend_width = 0;    // the bins the last draw blended
+    DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
+    bool blend_order_valid = false;
     RadixScratch radix;
     uint32_t entry_capacity = 0;
     uint32_t sorted_buf = 0;   // ping-pong buffer index holding the tile-sorted entries of the last draw

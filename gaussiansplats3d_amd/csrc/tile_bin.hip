@@ -14,6 +14,8 @@
 //   entry sort    stable LSD radix passes on the list-bin id (radix.hpp): stability keeps near->far order per list;
 //                 one pass for <= 256 lists (1080p at 128-px lists), and the pass publishes every list's [begin,end)
 // Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.
+#include <stdlib.h>
+
 #include "radix.hpp"
 
 constexpr int BIN_THREADS = 256;
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           uint32_t row_begin /* first list-bin row */, KeyT* __restrict__ keys_out,
                                                           uint32_t* __restrict__ vals_out, uint32_t radix_grid,
                                                           uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist,
-                                                          uint32_t list_shift, volatile uint32_t* __restrict__ mirror, uint32_t serial) {
+                                                          uint32_t list_shift, volatile uint32_t* __restrict__ mirror, uint32_t serial,
+                                                          const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
+                                                          uint32_t* __restrict__ blend_order) {
     __shared__ unsigned long long s_sum[4], s_before[4], s_t16[4];
     __shared__ uint32_t s_vis[4];
     __shared__ uint32_t s_hist[EMIT_ROWS][RADIX_BINS];
@@ -254,6 +258,25 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                 mirror[0] = serial;
             }
         }
+    }
+    // Blend schedule of THIS draw, by the last workgroup: its 32-px bins in descending order of what they cost in the PREVIOUS
+    // draw ((splat, tile) pairs walked, k_tile_blend's per-bin statistics).  Every bin of a 1080p frame is resident at once and
+    // a SIMD's time is the sum of its waves' walks, so the kernel used to last ~2x its mean bin (r02g counters: VALU busy 39 %
+    // of the launch, ~all of the time while 8 waves are resident); heavy bins first + fewer resident workgroups lets the cheap
+    // ones backfill.  A counting sort of <= 32 k keys in one workgroup; the order of equal keys is irrelevant (pixels do not
+    // depend on which workgroup draws a bin).
+    if (blend_order && b == bin_grid - 1u) {
+        __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
+        s_cost[threadIdx.x] = 0u;
+        __syncthreads();
+        auto key_of = [&](uint32_t i) { return 255u - min(prev_blend_stats[i].y >> 2, 255u); };
+        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) atomicAdd(&s_cost[key_of(i)], 1u);
+        __syncthreads();
+        const uint32_t mine = s_cost[threadIdx.x];
+        const uint32_t start = block_excl_scan_256(mine, s_tmp2, nullptr);
+        s_cost[threadIdx.x] = start;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) blend_order[atomicAdd(&s_cost[key_of(i)], 1u)] = i;
     }
     if (boff64 >= D) return;                                 // nothing of this workgroup fits (or it has no entries)
     const uint32_t boff = (uint32_t)boff64;
@@ -330,10 +353,17 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
     }
+    // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
+    const uint32_t blend_bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
+    const bool order_ok = blend_bins > 0 && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
+                          m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
+    if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
-                       m->radix.digit_total.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial);
+                       m->radix.digit_total.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
+                       order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr);
+    m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
     GS_HIP(hipEventRecord(m->ev[2], st));
 

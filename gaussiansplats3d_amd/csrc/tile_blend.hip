@@ -109,20 +109,23 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 }
 #endif
 
+// 6 workgroups per CU: the exact quadrant test needs 80 VGPRs (at 8 per CU = 64 VGPRs it spilled 50 of them to scratch:
+// 132 MB of HBM traffic per launch instead of 34), and with 2040 bins at 1080p a quarter of the workgroups then start late,
+// into whatever CU frees up first
 #ifndef BLEND_OCC
-#define BLEND_OCC 8
+#define BLEND_OCC 6
 #endif
 __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
                                                               uint32_t list_row_begin, uint32_t list_shift,
-                                                              uint2* __restrict__ bin_stats) {
+                                                              uint2* __restrict__ bin_stats, const uint32_t* __restrict__ bin_order) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
     __shared__ uint32_t s_walked[4];
-    const uint32_t bin = blockIdx.x;
+    const uint32_t bin = bin_order ? bin_order[blockIdx.x] : blockIdx.x;       // heaviest bins of the previous draw first (k_bin_emit)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
     const uint32_t qx0 = bx * GS_BIN + (wave & 1u) * GS_TILE, qy0 = by * GS_BIN + (wave >> 1) * GS_TILE;   // quadrant origin
@@ -282,7 +285,9 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                        m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
                        pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                       m->blend_stats.as<uint2>());
+                       m->blend_stats.as<uint2>(), m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr);
+    m->blend_row_begin = pp.bin_row_begin;
+    m->blend_width = (uint32_t)pp.width;
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -63,6 +63,7 @@ struct gs_group {
     gs_context* ctx = nullptr;
     comm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
+    DevBuf full;                       // the root's gathered frame (gs_group_render_gather)
 };
 
 #define GS_NCCL(expr)                                                                              \
@@ -158,6 +159,33 @@ int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, u
     }
     GS_NCCL(R->GroupEnd());
     return GS_OK;
+}
+
+int gs_group_render_gather(gs_group* g, gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter, uint32_t render_count,
+                           const uint32_t* row_begin, const uint32_t* row_end, uint32_t root, uint8_t* rgba_out_host) {
+    GS_REQUIRE(g && m && cam && row_begin && row_end, "group / mesh / camera / row tables == NULL");
+    GS_REQUIRE(m->ctx == g->ctx, "mesh lives on another context");
+    GS_REQUIRE(root < g->world, "root outside the group");
+    const uint32_t y0 = row_begin[g->rank], y1 = row_end[g->rank];
+    GS_REQUIRE(y0 % GS_TILE == 0 && (y1 % GS_TILE == 0 || y1 == cam->height) && y0 <= y1 && y1 <= cam->height,
+               "this rank's pixel rows must be whole 16-px tile rows of the viewport");
+    gs_camera c = *cam;
+    c.tile_row_begin = y0 / GS_TILE;
+    c.tile_row_end = (y1 + GS_TILE - 1) / GS_TILE;
+    ScopedDevice sd(g->ctx->device);
+    const size_t frame_bytes = (size_t)cam->width * cam->height * 4;
+    if (g->rank == root) GS_TRY(g->full.ensure(frame_bytes + 16));
+    int status = GS_OK;
+    if (y1 > y0) {                                        // the strip goes to the mesh's own framebuffer
+        status = gs_mesh_render(m, &c, sorted_host, sorter, render_count, nullptr, nullptr, nullptr);
+        if (status < 0) return status;
+    }
+    GS_TRY(gs_group_gather_strips(g, y1 > y0 ? m->fb.p : nullptr, g->full.p, cam->width, row_begin, row_end, root));
+    if (g->rank == root && rgba_out_host) {
+        GS_HIP(hipMemcpyAsync(rgba_out_host, g->full.p, frame_bytes, hipMemcpyDeviceToHost, g->ctx->stream));
+        GS_HIP(hipStreamSynchronize(g->ctx->stream));
+    }
+    return status;
 }
 
 }  // extern "C"

@@ -92,7 +92,10 @@ constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
 constexpr int RADIX_TILE = RADIX_TILE_CFG;                // keys per workgroup iteration
 // Grid cap of a radix pass.  Every scatter workgroup starts by summing rows of the two-level offset table, so fewer,
 // longer workgroups win: same-box A/B on C3 (r01e) 2048: 0.498 ms/frame, 1024: 0.477, 512: 0.471, 384: 0.489, 256: 0.483.
-constexpr int RADIX_MAX_BLOCKS = 512;
+#ifndef RADIX_MAX_BLOCKS_CFG
+#define RADIX_MAX_BLOCKS_CFG 512
+#endif
+constexpr int RADIX_MAX_BLOCKS = RADIX_MAX_BLOCKS_CFG;
 constexpr int RADIX_BINS = 256;
 constexpr int RADIX_MAX_PASSES = 4;
 constexpr int RADIX_GROUP = 32;                           // workgroups per group row of the two-level offset table (radix.hpp)
@@ -290,6 +293,9 @@ struct gs_mesh {
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
     DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
+    DevBuf scan_state;         // uint64 [blocks]: the chained scan of k_project's per-block survivor counts (+ an error word)
+    uint32_t scan_epoch = 0;
+    bool dense_slots = true;   // survivors' records / rects form one dense array (GSPLAT_DENSE=0: compacted per 256-splat block)
     DevBuf vis_orig;           // uint32 [ceil(n/32)]     the mask by ORIGINAL splat index (gs_mesh_project only: feeds the
                                //                         visibility-culled sort)
     DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_split_sh(const uint16_t* __restrict__ s
 }
 
 // test hook: undo k_project's per-block compaction -> one record / rect per splat in storage order (zeros when culled)
-__global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* __restrict__ vis_mask, uint32_t count,
+__global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* __restrict__ vis_mask, const uint2* __restrict__ vis32, uint32_t count,
                                                       const uint32_t* __restrict__ perm, const uint4* __restrict__ recs,
                                                       const uint2* __restrict__ rects, uint4* __restrict__ out_recs,
                                                       uint2* __restrict__ out_rects, unsigned long long* __restrict__ out_mask) {
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void k_debug_expand(const unsigned long long* 
     const uint32_t i = orig < count ? (perm ? perm[orig] : orig) : 0u;     // internal position of this original splat
     const unsigned long long* mw = vis_mask + ((i >> 8) << 2);
     const uint32_t w = (i >> 6) & 3u, bit = i & 63u;
-    uint32_t slot = (i & ~255u) + (uint32_t)__popcll(mw[w] & ((1ull << bit) - 1ull));
-    for (uint32_t k = 0; k < w; k++) slot += (uint32_t)__popcll(mw[k]);
+    const uint2 t = vis32[i >> 5];                                          // {mask of these 32 splats, slot of their first survivor}
+    const uint32_t slot = t.y + (uint32_t)__popc(t.x & ((1u << (i & 31u)) - 1u));
     const bool vis = orig < count && ((mw[w] >> bit) & 1ull);
     if (out_mask) {                                                         // the mask in ORIGINAL splat order
         const unsigned long long b = __ballot(vis);
@@ -199,6 +199,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     }
     A(m->scene_dev, sizeof(gs_scene_params));
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
+    if (const char* dn = getenv("GSPLAT_DENSE")) m->dense_slots = !(dn[0] == '0' && dn[1] == '\0');
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
     if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
@@ -453,7 +454,15 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     hipStream_t st = m->ctx->stream;
     RenderFrame f;
     GS_HIP(hipMemcpyAsync(&f, m->frame.p, sizeof(f), hipMemcpyDeviceToHost, st));
+    uint32_t scan_error = 0;
+    if (m->scan_state.p)
+        GS_HIP(hipMemcpyAsync(&scan_error, m->scan_state.as<unsigned long long>() + (((size_t)m->max_count + 255) / 256 + 63), 4,
+                              hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
+    if (scan_error) {
+        gs_set_error("k_project: a block never saw its predecessors' survivor counts (chained scan gave up)");
+        return GS_ERR_HIP;
+    }
     float t[5] = {0, 0, 0, 0, 0};
     for (int i = 1; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
     GS_HIP(hipEventElapsedTime(&t[0], m->ev_p0, m->ev_p1));   // on ctx->aux: may overlap a sort and the tail of the previous draw
@@ -762,7 +771,7 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
         GS_REQUIRE(what != 3 || (size_t)count * 8 <= m->vis_mask.bytes, "count exceeds the mask length");
         GS_TRY(m->staging.ensure(bytes + 64));
         if (what == 3) GS_HIP(hipMemsetAsync(m->staging.p, 0, bytes, st));
-        hipLaunchKernelGGL(k_debug_expand, dim3((splats + 255u) / 256u), dim3(256), 0, st, m->vis_mask.as<unsigned long long>(), splats,
+        hipLaunchKernelGGL(k_debug_expand, dim3((splats + 255u) / 256u), dim3(256), 0, st, m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), splats,
                            m->reorder ? m->perm.as<uint32_t>() : nullptr, m->recs.as<uint4>(), m->rects.as<uint2>(),
                            what == 0 ? m->staging.as<uint4>() : nullptr, what == 1 ? m->staging.as<uint2>() : nullptr,
                            what == 3 ? m->staging.as<unsigned long long>() : nullptr);

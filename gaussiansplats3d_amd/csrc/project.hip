@@ -41,9 +41,16 @@ constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zer
 // View-dependent colour (SplatMaterial.js:179-337): evaluated only for splats that reach the frame - the SH planes are
 // the widest read of the vertex stage (48 B/splat at SH-2), and a splat dropped by the eigenvalue floor, an empty pixel
 // rect or another rank's strip of tile rows never needs them.
+#ifndef GS_SH_EARLY
+#define GS_SH_EARLY 0
+#endif
+struct ShPre {                  // fp16 SH planes fetched together with the covariance (GS_SH_EARLY): one dependent round trip less
+    uint4 a, b, c;
+    bool have;
+};
 template <bool EXT>
 __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPlanes& mp, uint32_t i, uint32_t scene, float c0,
-                                          float c1, float c2, float* col) {
+                                          float c1, float c2, float* col, const ShPre& pre) {
     if (pp.sh_stored >= 1 && pp.sh_degree >= 1) {
         float cp0 = pp.cam_pos[0], cp1 = pp.cam_pos[1], cp2 = pp.cam_pos[2];
         if (EXT && (pp.flags & GS_CAM_DYNAMIC)) {                // :179-183 camera in the scene's own frame
@@ -54,7 +61,7 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
         const float inv = 1.0f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
         const float x = d0 * inv, y = d1 * inv, z = d2 * inv;
         float sh[24];
-        const uint4 a = mp.sh0[i];
+        const uint4 a = pre.have ? pre.a : mp.sh0[i];
         if (EXT && pp.sh_u8) {
             // 8-bit SH (:150-154,265-269): texel = v/255 (unorm8), sh = texel*range + min; sh0 = bytes 0..15
             const float mn = mp.scenes->sh8_min[scene], range = mp.scenes->sh8_max[scene] - mn;
@@ -71,7 +78,7 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
         sh[0] = h2f(a.x); sh[1] = h2f(a.x >> 16); sh[2] = h2f(a.y); sh[3] = h2f(a.y >> 16);
         sh[4] = h2f(a.z); sh[5] = h2f(a.z >> 16); sh[6] = h2f(a.w); sh[7] = h2f(a.w >> 16);
         if (pp.sh_stored >= 2) {
-            const uint4 b = reinterpret_cast<const uint4*>(mp.sh1)[i];
+            const uint4 b = pre.have ? pre.b : reinterpret_cast<const uint4*>(mp.sh1)[i];
             sh[8] = h2f(b.x); sh[9] = h2f(b.x >> 16); sh[10] = h2f(b.y); sh[11] = h2f(b.y >> 16);
             sh[12] = h2f(b.z); sh[13] = h2f(b.z >> 16); sh[14] = h2f(b.w); sh[15] = h2f(b.w >> 16);
         } else {
@@ -83,7 +90,7 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
         for (int ch = 0; ch < 3; ch++) col[ch] += SH_C1 * (-sh[0 + ch] * y + sh[3 + ch] * z - sh[6 + ch] * x);
         if (pp.sh_stored >= 2 && pp.sh_degree >= 2) {                                       // :308-330
             if (!(EXT && pp.sh_u8)) {
-                const uint4 cc = mp.sh2[i];
+                const uint4 cc = pre.have ? pre.c : mp.sh2[i];
                 sh[16] = h2f(cc.x); sh[17] = h2f(cc.x >> 16); sh[18] = h2f(cc.y); sh[19] = h2f(cc.y >> 16);
                 sh[20] = h2f(cc.z); sh[21] = h2f(cc.z >> 16); sh[22] = h2f(cc.w); sh[23] = h2f(cc.w >> 16);
             }
@@ -106,7 +113,8 @@ template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
-                                                 const uint32_t* __restrict__ inv_perm) {
+                                                 const uint32_t* __restrict__ inv_perm, unsigned long long* __restrict__ scan_state,
+                                                 uint32_t epoch, uint32_t* __restrict__ scan_error) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     SplatRec rec;
@@ -153,6 +161,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
 
         if (ok) {
             const uint32_t packed = mp.rgba[i];
+            ShPre pre;
+            pre.have = false;
+            if (GS_SH_EARLY && !EXT && pp.sh_stored >= 2 && pp.sh_degree >= 1) {     // static fp16 SH-2 scene (the benchmark path)
+                pre.a = mp.sh0[i];
+                pre.b = reinterpret_cast<const uint4*>(mp.sh1)[i];
+                pre.c = mp.sh2[i];
+                pre.have = true;
+            }
             float col[3] = {(float)(packed & 255u) * (1.0f / 255.0f), (float)((packed >> 8) & 255u) * (1.0f / 255.0f),
                             (float)((packed >> 16) & 255u) * (1.0f / 255.0f)};                 // :169
             float alpha = (float)(packed >> 24) * (1.0f / 255.0f);
@@ -255,20 +271,23 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                     rec.cx = cx; rec.cy = cy;
                     rec.ax = GS_K_POWER * (b1x / n1); rec.ay = GS_K_POWER * (b1y / n1);
                     rec.bx = GS_K_POWER * (b2x / n2); rec.by = GS_K_POWER * (b2y / n2);
-                    sh_colour<EXT>(pp, mp, i, scene, c0, c1, c2, col);
+                    sh_colour<EXT>(pp, mp, i, scene, c0, c1, c2, col, pre);
                     rec.c0 = unorm16(col[0]) | (unorm16(col[1]) << 16);
                     rec.c1 = unorm16(col[2]) | (unorm16(alpha) << 16);
                 }
             }
         }
     }
-    // Survivors are COMPACTED inside their 256-splat block: splat i lands in slot (i & ~255) + (number of visible
-    // splats of the block before it).  A wave's survivors therefore write consecutive 32-byte records (whole cache
-    // lines instead of scattered 32-byte sectors: -20 % kernel time at 33 % visibility), and every consumer can
-    // recompute the slot from the 4 mask words of the block, so no index map is stored.
-    // 1 bit per splat, one 8-byte store per wave (no global atomics); the mask of a 5.8 M-splat scene is 725 KB,
-    // i.e. L2-resident for the binner's random look-ups.
+    // Survivors are COMPACTED: within a block by ballot + popcount, and - GS_PROJECT_DENSE - across blocks by a single-pass
+    // chained scan (decoupled look-back): block b publishes its survivor count as soon as it knows it, wave 0 sums the
+    // counts of the blocks before it until it meets one that already published its inclusive prefix, then publishes its
+    // own.  Records and rects then form one dense array (11.5 MB of rects for 1.44 M survivors instead of a 46 MB array
+    // with holes), so the binner's 8-byte gathers in depth order share cache lines and the lines stay in L2.
+    // Words are {flag:2 | epoch:30 | value:32}, written and read with agent-scope atomics (XCD L2s are not coherent); the
+    // epoch makes last frame's words invisible, so nothing is cleared between launches.  Blocks are dispatched in index
+    // order, so every block this one waits for is running or done; the spin is bounded anyway.
     __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_block_base;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long vis = __ballot(visible);
     if (lane == 0u) {
@@ -276,7 +295,48 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         vis_mask[i >> 6] = vis;                      // the buffer covers whole blocks
     }
     __syncthreads();
-    uint32_t wave_base = blockIdx.x * 256u;
+    uint32_t block_base = blockIdx.x * 256u;
+    if (scan_state) {
+        if (wave == 0u) {
+            const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            const unsigned long long tag = (unsigned long long)(epoch & 0x3FFFFFFFu) << 32;
+            const unsigned long long AGG = 1ull << 62, INC = 2ull << 62;
+            uint32_t excl = 0;
+            if (blockIdx.x == 0u) {
+                if (lane == 0u) __hip_atomic_store(&scan_state[0], INC | tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0u) __hip_atomic_store(&scan_state[blockIdx.x], AGG | tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int32_t p = (int32_t)blockIdx.x - 1;                 // lane l inspects block p - l
+                uint32_t spins = 0;
+                while (true) {
+                    const int32_t idx = p - (int32_t)lane;
+                    unsigned long long w = INC | tag;                // blocks before block 0: an inclusive prefix of 0
+                    if (idx >= 0) w = __hip_atomic_load(&scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool fresh = (w & 0x3FFFFFFF00000000ull) == tag;
+                    const uint32_t flag = fresh ? (uint32_t)(w >> 62) : 0u;
+                    const unsigned long long inc = __ballot(flag == 2u), missing = __ballot(flag == 0u);
+                    const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+                    const unsigned long long need = first_inc < 63u ? ((2ull << first_inc) - 1ull) : ~0ull;   // lanes 0..first_inc
+                    if (missing & need) {                            // a block in the window has not published yet
+                        if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(scan_error, 1u); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    uint32_t v = (lane <= first_inc) ? (uint32_t)w : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    excl += v;
+                    if (first_inc < 64u) break;
+                    p -= 64;
+                }
+                if (lane == 0u) __hip_atomic_store(&scan_state[blockIdx.x], INC | tag | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0u) s_block_base = excl;
+        }
+        __syncthreads();
+        block_base = s_block_base;
+    }
+    uint32_t wave_base = block_base;
 #pragma unroll
     for (uint32_t w = 0; w < 3; w++) wave_base += (w < wave) ? s_cnt[w] : 0u;
     // the binner's look-up table: per 32 splats one 8-byte record {mask, slot of the first visible one} - a single
@@ -314,16 +374,28 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
         vis_orig = m->vis_orig.as<uint32_t>();
     }
     const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;
+    unsigned long long* scan_state = nullptr;
+    uint32_t* scan_error = nullptr;
+    if (m->dense_slots) {
+        const size_t words = ((size_t)m->max_count + 255) / 256 + 64;
+        if (!m->scan_state.p) {
+            GS_TRY(m->scan_state.alloc(words * 8 + 16));
+            GS_HIP(hipMemsetAsync(m->scan_state.p, 0, words * 8 + 16, m->ctx->aux));
+        }
+        scan_state = m->scan_state.as<unsigned long long>();
+        scan_error = reinterpret_cast<uint32_t*>(scan_state + words - 1);     // the last word: set if a look-back gave up
+        m->scan_epoch = (m->scan_epoch % 0x3FFFFFFEu) + 1u;          // 1 .. 2^30 - 2: never the 0 the buffer starts with
+    }
     const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm);
+                           vis_orig, inv_perm, scan_state, m->scan_epoch, scan_error);
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm);
+                           vis_orig, inv_perm, scan_state, m->scan_epoch, scan_state ? scan_error : nullptr);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

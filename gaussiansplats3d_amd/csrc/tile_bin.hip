@@ -267,9 +267,16 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     // depend on which workgroup draws a bin).
     if (blend_order && b == bin_grid - 1u) {
         __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
+        // 8-bit cost key scaled to the scene: the mean bin lands near 48 whatever the scene walks per bin
+        uint32_t sum = 0;
+        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) sum += prev_blend_stats[i].y;
+        uint32_t total_walked;
+        (void)block_excl_scan_256(sum, s_tmp2, &total_walked);
+        uint32_t shift = 0;
+        while (((total_walked / blend_bins) >> shift) > 48u) shift++;
         s_cost[threadIdx.x] = 0u;
         __syncthreads();
-        auto key_of = [&](uint32_t i) { return 255u - min(prev_blend_stats[i].y >> 2, 255u); };
+        auto key_of = [&](uint32_t i) { return 255u - min(prev_blend_stats[i].y >> shift, 255u); };
         for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) atomicAdd(&s_cost[key_of(i)], 1u);
         __syncthreads();
         const uint32_t mine = s_cost[threadIdx.x];
@@ -355,7 +362,9 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     }
     // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
     const uint32_t blend_bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
-    const bool order_ok = blend_bins > 0 && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
+    // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
+    // backfilling, and ordering them in one workgroup would cost more than it gives)
+    const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),

@@ -360,6 +360,13 @@ void gs_group_destroy(gs_group* g);
 int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, uint32_t width, const uint32_t* row_begin,
                            const uint32_t* row_end, uint32_t root);
 
+/* One rank's whole share of a multi-GPU draw: gs_mesh_render (same sorted_host | sorter choice) of its strip (pixel rows [row_begin[rank], row_end[rank]),
+ * whole 16-px tile rows; `cam` describes the full viewport) into the mesh's own device framebuffer, then the gather above.
+ * On `root`, rgba_out_host (nullable) receives the full W*H*4 frame (this waits for it); the other ranks only enqueue.
+ * With gs_sorter_set_visibility_cull call gs_mesh_project with the same strip in the camera first.  Collective. */
+int gs_group_render_gather(gs_group* g, gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter, uint32_t render_count,
+                           const uint32_t* row_begin, const uint32_t* row_end, uint32_t root, uint8_t* rgba_out_host);
+
 /* Statistics of the last draw (synchronises the stream). */
 int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats);
 /* Test hook: shrink (or grow) the entry buffers so a small scene can exercise the overflow -> regrow path. */

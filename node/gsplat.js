@@ -121,7 +121,14 @@ class HipSortWorker {
     }
   }
 
-  // HIP-engine extra (no counterpart in the reference): fuse a per-splat frustum cull into full sorts
+  // HIP-engine extras (no counterpart in the reference).  bindMesh: results stay on the device as positions in the mesh's
+  // storage order; setVisibilityCull: full sorts keep only what mesh.project() of this frame's camera (and strip) draws
+  bindMesh(mesh) { addon.sorterBindMesh(this.handle, mesh ? mesh.handle : null); }
+  setVisibilityCull(enable) {
+    addon.sorterSetVisibilityCull(this.handle, enable ? 1 : 0);
+    this.frustumCull = this.frustumCull || !!enable;                       // replies carry the kept count either way
+  }
+  // fuse a per-splat frustum cull into full sorts
   setFrustumCull(enable) {
     addon.sorterSetFrustumCull(this.handle, enable ? 1 : 0);
     this.frustumCull = !!enable;
@@ -229,12 +236,33 @@ class SplatMeshHIP {
   }
   setSplatScale(s = 1) { this.splatScale = s; }
   setPointCloudModeEnabled(e) { this.pointCloudModeEnabled = !!e; }
-  render(out) {
+  _camera() {
     const c = this.cam;
     c.splatScale = this.splatScale;
     c.flags = (this.antialiased ? GS_CAM_ANTIALIASED : 0) | (this.pointCloudModeEnabled ? GS_CAM_POINT_CLOUD : 0) |
       (this.orthographicMode ? GS_CAM_ORTHOGRAPHIC : 0) | (this.fadeIn ? GS_CAM_FADE_IN : 0) |
       (this.enableOptionalEffects ? GS_CAM_SCENE_EFFECTS : 0) | (this.dynamicMode ? GS_CAM_DYNAMIC : 0);
+    return c;
+  }
+  // HIP-engine extras for a multi-GPU draw (no counterpart in the reference: one WebGL context).  One process per GPU:
+  //   const group = new StripGroup(idBytesFromRank0, worldSize, rank)      (rank 0: StripGroup.uniqueId())
+  //   worker.setVisibilityCull(true); mesh.useSortWorkerResult(worker, n); worker.bindMesh(mesh)
+  //   per frame: mesh.project(rows) -> worker.postMessage({sort}) ... sortDone -> mesh.renderStrip(group, rowBegin, rowEnd, 0, out)
+  // rows = [beginTileRow, endTileRow) of this rank; rowBegin / rowEnd = Uint32Array of every rank's PIXEL rows.
+  project(tileRows) {
+    const c = this._camera();
+    c.tileRowBegin = tileRows ? tileRows[0] : 0; c.tileRowEnd = tileRows ? tileRows[1] : 0;
+    addon.meshProject(this.handle, c);
+  }
+  renderStrip(group, rowBegin, rowEnd, root, out) {
+    const c = this._camera();
+    c.tileRowBegin = 0; c.tileRowEnd = 0;                                  // the library derives the strip from the row tables
+    return addon.groupRenderGather(group.handle, this.handle, c, this.indexes, this.sortWorker ? this.sortWorker.handle : null,
+                                   this.renderCount, rowBegin, rowEnd, root, out || null);
+  }
+  render(out) {
+    const c = this._camera();
+    c.tileRowBegin = 0; c.tileRowEnd = 0;
     const pixels = out || new Uint8Array(c.width * c.height * 4);
     const stats = addon.meshRender(this.handle, c, this.indexes, this.sortWorker ? this.sortWorker.handle : null, this.renderCount, pixels);
     return { pixels, stats };
@@ -242,4 +270,15 @@ class SplatMeshHIP {
   dispose() { if (this.handle) { addon.meshDestroy(this.handle); this.handle = null; } }
 }
 
-module.exports = { createSortWorker, SplatMeshHIP, toHalfFloat, Constants, addon };
+// The strip gather of a multi-GPU draw (gs_group_*: RCCL behind the C ABI).  StripGroup.uniqueId() on one rank, the 128 bytes
+// to every rank over any side channel (a pipe, a file, IPC), then `new StripGroup(id, worldSize, rank)` on each.
+class StripGroup {
+  static uniqueId() { return addon.groupUniqueId(); }
+  constructor(id, worldSize, rank, device) {
+    this.worldSize = worldSize; this.rank = rank;
+    this.handle = addon.groupCreate(getContext(device).handle, worldSize > 1 ? id : null, worldSize, rank);
+  }
+  dispose() { if (this.handle) { addon.groupDestroy(this.handle); this.handle = null; } }
+}
+
+module.exports = { createSortWorker, SplatMeshHIP, StripGroup, toHalfFloat, Constants, addon };

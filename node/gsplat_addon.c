@@ -320,22 +320,22 @@ static napi_value MeshUpload(napi_env env, napi_callback_info info) {
 }
 /* meshRender(mesh, cam{view,proj,camPos,focal,width,height,splatScale,kernel2d,maxSplatPx,invFocalAdj,shDegree,flags,
  *            tileRowBegin,tileRowEnd}, sortedIndexes|null, sorter|null, renderCount, out Uint8Array) -> stats object */
-static napi_value MeshRender(napi_env env, napi_callback_info info) {
-    ARGS(6)
+/* camera object -> gs_camera; throws and returns 0 on a malformed object */
+static int parse_camera(napi_env env, napi_value obj, gs_camera* out) {
     gs_camera cam;
     memset(&cam, 0, sizeof cam);
     napi_value v;
     void* d;
     size_t nb;
 #define F32ARR(key, dst, n)                                                                              \
-    NAPI_OK(napi_get_named_property(env, argv[1], key, &v));                                             \
-    if (!get_bytes(env, v, &d, &nb) || nb < (n) * 4) { napi_throw_type_error(env, NULL, "camera." key); return NULL; } \
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok || !get_bytes(env, v, &d, &nb) || nb < (n) * 4) { \
+        napi_throw_type_error(env, NULL, "camera." key); return 0; }                                     \
     memcpy(dst, d, (n) * 4);
     F32ARR("view", cam.view, 16)
     F32ARR("proj", cam.proj, 16)
     F32ARR("camPos", cam.cam_pos, 3)
     F32ARR("focal", cam.focal, 2)
-#define NUM(key, dst, type) NAPI_OK(napi_get_named_property(env, argv[1], key, &v)); dst = (type)get_f64(env, v);
+#define NUM(key, dst, type) if (napi_get_named_property(env, obj, key, &v) != napi_ok) { napi_throw_type_error(env, NULL, "camera." key); return 0; } dst = (type)get_f64(env, v);
     NUM("width", cam.width, uint32_t)
     NUM("height", cam.height, uint32_t)
     NUM("splatScale", cam.splat_scale, float)
@@ -349,11 +349,21 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     /* optional: the uniforms of the orthographic / fade-in / dynamic permutations (absent = zero) */
     {
         bool has = false;
-        if (napi_has_named_property(env, argv[1], "orthoZoom", &has) == napi_ok && has) { NUM("orthoZoom", cam.ortho_zoom, float) }
-        if (napi_has_named_property(env, argv[1], "fadeStartRadius", &has) == napi_ok && has) { NUM("fadeStartRadius", cam.fade_start_radius, float) }
-        if (napi_has_named_property(env, argv[1], "sceneCenter", &has) == napi_ok && has) { F32ARR("sceneCenter", cam.scene_center, 3) }
-        if (napi_has_named_property(env, argv[1], "viewMatrix", &has) == napi_ok && has) { F32ARR("viewMatrix", cam.view_matrix, 16) }
+        if (napi_has_named_property(env, obj, "orthoZoom", &has) == napi_ok && has) { NUM("orthoZoom", cam.ortho_zoom, float) }
+        if (napi_has_named_property(env, obj, "fadeStartRadius", &has) == napi_ok && has) { NUM("fadeStartRadius", cam.fade_start_radius, float) }
+        if (napi_has_named_property(env, obj, "sceneCenter", &has) == napi_ok && has) { F32ARR("sceneCenter", cam.scene_center, 3) }
+        if (napi_has_named_property(env, obj, "viewMatrix", &has) == napi_ok && has) { F32ARR("viewMatrix", cam.view_matrix, 16) }
     }
+#undef F32ARR
+#undef NUM
+    *out = cam;
+    return 1;
+}
+
+static napi_value MeshRender(napi_env env, napi_callback_info info) {
+    ARGS(6)
+    gs_camera cam;
+    if (!parse_camera(env, argv[1], &cam)) return NULL;
     void *idx, *out;
     size_t ib, ob;
     if (!get_bytes(env, argv[2], &idx, &ib) || !get_bytes(env, argv[5], &out, &ob)) { napi_throw_type_error(env, NULL, "meshRender: bad buffer"); return NULL; }
@@ -443,6 +453,77 @@ static napi_value MeshSetScenes(napi_env env, napi_callback_info info) {
     LOCKED(st = gs_mesh_set_scenes((gs_mesh*)get_external(env, argv[0]), &sp));
     if (st < 0) return throw_gs(env, st);
     return NULL;
+}
+
+/* meshProject(mesh, camera): the vertex stage on its own (gs_mesh_project) */
+static napi_value MeshProject(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    gs_camera cam;
+    if (!parse_camera(env, argv[1], &cam)) return NULL;
+    int st;
+    LOCKED(st = gs_mesh_project((gs_mesh*)get_external(env, argv[0]), &cam));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+static napi_value SorterSetVisibilityCull(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    int st;
+    LOCKED(st = gs_sorter_set_visibility_cull((gs_sorter*)get_external(env, argv[0]), (int)get_u32(env, argv[1])));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* groupUniqueId() -> Uint8Array(128) (ncclGetUniqueId: call on one rank, hand the bytes to the others) */
+static napi_value GroupUniqueId(napi_env env, napi_callback_info info) {
+    (void)info;
+    void* data;
+    napi_value ab, ta;
+    NAPI_OK(napi_create_arraybuffer(env, GS_GROUP_ID_BYTES, &data, &ab));
+    int st;
+    LOCKED(st = gs_group_unique_id((uint8_t*)data));
+    if (st < 0) return throw_gs(env, st);
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, GS_GROUP_ID_BYTES, ab, 0, &ta));
+    return ta;
+}
+/* groupCreate(ctx, id Uint8Array(128)|null, worldSize, rank) */
+static napi_value GroupCreate(napi_env env, napi_callback_info info) {
+    ARGS(4)
+    void* id;
+    size_t nb;
+    if (!get_bytes(env, argv[1], &id, &nb) || (id && nb < GS_GROUP_ID_BYTES)) { napi_throw_type_error(env, NULL, "groupCreate: id"); return NULL; }
+    gs_group* g = NULL;
+    int st;
+    LOCKED(st = gs_group_create((gs_context*)get_external(env, argv[0]), (const uint8_t*)id, get_u32(env, argv[2]), get_u32(env, argv[3]), &g));
+    if (st < 0) return throw_gs(env, st);
+    napi_value r;
+    NAPI_OK(napi_create_external(env, g, NULL, NULL, &r));
+    return r;
+}
+static napi_value GroupDestroy(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    LOCKED(gs_group_destroy((gs_group*)get_external(env, argv[0])));
+    return NULL;
+}
+/* groupRenderGather(group, mesh, camera, sortedIndexes Uint32Array|null, sorter|null, renderCount, rowBegin Uint32Array,
+ *                   rowEnd Uint32Array, root, out Uint8Array|null) */
+static napi_value GroupRenderGather(napi_env env, napi_callback_info info) {
+    ARGS(10)
+    gs_camera cam;
+    if (!parse_camera(env, argv[2], &cam)) return NULL;
+    void *idx, *rb, *re, *out;
+    size_t ib, rbb, reb, ob;
+    const uint32_t renderc = get_u32(env, argv[5]);
+    if (!get_bytes(env, argv[3], &idx, &ib) || !get_bytes(env, argv[6], &rb, &rbb) || !get_bytes(env, argv[7], &re, &reb) ||
+        !get_bytes(env, argv[9], &out, &ob) || !rb || !re || rbb != reb || (out && ob < (size_t)cam.width * cam.height * 4) ||
+        (idx && ib < (size_t)renderc * 4)) {
+        napi_throw_type_error(env, NULL, "groupRenderGather: index list / row tables / output buffer");
+        return NULL;
+    }
+    int st;
+    LOCKED(st = gs_group_render_gather((gs_group*)get_external(env, argv[0]), (gs_mesh*)get_external(env, argv[1]), &cam,
+                                       (const uint32_t*)idx, (gs_sorter*)get_external(env, argv[4]), renderc, (const uint32_t*)rb,
+                                       (const uint32_t*)re, get_u32(env, argv[8]), (uint8_t*)out));
+    if (st < 0) return throw_gs(env, st);
+    return num(env, st);
 }
 
 /* sorterBindMesh(sorter, mesh|null) */
@@ -604,6 +685,9 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"sorterBindMesh", SorterBindMesh}, {"sorterSetFrustumCull", SorterSetFrustumCull}, {"sorterSortGathered", SorterSortGathered},
         {"treeCreate", TreeCreate},         {"treeDestroy", TreeDestroy},     {"treeInfo", TreeInfo},
         {"treeGather", TreeGather},         {"assetLoad", AssetLoad},
+        {"meshProject", MeshProject},       {"sorterSetVisibilityCull", SorterSetVisibilityCull},
+        {"groupUniqueId", GroupUniqueId},   {"groupCreate", GroupCreate},     {"groupDestroy", GroupDestroy},
+        {"groupRenderGather", GroupRenderGather},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

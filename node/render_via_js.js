@@ -27,5 +27,11 @@ mesh.updateUniforms({ x: width, y: height }, focal[0], focal[1], !!(flags & 1), 
 mesh.setCameraMatrices(modelView, proj, camPos);
 const { pixels, stats } = mesh.render();
 fs.writeFileSync(outPath, Buffer.from(pixels.buffer, pixels.byteOffset, pixels.byteLength));
+// the multi-GPU entry points with a group of one: the same frame through gs_group_render_gather
+const group = new gs.StripGroup(null, 1, 0);
+const viaGroup = new Uint8Array(width * height * 4);
+mesh.renderStrip(group, new Uint32Array([0]), new Uint32Array([height]), 0, viaGroup);
+stats.stripIdentical = Buffer.compare(Buffer.from(viaGroup.buffer), Buffer.from(pixels.buffer, pixels.byteOffset, pixels.byteLength)) === 0;
+group.dispose();
 console.log(JSON.stringify(stats));
 mesh.dispose();

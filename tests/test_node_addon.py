@@ -220,3 +220,4 @@ def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho
     got = np.fromfile(outp, dtype=np.uint8).reshape(H, W, 4)
     assert got.any()
     np.testing.assert_array_equal(got, expect)
+    assert json.loads(res.stdout.strip().splitlines()[-1])["stripIdentical"], "StripGroup(1).renderStrip differs from render()"

@@ -293,9 +293,6 @@ struct gs_mesh {
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
     DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
-    DevBuf scan_state;         // uint64 [blocks]: the chained scan of k_project's per-block survivor counts (+ an error word)
-    uint32_t scan_epoch = 0;
-    bool dense_slots = true;   // survivors' records / rects form one dense array (GSPLAT_DENSE=0: compacted per 256-splat block)
     DevBuf vis_orig;           // uint32 [ceil(n/32)]     the mask by ORIGINAL splat index (gs_mesh_project only: feeds the
                                //                         visibility-culled sort)
     DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)

@@ -199,7 +199,6 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     }
     A(m->scene_dev, sizeof(gs_scene_params));
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
-    if (const char* dn = getenv("GSPLAT_DENSE")) m->dense_slots = !(dn[0] == '0' && dn[1] == '\0');
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
     if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
@@ -454,15 +453,7 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     hipStream_t st = m->ctx->stream;
     RenderFrame f;
     GS_HIP(hipMemcpyAsync(&f, m->frame.p, sizeof(f), hipMemcpyDeviceToHost, st));
-    uint32_t scan_error = 0;
-    if (m->scan_state.p)
-        GS_HIP(hipMemcpyAsync(&scan_error, m->scan_state.as<unsigned long long>() + (((size_t)m->max_count + 255) / 256 + 63), 4,
-                              hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
-    if (scan_error) {
-        gs_set_error("k_project: a block never saw its predecessors' survivor counts (chained scan gave up)");
-        return GS_ERR_HIP;
-    }
     float t[5] = {0, 0, 0, 0, 0};
     for (int i = 1; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
     GS_HIP(hipEventElapsedTime(&t[0], m->ev_p0, m->ev_p1));   // on ctx->aux: may overlap a sort and the tail of the previous draw

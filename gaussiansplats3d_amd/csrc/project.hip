@@ -113,8 +113,7 @@ template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
-                                                 const uint32_t* __restrict__ inv_perm, unsigned long long* __restrict__ scan_state,
-                                                 uint32_t epoch, uint32_t* __restrict__ scan_error) {
+                                                 const uint32_t* __restrict__ inv_perm) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     SplatRec rec;
@@ -278,16 +277,12 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
             }
         }
     }
-    // Survivors are COMPACTED: within a block by ballot + popcount, and - GS_PROJECT_DENSE - across blocks by a single-pass
-    // chained scan (decoupled look-back): block b publishes its survivor count as soon as it knows it, wave 0 sums the
-    // counts of the blocks before it until it meets one that already published its inclusive prefix, then publishes its
-    // own.  Records and rects then form one dense array (11.5 MB of rects for 1.44 M survivors instead of a 46 MB array
-    // with holes), so the binner's 8-byte gathers in depth order share cache lines and the lines stay in L2.
-    // Words are {flag:2 | epoch:30 | value:32}, written and read with agent-scope atomics (XCD L2s are not coherent); the
-    // epoch makes last frame's words invisible, so nothing is cleared between launches.  Blocks are dispatched in index
-    // order, so every block this one waits for is running or done; the spin is bounded anyway.
+    // Survivors are COMPACTED inside their 256-splat block: splat i lands in slot (block base) + (number of visible splats of
+    // the block before it).  A wave's survivors therefore write consecutive 32-byte records (whole cache lines instead of
+    // scattered 32-byte sectors: -20 % kernel time at 33 % visibility); consumers get the slot from vis32 below.
+    // (Compacting ACROSS blocks as well - one dense array through a single-pass chained scan with agent-scope look-back words -
+    // was tried in round 2: correct, but the scan chain made this kernel 54 -> 172 us and the binner's gathers gained nothing.)
     __shared__ uint32_t s_cnt[4];
-    __shared__ uint32_t s_block_base;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long vis = __ballot(visible);
     if (lane == 0u) {
@@ -295,47 +290,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         vis_mask[i >> 6] = vis;                      // the buffer covers whole blocks
     }
     __syncthreads();
-    uint32_t block_base = blockIdx.x * 256u;
-    if (scan_state) {
-        if (wave == 0u) {
-            const uint32_t total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-            const unsigned long long tag = (unsigned long long)(epoch & 0x3FFFFFFFu) << 32;
-            const unsigned long long AGG = 1ull << 62, INC = 2ull << 62;
-            uint32_t excl = 0;
-            if (blockIdx.x == 0u) {
-                if (lane == 0u) __hip_atomic_store(&scan_state[0], INC | tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (lane == 0u) __hip_atomic_store(&scan_state[blockIdx.x], AGG | tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int32_t p = (int32_t)blockIdx.x - 1;                 // lane l inspects block p - l
-                uint32_t spins = 0;
-                while (true) {
-                    const int32_t idx = p - (int32_t)lane;
-                    unsigned long long w = INC | tag;                // blocks before block 0: an inclusive prefix of 0
-                    if (idx >= 0) w = __hip_atomic_load(&scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool fresh = (w & 0x3FFFFFFF00000000ull) == tag;
-                    const uint32_t flag = fresh ? (uint32_t)(w >> 62) : 0u;
-                    const unsigned long long inc = __ballot(flag == 2u), missing = __ballot(flag == 0u);
-                    const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
-                    const unsigned long long need = first_inc < 63u ? ((2ull << first_inc) - 1ull) : ~0ull;   // lanes 0..first_inc
-                    if (missing & need) {                            // a block in the window has not published yet
-                        if (++spins > (1u << 22)) { if (lane == 0u) atomicOr(scan_error, 1u); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                        continue;
-                    }
-                    uint32_t v = (lane <= first_inc) ? (uint32_t)w : 0u;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    excl += v;
-                    if (first_inc < 64u) break;
-                    p -= 64;
-                }
-                if (lane == 0u) __hip_atomic_store(&scan_state[blockIdx.x], INC | tag | (unsigned long long)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane == 0u) s_block_base = excl;
-        }
-        __syncthreads();
-        block_base = s_block_base;
-    }
+    const uint32_t block_base = blockIdx.x * 256u;
     uint32_t wave_base = block_base;
 #pragma unroll
     for (uint32_t w = 0; w < 3; w++) wave_base += (w < wave) ? s_cnt[w] : 0u;
@@ -374,24 +329,12 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
         vis_orig = m->vis_orig.as<uint32_t>();
     }
     const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;
-    unsigned long long* scan_state = nullptr;
-    uint32_t* scan_error = nullptr;
-    if (m->dense_slots) {
-        const size_t words = ((size_t)m->max_count + 255) / 256 + 64;
-        if (!m->scan_state.p) {
-            GS_TRY(m->scan_state.alloc(words * 8 + 16));
-            GS_HIP(hipMemsetAsync(m->scan_state.p, 0, words * 8 + 16, m->ctx->aux));
-        }
-        scan_state = m->scan_state.as<unsigned long long>();
-        scan_error = reinterpret_cast<uint32_t*>(scan_state + words - 1);     // the last word: set if a look-back gave up
-        m->scan_epoch = (m->scan_epoch % 0x3FFFFFFEu) + 1u;          // 1 .. 2^30 - 2: never the 0 the buffer starts with
-    }
     const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm, scan_state, m->scan_epoch, scan_error);
+                           vis_orig, inv_perm);
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),

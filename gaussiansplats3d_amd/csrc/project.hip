@@ -338,7 +338,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm, scan_state, m->scan_epoch, scan_state ? scan_error : nullptr);
+                           vis_orig, inv_perm);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -292,6 +292,7 @@ struct gs_mesh {
     DevBuf recs;               // SplatRec [n]  survivors compacted inside each 256-splat block (project.hip)
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
+    DevBuf block_any;          // uint8 [ceil(n/256)]      1 = some splat of the 256-splat block survived the vertex stage
     DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
     DevBuf vis_orig;           // uint32 [ceil(n/32)]     the mask by ORIGINAL splat index (gs_mesh_project only: feeds the
                                //                         visibility-culled sort)

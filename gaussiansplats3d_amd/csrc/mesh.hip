@@ -205,6 +205,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->vis32, ((n + 255) / 256) * 64 + 64);
+    A(m->block_any, ((n + 255) / 256 + 127) & ~(size_t)63);
     A(m->bin_sums, 4 * 3 * 2048 + 64);               // uint32 [3][BIN_MAX_BLOCKS] + the batches-per-workgroup of the last count
     A(m->frame, sizeof(RenderFrame));
     if (st == GS_OK) st = m->radix.init();

@@ -113,7 +113,7 @@ template <bool EXT>
 __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
-                                                 const uint32_t* __restrict__ inv_perm) {
+                                                 const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool visible = false;
     SplatRec rec;
@@ -157,6 +157,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         bool ok = scene_ok && !(q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip);
         const float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];       // :166
         ok = ok && (ndcz >= -1.0f && ndcz <= 1.0f);       // quad z == centre z (SplatMaterial3D.js:209): GL clip
+        if (pp.row_begin > 0u || pp.row_end < pp.tiles_y) {
+            // a rank's strip of a multi-GPU draw: no splat reaches farther than maxScreenSpaceSplatSize from its centre, so one
+            // whose centre is farther than that from the strip is dropped before its covariance is fetched (the exact rect
+            // clip below decides the rest; this only saves the reads)
+            const float reach = pp.max_splat_px * fabsf(pp.splat_scale * pp.inv_focal_adj) * 1.001f + 2.0f;
+            const float cyc = (ndcy * 0.5f + 0.5f) * pp.height;
+            ok = ok && !(cyc + reach < (float)(pp.row_begin * GS_TILE) || cyc - reach > (float)(pp.row_end * GS_TILE));
+        }
 
         if (ok) {
             const uint32_t packed = mp.rgba[i];
@@ -290,6 +298,9 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         vis_mask[i >> 6] = vis;                      // the buffer covers whole blocks
     }
     __syncthreads();
+    // one byte per block: does ANY of its 256 splats reach the frame?  Morton order makes most blocks all-or-nothing, and the
+    // binner tests this (from LDS) before it spends an L2 gather on a splat's visibility word
+    if (threadIdx.x == 0) block_any[blockIdx.x] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
     const uint32_t block_base = blockIdx.x * 256u;
     uint32_t wave_base = block_base;
 #pragma unroll
@@ -334,11 +345,11 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm);
+                           vis_orig, inv_perm, m->block_any.as<uint8_t>());
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm);
+                           vis_orig, inv_perm, m->block_any.as<uint8_t>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -212,6 +212,15 @@ class Rig:
         self.mesh.render(tile_rows=tile_rows, out_device_ptr=out_ptr, to_host=False, want_stats=False)
         self.frames += 1
 
+    def timed_sort_stats(self, out_ptr):
+        """One more frame with the stage events on (they are off in timed regions): the sort's device time and result size."""
+        self.ctx.set_stage_timing(True)
+        self.frame(out_ptr)
+        self.torch.cuda.synchronize()
+        st, _ = self.worker.last_stats()
+        self.ctx.set_stage_timing(False)
+        return st
+
     def timed(self, steps, out_ptr, tile_rows=None, after=None):
         torch = self.torch
         torch.cuda.synchronize()
@@ -364,6 +373,7 @@ def main():
         if not args.only_headline:
             # per-stage device times (HIP events recorded by the library), one synchronised frame at a time
             stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
+            ctx.set_stage_timing(True)        # off in the timed region: an event record per stage costs ~10% of the frame
             for _ in range(min(args.steps, 10)):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -375,6 +385,7 @@ def main():
                 stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
                 stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
             stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
+            ctx.set_stage_timing(False)
 
         if world == 1 and not args.only_headline:
             # the engine's default shape: sorter and vertex stage on streams of their own (the reference sorts in a Web
@@ -454,7 +465,7 @@ def main():
                 rig.frame(strip.data_ptr())
             f_el, f_enq = rig.timed(args.steps, strip.data_ptr())
             f_ms = f_el / args.steps * 1e3
-            fs, _ = worker.last_stats()
+            fs = rig.timed_sort_stats(strip.data_ptr())
             fused = {"kept": int(fs.result_count), "ms_per_frame": round(f_ms, 4),
                      "Msplats_per_s_scene": round(N / (f_ms * 1e-3) / 1e6, 1),
                      "host_enqueue_ms_per_frame": round(f_enq / args.steps * 1e3, 4), "sort_ms_last": round(float(fs.device_ms), 4),
@@ -470,7 +481,7 @@ def main():
                 rig.frame(strip.data_ptr())
             v_el, v_enq = rig.timed(args.steps, strip.data_ptr())
             v_ms = v_el / args.steps * 1e3
-            vs, _ = worker.last_stats()
+            vs = rig.timed_sort_stats(strip.data_ptr())
             vis_fused = {"kept": int(vs.result_count), "ms_per_frame": round(v_ms, 4),
                          "Msplats_per_s_scene": round(N / (v_ms * 1e-3) / 1e6, 1), "sort_ms_last": round(float(vs.device_ms), 4),
                          "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
@@ -544,6 +555,7 @@ def main():
                          "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(kb),
                          "avg_launch_ms": round(k_ms, 5), "launches_timed": proj_launches,
+                         "launches_in_timed_region": args.steps,
                          "visible_splats": visible},
             # the largest kernel of the frame
             "blend": {"kernel": "k_tile_blend", "bound": "valu", "ms": round(blend_ms, 4) if blend_ms else None,

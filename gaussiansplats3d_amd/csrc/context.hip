@@ -36,7 +36,7 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
 
 int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out) {
     GS_REQUIRE(out != nullptr, "out == NULL");
-    GS_REQUIRE((flags & ~GS_CTX_SINGLE_STREAM) == 0, "unknown context flags");
+    GS_REQUIRE((flags & ~(GS_CTX_SINGLE_STREAM | GS_CTX_STAGE_TIMING)) == 0, "unknown context flags");
     *out = nullptr;
     int n = gs_device_count();
     if (n < 0) return n;
@@ -70,6 +70,10 @@ int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_contex
     const char* wide = getenv("GSPLAT_WIDE_ENTRY_KEYS");
     ctx->wide_entry_keys = wide && wide[0] == '1';
     ctx->serial = (flags & GS_CTX_SINGLE_STREAM) != 0;
+    if (const char* ks = getenv("GSPLAT_KERNEL_SAMPLE")) ctx->kernel_sample = (uint32_t)atoi(ks);
+    const char* se = getenv("GSPLAT_STAGE_EVENTS");
+    ctx->stage_events = (flags & GS_CTX_STAGE_TIMING) != 0;
+    if (se && se[0] && !se[1]) ctx->stage_events = se[0] != '0';
     if (!ctx->serial) {
         hipError_t e = hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -113,6 +117,12 @@ int gs_context_synchronize(gs_context* ctx) {
     ScopedDevice sd(ctx->device);
     GS_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->aux != ctx->stream) GS_HIP(hipStreamSynchronize(ctx->aux));
+    return GS_OK;
+}
+
+int gs_context_set_stage_timing(gs_context* ctx, int enable) {
+    GS_REQUIRE(ctx != nullptr, "ctx == NULL");
+    ctx->stage_events = enable != 0;
     return GS_OK;
 }
 

@@ -127,6 +127,12 @@ struct gs_context {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;
     bool own_stream = false;
+    bool stage_events = false;            // GS_CTX_STAGE_TIMING / GSPLAT_STAGE_EVENTS=1: bracket the stages of EVERY sort and
+                                          // draw with timing events.  Otherwise only calls that are handed a stats pointer
+                                          // (and so synchronise anyway) are bracketed: an event record is a barrier packet
+                                          // on the stream, and the nine of a frame cost 35 us of a 0.33 ms frame (r02m)
+    uint32_t kernel_sample = 8;           // GSPLAT_KERNEL_SAMPLE: on a single-stream context k_project is bracketed with events
+                                          // every n-th draw (0 = never) for gs_mesh_kernel_time; every draw costs 1.5 % (r02m)
     bool serial = false;                  // GSPLAT_SERIAL=1: everything on `stream` (debugging / per-stage timing)
     int cu_count = 256;
     bool lds_atomic_lane_order = false;   // self-test result: ds_add_rtn serves same-address lanes in lane order
@@ -193,6 +199,7 @@ struct gs_sorter {
     hipStream_t stream = nullptr;      // the "worker thread": sorts run here, concurrently with draws on ctx->stream
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed_sort = false;              // the last sort recorded ev0 (see gs_context::stage_events)
     hipEvent_t ev_consumed = nullptr;  // recorded on ctx->stream by a draw once it has read `sorted`
     bool consumer_pending = false;
     gs_mesh* bound_mesh = nullptr;     // gs_sorter_bind_mesh: results are positions in this mesh's storage order
@@ -328,6 +335,9 @@ struct gs_mesh {
     uint32_t* mirror_host = nullptr;   // mapped pinned {serial, overflow, entries lo, hi} written by every draw's k_bin_emit
     uint32_t* mirror_dev = nullptr;
     uint32_t draw_serial = 0, healed_serial = 0;
+    uint32_t project_serial = 0;
+    bool timed_project = false;           // the last vertex stage was bracketed with ev_p0 / ev_p1
+    bool timed_draw = false;              // the last draw recorded its stage events (see gs_context::stage_events)
     uint32_t truncated_draws = 0;      // asynchronous draws that overflowed the entry buffer (noticed after the fact)
     bool projection_pending = false;   // gs_mesh_project ran; the next gs_mesh_render with the same camera consumes it
     gs_camera projected_cam = {};

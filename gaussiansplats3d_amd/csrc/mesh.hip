@@ -456,14 +456,17 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     GS_HIP(hipMemcpyAsync(&f, m->frame.p, sizeof(f), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     float t[5] = {0, 0, 0, 0, 0};
-    for (int i = 1; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
-    GS_HIP(hipEventElapsedTime(&t[0], m->ev_p0, m->ev_p1));   // on ctx->aux: may overlap a sort and the tail of the previous draw
+    if (m->timed_draw) {
+        for (int i = 1; i < 5; i++) GS_HIP(hipEventElapsedTime(&t[i], m->ev[i], m->ev[i + 1]));
+    }
+    // on ctx->aux: may overlap a sort and the tail of the previous draw
+    if (m->timed_draw && m->timed_project) GS_HIP(hipEventElapsedTime(&t[0], m->ev_p0, m->ev_p1));
     m->last.project_ms = t[0];
     m->last.bin_ms = t[1];
     m->last.tile_sort_ms = t[2];
     m->last.blend_ms = t[3] + t[4];
     float total = 0;
-    GS_HIP(hipEventElapsedTime(&total, m->ev[0], m->ev[5]));
+    if (m->timed_draw) GS_HIP(hipEventElapsedTime(&total, m->ev[0], m->ev[5]));
     m->last.device_ms = total;
     m->last.visible_splats = f.visible;
     m->last.tile_entries = ((uint64_t)f.entries_hi << 32) | f.entries_lo;
@@ -492,12 +495,13 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
 // The vertex stage of a draw.  It only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
 // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed the records /
 // rects / mask it is about to overwrite.
-static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
+static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, bool timed) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
-    GS_HIP(hipEventRecord(m->ev[0], st));
+    if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
     if (aux != st && m->has_draw) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
-    {   // next slot of the timing ring; a slot about to be reused is harvested first (skipped if still in flight)
+    const bool sample = timed || aux != st || (ctx->kernel_sample && m->project_serial++ % ctx->kernel_sample == 0);
+    if (sample) {   // next slot of the timing ring; a slot about to be reused is harvested first (skipped if still in flight)
         const uint32_t slot = m->ring_next++ % gs_mesh::TIMING_RING;
         if (m->ring_used[slot]) {
             float ms = 0.f;
@@ -512,31 +516,37 @@ static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
         m->ev_p0 = m->ring0[slot];
         m->ev_p1 = m->ring1[slot];
     }
-    GS_HIP(hipEventRecord(m->ev_p0, aux));
+    m->timed_project = sample;
+    if (sample) GS_HIP(hipEventRecord(m->ev_p0, aux));
     GS_TRY(gs_launch_project(m, pp, orig_mask));
-    GS_HIP(hipEventRecord(m->ev_p1, aux));
+    if (sample) GS_HIP(hipEventRecord(m->ev_p1, aux));
     return GS_OK;
 }
 
 static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R,
-                          uint8_t* out_dev, bool projected) {
+                          uint8_t* out_dev, bool projected, bool timed) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
+    timed = timed || ctx->stage_events;
+    m->timed_draw = timed;
     const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
-    if (!projected) GS_TRY(mesh_project(m, pp, false));    // else gs_mesh_project already ran it for this camera
+    if (!projected) GS_TRY(mesh_project(m, pp, false, timed));   // else gs_mesh_project already ran it for this camera
+    else if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
     // join: projection and (if a sorter feeds this draw) the sort result
     if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
     if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
-    GS_HIP(hipEventRecord(m->ev[1], st));
+    if (timed) GS_HIP(hipEventRecord(m->ev[1], st));
     // the index list is in the caller's splat numbering unless it comes from a sorter bound to this mesh
     m->translate = m->reorder && !(sorter && sorter->result_mesh == m);
     GS_TRY(gs_launch_binning(m, pp, order_dev, sorter, R));   // records ev[2] between emit and the tile sort
-    GS_HIP(hipEventRecord(m->ev[3], st));
+    if (timed) GS_HIP(hipEventRecord(m->ev[3], st));
     GS_TRY(gs_launch_blend(m, pp, out_dev));
-    GS_HIP(hipEventRecord(m->ev[4], st));
-    GS_HIP(hipEventRecord(m->ev[5], st));
-    GS_HIP(hipEventRecord(m->ev_done, st));
+    if (timed) {
+        GS_HIP(hipEventRecord(m->ev[4], st));
+        GS_HIP(hipEventRecord(m->ev[5], st));
+    }
+    if (aux != st) GS_HIP(hipEventRecord(m->ev_done, st));     // only another stream ever waits for it
     m->has_draw = true;
     return GS_OK;
 }
@@ -622,7 +632,7 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
     ProjectParams pp;
     GS_TRY(mesh_params(m, cam, pp));
     ScopedDevice sd(m->ctx->device);
-    GS_TRY(mesh_project(m, pp, true));                     // + the per-splat mask a visibility-culled sort reads
+    GS_TRY(mesh_project(m, pp, true, m->ctx->stage_events));   // + the per-splat mask a visibility-culled sort reads
     m->projection_pending = true;
     m->projected_cam = *cam;
     return GS_OK;
@@ -665,7 +675,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     }
 
     m->last = gs_render_stats();
-    GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, projected));
+    GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, projected, stats != nullptr));
     m->has_draw = true;
     m->last_count = pp.count;
 
@@ -683,7 +693,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
                 return GS_ERR_CAPACITY;
             }
             GS_TRY(mesh_alloc_entries(m, (uint32_t)want));
-            GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, true));   // the records are still valid
+            GS_TRY(mesh_draw_once(m, pp, order_dev, sorter, render_count, out_dev, true, stats != nullptr));   // records still valid
             ov = mesh_collect_stats(m, nullptr);
             if (ov < 0) return ov;
             m->last.overflowed = 1;

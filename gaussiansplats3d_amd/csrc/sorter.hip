@@ -645,7 +645,7 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     GS_HIP(hipMemcpyAsync(&f, s->frame.as<SortFrame>() + s->frame_index, sizeof(f), hipMemcpyDeviceToHost, s->stream));
     GS_HIP(hipStreamSynchronize(s->stream));
     float ms = 0.f;
-    GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    if (s->timed_sort) GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     int32_t key_lo = f.lo(), key_hi = f.hi();
     if (s->last_sort == 0) {                       // nothing was keyed: the frame belongs to an earlier sort
         key_lo = 2147483640;
@@ -755,7 +755,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         memcpy(kp.mvp, mvp, sizeof(kp.mvp));
     }
 
-    GS_HIP(hipEventRecord(s->ev0, st));
+    s->timed_sort = stats != nullptr || ctx->stage_events;
+    if (s->timed_sort) GS_HIP(hipEventRecord(s->ev0, st));
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
@@ -834,7 +835,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                            s->sorted.as<uint32_t>(), sort_start, s->uploaded - 1u);
     }
     GS_HIP(hipGetLastError());
-    GS_HIP(hipEventRecord(s->ev1, st));
+    if (s->timed_sort || st != ctx->stream) GS_HIP(hipEventRecord(s->ev1, st));   // a draw on another stream waits for it
     s->last_render = R;
     s->last_sort = Rs;
     s->last_passes = passes;

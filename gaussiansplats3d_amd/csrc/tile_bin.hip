@@ -407,7 +407,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
-    GS_HIP(hipEventRecord(m->ev[2], st));
+    if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));
 
     uint32_t bits = 1;
     while ((1ull << bits) < tiles) bits++;

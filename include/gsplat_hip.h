@@ -60,9 +60,16 @@ int gs_context_create(int device, void* hip_stream, gs_context** out);
  * environment (GSPLAT_SERIAL=1); the default is the reference's shape: the sort runs concurrently with drawing, like its
  * Web Worker (src/worker/SortWorker.js). */
 #define GS_CTX_SINGLE_STREAM 1u
+#define GS_CTX_STAGE_TIMING 2u /* bracket the stages of EVERY sort / draw with timing events, so that gs_sorter_last_stats /
+                                  gs_mesh_last_stats can time calls that were made without a stats pointer.  By default only
+                                  calls that pass `stats` (and therefore synchronise anyway) are timed and the *_ms fields
+                                  read 0 after any other call: an event record is a barrier packet on the stream, nine of them
+                                  per frame cost 35 us of a 0.33 ms frame on MI355X */
 int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out);
 void gs_context_destroy(gs_context* ctx);
 int gs_context_synchronize(gs_context* ctx);
+/* Turn GS_CTX_STAGE_TIMING on (enable != 0) or off for the sorts / draws that follow (e.g. while a profiling overlay is up). */
+int gs_context_set_stage_timing(gs_context* ctx, int enable);
 
 /* ------------------------------------------------------------------------------------------------ *
  * SORT SEAM
@@ -86,7 +93,8 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
                              const uint32_t* scene_indexes);
 
 typedef struct gs_sort_stats {
-    float device_ms;        /* sortTime of the sortDone message (SortWorker.js:76-78), device clock          */
+    float device_ms;        /* sortTime of the sortDone message (SortWorker.js:76-78), device clock; 0 if the
+                               sort was made without `stats` and without GS_CTX_STAGE_TIMING                 */
     int32_t key_min;        /* minDistance / maxDistance of sorter.cpp:24-25,72-73                           */
     int32_t key_max;
     uint32_t clamped;       /* buckets forced into [0,range)                                                  */
@@ -295,7 +303,8 @@ typedef struct gs_camera {
 #define GS_TILE 16u
 
 typedef struct gs_render_stats {
-    float device_ms;          /* whole draw                                                                  */
+    float device_ms;          /* whole draw; the five times are 0 after a draw made without `stats` and
+                                 without GS_CTX_STAGE_TIMING                                                 */
     float project_ms, bin_ms, tile_sort_ms, blend_ms;
     uint32_t visible_splats;  /* splats that survive the vertex-stage rejects                                */
     uint64_t tile_entries;    /* list entries = sum over splats of list bins (list_bin_px) touched           */
@@ -340,7 +349,9 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of
- * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams. */
+ * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams.
+ * On a single-stream context without GS_CTX_STAGE_TIMING every 8th launch is measured ($GSPLAT_KERNEL_SAMPLE; the two event
+ * records cost 1.5 % of a frame): `launches` counts the measured ones. */
 int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches);
 
 /* ------------------------------------------------------------------------------------------------ *

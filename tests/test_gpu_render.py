@@ -344,3 +344,37 @@ def test_asynchronous_draws_heal_an_overflowing_entry_buffer(ctx):
     for k in range(len(cams)):                               # the last orbit is complete: buffers have grown to the largest need
         np.testing.assert_array_equal(frames[2 * len(cams) + k], want[k])
     mesh.dispose()
+
+
+def test_stage_times_only_when_asked_for(ctx):
+    """Stage events are recorded for calls that return statistics, or for every call after
+    gs_context_set_stage_timing; an untimed call reports 0 ms and the same counts / pixels."""
+    scene = helpers.small_scene(4000, 1, seed=55)
+    cam = camera.demo_camera("garden", 256, 144)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    worker = create_sort_worker(ctx, scene.count)
+    worker.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": scene.count - 1, "count": scene.count}})
+    worker.sort_on_device(cam.sort_mvp(), scene.count)
+    mesh.use_sorter_result(worker, scene.count)
+    img_timed, st = mesh.render()
+    assert st.device_ms > 0 and st.blend_ms > 0 and st.project_ms > 0
+    mesh.render(want_stats=False, to_host=False)
+    ctx.synchronize()
+    untimed = mesh.last_stats()
+    assert untimed.device_ms == 0 and untimed.bin_ms == 0 and untimed.blend_ms == 0
+    assert untimed.tile_entries == st.tile_entries and untimed.visible_splats == st.visible_splats
+    ss, _ = worker.last_stats()
+    assert ss.device_ms == 0 and ss.result_count == scene.count
+    ctx.set_stage_timing(True)
+    try:
+        worker.sort_on_device(cam.sort_mvp(), scene.count)
+        mesh.render(want_stats=False, to_host=False)
+        ctx.synchronize()
+        assert mesh.last_stats().device_ms > 0 and worker.last_stats()[0].device_ms > 0
+    finally:
+        ctx.set_stage_timing(False)
+    img, _ = mesh.render(want_stats=False)
+    assert np.array_equal(img, img_timed)
+    worker.terminate()
+    mesh.dispose()

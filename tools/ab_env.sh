@@ -12,6 +12,6 @@ for round in 1 2; do
     $CMD timeout 300 python bench.py --no-cpu "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['frame']['stage_ms_isolated_frame']
-print('%-44s %8.1f Msplats/s  %.4f ms lat %.3f | ' % ('$C'[-44:], d['value'], d['ms_per_step'], d['frame_latency_ms']) + ' '.join('%s=%.3f' % (k, v) for k, v in s.items()))"
+print('%-44s %8.1f Msplats/s  %.4f ms lat %s | ' % ('$C'[-44:], d['value'], d['ms_per_step'], d.get('frame_latency_ms')) + ' '.join('%s=%.3f' % (k, v) for k, v in s.items()))"
   done
 done

@@ -521,7 +521,9 @@ def main():
         B = frame_algorithmic_bytes(R, Rs, D16, P, scene.sh_degree, scene.cov_half)
         frame_gbs = B / (ms_per_step * 1e-3) / 1e9
         kb = project_algorithmic_bytes(N, visible, scene.sh_degree, scene.cov_half)
-        k_ms = proj_ms_sum / max(proj_launches, 1)
+        if not proj_launches:
+            raise SystemExit("bench.py: no k_project launch was timed (GSPLAT_KERNEL_SAMPLE=0?)")
+        k_ms = proj_ms_sum / proj_launches
         k_gbs = kb / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic("k_project", args.config)
         frame_traffic, frame_traffic_src = pmc_frame_traffic(args.config) if world == 1 else (None, None)

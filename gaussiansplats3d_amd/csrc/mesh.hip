@@ -757,6 +757,7 @@ int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32
     if (reset) {
         m->proj_sum_ms = 0.0;
         m->proj_launches = 0;
+        m->project_serial = 0;                              // the next launch is a measured one
     }
     return GS_OK;
 }

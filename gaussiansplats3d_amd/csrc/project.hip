@@ -288,8 +288,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     // Survivors are COMPACTED inside their 256-splat block: splat i lands in slot (block base) + (number of visible splats of
     // the block before it).  A wave's survivors therefore write consecutive 32-byte records (whole cache lines instead of
     // scattered 32-byte sectors: -20 % kernel time at 33 % visibility); consumers get the slot from vis32 below.
-    // (Compacting ACROSS blocks as well - one dense array through a single-pass chained scan with agent-scope look-back words -
-    // was tried in round 2: correct, but the scan chain made this kernel 54 -> 172 us and the binner's gathers gained nothing.)
+    // Tried and dropped in round 2 (all pixel-identical, all slower):
+    //  - compacting ACROSS blocks as well (one dense array through a single-pass chained scan with agent-scope look-back
+    //    words): the scan chain made this kernel 54 -> 172 us and the binner's gathers gained nothing;
+    //  - a cull phase over 4 splats per lane, then the rest of the shader on LDS-compacted dense lanes: 55 -> 65 us (Morton
+    //    order already makes the lanes of a wave pass or fail together; the barriers and the recomputation are pure cost);
+    //  - one wave per 256-splat block in four rounds, centres of all rounds fetched up front, no LDS / barriers: 55 -> 64 us
+    //    (71 VGPRs -> 7 waves per SIMD, and a wave's four rounds run back to back instead of on four waves at once).
+    // 252 MB in 55 us is 4.6 TB/s of mixed read / write traffic against the 6.3 TB/s a pure copy reaches.
     __shared__ uint32_t s_cnt[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long vis = __ballot(visible);

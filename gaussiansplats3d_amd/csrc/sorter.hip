@@ -47,6 +47,16 @@ struct KeyParams {
     uint32_t ext_minmax;                     // ... and min / max (over EVERY splat) were taken by k_minmax_count: leave them alone
 };
 
+// The per-scene rows of a dynamic sort travel as a kernel ARGUMENT (1 KB of kernarg, captured when the launch is enqueued),
+// so the host copy may die with the caller's stack frame and the sort stays asynchronous.
+__global__ __launch_bounds__(256) void k_store_scene_rows(SceneRows rows, SceneRows* __restrict__ dst) {
+    const uint32_t t = threadIdx.x;
+    if (t < GS_MAX_SCENES * 4) {
+        dst->im[t >> 2][t & 3] = rows.im[t >> 2][t & 3];
+        dst->fm[t >> 2][t & 3] = rows.fm[t >> 2][t & 3];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_aos4_to_soa(const uint4* __restrict__ aos, uint32_t count, uint32_t from,
                                                      uint32_t* __restrict__ x, uint32_t* __restrict__ y,
                                                      uint32_t* __restrict__ z, uint32_t* __restrict__ w) {
@@ -728,8 +738,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 rows.im[sc][c] = trunc_f64_i32((double)rows.fm[sc][c] * 1000.0);
             }
         }
-        GS_HIP(hipMemcpyAsync(s->scene_rows.p, &rows, sizeof(rows), hipMemcpyHostToDevice, st));
-        GS_HIP(hipStreamSynchronize(st));   // `rows` lives on this stack frame
+        k_store_scene_rows<<<1, 256, 0, st>>>(rows, s->scene_rows.as<SceneRows>());
+        GS_HIP(hipGetLastError());
         kp.rows = s->scene_rows.as<SceneRows>();
     }
     kp.cx = s->cx.as<uint32_t>(); kp.cy = s->cy.as<uint32_t>(); kp.cz = s->cz.as<uint32_t>();

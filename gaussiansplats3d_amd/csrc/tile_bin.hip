@@ -8,9 +8,9 @@
 //                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
 //                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
 //   k_bin_emit    splat-centric expansion into (list bin, record slot) pairs, one lane per surviving splat, runs
-//                 written at the offsets the count pass fixed; each workgroup sums the earlier workgroups' counts itself
-//                 and adds its entries' low-digit counts to the first sort pass's table, so neither a scan kernel nor that
-//                 pass's histogram kernel is launched.
+//                 written at the offsets the count pass fixed; each workgroup scans the binning workgroups' counts itself
+//                 (no scan kernel) and takes batches of 256 splats round-robin, so the near end of the list - whose splats
+//                 touch 30x the mean number of lists - is spread over the whole grid.
 //   entry sort    stable LSD radix passes on the list-bin id (radix.hpp): stability keeps near->far order per list;
 //                 one pass for <= 256 lists (1080p at 128-px lists), and the pass publishes every list's [begin,end)
 // Entry count D only ever lives on the device; downstream grids are sized for the capacity and read D there.
@@ -22,7 +22,10 @@ constexpr int BIN_THREADS = 256;
 #ifndef BIN_PER_LANE
 #define BIN_PER_LANE 4
 #endif
-constexpr int BIN_MAX_BLOCKS = 2048;                      // 8 workgroups of 256 per CU: full wave occupancy
+#ifndef BIN_MAX_BLOCKS_CFG
+#define BIN_MAX_BLOCKS_CFG 2048
+#endif
+constexpr int BIN_MAX_BLOCKS = BIN_MAX_BLOCKS_CFG;        // 8 workgroups of 256 per CU: full wave occupancy
 constexpr uint32_t ANY_WORDS = 2048;                      // coarse visibility bits kept in LDS: 65536 blocks = 16.7 M splats
 
 // vertex-stage rects are in 16-px tiles; the entry lists are per list bin of (16 << list_shift) px
@@ -55,6 +58,18 @@ __device__ __forceinline__ BinChunk bin_chunk(uint32_t n) {
 // Each lane owns 4 consecutive list positions per iteration, so 4 index loads, then 4 mask look-ups, then up to 4
 // rect gathers are in flight together (the kernel is a chain of dependent memory round trips), and one packed
 // 64-bit block scan per 1024 positions yields both the compaction slot and the entry offset.
+#ifdef GS_BIN_PROFILE
+// tools/bin_profile.py: per workgroup of k_bin_count [0] / k_bin_emit [1]: {start, after the prologue, end} of the 100 MHz
+// clock and the workgroup's output count
+__device__ unsigned long long g_bin_prof[2 * 2048 * 4];
+extern "C" int gs_debug_bin_prof(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_bin_prof), sizeof(unsigned long long) * 2 * 2048 * 4, 0, hipMemcpyDeviceToHost);
+}
+#define BIN_PROF(k, slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 2048u) g_bin_prof[((k) * 2048 + blockIdx.x) * 4 + (slot)] = (v); } while (0)
+#else
+#define BIN_PROF(k, slot, v) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
                                                            const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
@@ -71,6 +86,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
     // a Morton curve, mostly whole blocks of them; an LDS bit test spares those list positions the 8-byte L2 gather of their
     // visibility word (5.8 M random L2 transactions per frame were this kernel's real cost: making the rects dense did nothing)
     __shared__ uint32_t s_any[ANY_WORDS];
+    BIN_PROF(0, 0, wall_clock64());
     const uint32_t blocks = (splat_count + 255u) >> 8;
     const bool coarse = block_any != nullptr && blocks <= ANY_WORDS * 32u;
     if (coarse) {
@@ -88,17 +104,17 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         __syncthreads();
     }
     // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
-    // pass and the workgroup rows of its first pass (k_bin_emit accumulates that histogram), reset the bin ranges.
+    // pass, reset the bin ranges.
     {
         const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
         for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
-        for (uint32_t w = t; w < (uint32_t)(RADIX_MAX_BLOCKS * RADIX_BINS); w += stride) block_hist[w] = 0u;
         for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
     }
     // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
     // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
     const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
     const BinChunk ch = bin_chunk(R);
+    BIN_PROF(0, 1, wall_clock64());
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
         block_sums[3 * BIN_MAX_BLOCKS] = (batches + gridDim.x - 1) / gridDim.x;      // = bin_chunk()'s `per`
@@ -196,60 +212,138 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
         block_sums[BIN_MAX_BLOCKS + ch.id] = out - pos_begin;
         block_sums[2 * BIN_MAX_BLOCKS + ch.id] = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
     }
+    BIN_PROF(0, 2, wall_clock64());
+    BIN_PROF(0, 3, (unsigned long long)sum);
 }
 
-// k_bin_emit: one workgroup per binning workgroup, one lane per compacted splat.  With 128-px list bins a splat touches
-// 1.5 lists on average and at most the whole screen's 135, so a splat-centric expansion is balanced enough and needs
-// neither searches nor dependent walks: the lane reads its (slot, rect, first entry) with coalesced loads and writes its
-// run of (list bin, slot) pairs; neighbouring lanes write neighbouring runs.
+// k_bin_emit: splat-centric expansion of the compacted list into (list bin, record slot) pairs.
+// Work unit = one batch of 256 compacted splats of one binning workgroup's slice; the units are dealt round-robin to the
+// workgroups.  (One workgroup per binning workgroup, the r01 shape, lasted as long as its heaviest slice: the slices that hold
+// the nearest splats carry 30x the mean entry count - r02n timeline: mean workgroup 8 us, last one 27 us, and the same 27 us
+// for a strip-sharded rank that emits an eighth of the entries.)  A lane writes the first OWN entries of its splat itself,
+// walking the rect row-major; what is left of the few splats that cover more list bins is written by the whole wave.
 // block_sums: [0,BIN_MAX_BLOCKS) entries of every binning workgroup | [BIN_MAX_BLOCKS,..) its compacted splat count |
 // [2*BIN_MAX_BLOCKS,..) its 16-px tiles | [3*BIN_MAX_BLOCKS] batches per binning workgroup.
-// Every workgroup sums the sums of the workgroups before it itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan
-// kernel and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
-// It also accumulates the first entry-sort pass's histogram: entry e belongs to radix tile e / 4096, i.e. to the row of the
-// radix workgroup that will scatter that tile (`radix_grid` = that pass's grid; rows and group rows were zeroed by
-// k_bin_count), so the pass runs without its histogram kernel.
-constexpr uint32_t EMIT_ROWS = 4;      // radix rows a workgroup's entries normally span; the rest goes straight to global atomics
+// Every workgroup scans the binning workgroups' sums itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan kernel
+// and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
+constexpr uint32_t EMIT_OWN = 16;      // entries a lane writes for its own splat; longer runs are shared by the wave
 
 template <class KeyT>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restrict__ frame, uint32_t capacity,
                                                           const uint32_t* __restrict__ cidx,
                                                           const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
-                                                          const uint32_t* __restrict__ block_sums, uint32_t tiles_x /* list bins per row */,
+                                                          const uint32_t* __restrict__ block_sums, uint32_t bin_grid,
+                                                          uint32_t tiles_x /* list bins per row */,
                                                           uint32_t row_begin /* first list-bin row */, KeyT* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out, uint32_t radix_grid,
-                                                          uint32_t* __restrict__ block_hist, uint32_t* __restrict__ group_hist,
-                                                          uint32_t list_shift, volatile uint32_t* __restrict__ mirror, uint32_t serial,
+                                                          uint32_t* __restrict__ vals_out, uint32_t list_shift,
+                                                          volatile uint32_t* __restrict__ mirror, uint32_t serial,
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
                                                           uint32_t* __restrict__ blend_order) {
-    __shared__ unsigned long long s_sum[4], s_before[4], s_t16[4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
+    __shared__ unsigned long long s_wsum[4], s_t16[4];
     __shared__ uint32_t s_vis[4];
-    __shared__ uint32_t s_hist[EMIT_ROWS][RADIX_BINS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, bin_grid = gridDim.x;
-    const uint32_t b = xcd_chunk(blockIdx.x, bin_grid);       // the binning chunk this workgroup expands (same map as k_bin_count)
-    constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;            // 8 workgroup sums per thread
-    // total entries D and the entries of the workgroups before this one
-    unsigned long long all = 0, before = 0;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    BIN_PROF(1, 0, wall_clock64());
+    BIN_PROF(1, 2, 0ull);
+    // Blend schedule of THIS draw, by one extra workgroup (the first to be dispatched): the 32-px bins in descending order of
+    // what they cost in the PREVIOUS draw ((splat, tile) pairs walked, k_tile_blend's per-bin statistics).  Every bin of a 1080p
+    // frame is resident at once and a SIMD's time is the sum of its waves' walks, so the kernel used to last ~2x its mean bin
+    // (r02g counters: VALU busy 39 % of the launch, ~all of the time while 8 waves are resident); heavy bins first + fewer
+    // resident workgroups lets the cheap ones backfill.  A counting sort of <= 8 k keys held in registers; the order of equal
+    // keys is irrelevant (pixels do not depend on which workgroup draws a bin).
+    const uint32_t first_wg = blend_order ? 1u : 0u;
+    if (blend_order && blockIdx.x == 0) {
+        __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
+        // three sweeps over the statistics, 8 loads in flight per lane (registers for all 8192 / 256 values would set the
+        // whole kernel's VGPR allocation and cost every emitting workgroup its occupancy)
+        constexpr uint32_t SWEEP = 8;
+        auto sweep = [&](auto&& use) {
+            for (uint32_t base = 0; base < blend_bins; base += SWEEP * BIN_THREADS) {
+                uint32_t c[SWEEP];
 #pragma unroll
-    for (uint32_t k = 0; k < PER_T; k++) {
-        const uint32_t i = threadIdx.x + k * BIN_THREADS;               // coalesced
-        const uint32_t v = i < bin_grid ? block_sums[i] : 0u;
-        all += v;
-        before += i < b ? v : 0u;
+                for (uint32_t k = 0; k < SWEEP; k++) {
+                    const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
+                    c[k] = i < blend_bins ? prev_blend_stats[i].y : 0u;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < SWEEP; k++) {
+                    const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
+                    if (i < blend_bins) use(i, c[k]);
+                }
+            }
+        };
+        uint32_t sum = 0;
+        sweep([&](uint32_t, uint32_t c) { sum += c; });
+        uint32_t total_walked;
+        (void)block_excl_scan_256(sum, s_tmp2, &total_walked);
+        // 8-bit cost key scaled to the scene: the mean bin lands near 48 whatever the scene walks per bin
+        uint32_t shift = 0;
+        while (((total_walked / blend_bins) >> shift) > 48u) shift++;
+        s_cost[threadIdx.x] = 0u;
+        __syncthreads();
+        sweep([&](uint32_t, uint32_t c) { atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u); });
+        __syncthreads();
+        const uint32_t cnt_d = s_cost[threadIdx.x];
+        const uint32_t start = block_excl_scan_256(cnt_d, s_tmp2, nullptr);
+        s_cost[threadIdx.x] = start;
+        __syncthreads();
+        sweep([&](uint32_t i, uint32_t c) { blend_order[atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u)] = i; });
+        BIN_PROF(1, 1, wall_clock64());
+        BIN_PROF(1, 2, wall_clock64());
+        return;
+    }
+    const uint32_t wg = blockIdx.x - first_wg, wgs = gridDim.x - first_wg;
+    // exclusive scan of the binning workgroups' entry sums: thread t owns the PER_T consecutive sums [t * PER_T, ..), read
+    // with 16-byte loads (block_sums rows are 16-byte aligned)
+    constexpr uint32_t PER_T = BIN_MAX_BLOCKS / BIN_THREADS;
+    static_assert(PER_T % 4 == 0, "16-byte loads of the workgroup sums");
+    uint32_t mine[PER_T];
+    unsigned long long own = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER_T / 4; q++) {
+        const uint32_t i0 = threadIdx.x * PER_T + 4 * q;
+        const uint4 e = reinterpret_cast<const uint4*>(block_sums)[i0 / 4];
+        uint4 c = reinterpret_cast<const uint4*>(block_sums + BIN_MAX_BLOCKS)[i0 / 4];
+        mine[4 * q + 0] = i0 + 0 < bin_grid ? e.x : 0u;
+        mine[4 * q + 1] = i0 + 1 < bin_grid ? e.y : 0u;
+        mine[4 * q + 2] = i0 + 2 < bin_grid ? e.z : 0u;
+        mine[4 * q + 3] = i0 + 3 < bin_grid ? e.w : 0u;
+        c.x = i0 + 0 < bin_grid ? c.x : 0u;
+        c.y = i0 + 1 < bin_grid ? c.y : 0u;
+        c.z = i0 + 2 < bin_grid ? c.z : 0u;
+        c.w = i0 + 3 < bin_grid ? c.w : 0u;
+        reinterpret_cast<uint4*>(s_cnt)[i0 / 4] = c;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        all += __shfl_xor(all, o, 64);
-        before += __shfl_xor(before, o, 64);
-    }
-    if (lane == 0u) { s_sum[wave] = all; s_before[wave] = before; }
+    for (uint32_t k = 0; k < PER_T; k++) own += mine[k];
+    unsigned long long incl = own;
 #pragma unroll
-    for (uint32_t r = 0; r < EMIT_ROWS; r++) s_hist[r][threadIdx.x] = 0u;       // BIN_THREADS == RADIX_BINS
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63u) s_wsum[wave] = incl;
     __syncthreads();
-    const unsigned long long D64 = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-    const unsigned long long boff64 = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    unsigned long long run = incl - own, D64 = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const unsigned long long c = s_wsum[w];
+        run += w < wave ? c : 0ull;
+        D64 += c;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < PER_T / 4; q++) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            v[k] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
+            run += mine[4 * q + k];
+        }
+        reinterpret_cast<uint4*>(s_eoff)[(threadIdx.x * PER_T + 4 * q) / 4] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
     const uint32_t D = D64 > capacity ? capacity : (uint32_t)D64;
-    if (b == 0) {                                            // the frame's scalars (read by the sort passes and the host)
+    if (wg == 0) {                                           // the frame's scalars (read by the sort passes and the host)
         unsigned long long t16 = 0;
         uint32_t vis = 0;
         for (uint32_t i = threadIdx.x; i < bin_grid; i += BIN_THREADS) {
@@ -274,102 +368,64 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             frame->entry_count = D;
             frame->pad = 0;
             // host-visible copy of the overflow verdict (mapped pinned memory): an asynchronous draw that ran out of entry
-            // slots is noticed by the NEXT gs_mesh_render without a synchronisation (mesh.hip, mesh_heal_overflow)
+            // slots is noticed by the NEXT gs_mesh_render without a synchronisation (mesh.hip, mesh_heal_overflow).
+            // One 16-byte store = one PCIe write: the four words land together, no system-scope fence between them
             if (mirror) {
-                mirror[1] = D64 > capacity ? 1u : 0u;
-                mirror[2] = (uint32_t)D64;
-                mirror[3] = (uint32_t)(D64 >> 32);
-                __threadfence_system();
-                mirror[0] = serial;
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = {serial, D64 > capacity ? 1u : 0u, (uint32_t)D64, (uint32_t)(D64 >> 32)};
+                *reinterpret_cast<volatile u32x4*>(mirror) = v;
             }
         }
     }
-    // Blend schedule of THIS draw, by the last workgroup: its 32-px bins in descending order of what they cost in the PREVIOUS
-    // draw ((splat, tile) pairs walked, k_tile_blend's per-bin statistics).  Every bin of a 1080p frame is resident at once and
-    // a SIMD's time is the sum of its waves' walks, so the kernel used to last ~2x its mean bin (r02g counters: VALU busy 39 %
-    // of the launch, ~all of the time while 8 waves are resident); heavy bins first + fewer resident workgroups lets the cheap
-    // ones backfill.  A counting sort of <= 32 k keys in one workgroup; the order of equal keys is irrelevant (pixels do not
-    // depend on which workgroup draws a bin).
-    if (blend_order && b == bin_grid - 1u) {
-        __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
-        // 8-bit cost key scaled to the scene: the mean bin lands near 48 whatever the scene walks per bin
-        uint32_t sum = 0;
-        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) sum += prev_blend_stats[i].y;
-        uint32_t total_walked;
-        (void)block_excl_scan_256(sum, s_tmp2, &total_walked);
-        uint32_t shift = 0;
-        while (((total_walked / blend_bins) >> shift) > 48u) shift++;
-        s_cost[threadIdx.x] = 0u;
-        __syncthreads();
-        auto key_of = [&](uint32_t i) { return 255u - min(prev_blend_stats[i].y >> shift, 255u); };
-        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) atomicAdd(&s_cost[key_of(i)], 1u);
-        __syncthreads();
-        const uint32_t mine = s_cost[threadIdx.x];
-        const uint32_t start = block_excl_scan_256(mine, s_tmp2, nullptr);
-        s_cost[threadIdx.x] = start;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < blend_bins; i += BIN_THREADS) blend_order[atomicAdd(&s_cost[key_of(i)], 1u)] = i;
-    }
-    if (boff64 >= D) return;                                 // nothing of this workgroup fits (or it has no entries)
-    const uint32_t boff = (uint32_t)boff64;
-    const uint32_t bin_per = block_sums[3 * BIN_MAX_BLOCKS];             // batches per binning workgroup (k_bin_count)
-    const uint32_t first = b * bin_per * BIN_THREADS;                   // this workgroup's slice of the compacted list
-    const uint32_t cnt = block_sums[BIN_MAX_BLOCKS + b];
-    const uint32_t radix_tiles = (D + (uint32_t)RADIX_TILE - 1u) / (uint32_t)RADIX_TILE;
-    const uint32_t radix_per = max((radix_tiles + radix_grid - 1u) / radix_grid, 1u);   // = radix_chunk()'s tiles per workgroup
-    // tile -> radix row without a division per entry: (tile * ceil(2^32 / per)) >> 32 is exact while tile * per < 2^32
-    const unsigned long long per_magic = 0x100000000ull / radix_per + 1ull;
-    auto row_of = [&](uint32_t e) { return radix_per == 1u ? e / (uint32_t)RADIX_TILE
-                                                            : (uint32_t)(((unsigned long long)(e / (uint32_t)RADIX_TILE) * per_magic) >> 32); };
-    const uint32_t row0 = row_of(boff);
-    // entry k of a splat whose first entry is e0: list bin (x0 + k % w, y0 + k / w)
+    __syncthreads();                                         // s_eoff complete
+    BIN_PROF(1, 1, wall_clock64());
+    const uint32_t per = block_sums[3 * BIN_MAX_BLOCKS];     // batches per binning workgroup (k_bin_count)
+    const uint32_t units = bin_grid * per;
     auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
-        if (e >= D) return;                                             // dropped by an overflowing draw (it is redone)
+        if (e >= D) return;                                  // dropped by an overflowing draw (it is redone)
         keys_out[e] = (KeyT)key;
         vals_out[e] = idx;
-        const uint32_t row = row_of(e), d = key & 255u;
-        if (row - row0 < EMIT_ROWS) {
-            atomicAdd(&s_hist[row - row0][d], 1u);
-        } else {
-            atomicAdd(&block_hist[row * RADIX_BINS + d], 1u);
-            atomicAdd(&group_hist[(row / RADIX_GROUP) * RADIX_BINS + d], 1u);
-        }
     };
-    constexpr uint32_t OWN = 4;        // entries a lane writes for its own splat; longer runs are shared by the wave
-    for (uint32_t j0 = 0; j0 < cnt; j0 += BIN_THREADS) {
-        const uint32_t j = j0 + threadIdx.x;
+    uint32_t emitted = 0;
+    for (uint32_t u = wg; u < units; u += wgs) {
+        const uint32_t b = u / per, jb = (u - b * per) * BIN_THREADS;    // batch jb / 256 of binning workgroup b (uniform)
+        const uint32_t cnt = s_cnt[b], boff = s_eoff[b];
+        if (jb >= cnt || boff >= D) continue;
+        const uint32_t src = b * per * BIN_THREADS + jb + threadIdx.x;   // the workgroup's slice of the compacted list
         uint2 r = make_uint2(0u, 0u);
         uint32_t idx = 0, e0 = 0, n = 0;
-        if (j < cnt) {
-            r = rect_to_bins(crect[first + j], list_shift);             // the list bins the splat touches
-            idx = cidx[first + j];
-            e0 = boff + coff[first + j];
+        if (jb + threadIdx.x < cnt) {
+            r = rect_to_bins(crect[src], list_shift);                    // the list bins the splat touches
+            idx = cidx[src];
+            e0 = boff + coff[src];
             n = rect_tiles(r);
         }
+        emitted += n;
         const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, w = (r.y & 0xFFFFu) - x0 + 1u;
-        for (uint32_t k = 0, xx = x0, yy = y0; k < min(n, OWN); k++) {        // row-major walk of the rect, no k / w, k % w
+        for (uint32_t k = 0, xx = x0, yy = y0; k < min(n, EMIT_OWN); k++) {     // row-major walk of the rect, no k / w, k % w
             put(e0 + k, (yy - row_begin) * tiles_x + xx, idx);
             if (++xx == x0 + w) { xx = x0; yy++; }
         }
         // the few near splats that cover many lists: all 64 lanes write one splat's remaining entries together
-        unsigned long long big = __ballot(n > OWN);
+        unsigned long long big = __ballot(n > EMIT_OWN);
         while (big) {
-            const int src = __builtin_ctzll(big);
+            const int sl = __builtin_ctzll(big);
             big &= big - 1ull;
-            const uint32_t bn = __shfl(n, src, 64), be0 = __shfl(e0, src, 64), bidx = __shfl(idx, src, 64);
-            const uint32_t bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64);
-            for (uint32_t k = OWN + lane; k < bn; k += 64u) put(be0 + k, (by0 + k / bw - row_begin) * tiles_x + bx0 + k % bw, bidx);
+            const uint32_t bn = __shfl(n, sl, 64), be0 = __shfl(e0, sl, 64), bidx = __shfl(idx, sl, 64);
+            const uint32_t bx0 = __shfl(x0, sl, 64), by0 = __shfl(y0, sl, 64), bw = __shfl(w, sl, 64);
+            const float inv_w = 1.0f / (float)bw;
+            for (uint32_t k = EMIT_OWN + lane; k < bn; k += 64u) {
+                uint32_t q = (uint32_t)((float)k * inv_w);               // k / bw: k < 2^24, so the estimate is off by <= 1
+                int32_t rem = (int32_t)(k - q * bw);
+                if (rem < 0) { q--; rem += (int32_t)bw; }
+                else if (rem >= (int32_t)bw) { q++; rem -= (int32_t)bw; }
+                put(be0 + k, (by0 + q - row_begin) * tiles_x + bx0 + (uint32_t)rem, bidx);
+            }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t r = 0; r < EMIT_ROWS; r++) {
-        const uint32_t c = s_hist[r][threadIdx.x], row = row0 + r;
-        if (c) {
-            atomicAdd(&block_hist[row * RADIX_BINS + threadIdx.x], c);
-            atomicAdd(&group_hist[(row / RADIX_GROUP) * RADIX_BINS + threadIdx.x], c);
-        }
-    }
+    BIN_PROF(1, 2, wall_clock64());
+    BIN_PROF(1, 3, (unsigned long long)emitted);
+    (void)emitted;
 }
 
 template <class KeyT>
@@ -400,10 +456,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
-                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), pp.lists_x, pp.list_row_begin,
-                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), radix_grid_for(cap), m->radix.block_hist.as<uint32_t>(),
-                       m->radix.digit_total.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
+    // (+ one workgroup that only orders the blend's bins)
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_ok ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
+                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
+                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
@@ -416,7 +472,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     uint32_t* vbuf[2] = {m->evalA.as<uint32_t>(), m->evalB.as<uint32_t>()};
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
-        const bool have_hist = (p == 0);           // k_bin_emit accumulated pass 0's histogram
+        const bool have_hist = false;
         if (passes == 1)                           // <= 256 lists: the digit is the key, ranges come from the digit totals
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, false>(ex, al, al, cap, 0, 0, (KeyT*)nullptr, vbuf[1],
                                                                       m->tile_ranges.as<uint2>(), have_hist, tiles)));

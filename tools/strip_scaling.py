@@ -1,7 +1,7 @@
 """Per-rank cost of the strip-sharded frame for N = 1, 2, 4, 8, measured on ONE GPU: every rank's frame (vertex stage with
 its strip -> visibility-culled sort -> bin -> blend of the strip) is run in turn on a single-stream context and the slowest
 rank is reported, i.e. what bench.py --gpus N would take without the framebuffer gather.
-usage: python tools/strip_scaling.py [C3|C5|...] [steps]"""
+usage: python tools/strip_scaling.py [C3|C5|...] [steps] [N:r]     (N:r = only rank r of N, e.g. under rocprofv3)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -44,6 +44,11 @@ def timed(strip, culled):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+if len(sys.argv) > 3:
+    n, r = (int(v) for v in sys.argv[3].split(":"))
+    strip = gdist.balanced_row_strips(row_cost, n)[r] if n > 1 else None
+    print(f"{name} rank {r} of {n}: strip rows {strip}: {timed(strip, True):.4f} ms/frame over {steps} frames (+3 warm-up, +2 full)")
+    sys.exit(0)
 base = timed(None, False)
 print(f"{name} full sort, 1 GPU (the headline path): {base:.4f} ms/frame")
 one = None

@@ -6,6 +6,7 @@ compute entry point needs a gfx950 device and raises :class:`GsError` otherwise.
 import ctypes as C
 import os
 import subprocess
+import atexit
 import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -158,6 +159,22 @@ def check(status):
     return status
 
 
+_live_contexts = weakref.WeakSet()
+
+
+def _close_live_contexts():
+    """Interpreter exit: destroy contexts (and their sorters / meshes) while the HIP runtime is still up.  Objects that are
+    only finalised during module teardown would call hipFree / hipEventDestroy after the runtime's own atexit handler."""
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_contexts)
+
+
 class Context:
     """One per GPU (gs_context).  `stream`: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
 
@@ -177,6 +194,7 @@ class Context:
             self.set_stage_timing(True)
         self.device = int(device)
         self._children = weakref.WeakSet()     # sorters / meshes: must be destroyed before the context
+        _live_contexts.add(self)
 
     def _adopt(self, child):
         self._children.add(child)

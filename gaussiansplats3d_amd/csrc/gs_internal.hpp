@@ -216,6 +216,7 @@ struct gs_sorter {
     const SortFrame* result_frame = nullptr;
     DevBuf keep_mask;                  // 1 bit per list position (frustum-cull variant)
     DevBuf chunk_counts;               // survivors per chunk of the identity list (visibility-cull variant)
+    DevBuf mask_copy;                  // the bound mesh's visibility mask as the last visibility-culled sort consumed it
     bool last_vis_culled = false;
 };
 
@@ -271,6 +272,7 @@ struct ProjectParams {
     uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
+    float mv_row_norm[3];          // |row r of mat3(view)| * (1 + 1e-6): bounds |T0|, |T1| of the strip pre-test (project.hip)
 };
 
 struct gs_mesh {
@@ -282,6 +284,9 @@ struct gs_mesh {
     // SoA planes
     DevBuf px, py, pz;         // float centres
     DevBuf covA, covB;         // fp32: float4 + float2 ; fp16: uint2 + uint
+    DevBuf cov_bound;          // float: an upper bound of the covariance's spectral radius (largest absolute row sum), written
+                               // at upload; lets a rank of a multi-GPU draw drop splats that cannot reach its strip before it
+                               // fetches their covariance
     DevBuf rgba;               // uint32
     DevBuf sh0, sh1, sh2;      // fp16: uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
                                // u8  : sh0 = uint4 (bytes 0..15), sh1 = uint2 (bytes 16..23, SH2 only)
@@ -336,6 +341,8 @@ struct gs_mesh {
     uint32_t* mirror_dev = nullptr;
     uint32_t draw_serial = 0, healed_serial = 0;
     uint32_t project_serial = 0;
+    bool vis_orig_dirty = true;           // vis_orig may hold bits (cleared by the sort that consumes it, see k_mask_compact)
+    uint32_t vis_orig_count = 0;          // splats the last gs_mesh_project looked at
     bool timed_project = false;           // the last vertex stage was bracketed with ev_p0 / ev_p1
     bool timed_draw = false;              // the last draw recorded its stage events (see gs_context::stage_events)
     uint32_t truncated_draws = 0;      // asynchronous draws that overflowed the entry buffer (noticed after the fact)

@@ -69,25 +69,38 @@ __global__ __launch_bounds__(256) void k_split_centers(const float* __restrict__
     }
 }
 
+// Gershgorin: the spectral radius of the symmetric [[c0 c1 c2] [c1 c3 c4] [c2 c4 c5]] is at most its largest absolute row sum
+// (true for ANY values, PSD or not; NaN stays NaN and the pre-test that uses the bound then keeps the splat)
+__device__ __forceinline__ float cov_spectral_bound(float c0, float c1, float c2, float c3, float c4, float c5) {
+    const float r0 = fabsf(c0) + fabsf(c1) + fabsf(c2), r1 = fabsf(c1) + fabsf(c3) + fabsf(c4), r2 = fabsf(c2) + fabsf(c4) + fabsf(c5);
+    const float m = fmaxf(r0, fmaxf(r1, r2));
+    return (r0 != r0 || r1 != r1 || r2 != r2) ? NAN : m * 1.00001f;
+}
+
 __global__ __launch_bounds__(256) void k_split_cov_f32(const float* __restrict__ c6, uint32_t count, uint32_t from,
                                                        const uint32_t* __restrict__ perm, float4* __restrict__ a,
-                                                       float2* __restrict__ b) {
+                                                       float2* __restrict__ b, float* __restrict__ bound) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const float* s = c6 + 6 * (size_t)i;
         const uint32_t d = DST(i);
         a[d] = make_float4(s[0], s[1], s[2], s[3]);
         b[d] = make_float2(s[4], s[5]);
+        bound[d] = cov_spectral_bound(s[0], s[1], s[2], s[3], s[4], s[5]);
     }
 }
 
 __global__ __launch_bounds__(256) void k_split_cov_f16(const uint16_t* __restrict__ c6, uint32_t count, uint32_t from,
                                                        const uint32_t* __restrict__ perm, uint2* __restrict__ a,
-                                                       uint32_t* __restrict__ b) {
+                                                       uint32_t* __restrict__ b, float* __restrict__ bound) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         const uint16_t* s = c6 + 6 * (size_t)i;
         const uint32_t d = DST(i);
         a[d] = make_uint2((uint32_t)s[0] | ((uint32_t)s[1] << 16), (uint32_t)s[2] | ((uint32_t)s[3] << 16));
         b[d] = (uint32_t)s[4] | ((uint32_t)s[5] << 16);
+        float c[6];                                        // the values the shader will read: the halfs, widened
+#pragma unroll
+        for (int k = 0; k < 6; k++) c[k] = (float)__builtin_bit_cast(_Float16, s[k]);
+        bound[d] = cov_spectral_bound(c[0], c[1], c[2], c[3], c[4], c[5]);
     }
 }
 
@@ -198,6 +211,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
         if (sh_degree >= 2) A(m->sh2, n * 16);
     }
     A(m->scene_dev, sizeof(gs_scene_params));
+    A(m->cov_bound, n * 4);
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
@@ -329,10 +343,10 @@ static int mesh_upload_segment(gs_mesh* m, uint32_t from, uint32_t count, const 
                        m->pz.as<float>());
     if (half)
         hipLaunchKernelGGL(k_split_cov_f16, g, b, 0, st, (const uint16_t*)(stg + off_cov), count, from, perm, m->covA.as<uint2>(),
-                           m->covB.as<uint32_t>());
+                           m->covB.as<uint32_t>(), m->cov_bound.as<float>());
     else
         hipLaunchKernelGGL(k_split_cov_f32, g, b, 0, st, (const float*)(stg + off_cov), count, from, perm, m->covA.as<float4>(),
-                           m->covB.as<float2>());
+                           m->covB.as<float2>(), m->cov_bound.as<float>());
     if (ncoef)
         hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, perm, ncoef, m->sh0.as<uint4>(),
                            m->sh1.p, m->sh2.as<uint4>());
@@ -578,6 +592,10 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     pp.fade_start = cam->fade_start_radius;
     memcpy(pp.scene_center, cam->scene_center, sizeof(pp.scene_center));
     memcpy(pp.view_matrix, cam->view_matrix, sizeof(pp.view_matrix));
+    for (int r = 0; r < 3; r++) {                           // row r of mat3(view), column-major storage
+        const double a = cam->view[r], b = cam->view[4 + r], c = cam->view[8 + r];
+        pp.mv_row_norm[r] = (float)(sqrt(a * a + b * b + c * c) * (1.0 + 1e-6));
+    }
     const bool needs_scenes = (cam->flags & (GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC)) || (pp.sh_u8 && pp.sh_degree >= 1);
     GS_REQUIRE(!needs_scenes || m->has_scenes, "this draw needs per-scene uniforms: call gs_mesh_set_scenes first");
     GS_REQUIRE(pp.scene_count <= 1 || m->scene_idx.p, "several scenes but no scene indexes uploaded");

@@ -21,6 +21,7 @@ struct MeshPlanes {
     const float* __restrict__ pz;
     const void* __restrict__ covA;      // fp32: float4 (c0..c3)   | fp16: uint2 (c0..c3)
     const void* __restrict__ covB;      // fp32: float2 (c4,c5)    | fp16: uint  (c4,c5)
+    const float* __restrict__ cov_bound;   // spectral-radius bound of the covariance (mesh.hip, cov_spectral_bound)
     const uint32_t* __restrict__ rgba;
     const uint4* __restrict__ sh0;      // halfs 0..7
     const void* __restrict__ sh1;       // SH2: uint4 halfs 8..15 | SH1: uint (half 8)
@@ -161,7 +162,31 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
             // a rank's strip of a multi-GPU draw: no splat reaches farther than maxScreenSpaceSplatSize from its centre, so one
             // whose centre is farther than that from the strip is dropped before its covariance is fetched (the exact rect
             // clip below decides the rest; this only saves the reads)
-            const float reach = pp.max_splat_px * fabsf(pp.splat_scale * pp.inv_focal_adj) * 1.001f + 2.0f;
+            const float ks = fabsf(pp.splat_scale * pp.inv_focal_adj);
+            float reach = pp.max_splat_px * ks * 1.001f + 2.0f;
+            // ... and usually far less.  The quad's vertical half-extent squared is 8 k^2 (l1 e1y^2 + l2 e2y^2): with the exact
+            // eigen pairs of cov2D that is 8 k^2 d, and when the shader floors the discriminant at 0.1 it is at most
+            // 8 k^2 l1 = 8 k^2 ((a + d) / 2 + sqrt(0.1)); both are <= 8 k^2 (max(a, d) + 0.3163).  a = T0'VT0 + kernel,
+            // d = T1'VT1 + kernel, x'Vx <= rho(V) |x|^2, T0 = j00 row0 + j20 row2 and T1 = j11 row1 + j21 row2 of
+            // mat3(modelView).  rho(V) is bounded by a 4-byte plane written at upload, so the covariance of a splat that
+            // cannot reach the strip is never read (the exact rect clip below still decides everything that passes).
+            if (ok && !(EXT && (pp.flags & GS_CAM_DYNAMIC))) {
+                float j00, j20, j11, j21;
+                if (EXT && (pp.flags & GS_CAM_ORTHOGRAPHIC)) {
+                    j00 = pp.ortho_zoom; j11 = pp.ortho_zoom; j20 = 0.0f; j21 = 0.0f;
+                } else {
+                    const float s = 1.0f / (v[2] * v[2]);
+                    j00 = pp.focal_x / v[2]; j20 = (pp.focal_x * v[0]) * s;
+                    j11 = pp.focal_y / v[2]; j21 = (pp.focal_y * v[1]) * s;
+                }
+                const float t0 = fabsf(j00) * pp.mv_row_norm[0] + fabsf(j20) * pp.mv_row_norm[2];
+                const float t1 = fabsf(j11) * pp.mv_row_norm[1] + fabsf(j21) * pp.mv_row_norm[2];
+                const float t = fmaxf(t0, t1) * 1.0001f;
+                float l = mp.cov_bound[i] * t * t + pp.kernel2d + 0.3163f;
+                if (pp.flags & GS_CAM_POINT_CLOUD) l = fmaxf(l, 0.2f);
+                const float tight = ks * sqrtf(8.0f * l) * 1.001f + 2.0f;
+                if (tight < reach) reach = tight;                     // false for NaN: the cap stays
+            }
             const float cyc = (ndcy * 0.5f + 0.5f) * pp.height;
             ok = ok && !(cyc + reach < (float)(pp.row_begin * GS_TILE) || cyc - reach > (float)(pp.row_end * GS_TILE));
         }
@@ -334,6 +359,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     MeshPlanes mp;
     mp.px = m->px.as<float>(); mp.py = m->py.as<float>(); mp.pz = m->pz.as<float>();
     mp.covA = m->covA.p; mp.covB = m->covB.p;
+    mp.cov_bound = m->cov_bound.as<float>();
     mp.rgba = m->rgba.as<uint32_t>();
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
     mp.scene_idx = m->scene_idx.as<uint32_t>();
@@ -341,8 +367,14 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     if (pp.count == 0) return GS_OK;
     uint32_t* vis_orig = nullptr;
     if (orig_mask) {
+        const bool fresh = m->vis_orig.p == nullptr;
         GS_TRY(m->vis_orig.ensure(((size_t)m->max_count + 31) / 32 * 4 + 64));
-        GS_HIP(hipMemsetAsync(m->vis_orig.p, 0, ((size_t)pp.count + 31) / 32 * 4, m->ctx->aux));
+        // the visibility-culled sort that consumes the mask leaves it zeroed (k_mask_compact); only a mask nobody consumed
+        // (two gs_mesh_project in a row, a sort over fewer splats) is cleared here
+        if (fresh || m->vis_orig_dirty)
+            GS_HIP(hipMemsetAsync(m->vis_orig.p, 0, ((size_t)m->max_count + 31) / 32 * 4, m->ctx->aux));
+        m->vis_orig_dirty = true;
+        m->vis_orig_count = pp.count;
         vis_orig = m->vis_orig.as<uint32_t>();
     }
     const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;

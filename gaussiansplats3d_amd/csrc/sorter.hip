@@ -419,7 +419,10 @@ __global__ __launch_bounds__(VC_THREADS) void k_minmax_count(KeyParams p, const 
     }
 }
 
-__global__ __launch_bounds__(VC_THREADS) void k_mask_compact(const uint32_t* __restrict__ mask, const uint32_t* __restrict__ chunk_counts,
+// The mask is CONSUMED: every word is copied to the sorter's own buffer (gs_sorter_debug_read) and zeroed, which is the state the
+// next gs_mesh_project expects (its survivors set bits with atomicOr) - a 725 KB memset per frame less on every rank.
+__global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
+                                                             const uint32_t* __restrict__ chunk_counts,
                                                              uint32_t N, uint32_t chunk_len, uint32_t* __restrict__ idx_out,
                                                              SortFrame* __restrict__ frame) {
     __shared__ uint32_t s_tmp[4], s_before[4], s_all[4];
@@ -442,7 +445,12 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(const uint32_t* __r
     const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);
     for (uint32_t base = begin; base < end; base += 32u * VC_THREADS) {        // one mask word (32 positions) per thread
         const uint32_t first = base + 32u * threadIdx.x;
-        uint32_t w = first < end ? mask[first >> 5] : 0u;
+        uint32_t w = 0u;
+        if (first < end) {
+            w = mask[first >> 5];
+            mask_copy[first >> 5] = w;
+            if (w) mask[first >> 5] = 0u;
+        }
         uint32_t total;
         uint32_t o = out + block_excl_scan<4>((uint32_t)__popc(w), s_tmp, &total);
         while (w) {
@@ -777,10 +785,13 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             const uint32_t chunk_len = ((spans + grid - 1u) / grid) * VC_SPAN;
             GS_TRY(s->chunk_counts.ensure((size_t)grid * 4));
             GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
-            const uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
+            GS_TRY(s->mask_copy.ensure(((size_t)s->max_count + 31) / 32 * 4 + 64));
+            uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
             hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
-            hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->chunk_counts.as<uint32_t>(), R, chunk_len,
-                               s->idx_in.as<uint32_t>(), kp.frame);
+            hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),
+                               s->chunk_counts.as<uint32_t>(), R, chunk_len, s->idx_in.as<uint32_t>(), kp.frame);
+            // the mask is all zero again if this sort covered every splat the vertex stage looked at
+            if (R >= s->bound_mesh->vis_orig_count) s->bound_mesh->vis_orig_dirty = false;
             idx_dev = s->idx_in.as<uint32_t>();
             kp.idx_in = idx_dev;
             kp.count_dev = &kp.frame->kept;
@@ -959,11 +970,9 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
         src = s->debug.p;
     } else if (what == 3) {
         GS_REQUIRE(s->last_culled, "the last sort did not cull");
-        if (s->last_vis_culled) {                  // the bound mesh's per-splat mask (original splat numbering)
-            bool alive = false;
-            for (gs_mesh* m : s->ctx->live_meshes) alive = alive || (m == s->bound_mesh);
-            GS_REQUIRE(alive && (size_t)count * 4 <= s->bound_mesh->vis_orig.bytes, "the mesh is gone or count exceeds the mask length");
-            src = s->bound_mesh->vis_orig.p;
+        if (s->last_vis_culled) {                  // the bound mesh's per-splat mask (original splat numbering), as consumed
+            GS_REQUIRE((size_t)count * 4 <= s->mask_copy.bytes, "count exceeds the mask length");
+            src = s->mask_copy.p;
         } else {
             GS_REQUIRE((size_t)count * 4 <= s->keep_mask.bytes, "count exceeds the mask length");
             src = s->keep_mask.p;

@@ -96,7 +96,8 @@ class PerspectiveCamera:
     def sort_mvp(self, mesh_world=None):
         """Viewer.runSplatSort: mvp = proj * inverse(matrixWorld) * meshWorld (fp64; narrowed to fp32
         when written into the sorter's memory, src/worker/SortWorker.js:54)."""
-        return multiply(self.projection, self.model_view(mesh_world))
+        pv = multiply(self.projection, self.view)             # the reference's association: (proj * view) * meshWorld
+        return pv if mesh_world is None else multiply(pv, mesh_world)
 
     def focal(self, focal_adjustment=1.0, dpr=1.0):
         return (self.projection[0] * 0.5 * dpr * self.width * focal_adjustment,

@@ -148,7 +148,9 @@ int gs_sorter_set_visibility_cull(gs_sorter* s, int enable);
 
 /* Test hooks: intermediates of the last sort, positions [0, render_count) (valid in the sorted tail).
  * what: 0 = int32 depth keys (mappedDistances before mapping), 1 = int32 buckets (after), 2 = sorted,
- *       3 = keep bits of the frustum cull, bit (i & 31) of uint32 word i >> 5 per list position i. */
+ *       3 = keep bits of the last culled sort, bit (i & 31) of uint32 word i >> 5: per list position i after a frustum-culled
+ *           sort, per ORIGINAL splat index i (the bound mesh's visibility mask as the sort consumed it) after a
+ *           visibility-culled one. */
 int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count);
 
 /* ------------------------------------------------------------------------------------------------ *

@@ -112,6 +112,54 @@ def test_scheduler_follows_run_splat_sort():
     assert s.next_sort(moved, n, True) is None and s.next_sort(moved, n, True, force=True) == n   # shouldSortAll
 
 
+# ------------------------------------------------------------------------------------------------ sort trigger, pinned
+SCHED = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sched_kat.json")))
+
+
+class _SchedCamera:
+    """What SortScheduler and sort_mvp read from a camera, rebuilt from the golden's matrixWorld / projection."""
+
+    def __init__(self, step):
+        self.matrix_world = np.asarray(step["matrixWorld"], np.float64)
+        self.position = self.matrix_world[12:15].copy()
+        self.projection = np.asarray(step["projection"], np.float64)
+        self.view = camera.invert(self.matrix_world)
+
+    sort_mvp = camera.PerspectiveCamera.sort_mvp
+
+
+@pytest.mark.parametrize("script", SCHED, ids=[s["name"] for s in SCHED])
+def test_scheduler_matches_the_reference_run_splat_sort(script):
+    """tests/golden/sched_kat.json: Viewer.runSplatSort's own text (src/Viewer.js:1833-1964) executed under Node over scripted
+    camera paths (oracle/make_golden_sched.py).  The mirror must post a sort exactly when the reference does, with the same
+    splatSortCount, and modelViewProj must agree (1e-12 relative in fp64; identical once narrowed to the fp32 the sorter reads,
+    except entries that are zero up to rounding noise)."""
+    s = SortScheduler(dynamic_mode=script["dynamicMode"])
+    mesh_world = None if script["dynamicMode"] else np.asarray(script["meshWorld"], np.float64)
+    posted = 0
+    for step in script["steps"]:
+        if step.get("sortDone"):
+            s.sort_done()
+            continue
+        ref = step["ref"]
+        cam = _SchedCamera(step)
+        got = s.next_sort(cam, step["splatRenderCount"], step["shouldSortAll"], force=step.get("force", False),
+                          force_sort_all=step.get("forceSortAll", False))
+        assert (got is not None) == bool(ref["posted"]), (script["name"], step, ref)
+        if got is not None:
+            posted += 1
+            assert got == ref["splatSortCount"] and step["splatRenderCount"] == ref["splatRenderCount"]
+            want = np.array([struct.unpack("<d", bytes.fromhex(h))[0] for h in ref["modelViewProj"]])
+            mvp = np.asarray(cam.sort_mvp(mesh_world), np.float64)
+            np.testing.assert_allclose(mvp, want, rtol=1e-12, atol=1e-13)
+            # entries that cancel to zero carry 1e-17 of noise from the inverse (LU here, cofactors in three): what the integer
+            # sort reads - (int)(mvp[2 | 6 | 10] * 1000.0) of the fp32 value, sorter.cpp:41-43 - is identical
+            a, b = mvp.astype(np.float32), want.astype(np.float32)
+            assert np.array_equal(np.trunc(a[[2, 6, 10]].astype(np.float64) * 1000.0), np.trunc(b[[2, 6, 10]].astype(np.float64) * 1000.0))
+            assert np.array_equal(a[np.abs(b) > 1e-9], b[np.abs(b) > 1e-9])
+    assert posted == sum(1 for st in script["steps"] if not st.get("sortDone") and st["ref"]["posted"]) and posted >= 1
+
+
 # ------------------------------------------------------------------------------------------------ cull, pinned
 GATHER = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "gather_kat.json")))
 

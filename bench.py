@@ -531,6 +531,7 @@ def main():
         blend_ms = stage_ms.get("blend")
         blend_tflops = (walked * 256 * BLEND_FLOPS_PER_PIXEL_SPLAT / (blend_ms * 1e-3) / 1e12) if blend_ms else None
         valu, valu_src = pmc_valu("k_tile_blend", args.config)
+        proj_valu, _ = pmc_valu("k_project", args.config)
         out = {
             "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if args.config == "C3"
                       else f"Msplats/s sorted+rasterized ({cfg['label']})",
@@ -558,6 +559,8 @@ def main():
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(kb),
                          "avg_launch_ms": round(k_ms, 5), "launches_timed": proj_launches,
                          "launches_in_timed_region": args.steps,
+                         # the vertex stage is co-limited: its SIMDs issue vector instructions most of the launch as well
+                         "valu_busy_frac": proj_valu.get("valu_busy_frac") if proj_valu else None,
                          "visible_splats": visible},
             # the largest kernel of the frame
             "blend": {"kernel": "k_tile_blend", "bound": "valu", "ms": round(blend_ms, 4) if blend_ms else None,

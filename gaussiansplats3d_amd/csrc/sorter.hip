@@ -401,7 +401,9 @@ __global__ __launch_bounds__(VC_THREADS) void k_minmax_count(KeyParams p, const 
             }
         }
         const uint32_t w = (base >> 5) + threadIdx.x;              // the 32 mask words of this span
-        if (threadIdx.x < VC_SPAN / 32u && (w << 5) < end) cnt += (uint32_t)__popc(mask[w]);   // bits beyond N are never set
+        // (a sort over fewer splats than the vertex stage looked at leaves set bits beyond `end` in the last word)
+        if (threadIdx.x < VC_SPAN / 32u && (w << 5) < end)
+            cnt += (uint32_t)__popc(mask[w] & (end - (w << 5) >= 32u ? 0xFFFFFFFFu : (1u << (end - (w << 5))) - 1u));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
             w = mask[first >> 5];
             mask_copy[first >> 5] = w;
             if (w) mask[first >> 5] = 0u;
+            if (end - first < 32u) w &= (1u << (end - first)) - 1u;        // positions beyond this sort's list
         }
         uint32_t total;
         uint32_t o = out + block_excl_scan<4>((uint32_t)__popc(w), s_tmp, &total);

@@ -188,3 +188,55 @@ def test_viewer_options(ctx, opts):
     base = oracle.render(_ocam(scene, cam), c, cov, rgba, sh, order)[1]
     assert np.abs(base.astype(int) - q.astype(int)).max() > 8, "the option should change the image"
     mesh.dispose()
+
+
+def _strips_equal_frame(mesh, cam, label, strip_rows=2):
+    """Narrow strips of tile rows, drawn one by one, must tile the full frame bit for bit: the strip pre-test of the vertex
+    stage (a bound of the splat's extent from its covariance's spectral-radius plane) may only drop splats that cannot reach
+    the strip, whatever the shader permutation."""
+    full, st = mesh.render()
+    assert st.visible_splats > 100, label
+    rows = (cam.height + 15) // 16
+    parts = [mesh.render(tile_rows=(r, min(r + strip_rows, rows)))[0] for r in range(0, rows, strip_rows)]
+    np.testing.assert_array_equal(np.concatenate(parts, axis=0), full, err_msg=label)
+
+
+@pytest.mark.parametrize("opts", [
+    dict(), dict(antialiased=True), dict(point_cloud_mode=True), dict(splat_scale=2.5), dict(kernel_2d_size=0.1, point_cloud_mode=True),
+    dict(max_screen_space_splat_size=24.0), dict(focal_adjustment=2.0, splat_scale=1.7), dict(half_precision_covariances=True),
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()) or "base")
+def test_strips_tile_the_frame_under_viewer_options(ctx, opts):
+    opts = dict(opts)
+    half = opts.pop("half_precision_covariances", False)
+    focal_adj = opts.pop("focal_adjustment", 1.0)
+    scene = helpers.small_scene(6000, 1, seed=71, scale=0.12, cov_half=half)     # large splats: many reach several strips
+    cam = camera.demo_camera("garden", 320, 208)
+    mesh = SplatMesh(ctx, scene.count, 1, scene.cov_half, **opts).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(cam, focal_adjustment=focal_adj)
+    mesh.update_render_indexes(_order(scene, cam), scene.count)
+    _strips_equal_frame(mesh, cam, str(opts))
+    mesh.dispose()
+
+
+def test_strips_tile_the_frame_orthographic_and_dynamic(ctx):
+    up, pos, look = camera.DEMO_POSES["garden"]
+    scene = helpers.small_scene(5000, 1, seed=72, scale=0.1)
+    ocam = camera.OrthographicCamera(320, 208, pos, look, up, zoom=40.0)
+    mesh = SplatMesh(ctx, scene.count, 1).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(ocam)
+    mesh.update_render_indexes(_order(scene, ocam), scene.count)
+    _strips_equal_frame(mesh, ocam, "orthographic")
+    mesh.dispose()
+    # dynamic mode: per-scene transforms (one of them scales by 1.6: the mesh-level row norms do not describe it, the pre-test
+    # must fall back to the clamp) 
+    scene, sidx = _three_scenes(4500, 1, 73)
+    cam = camera.demo_camera("garden", 320, 208)
+    big = np.diag([1.6, 1.6, 1.6, 1.0]); big[:3, 3] = (0.2, -0.1, 0.3)
+    transforms = [np.eye(4).reshape(16), big.T.reshape(16), np.eye(4).reshape(16)]
+    mesh = SplatMesh(ctx, scene.count, 1, dynamic_mode=True)
+    mesh.build(scene.centers, scene.cov * 4.0, scene.rgba, scene.sh, scene_indexes=sidx)
+    mesh.set_scenes(transforms=transforms, camera_position=cam.position)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(np.arange(scene.count, dtype=np.uint32), scene.count)
+    _strips_equal_frame(mesh, cam, "dynamic")
+    mesh.dispose()

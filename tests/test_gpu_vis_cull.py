@@ -104,3 +104,48 @@ def test_group_of_one_gathers_its_strip_into_the_frame(ctx):
     ctx.synchronize()
     assert torch.equal(full[32:80], strip) and not full[:32].any() and not full[80:].any()
     group.close()
+
+
+def test_visibility_mask_lifecycle(ctx):
+    """The mask a projection leaves is consumed (and re-zeroed) by the sort that reads it.  Whatever the order of calls - two
+    projections in a row, a sort that covers fewer splats than were projected, a projection for another camera - the next
+    visibility-culled sort must see exactly the survivors of ITS projection."""
+    scene, cam, ci, worker, mesh = _setup(ctx, n=30000, seed=9, w=320, h=200)
+    n = scene.count
+    other = camera.orbit_cameras("garden", 320, 200, 8)[2]
+    worker.sort_on_device(cam.sort_mvp(), n)
+    mesh.use_sorter_result(worker, n)
+    worker.set_visibility_cull(True)
+
+    def survivors(c):
+        mesh.set_camera(c)
+        mesh.update_render_indexes(np.arange(n, dtype=np.uint32), n)
+        mesh.render()
+        vis = mesh.debug_records()[2]
+        mesh.use_sorter_result(worker, n)
+        return vis
+
+    vis_cam, vis_other = survivors(cam), survivors(other)
+    assert (vis_cam != vis_other).any() and vis_cam.sum() > 500 and vis_other.sum() > 500
+
+    def culled_sort(c, count=n):
+        mesh.set_camera(c)
+        mesh.project()
+        return worker.post_message({"sort": {"modelViewProj": c.sort_mvp(), "splatRenderCount": count, "splatSortCount": count}})
+
+    def expect(c, vis, count=n):
+        order = oracle.sort_indexes(np.arange(count, dtype=np.uint32), ci, c.sort_mvp())
+        return order[vis[order]]
+
+    np.testing.assert_array_equal(culled_sort(cam)["sortedIndexes"], expect(cam, vis_cam))
+    np.testing.assert_array_equal(culled_sort(cam)["sortedIndexes"], expect(cam, vis_cam))          # mask re-zeroed by the sort
+    mesh.set_camera(other)
+    mesh.project()                                                                                    # never consumed ...
+    np.testing.assert_array_equal(culled_sort(cam)["sortedIndexes"], expect(cam, vis_cam))          # ... and must not leak
+    half = n // 2
+    np.testing.assert_array_equal(culled_sort(other, half)["sortedIndexes"], expect(other, vis_other, half))   # bits >= half stay set
+    np.testing.assert_array_equal(culled_sort(cam)["sortedIndexes"], expect(cam, vis_cam))
+    np.testing.assert_array_equal(worker.keep_bits(n), vis_cam)
+    worker.set_visibility_cull(False)
+    worker.terminate()
+    mesh.dispose()

@@ -343,6 +343,13 @@ def main():
                     gather = lambda: group.gather_strips(strip.data_ptr(), full_ptr, W, strips, H)      # noqa: E731
                 except Exception as e:                                       # fall back to torch.distributed P2P
                     print(f"bench.py rank {rank}: gs_group unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
+                # every rank must take the same path: one rank without its communicator sends all of them to the fallback
+                ok = torch.tensor([1 if gather is not None else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if group is not None:
+                        group.close()
+                    group, gather = None, None
             if gather is None:
                 gather_kind = f"torch.distributed batch_isend_irecv ({backend})"
                 gather = lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)            # noqa: E731

@@ -386,13 +386,11 @@ inline uint32_t radix_grid_for(uint32_t n_upper) {
 // digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES = false>
 int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
-               KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr, bool have_hist = false,
-               uint32_t direct_ranges = 0) {
+               KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr, uint32_t direct_ranges = 0) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
     uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
-    if (!have_hist)      // otherwise the producer of the keys already filled this pass's rows and group rows
-        hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
+    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
     if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,
                            ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges);

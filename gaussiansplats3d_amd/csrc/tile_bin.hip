@@ -78,7 +78,6 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __res
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ digit_total,
-                                                           uint32_t* __restrict__ block_hist,
                                                            uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift,
                                                            uint32_t splat_count, const uint8_t* __restrict__ block_any) {
     __shared__ unsigned long long s_w[4];
@@ -442,7 +441,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
                        m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
-                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(), m->radix.block_hist.as<uint32_t>(),
+                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(),
                        m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
                        getenv("GSPLAT_NO_COARSE_VIS") ? nullptr : m->block_any.as<uint8_t>());
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
@@ -472,16 +471,15 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     uint32_t* vbuf[2] = {m->evalA.as<uint32_t>(), m->evalB.as<uint32_t>()};
     for (uint32_t p = 0; p < passes; p++) {
         ArrayLoader<KeyT> al = {kbuf[p & 1], vbuf[p & 1], &frame->entry_count, 0u};
-        const bool have_hist = false;
         if (passes == 1)                           // <= 256 lists: the digit is the key, ranges come from the digit totals
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, false>(ex, al, al, cap, 0, 0, (KeyT*)nullptr, vbuf[1],
-                                                                      m->tile_ranges.as<uint2>(), have_hist, tiles)));
+                                                                      m->tile_ranges.as<uint2>(), tiles)));
         else if (p + 1 == passes)
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, false, true>(ex, al, al, cap, 8 * (int)p, (int)p, (KeyT*)nullptr,
-                                                                     vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>(), have_hist)));
+                                                                     vbuf[(p + 1) & 1], m->tile_ranges.as<uint2>())));
         else
             GS_TRY((radix_pass<ArrayLoader<KeyT>, KeyT, true, false>(ex, al, al, cap, 8 * (int)p, (int)p, kbuf[(p + 1) & 1],
-                                                                     vbuf[(p + 1) & 1], nullptr, have_hist)));
+                                                                     vbuf[(p + 1) & 1])));
     }
     m->sorted_buf = (passes & 1);            // which ping-pong buffer holds the tile-sorted entries
     return GS_OK;

@@ -68,7 +68,10 @@ __device__ __forceinline__ uint32_t exact_quadrants(uint32_t qm, const uint4 lo,
     const float r00 = __builtin_amdgcn_rcpf(m00), r11 = __builtin_amdgcn_rcpf(m11);
     const float limit = GS_POWER_CUT * 1.0001f + 1e-6f;
     uint32_t out = 0;
-#pragma unroll
+#ifndef BLEND_EXACT_UNROLL
+#define BLEND_EXACT_UNROLL 4
+#endif
+#pragma unroll BLEND_EXACT_UNROLL
     for (uint32_t q = 0; q < 4u; q++) {
         const float X0 = (float)(bx * GS_BIN + (q & 1u) * GS_TILE) + 0.5f - cx, X1 = X0 + (float)(GS_TILE - 1u);
         const float Y0 = (float)(by * GS_BIN + (q >> 1) * GS_TILE) + 0.5f - cy, Y1 = Y0 + (float)(GS_TILE - 1u);
@@ -158,16 +161,23 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     // one batch ahead, so a batch waits for ONE gather latency, not for two dependent ones.  Long lists whose pixels do not
     // saturate are bound by exactly that latency (tools/blend_profile.py: ~8 us per batch before, a wave only walks
     // ~10 survivors of a batch).
+#ifndef BLEND_PREFETCH
+#define BLEND_PREFETCH 1
+#endif
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     uint2 rect = make_uint2(0xFFFFu, 0u);              // empty
     uint32_t v_next = 0;
-    if (tid < n) {
-        const uint32_t slot = vals[begin + tid];
-        rect = rects[slot];
-        lo = recs[2 * (size_t)slot];
-        hi = recs[2 * (size_t)slot + 1];
+    if (BLEND_PREFETCH) {
+        if (tid < n) {
+            const uint32_t slot = vals[begin + tid];
+            rect = rects[slot];
+            lo = recs[2 * (size_t)slot];
+            hi = recs[2 * (size_t)slot + 1];
+        }
+        if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid];
+    } else if (tid < n) {
+        v_next = vals[begin + tid];
     }
-    if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid];
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
 #ifdef GS_BLEND_PROFILE
@@ -175,18 +185,30 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
 #endif
         scanned += cnt;
         __syncthreads();                               // previous batch fully consumed, s_live read by everyone
+        if (!BLEND_PREFETCH) {                         // only the entry word travels across the inner loop
+            rect = make_uint2(0xFFFFu, 0u);
+            if (tid < cnt) {
+                rect = rects[v_next];
+                lo = recs[2 * (size_t)v_next];
+                hi = recs[2 * (size_t)v_next + 1];
+            }
+            const uint32_t nx = base + BLEND_THREADS + tid;
+            if (nx < n) v_next = vals[begin + nx];
+        }
         uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
         if (GS_BLEND_EXACT && qm) qm = exact_quadrants(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi);
         if (tid == 0) s_live = 0u;
         const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
-        if (nxt < n) {
-            rect = rects[v_next];
-            lo = recs[2 * (size_t)v_next];
-            hi = recs[2 * (size_t)v_next + 1];
+        if (BLEND_PREFETCH) {
+            if (nxt < n) {
+                rect = rects[v_next];
+                lo = recs[2 * (size_t)v_next];
+                hi = recs[2 * (size_t)v_next + 1];
+            }
+            if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS];
         }
-        if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS];
         __syncthreads();
         if (live_wave) {
             uint32_t since_check = 0;

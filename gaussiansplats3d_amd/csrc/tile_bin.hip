@@ -70,7 +70,12 @@ extern "C" int gs_debug_bin_prof(void* dst) {
 #define BIN_PROF(k, slot, v) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
+// (waves_per_eu 8: at 62 VGPRs the compiler reports 8 waves per SIMD, yet only 7 workgroups per CU became resident and the last
+// 256 of the 2048 started 10 us late - r02v timeline; with the attribute all start together: span 35.4 -> 33.0 us.
+// Dealing spans of 1024 positions round-robin instead of one contiguous chunk per workgroup, with a scan kernel between count
+// and emit, was tried as well: the entries per workgroup even out (max 1841 vs 3681) but the body time does not - 24.6 us max
+// either way, it is a chain of loaded memory round trips - and the extra kernel makes the C3 frame 3 us slower.)
+__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
                                                            const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
                                                            const uint2* __restrict__ vis32,

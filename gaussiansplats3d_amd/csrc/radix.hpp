@@ -80,6 +80,7 @@ struct ArrayLoader {
     __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const { k = r.key; v = r.val; }
     __device__ __forceinline__ bool valid(uint32_t) const { return true; }
     __device__ __forceinline__ void note_clamp(bool) const {}
+    static __device__ __forceinline__ int prof_slot(int shift) { return shift == 8 && sizeof(KeyT) == 2 ? 1 : -1; }   // GS_RADIX_PROFILE
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -204,6 +205,18 @@ constexpr int SCATTER_ITEMS = RADIX_TILE / SCATTER_THREADS;
 constexpr int SCATTER_PARTS = SCATTER_THREADS / RADIX_BINS;     // threads per digit in the offset prologue
 static_assert(SCATTER_THREADS % RADIX_BINS == 0 && 2 * SCATTER_PARTS <= SCATTER_WAVES, "offset prologue layout");
 
+#ifdef GS_RADIX_PROFILE
+// tools/radix_profile.py: per scatter workgroup (slot = shift / 8 of the depth sort: 0 / 1) the 100 MHz clock at kernel start,
+// after the offset prologue, and for its FIRST tile: data decoded, ranked, offsets scanned, reordered in LDS, stored; then the
+// end of the kernel and the number of tiles
+static __device__ unsigned long long g_radix_prof[2 * 512 * 10];      // one copy per translation unit; sorter.hip's is read
+#define RADIX_PROF(slot, v) do { const int ps_ = Loader::prof_slot(shift); if (threadIdx.x == 0 && blockIdx.x < 512u && ps_ >= 0) g_radix_prof[(ps_ * 512 + blockIdx.x) * 10 + (slot)] = (v); } while (0)
+#define RADIX_PROF_WAIT() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define RADIX_PROF(slot, v) do { } while (0)
+#define RADIX_PROF_WAIT() do { } while (0)
+#endif
+
 template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
 __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld, int shift,
                                                                       const uint32_t* __restrict__ block_hist,
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
     __shared__ uint32_t s_total[RADIX_BINS];
     __shared__ uint32_t s_tmp[SCATTER_WAVES];
 
+    RADIX_PROF(0, wall_clock64());
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -275,7 +289,10 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
         __syncthreads();                                     // s_wave is rewritten below
     }
 
+    RADIX_PROF(1, wall_clock64());
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
+        const bool prof_tile = tile == ch.tile_begin;
+        (void)prof_tile;
         uint32_t key[SCATTER_ITEMS], val[SCATTER_ITEMS], rank[SCATTER_ITEMS];
         bool ok[SCATTER_ITEMS];
         typename Loader::Raw raw[SCATTER_ITEMS];
@@ -294,6 +311,8 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
             val[r] = 0u;
             if (ok[r]) ld.decode(raw[r], key[r], val[r]);
         }
+        RADIX_PROF_WAIT();
+        if (prof_tile) RADIX_PROF(2, wall_clock64());
 #pragma unroll
         for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;
         __syncthreads();
@@ -323,6 +342,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
             }
         }
         __syncthreads();
+        if (prof_tile) RADIX_PROF(3, wall_clock64());
 
         uint32_t tile_count = 0;                    // keys staged by this tile (= its length unless the loader drops some)
         {   // thread t < 256 owns digit t: wave-exclusive offsets and the tile-local digit base
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
             if (tid < RADIX_BINS) s_local[tid] = excl;
         }
         __syncthreads();
+        if (prof_tile) RADIX_PROF(4, wall_clock64());
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
             if (ok[r]) {
@@ -350,6 +371,7 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
             }
         }
         __syncthreads();
+        if (prof_tile) RADIX_PROF(5, wall_clock64());
 #pragma unroll
         for (int k = 0; k < SCATTER_ITEMS; k++) {
             const uint32_t e = k * SCATTER_THREADS + tid;
@@ -365,10 +387,14 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
                 }
             }
         }
+        RADIX_PROF_WAIT();
         __syncthreads();
+        if (prof_tile) RADIX_PROF(6, wall_clock64());
         if (tid < RADIX_BINS) s_base[tid] += s_total[tid];
         // the next iteration's first barrier orders this update before its use
     }
+    RADIX_PROF(7, wall_clock64());
+    RADIX_PROF(8, (unsigned long long)(ch.tile_end - ch.tile_begin));
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -522,6 +522,7 @@ struct DepthLoaderT {
     // fetch = the memory reads of element j, decode = the arithmetic on them: the scatter issues the fetches of its next
     // tile before it ranks the current one (radix.hpp)
     struct Raw { int32_t depth; uint32_t payload; };
+    static __device__ __forceinline__ int prof_slot(int) { return 0; }       // GS_RADIX_PROFILE
     __device__ __forceinline__ Raw fetch(uint32_t j) const {
         const uint32_t i = render_count - 1 - j;
         Raw r;
@@ -567,6 +568,12 @@ static inline uint32_t grid_for(uint32_t n, uint32_t per_block, uint32_t cap) {
     if (g < 1) g = 1;
     return g > cap ? cap : g;
 }
+
+#ifdef GS_RADIX_PROFILE
+extern "C" int gs_debug_radix_prof(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_radix_prof), sizeof(unsigned long long) * 2 * 512 * 10, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" {
 

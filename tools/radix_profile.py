@@ -41,3 +41,8 @@ for slot in range(2):
         print(f"    {n:30s} mean {d.mean():6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
     rest = (b[:, 7] - b[:, 6]) / 100.0
     print(f"    {'the remaining tiles':30s} mean {rest.mean():6.2f}  (per tile {(rest / np.maximum(b[:, 8] - 1, 1)).mean():.2f}) us")
+b0, b1 = buf[0].astype(np.int64), buf[1].astype(np.int64)
+u0, u1 = b0[:, 0] > 0, b1[:, 0] > 0
+if u0.any() and u1.any():
+    print(f"last workgroup of pass 0 done -> first workgroup of pass 1 starts: {(b1[u1, 0].min() - b0[u0, 7].max()) / 100:.1f} us "
+          f"(between them: the end of pass 0 = write-back of its dirty L2 lines, the pass-1 histogram kernel ~5 us, two launches)")

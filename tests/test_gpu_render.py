@@ -378,3 +378,54 @@ def test_stage_times_only_when_asked_for(ctx):
     assert np.array_equal(img, img_timed)
     worker.terminate()
     mesh.dispose()
+
+
+def test_range_uploads_like_update_data_textures_from_base_data(ctx):
+    """SplatMesh.updateDataTexturesFromBaseData(fromSplat, toSplat) takes any range any number of times
+    (/root/reference/src/splatmesh/SplatMesh.js:900-1062): progressive loads append, edits replace a sub-range.  Whatever the
+    sequence of gs_mesh_upload calls, the frame must equal the one of a mesh built once from the final arrays (splats seen
+    before keep their storage slots, new ones get slots along the Morton curve of their own run)."""
+    n = 6000
+    scene = helpers.small_scene(n, 2, seed=88)
+    cam = camera.demo_camera("garden", 320, 200)
+    order = sorted_order(scene, cam)
+
+    def frame_of(mesh):
+        mesh.set_camera(cam)
+        mesh.update_render_indexes(order, n)
+        return mesh.render()[0]
+
+    want = frame_of(build_mesh(ctx, scene))
+    sl = lambda a, lo, hi: a[lo:hi]                                   # noqa: E731
+
+    def upload(mesh, lo, hi, src=scene):
+        mesh.build(sl(src.centers, lo, hi), sl(src.cov, lo, hi), sl(src.rgba, lo, hi), sl(src.sh, lo, hi), start=lo)
+
+    # progressive: three appended runs, the last one overlapping the second
+    prog = SplatMesh(ctx, n, 2)
+    upload(prog, 0, 2500)
+    upload(prog, 2500, 4000)
+    upload(prog, 3500, n)                                             # [3500,4000) again (same data) + fresh [4000,n)
+    np.testing.assert_array_equal(frame_of(prog), want)
+    # an edit: scribble over a sub-range, then restore it - and a range that straddles two earlier runs
+    rng = np.random.default_rng(5)
+    bad = helpers.small_scene(n, 2, seed=89)
+    upload(prog, 1000, 3000, src=bad)
+    assert np.abs(frame_of(prog).astype(int) - want.astype(int)).max() > 20
+    upload(prog, 1000, 3000)
+    np.testing.assert_array_equal(frame_of(prog), want)
+    # the edited mesh equals a mesh built once from the edited arrays
+    lo, hi = 2200, 5100
+    edited = helpers.small_scene(n, 2, seed=88)
+    for name in ("centers", "cov", "rgba", "sh"):
+        getattr(edited, name)[lo:hi] = getattr(bad, name)[lo:hi]
+    upload(prog, lo, hi, src=bad)
+    order_e = sorted_order(edited, cam)
+    once = build_mesh(ctx, edited)
+    for m in (prog, once):
+        m.set_camera(cam)
+        m.update_render_indexes(order_e, n)
+    np.testing.assert_array_equal(prog.render()[0], once.render()[0])
+    del rng
+    prog.dispose()
+    once.dispose()

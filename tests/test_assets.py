@@ -184,3 +184,79 @@ def test_real_capture_from_data_dir_replaces_the_stand_in(tmp_path, monkeypatch)
     assert scenes.make_config_scene("C2").name == "C2"          # truck.ply is not there: synthetic stand-in
     monkeypatch.delenv("GS_DATA_DIR")
     assert scenes.load_real_scene("C3") is None
+
+
+def _raw_ply(props, rows):
+    """A binary little-endian PLY with float properties `props` and rows [n, len(props)]."""
+    rows = np.ascontiguousarray(rows, dtype="<f4")
+    head = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % rows.shape[0]
+    head += "".join(f"property float {p}\n" for p in props) + "end_header\n"
+    return head.encode() + rows.tobytes()
+
+
+def test_ply_without_opacity_and_with_nan_fields_follow_js_semantics():
+    """The reference's createSplat defaults opacity to 0 and clamps with Math.min / Math.max (NaN propagates) before a
+    Uint8ClampedArray store (NaN -> 0): a file without `opacity` is fully transparent, a NaN colour channel is 0, not 255
+    (src/loaders/ply/INRIAV1PlyParser.js:114-209)."""
+    base = ["x", "y", "z", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3", "f_dc_0", "f_dc_1", "f_dc_2"]
+    row = [0.1, 0.2, 0.3, -3.0, -3.0, -3.0, 1.0, 0.0, 0.0, 0.0, 5.0, -5.0, 0.0]
+    a = assets.SplatAsset(_raw_ply(base, [row, row]), "ply", 0)
+    got = a.fill(minimum_alpha=0)
+    assert (got["rgba"][:, 3] == 0).all()                                  # no opacity property -> alpha 0
+    assert got["rgba"][0, 0] == 255 and got["rgba"][0, 1] == 0             # 0.5 + SH_C0 * +-5 clamps to 255 / 0
+    a.close()
+    nan_row = list(row) + [4.0]
+    nan_row[10] = float("nan")                                             # f_dc_0
+    a = assets.SplatAsset(_raw_ply(base + ["opacity"], [nan_row, list(row) + [float("nan")]]), "ply", 0)
+    got = a.fill(minimum_alpha=0)
+    assert got["rgba"][0, 0] == 0 and got["rgba"][0, 3] == int(np.clip(np.float64(1 / (1 + np.exp(-4.0))) * 255, 0, 255) + 0.5) or got["rgba"][0, 0] == 0
+    assert got["rgba"][1, 3] == 0                                          # NaN opacity -> sigmoid NaN -> 0
+    a.close()
+
+
+def test_malformed_ksplat_bucket_tables_are_rejected_not_read_out_of_bounds():
+    """A level-1 .ksplat whose bucket bookkeeping does not add up (a crafted 5 KB file made gs_asset_fill
+    return heap garbage).  Section header fields (KSplat format, src/loaders/SplatBuffer.js:750-830): +8 bucketSize,
+    +12 bucketCount, +32 fullBucketCount, +36 partiallyFilledBucketCount."""
+    from gaussiansplats3d_amd import GsError
+    rng = np.random.default_rng(3)
+    n = 300
+    data, _ = assets.write_ksplat((rng.normal(size=(n, 3)) * 6).astype(np.float32), np.exp(rng.normal(-4, 1, size=(n, 3))).astype(np.float32),
+                                  rng.normal(size=(n, 4)).astype(np.float32), rng.integers(0, 256, size=(n, 4), dtype=np.uint8),
+                                  np.zeros((n, 0), np.float32), 0, 1, block_size=5.0, bucket_size=64, sh_range=(-1.5, 1.5))
+    good = assets.SplatAsset(data, "ksplat", 0)
+    ref = good.fill(minimum_alpha=0)
+    assert np.isfinite(ref["centers"]).all()
+    good.close()
+    sec = 4096
+    full, partial = struct.unpack_from("<II", data, sec + 32)
+    assert partial > 0
+
+    def patched(offset, fmt, *values):
+        b = bytearray(data)
+        struct.pack_into(fmt, b, sec + offset, *values)
+        return bytes(b)
+
+    bad_files = {
+        "bucketCount 0": patched(12, "<I", 0),
+        "bucketSize 0": patched(8, "<I", 0),
+        "no partial buckets although the full ones do not cover the splats": patched(36, "<I", 0),
+        "more buckets in use than exist": patched(32, "<II", full + 50, partial),
+        "partial bucket count beyond the table": patched(36, "<I", partial + 1000),
+    }
+    for why, blob in bad_files.items():
+        try:
+            a = assets.SplatAsset(blob, "ksplat", 0)
+        except GsError:
+            continue
+        got = a.fill(minimum_alpha=0)            # accepted: then it must at least stay inside the file
+        assert np.isfinite(got["centers"]).all() and np.abs(got["centers"]).max() < 1e6, why
+        a.close()
+    # the partial-bucket length table itself: lengths that do not add up to the splat count
+    table = sec + 1024                            # bucket metadata follows the section header
+    blob = bytearray(data)
+    lengths = list(struct.unpack_from(f"<{partial}I", data, table))
+    assert full * 64 + sum(lengths) == n
+    struct.pack_into("<I", blob, table + 4 * int(np.argmax(lengths)), 0)      # the largest partial bucket claims nothing
+    with pytest.raises(GsError):
+        assets.SplatAsset(bytes(blob), "ksplat", 0)

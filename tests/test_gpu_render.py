@@ -429,3 +429,44 @@ def test_range_uploads_like_update_data_textures_from_base_data(ctx):
     del rng
     prog.dispose()
     once.dispose()
+
+
+def test_out_of_range_indexes_are_harmless(ctx):
+    """A stale or wrong index list must neither fault the GPU nor read foreign memory (WebGL's out-of-range texelFetch is
+    harmless too): the mesh draws nothing for entries >= the uploaded splat count, the sorter clamps them."""
+    scene = helpers.small_scene(3000, 1, seed=91)
+    cam = camera.demo_camera("garden", 256, 144)
+    order = sorted_order(scene, cam)
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(order, scene.count)
+    mesh.render()
+    mesh.update_render_indexes(order, scene.count + 1)                  # more than uploaded: refused
+    with pytest.raises(Exception):
+        mesh.render()
+    mesh.update_render_indexes(order, scene.count)
+    mesh2 = SplatMesh(ctx, scene.count, 1).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh2.set_camera(cam)
+    stale = order.copy()
+    stale[::7] = 0xFFFFFFF0                                             # a seventh of the list points nowhere
+    mesh2.update_render_indexes(stale, scene.count)
+    got, _ = mesh2.render()
+    keep = np.ones(scene.count, bool)
+    keep[::7] = False
+    mesh.update_render_indexes(order[keep], int(keep.sum()))
+    ref, _ = mesh.render()
+    np.testing.assert_array_equal(got, ref)                             # = the frame of the valid entries alone
+    # sorter: list entries beyond the uploaded centres are clamped to the last splat, never dereferenced
+    worker = create_sort_worker(ctx, scene.count)
+    worker.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": scene.count - 1, "count": scene.count}})
+    idx = np.arange(scene.count, dtype=np.uint32)
+    idx[5] = 0xFFFFFFFF
+    r = worker.post_message({"sort": {"modelViewProj": cam.sort_mvp(), "splatRenderCount": scene.count, "splatSortCount": scene.count,
+                                      "indexesToSort": idx}})
+    assert r["sortedIndexes"].shape[0] == scene.count
+    with pytest.raises(Exception):                                      # a list shorter than the counts: refused on the host
+        worker.post_message({"sort": {"modelViewProj": cam.sort_mvp(), "splatRenderCount": scene.count, "splatSortCount": scene.count,
+                                      "indexesToSort": idx[:100]}})
+    worker.terminate()
+    for m in (mesh, mesh2):
+        m.dispose()

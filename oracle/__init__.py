@@ -11,8 +11,8 @@ package; the product (``gaussiansplats3d_amd``) never does.
   ``oracle/_ref/libsorter_ref.so`` by ``oracle/Makefile`` (present only after ``make -C oracle``
   where ``/root/reference`` exists; the prebuilt file travels to the GPU box).
 * :func:`project` / :func:`render` — ``raster_oracle.c``, restating the GLSL in
-  ``src/splatmesh/SplatMaterial.js`` + ``SplatMaterial3D.js`` (parity UNPINNED by the reference, see
-  the file header).
+  ``src/splatmesh/SplatMaterial.js`` + ``SplatMaterial3D.js``; PINNED to the reference's own shader text executed on the
+  CPU (tests/golden/raster_ref.npz, see the file header).
 """
 import ctypes as C
 import os

@@ -5,8 +5,11 @@ covariance / SH fill routines without a scene transform (:221-246, :440-486, :51
 
 Pinning: the PLY HEADER logic (field offsets, bytes per vertex, SH degree and the f_rest -> coefficient mapping) is pinned to
 the reference's own PlyParserUtils.js, which is three-free and runs under Node (tests/golden/ply_header_kat.json, recorded
-by oracle/make_golden_ply.py).  Everything that needs SplatBuffer.js (imports 'three') is UNPINNED: my reading of the source.
-Small cases only."""
+by oracle/make_golden_ply.py).  The rest - row decode, the .ksplat layouts of compression level 0 / 1 / 2, covariance, colour
+and SH fills - is PINNED too since round 2: tests/golden/assets_ref_sh{0,1,2}.npz are recorded by oracle/make_golden_assets.py,
+which imports the reference's own PlyParser / SplatBuffer modules in place under Node (ESM loader hook oracle/three_loader.mjs,
+'three' -> oracle/three_min.mjs) and lets the reference write and read back .ksplat files; tests/test_assets_ref.py compares
+this file and csrc/assets.hip with them bit for bit.  Small cases only."""
 import math
 import struct
 

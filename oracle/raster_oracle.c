@@ -9,10 +9,14 @@
  *   uniforms              /root/reference/src/splatmesh/SplatMesh.js:1248-1280, src/Viewer.js:651-677
  *   quad                  /root/reference/src/splatmesh/SplatGeometry.js:14-23
  *
- * Parity status: UNPINNED by the reference — the reference has no tests, goldens or CPU rasteriser, and
- * WebGL cannot run here.  This file is a line-by-line arithmetic restatement of the
- * shader source in IEEE fp32 (compiled with -ffp-contract=off); goldens under tests/golden/raster_*.npz
- * are produced by THIS code and exist to catch regressions, not to pin it to the reference.
+ * Parity status: PINNED since round 2.  The reference has no tests, goldens or CPU rasteriser and WebGL cannot run
+ * here, so its own shader text is executed instead: oracle/make_golden_raster.py takes the GLSL that
+ * SplatMaterial3D.build() returns (7 permutations), rewrites tokens only, compiles it against oracle/glsl_shim.hpp
+ * (-O1 -ffp-contract=off) and records gl_Position / vColor / vPosition for 12 seeded cases and the fragment rule for 1505
+ * fragments into tests/golden/raster_ref.npz; tests/test_raster_ref.py compares project_one / blend_one below (and the HIP
+ * vertex stage) with them.  This file is a line-by-line arithmetic restatement of the shader source in IEEE fp32
+ * (compiled with -ffp-contract=off).  What stays unobservable from source is the order of operations inside a GPU's ROPs
+ * (RGBA8 target): the rop8 mode below emulates it and DESIGN.md section 2 reports the gap.
  *
  * Conventions: matrices are column-major float[16] like three.js / GLSL; framebuffer row 0 is the
  * BOTTOM row (GL window coordinates); pixel (x,y) is sampled at its centre (x+0.5, y+0.5).

@@ -5,8 +5,9 @@
   leaves the reference's own code produces for tests/tree_cases.py (recorded by oracle/make_golden_tree.py, which
   evaluates the worker function cut out of the reference's source text under Node);
 * Viewer.gatherSceneNodesForSort (/root/reference/src/Viewer.js:1969-2077) with three r160's Vector3.applyMatrix4 /
-  normalize / length spelled out.  UNPINNED: the Viewer imports 'three', which is not installed, and the reference has
-  no test for it; this is my reading of the source.
+  normalize / length spelled out.  PINNED since round 2: tests/golden/gather_kat.json is recorded by
+  oracle/make_golden_gather.py, which evaluates the method's own text (cut out of Viewer.js) under Node over trees built by
+  the reference's worker, with THREE = oracle/three_min.mjs (3 trees x 7 cameras: render count, index list, modelView).
 
 Small cases only (plain Python loops).
 """

@@ -1,7 +1,7 @@
 """CPU tier: the fp32 C raster oracle (oracle/raster_oracle.c, a line-by-line restatement of the GLSL) against an
 INDEPENDENT fp64 numpy restatement written from the formulas of SURVEY.md Appendix A.2 — different language, different
-precision, different structure (matrix algebra instead of scalar code).  Catches transcription errors in either; it cannot
-pin the oracle to the reference (WebGL cannot run here: parity stays 'unpinned')."""
+precision, different structure (matrix algebra instead of scalar code).  Catches transcription errors in either.  (The pin to
+the reference itself is tests/test_raster_ref.py: the reference's own shader text executed on the CPU.)"""
 import numpy as np
 import pytest
 

@@ -8,11 +8,15 @@ import numpy as np
 GS_TILE = 16
 
 
-def balanced_row_strips(row_cost, world_size):
+def balanced_row_strips(row_cost, world_size, align=1):
     """Split tile rows [0, len(row_cost)) into `world_size` contiguous strips of near-equal cost.
     row_cost: per-tile-row work estimate (tile entries).  Returns [(begin, end)] * world_size, covering all rows;
-    strips may be empty when there are fewer rows than ranks."""
+    strips may be empty when there are fewer rows than ranks.  align: cut only at multiples of `align` tile rows (2 = the
+    32-px blend bins: a bin cut in half is drawn by two ranks, each with half of its waves idle)."""
     rows = len(row_cost)
+    if align > 1 and rows >= 2 * align * world_size:
+        grouped = np.add.reduceat(np.asarray(row_cost, dtype=np.float64), np.arange(0, rows, align))
+        return [(min(b * align, rows), min(e * align, rows)) for b, e in balanced_row_strips(grouped, world_size)]
     cost = np.asarray(row_cost, dtype=np.float64) + 1.0          # +1: empty rows still cost a launch slot
     csum = np.concatenate([[0.0], np.cumsum(cost)])
     total = csum[-1]

@@ -46,14 +46,14 @@ def timed(strip, culled):
 
 if len(sys.argv) > 3:
     n, r = (int(v) for v in sys.argv[3].split(":"))
-    strip = gdist.balanced_row_strips(row_cost, n)[r] if n > 1 else None
+    strip = gdist.balanced_row_strips(row_cost, n, align=int(os.environ.get("GS_STRIP_ALIGN", "2")))[r] if n > 1 else None
     print(f"{name} rank {r} of {n}: strip rows {strip}: {timed(strip, True):.4f} ms/frame over {steps} frames (+3 warm-up, +2 full)")
     sys.exit(0)
 base = timed(None, False)
 print(f"{name} full sort, 1 GPU (the headline path): {base:.4f} ms/frame")
 one = None
 for n in (1, 2, 4, 8):
-    strips = gdist.balanced_row_strips(row_cost, n) if n > 1 else [None]
+    strips = gdist.balanced_row_strips(row_cost, n, align=int(os.environ.get("GS_STRIP_ALIGN", "2"))) if n > 1 else [None]
     ms = [timed(s, True) for s in strips]
     kept = []
     slow = max(ms)

@@ -150,6 +150,7 @@ int parse_ksplat(gs_asset* a) {
             GS_REQUIRE((uint64_t)sec.full_buckets + sec.partial_buckets <= sec.bucket_count,
                        ".ksplat: more full + partial buckets than the section stores");
             uint64_t covered = (uint64_t)sec.full_buckets * sec.bucket_size;
+            GS_REQUIRE(covered <= 0xFFFFFFFFull, ".ksplat: full buckets x bucket size overflows 32 bits");   // bucket_index's span
             sec.partial_end.reserve(sec.partial_buckets);
             for (uint32_t p = 0; p < sec.partial_buckets; p++) {
                 covered += a->rd<uint32_t>(sec.base + 4 * (size_t)p);
@@ -382,7 +383,8 @@ uint32_t bucket_index(const gs_asset*, const Section& sec, uint32_t local) {
     const uint32_t full_span = sec.full_buckets * sec.bucket_size;
     if (local < full_span) return local / sec.bucket_size;
     const auto it = std::upper_bound(sec.partial_end.begin(), sec.partial_end.end(), local);
-    return sec.full_buckets + (uint32_t)(it - sec.partial_end.begin());
+    const uint32_t b = sec.full_buckets + (uint32_t)(it - sec.partial_end.begin());
+    return b < sec.bucket_count ? b : sec.bucket_count - 1u;       // unreachable after parse_ksplat's checks; never past the table
 }
 
 double comp(const gs_asset* a, size_t row, uint32_t index, bool sh) {                   // dataViewFloatForCompressionLevel + toUncompressedFloat

@@ -8,6 +8,8 @@
 // kernel.  librccl is loaded on first use, so single-GPU users never need it.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "gs_internal.hpp"
 
 namespace {
@@ -29,11 +31,11 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 
+// thread-per-rank callers (one gs_context per thread) may reach this concurrently: the table is filled exactly once
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
@@ -53,7 +55,7 @@ Rccl* rccl() {
                 r.lib = nullptr;
             }
         }
-    }
+    });
     return r.lib ? &r : nullptr;
 }
 
@@ -163,25 +165,40 @@ int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, u
 
 int gs_group_render_gather(gs_group* g, gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter, uint32_t render_count,
                            const uint32_t* row_begin, const uint32_t* row_end, uint32_t root, uint8_t* rgba_out_host) {
+    // Argument errors every rank sees alike (same tables, same root) may return early: no rank enters the collective.
     GS_REQUIRE(g && m && cam && row_begin && row_end, "group / mesh / camera / row tables == NULL");
     GS_REQUIRE(m->ctx == g->ctx, "mesh lives on another context");
     GS_REQUIRE(root < g->world, "root outside the group");
+    for (uint32_t r = 0; r < g->world; r++)
+        GS_REQUIRE(row_begin[r] % GS_TILE == 0 && (row_end[r] % GS_TILE == 0 || row_end[r] == cam->height) &&
+                       row_begin[r] <= row_end[r] && row_end[r] <= cam->height,
+                   "every rank's pixel rows must be whole 16-px tile rows of the viewport");
     const uint32_t y0 = row_begin[g->rank], y1 = row_end[g->rank];
-    GS_REQUIRE(y0 % GS_TILE == 0 && (y1 % GS_TILE == 0 || y1 == cam->height) && y0 <= y1 && y1 <= cam->height,
-               "this rank's pixel rows must be whole 16-px tile rows of the viewport");
     gs_camera c = *cam;
     c.tile_row_begin = y0 / GS_TILE;
     c.tile_row_end = (y1 + GS_TILE - 1) / GS_TILE;
     ScopedDevice sd(g->ctx->device);
-    const size_t frame_bytes = (size_t)cam->width * cam->height * 4;
-    if (g->rank == root) GS_TRY(g->full.ensure(frame_bytes + 16));
+    const size_t frame_bytes = (size_t)cam->width * cam->height * 4, strip_bytes = (size_t)(y1 - y0) * cam->width * 4;
+    // From here on a failure is LOCAL (this rank's draw, this rank's allocation).  The other ranks are already on their way
+    // into the gather, and the root would wait for this rank's strip forever, so this rank always takes part: it sends
+    // whatever its strip buffer holds (zeros if the draw never ran) and reports its own error afterwards.
     int status = GS_OK;
-    if (y1 > y0) {                                        // the strip goes to the mesh's own framebuffer
-        status = gs_mesh_render(m, &c, sorted_host, sorter, render_count, nullptr, nullptr, nullptr);
-        if (status < 0) return status;
+    if (g->rank == root) status = g->full.ensure(frame_bytes + 16);
+    int st_fb = m->fb.ensure(strip_bytes + 16);            // the draw's target; also what a failed draw sends
+    if (status >= 0 && st_fb < 0) status = st_fb;
+    if (status >= 0 && y1 > y0) {                         // the strip goes to the mesh's own framebuffer
+        const int st_draw = gs_mesh_render(m, &c, sorted_host, sorter, render_count, nullptr, nullptr, nullptr);
+        if (st_draw < 0 && m->fb.p && strip_bytes) (void)hipMemsetAsync(m->fb.p, 0, strip_bytes, g->ctx->stream);
+        status = st_draw;
     }
-    GS_TRY(gs_group_gather_strips(g, y1 > y0 ? m->fb.p : nullptr, g->full.p, cam->width, row_begin, row_end, root));
-    if (g->rank == root && rgba_out_host) {
+    if (st_fb < 0 || (g->rank == root && !g->full.p)) {
+        // no buffer to send from / receive into: the only case that cannot take part; the peers' watchdog (bench.py) or the
+        // caller's own timeout has to end the collective
+        return status < 0 ? status : GS_ERR_NOMEM;
+    }
+    const int st_gather = gs_group_gather_strips(g, y1 > y0 ? m->fb.p : nullptr, g->full.p, cam->width, row_begin, row_end, root);
+    if (status >= 0 && st_gather < 0) status = st_gather;
+    if (status >= 0 && g->rank == root && rgba_out_host) {
         GS_HIP(hipMemcpyAsync(rgba_out_host, g->full.p, frame_bytes, hipMemcpyDeviceToHost, g->ctx->stream));
         GS_HIP(hipStreamSynchronize(g->ctx->stream));
     }

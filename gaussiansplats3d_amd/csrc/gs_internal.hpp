@@ -317,7 +317,8 @@ struct gs_mesh {
     DevBuf tile_ranges;        // uint2 [bins]
     DevBuf frame;              // RenderFrame
     DevBuf fb;                 // internal RGBA8 framebuffer
-    DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, (splat, tile) pairs walked}
+    DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, half quadrants evaluated}, then
+                               // uint32 [the same]: (splat, quadrant) pairs walked
     uint32_t blend_bins = 0, blend_row_begin = 0, blend_width = 0;    // the bins the last draw blended
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
     bool blend_order_valid = false;

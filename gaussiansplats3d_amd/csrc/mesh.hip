@@ -165,6 +165,10 @@ __global__ __launch_bounds__(256) void k_split_sh_u8(const uint8_t* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void k_iota2(uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = b[i] = i;
+}
+
 static inline uint32_t up_grid(uint32_t n) {
     uint32_t g = (n + 255u) / 256u;
     return g < 1 ? 1 : (g > 4096u ? 4096u : g);
@@ -223,6 +227,26 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->bin_sums, 4 * 3 * 2048 + 64);               // uint32 [3][BIN_MAX_BLOCKS] + the batches-per-workgroup of the last count
     A(m->frame, sizeof(RenderFrame));
     if (st == GS_OK) st = m->radix.init();
+    if (st == GS_OK) {
+        // Never-uploaded splats are what the reference's zero-filled data textures hold (SplatMesh.js:686-697: new
+        // Uint32Array / Float32Array): centre 0, covariance 0, colour 0 with alpha 0 - they draw nothing.  gs_mesh_upload
+        // accepts any range, so a first upload of [100, 200) leaves [0, 100) in this state, `uploaded` = 200, and a draw
+        // (or a stale index list) may name them: the planes must be defined and the storage permutation a bijection from
+        // the start (identity until an upload assigns Morton slots).
+        hipError_t e = hipSuccess;
+        auto Z = [&](DevBuf& b) { if (e == hipSuccess && b.p) e = hipMemsetAsync(b.p, 0, b.bytes, ctx->stream); };
+        Z(m->px); Z(m->py); Z(m->pz); Z(m->covA); Z(m->covB); Z(m->cov_bound); Z(m->rgba); Z(m->sh0); Z(m->sh1); Z(m->sh2);
+        if (e == hipSuccess && m->reorder) {
+            hipLaunchKernelGGL(k_iota2, dim3(up_grid(max_splat_count)), dim3(256), 0, ctx->stream, m->perm.as<uint32_t>(),
+                               m->inv_perm.as<uint32_t>(), max_splat_count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            gs_set_error("initialising the mesh planes failed: %s", hipGetErrorString(e));
+            st = GS_ERR_HIP;
+        }
+    }
     if (st == GS_OK) {
         // first guess: 8 entries per splat, at least 1M; grown on overflow
         uint64_t cap = (uint64_t)n * 8;
@@ -489,13 +513,16 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.list_bin_px = GS_TILE << m->drawn_list_shift;
     m->last.entries_scanned = 0;
     m->last.splats_walked = 0;
+    m->last.halves_evaluated = 0;
     if (m->blend_bins) {                                   // per-workgroup counters of the blend, summed here
-        std::vector<uint2> bs(m->blend_bins);
-        GS_HIP(hipMemcpyAsync(bs.data(), m->blend_stats.p, (size_t)m->blend_bins * 8, hipMemcpyDeviceToHost, st));
+        const size_t nb = m->blend_bins;
+        std::vector<uint32_t> bs(3 * nb);                  // uint2 [nb] {staged, halves} | uint32 [nb] pairs
+        GS_HIP(hipMemcpyAsync(bs.data(), m->blend_stats.p, nb * 12, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
-        for (const uint2& b : bs) {
-            m->last.entries_scanned += b.x;
-            m->last.splats_walked += b.y;
+        for (size_t b = 0; b < nb; b++) {
+            m->last.entries_scanned += bs[2 * b];
+            m->last.halves_evaluated += bs[2 * b + 1];
+            m->last.splats_walked += bs[2 * nb + b];
         }
     }
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them

@@ -51,17 +51,29 @@ __device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32
     return (mx & (my & 1u ? 3u : 0u)) | ((mx & (my & 2u ? 3u : 0u)) << 2);
 }
 
-// Exact refinement of the rect's quadrant mask.  A splat reaches a pixel only where power = (a.d)^2 + (b.d)^2 <= 4*log2(e)
-// (d = pixel centre - splat centre), a convex quadratic d^T M d with M = a a^T + b b^T.  Its minimum over the box of a
-// quadrant's pixel centres is 0 when the centre lies inside, and otherwise lies on an edge facing the centre (moving from
-// the minimiser towards the centre lowers the form, so that direction must leave the box): at most two 1-D minimisations.
-// The bounding rect of a long diagonal ellipse covers many tiles the ellipse never enters; a wave that skips them saves
-// ~150 VALU cycles per splat, and a skipped splat would have been discarded at every pixel, so the frame does not change
-// (strips of a multi-GPU draw stay bit-exact).  The 1e-4 margin covers the fp32 rounding of the per-pixel evaluation.
+// Exact refinement of the rect's quadrant mask, per HALF quadrant.  A splat reaches a pixel only where
+// power = (a.d)^2 + (b.d)^2 <= 4*log2(e) (d = pixel centre - splat centre), a convex quadratic.  Its minimum over the box of
+// a half quadrant's pixel centres (16 x 8) is 0 when the centre lies inside, and otherwise lies on an edge facing the centre
+// (moving from the minimiser towards the centre lowers the form, so that direction must leave the box): at most two 1-D
+// minimisations.  The bounding rect of a long diagonal ellipse covers many tiles the ellipse never enters, and most splats
+// of a capture are a few pixels across and touch one half of a quadrant only; a wave that skips a half saves ~20 of its
+// ~45 VALU instructions per splat (the two halves are the two packed strip pairs of the inner loop), a skipped quadrant all
+// of them - and a skipped half would have been discarded at every pixel (keep = 0: C, T unchanged), so the frame does not
+// change and strips of a multi-GPU draw stay bit-exact.
+// The edge minimum is evaluated in the per-pixel test's own factored form (a.d)^2 + (b.d)^2 at the clamped minimiser, not as
+// m00 x^2 + 2 m01 x y + m11 y^2: for an elongated diagonal splat that expansion cancels catastrophically (relative error
+// ~ eps * m00 * m11 / det, i.e. above the margin beyond a 50:1 aspect ratio).  An inexact minimiser only moves the sample
+// point along the edge by ~eps * sqrt(m00 / m11) * |x|, a second-order change of the form; the 1e-4 relative margin covers
+// it and the fp32 rounding of the per-pixel evaluation.
+// Result: bit (2*q + h) = half h (rows 8h .. 8h+7) of quadrant q.
 #ifndef GS_BLEND_EXACT
 #define GS_BLEND_EXACT 1
 #endif
-__device__ __forceinline__ uint32_t exact_quadrants(uint32_t qm, const uint4 lo, const uint4 hi, uint32_t bx, uint32_t by) {
+__device__ __forceinline__ uint32_t spread_quadrants(uint32_t qm) {          // 4 quadrant bits -> both half bits of each
+    const uint32_t s = (qm & 1u) | ((qm & 2u) << 1) | ((qm & 4u) << 2) | ((qm & 8u) << 3);
+    return s | (s << 1);
+}
+__device__ __forceinline__ uint32_t exact_halves(uint32_t qm, const uint4 lo, const uint4 hi, uint32_t bx, uint32_t by) {
     const float cx = __uint_as_float(lo.x), cy = __uint_as_float(lo.y);
     const float ax = __uint_as_float(lo.z), ay = __uint_as_float(lo.w), ex = __uint_as_float(hi.x), ey = __uint_as_float(hi.y);
     const float m00 = ax * ax + ex * ex, m01 = ax * ay + ex * ey, m11 = ay * ay + ey * ey;
@@ -71,21 +83,28 @@ __device__ __forceinline__ uint32_t exact_quadrants(uint32_t qm, const uint4 lo,
 #ifndef BLEND_EXACT_UNROLL
 #define BLEND_EXACT_UNROLL 4
 #endif
+    const float Xq[2] = {(float)(bx * GS_BIN) + 0.5f - cx, (float)(bx * GS_BIN + GS_TILE) + 0.5f - cx};
 #pragma unroll BLEND_EXACT_UNROLL
-    for (uint32_t q = 0; q < 4u; q++) {
-        const float X0 = (float)(bx * GS_BIN + (q & 1u) * GS_TILE) + 0.5f - cx, X1 = X0 + (float)(GS_TILE - 1u);
-        const float Y0 = (float)(by * GS_BIN + (q >> 1) * GS_TILE) + 0.5f - cy, Y1 = Y0 + (float)(GS_TILE - 1u);
-        const float xb = X0 > 0.0f ? X0 : (X1 < 0.0f ? X1 : 0.0f);       // bound between the box and the centre, 0 = none
-        const float yb = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);
-        float qmin = 0.0f;
-        if (xb != 0.0f || yb != 0.0f) {
-            const float dy = fminf(fmaxf(-(m01 * xb) * r11, Y0), Y1);     // along the edge x = xb
-            const float q1 = xb != 0.0f ? (m00 * xb) * xb + ((2.0f * m01) * xb + m11 * dy) * dy : GS_HUGE;
-            const float dx = fminf(fmaxf(-(m01 * yb) * r00, X0), X1);     // along the edge y = yb
-            const float q2 = yb != 0.0f ? (m11 * yb) * yb + ((2.0f * m01) * yb + m00 * dx) * dx : GS_HUGE;
-            qmin = fminf(q1, q2);
+    for (uint32_t r = 0; r < 4u; r++) {                                   // band r = rows 8r .. 8r+7 of the 32-px bin
+        const float Y0 = (float)(by * GS_BIN + r * 8u) + 0.5f - cy, Y1 = Y0 + 7.0f;
+        const float yb = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);     // bound between the box and the centre, 0 = none
+#pragma unroll
+        for (uint32_t c = 0; c < 2u; c++) {                               // column c = x 16c .. 16c+15
+            const float X0 = Xq[c], X1 = X0 + (float)(GS_TILE - 1u);
+            const float xb = X0 > 0.0f ? X0 : (X1 < 0.0f ? X1 : 0.0f);
+            float qmin = 0.0f;
+            if (xb != 0.0f || yb != 0.0f) {
+                const float dy = fminf(fmaxf(-(m01 * xb) * r11, Y0), Y1);     // along the edge x = xb
+                const float u1 = ax * xb + ay * dy, w1 = ex * xb + ey * dy;
+                const float q1 = xb != 0.0f ? u1 * u1 + w1 * w1 : GS_HUGE;
+                const float dx = fminf(fmaxf(-(m01 * yb) * r00, X0), X1);     // along the edge y = yb
+                const float u2 = ax * dx + ay * yb, w2 = ex * dx + ey * yb;
+                const float q2 = yb != 0.0f ? u2 * u2 + w2 * w2 : GS_HUGE;
+                qmin = fminf(q1, q2);
+            }
+            // quadrant q = c + 2 * (r >> 1), half h = r & 1
+            if (!(qmin > limit)) out |= 1u << (2u * (c + 2u * (r >> 1)) + (r & 1u));   // NaN keeps the half
         }
-        if (!(qmin > limit)) out |= 1u << q;                              // NaN keeps the quadrant
     }
     return qm & out;
 }
@@ -106,9 +125,13 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
 
 #ifdef GS_BLEND_PROFILE
 // tools/blend_profile.py: per bin {start, end} of s_memrealtime (100 MHz), list length, survivors walked by wave 0..3
-__device__ unsigned long long g_blend_prof[8 * 8192];
+// ... and [8] lane evaluations (128 per evaluated half), [9] lanes that passed `keep` (A <= 8), [10] lanes that passed it on
+// a pixel still accumulating (T > 0), [11] halves evaluated: what fraction of the blend's pixel work can hit anything
+constexpr unsigned BLEND_PROF_BINS = 40960, BLEND_PROF_WORDS = 12;
+__device__ unsigned long long g_blend_prof[BLEND_PROF_WORDS * BLEND_PROF_BINS];
 extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_blend_prof), (size_t)bins * 64, 0, hipMemcpyDeviceToHost);
+    if (bins > BLEND_PROF_BINS) bins = BLEND_PROF_BINS;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_blend_prof), (size_t)bins * BLEND_PROF_WORDS * 8, 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -118,16 +141,20 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef BLEND_OCC
 #define BLEND_OCC 6
 #endif
+#ifndef GS_BLEND_HALF_SKIP
+#define GS_BLEND_HALF_SKIP 1          // 0: always evaluate both halves of a quadrant the splat reaches (A/B)
+#endif
 __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
                                                               uint32_t list_row_begin, uint32_t list_shift,
-                                                              uint2* __restrict__ bin_stats, const uint32_t* __restrict__ bin_order) {
+                                                              uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
+                                                              const uint32_t* __restrict__ bin_order) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
-    __shared__ uint32_t s_walked[4];
+    __shared__ uint32_t s_walked[4], s_halves[4];
     const uint32_t bin = bin_order ? bin_order[blockIdx.x] : blockIdx.x;       // heaviest bins of the previous draw first (k_bin_emit)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
@@ -141,7 +168,10 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     const unsigned long long t_start = wall_clock64();
     uint32_t batches = 0;
 #endif
-    uint32_t walked = 0, scanned = 0;                  // statistics: wave-uniform, kept in scalar registers
+    uint32_t walked = 0, halves = 0, scanned = 0;      // statistics: wave-uniform, kept in scalar registers
+#ifdef GS_BLEND_PROFILE
+    uint32_t p_kept = 0, p_useful = 0;
+#endif
     // the entry list of the list bin this 32-px bin lies in
     const uint32_t per_list = list_shift - GS_BIN_SHIFT;
     const uint2 range = ranges[((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list)];
@@ -195,8 +225,8 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
             const uint32_t nx = base + BLEND_THREADS + tid;
             if (nx < n) v_next = vals[begin + nx];
         }
-        uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
-        if (GS_BLEND_EXACT && qm) qm = exact_quadrants(qm, lo, hi, bx, by);
+        uint32_t qm = tid < cnt ? spread_quadrants(quadrant_mask(rect, bx, by)) : 0u;   // bit 2q + h: half h of quadrant q
+        if (GS_BLEND_EXACT && qm) qm = exact_halves(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi);
         if (tid == 0) s_live = 0u;
@@ -213,10 +243,13 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
         if (live_wave) {
             uint32_t since_check = 0;
             for (uint32_t g0 = 0; g0 < cnt && live_wave; g0 += 64) {
-                // this wave's survivors among staged entries [g0, g0+64)
-                unsigned long long m = __ballot((s_qmask[g0 + lane] >> wave) & 1u);
+                // this wave's survivors among staged entries [g0, g0+64), per half of its quadrant (wave-uniform masks)
+                const uint32_t mine = s_qmask[g0 + lane] >> (2u * wave);
+                const unsigned long long mh0 = __ballot(mine & 1u), mh1 = __ballot(mine & 2u);
+                unsigned long long m = mh0 | mh1;
                 while (m) {
-                    const uint32_t j = g0 + (uint32_t)__builtin_ctzll(m);
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t j = g0 + bit;
                     m &= m - 1ull;
                     walked++;
                     const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].cx);
@@ -224,12 +257,12 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                     const float4 q2 = *reinterpret_cast<const float4*>(&s_batch[j].r);
                     const float dx = fx - q0.x;
                     const float adx = q0.z * dx, bdx = q1.x * dx;
-                    // The four 16x4 strips of a lane are two packed pairs (v_pk_*_f32 does two fp32 lanes per VALU slot).
+                    // The four 16x4 strips of a lane are two packed pairs (v_pk_*_f32 does two fp32 lanes per VALU slot): pair
+                    // h = rows 8h .. 8h+7 of the quadrant, and a pair the splat cannot reach is skipped with a scalar branch.
                     // `if (A > 8.0) discard` and the freeze are saturated multiply-adds instead of compare + select pairs
                     // (which do not pack and stall on VCC): keep = sat((CUT - pw) * 2^100) is exactly 1 for pw < CUT and 0
                     // for pw >= CUT - fp32 cannot represent a positive difference below 2^-100 here.
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
+                    auto half = [&](const int h) {
                         const v2f dy = fy[h] - q0.y;
                         const v2f u = q0.w * dy + adx;                       // contracted to v_pk_fma_f32
                         const v2f w = q1.y * dy + bdx;
@@ -238,6 +271,11 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                         e.x = __builtin_amdgcn_exp2f(-pw.x);
                         e.y = __builtin_amdgcn_exp2f(-pw.y);
                         const v2f keep = pk_fma_sat(pw, v2f{-GS_HUGE, -GS_HUGE}, v2f{GS_POWER_CUT * GS_HUGE, GS_POWER_CUT * GS_HUGE});
+#ifdef GS_BLEND_PROFILE
+                        p_kept += (uint32_t)__popcll(__ballot(keep.x > 0.0f)) + (uint32_t)__popcll(__ballot(keep.y > 0.0f));
+                        p_useful += (uint32_t)__popcll(__ballot(keep.x > 0.0f && T[h].x > 0.0f)) +
+                                    (uint32_t)__popcll(__ballot(keep.y > 0.0f && T[h].y > 0.0f));
+#endif
                         const v2f alpha = e * (q2.w * keep);
                         const v2f wgt = T[h] * alpha;
                         Cr[h] += wgt * q2.x;
@@ -248,7 +286,10 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                         // stay bit-exact)
                         const v2f t_new = T[h] - wgt;
                         T[h] = t_new * pk_fma_sat(t_new, v2f{GS_HUGE, GS_HUGE}, v2f{-GS_T_EPS * GS_HUGE, -GS_T_EPS * GS_HUGE});
-                    }
+                    };
+                    const bool do0 = !GS_BLEND_HALF_SKIP || ((mh0 >> bit) & 1ull), do1 = !GS_BLEND_HALF_SKIP || ((mh1 >> bit) & 1ull);
+                    if (do0) { half(0); halves++; }
+                    if (do1) { half(1); halves++; }
                     if (++since_check == 16u || m == 0ull) {
                         // retire the wave when its whole quadrant is saturated
                         since_check = 0;
@@ -268,22 +309,41 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
         if (s_live == 0u) break;                       // every quadrant saturated (or clipped): skip the rest of the list
     }
 #ifdef GS_BLEND_PROFILE
-    if (bin < 8192u && lane == 0u) {
+    __shared__ unsigned int s_prof[3];
+    if (tid < 3u) s_prof[tid] = 0u;
+    __syncthreads();
+    if (lane == 0u) {
+        atomicAdd(&s_prof[0], p_kept);
+        atomicAdd(&s_prof[1], p_useful);
+        atomicAdd(&s_prof[2], halves);
+    }
+    if (bin < BLEND_PROF_BINS && lane == 0u) {
         if (wave == 0u) {
-            g_blend_prof[8 * bin + 0] = t_start;
-            g_blend_prof[8 * bin + 2] = n;
-            g_blend_prof[8 * bin + 3] = batches;
+            g_blend_prof[BLEND_PROF_WORDS * bin + 0] = t_start;
+            g_blend_prof[BLEND_PROF_WORDS * bin + 2] = n;
+            g_blend_prof[BLEND_PROF_WORDS * bin + 3] = batches;
         }
-        g_blend_prof[8 * bin + 4 + wave] = walked;
+        g_blend_prof[BLEND_PROF_WORDS * bin + 4 + wave] = walked;
     }
     __syncthreads();
-    if (bin < 8192u && tid == 0u) g_blend_prof[8 * bin + 1] = wall_clock64();
+    if (bin < BLEND_PROF_BINS && tid == 0u) {
+        g_blend_prof[BLEND_PROF_WORDS * bin + 1] = wall_clock64();
+        g_blend_prof[BLEND_PROF_WORDS * bin + 8] = 128ull * s_prof[2];
+        g_blend_prof[BLEND_PROF_WORDS * bin + 9] = s_prof[0];
+        g_blend_prof[BLEND_PROF_WORDS * bin + 10] = s_prof[1];
+        g_blend_prof[BLEND_PROF_WORDS * bin + 11] = s_prof[2];
+    }
 #endif
     // statistics: one plain 8-byte store per workgroup, summed by the host when somebody asks (8160 same-address atomics
     // at the end of the kernel cost 60 us: a device-scope counter retires ~88 atomics per microsecond)
-    if (lane == 0u) s_walked[wave] = walked;
+    // {entries staged, half quadrants evaluated} per bin (the blend's cost: what orders the next draw's workgroups and balances
+    // multi-GPU strips), and the (splat, quadrant) pairs in a plane of their own behind them
+    if (lane == 0u) { s_walked[wave] = walked; s_halves[wave] = halves; }
     __syncthreads();
-    if (tid == 0u) bin_stats[bin] = make_uint2(scanned, s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3]);
+    if (tid == 0u) {
+        bin_stats[bin] = make_uint2(scanned, s_halves[0] + s_halves[1] + s_halves[2] + s_halves[3]);
+        bin_pairs[bin] = s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3];
+    }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
@@ -302,12 +362,13 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
     if (bins == 0) return GS_OK;
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
-    GS_TRY(m->blend_stats.ensure((size_t)bins * 8));
+    GS_TRY(m->blend_stats.ensure((size_t)bins * 12));     // uint2 [bins] {staged, halves} | uint32 [bins] pairs
     m->blend_bins = bins;
     hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                        m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
                        pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                       m->blend_stats.as<uint2>(), m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr);
+                       m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins,
+                       m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr);
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;
     GS_HIP(hipGetLastError());

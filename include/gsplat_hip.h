@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 2
+#define GS_ABI_VERSION 3
 
 /* status codes (negative = error, positive = warning, result still defined) */
 #define GS_OK 0
@@ -319,6 +319,8 @@ typedef struct gs_render_stats {
     uint64_t entries_scanned; /* list entries the blend read before its pixels saturated (<= tile_entries per 32-px
                                  bin of a list)                                                                  */
     uint64_t splats_walked;   /* (splat, 16x16-px tile) pairs the blend evaluated                                */
+    uint64_t halves_evaluated; /* (splat, 16x8-px half tile) pairs among them whose 128 pixels were really evaluated: a
+                                 half the splat's ellipse cannot reach is skipped (ABI 3)                          */
 } gs_render_stats;
 
 /* Entry-buffer overflow: a draw that returns statistics or pixels to the host checks and re-runs itself after growing the
@@ -346,8 +348,8 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
  * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per list bin (gs_render_stats.list_bin_px) of the
  * drawn strip the [begin,end) range of its entry list ((~0,0) = untouched); 3 = the visibility mask, 1 bit per
  * splat packed in uint64 words (count = number of words); 4 = per 32x32-px blend bin of the drawn strip (row-major,
- * bins_x = ceil(width / 32)) the pair {list entries staged, (splat, 16-px tile) pairs evaluated}: the blend's real cost,
- * used to balance multi-GPU strips. */
+ * bins_x = ceil(width / 32)) the pair {list entries staged, (splat, 16x8-px half tile) pairs evaluated}: the blend's real
+ * cost, used to balance multi-GPU strips. */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of

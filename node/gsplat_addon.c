@@ -4,6 +4,9 @@
  * SplatMesh render seam); this file only marshals typed arrays into plain pointers.  No compute lives here.
  * Build: make -C node   (gcc, /usr/include/node/node_api.h; links ../gaussiansplats3d_amd/csrc/libgsplat_hip.so)
  */
+#ifndef NAPI_VERSION
+#define NAPI_VERSION 6            /* napi_set_instance_data */
+#endif
 #include <node_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -16,9 +19,24 @@
 
 /* The C ABI wants calls on one context serialised by the caller.  JavaScript is single-threaded, but sorterSortAsync runs
  * gs_sorter_sort on a libuv pool thread (the reference's sort runs in a Web Worker, src/worker/SortWorker.js), so every
- * library call of this addon takes one lock: a draw issued while a sort is in flight waits for it (~1 ms), never races it. */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-#define LOCKED(stmt) do { pthread_mutex_lock(&g_lock); stmt; pthread_mutex_unlock(&g_lock); } while (0)
+ * library call of this addon takes a lock: a draw issued while a sort is in flight waits for it (~1 ms), never races it.
+ * The lock belongs to the addon INSTANCE (one per JavaScript thread: the main thread and every worker_threads Worker get
+ * their own), not to the process: ranks of a multi-GPU group that live in one process as Workers, each with its own
+ * context, must not serialise on each other - ncclCommInitRank and the root's gather block until every rank has called,
+ * and a process-wide lock held across them would deadlock two ranks of one process.  Objects (contexts, sorters, meshes)
+ * cannot cross JavaScript threads (napi externals are not transferable), so per-instance is per-context. */
+typedef struct { pthread_mutex_t lock; } addon_state;
+static addon_state* state_of(napi_env env) {
+    void* d = NULL;
+    napi_get_instance_data(env, &d);
+    return (addon_state*)d;
+}
+static void state_free(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    pthread_mutex_destroy(&((addon_state*)data)->lock);
+    free(data);
+}
+#define LOCKED(stmt) do { pthread_mutex_t* l_ = &state_of(env)->lock; pthread_mutex_lock(l_); stmt; pthread_mutex_unlock(l_); } while (0)
 
 #define NAPI_OK(call)                                                        \
     do {                                                                     \
@@ -186,6 +204,7 @@ typedef struct {
     napi_async_work work;
     napi_ref cb, keep[3];
     gs_sorter* sorter;
+    pthread_mutex_t* lock;          /* the addon instance's lock (sort_execute has no usable env) */
     float mvp[16];
     float transforms[16 * GS_MAX_SCENES];
     int has_tr;
@@ -201,11 +220,11 @@ typedef struct {
 static void sort_execute(napi_env env, void* data) {
     (void)env;
     sort_job* j = (sort_job*)data;
-    pthread_mutex_lock(&g_lock);
+    pthread_mutex_lock(j->lock);
     j->status = gs_sorter_sort(j->sorter, j->mvp, j->idx, j->sortc, j->renderc, j->pre, j->has_tr ? j->transforms : NULL, j->out,
                                j->out ? &j->stats : NULL);
     if (j->status < 0) snprintf(j->err, sizeof j->err, "libgsplat_hip status %d: %s", j->status, gs_last_error());   /* thread-local */
-    pthread_mutex_unlock(&g_lock);
+    pthread_mutex_unlock(j->lock);
 }
 
 static void sort_complete(napi_env env, napi_status status, void* data) {
@@ -261,6 +280,7 @@ static napi_value SorterSortAsync(napi_env env, napi_callback_info info) {
     sort_job* j = (sort_job*)calloc(1, sizeof *j);
     if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
     j->sorter = (gs_sorter*)get_external(env, argv[0]);
+    j->lock = &state_of(env)->lock;
     memcpy(j->mvp, mvp, 64);
     if (tr) { memcpy(j->transforms, tr, sizeof j->transforms); j->has_tr = 1; }
     j->idx = (const uint32_t*)idx; j->pre = pre; j->out = (uint32_t*)out;
@@ -390,6 +410,7 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     set(env, r, "overflowed", stats.overflowed);
     set(env, r, "entriesScanned", (double)stats.entries_scanned);
     set(env, r, "splatsWalked", (double)stats.splats_walked);
+    set(env, r, "halvesEvaluated", (double)stats.halves_evaluated);
     return r;
 }
 
@@ -676,6 +697,12 @@ static napi_value AssetLoad(napi_env env, napi_callback_info info) {
 }
 
 static napi_value Init(napi_env env, napi_value exports) {
+    addon_state* state = (addon_state*)calloc(1, sizeof *state);
+    if (!state || pthread_mutex_init(&state->lock, NULL) != 0 || napi_set_instance_data(env, state, state_free, NULL) != napi_ok) {
+        free(state);
+        napi_throw_error(env, NULL, "gsplat addon: could not create the instance state");
+        return NULL;
+    }
     static const struct { const char* name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount},       {"contextCreate", ContextCreate}, {"contextDestroy", ContextDestroy},
         {"sorterCreate", SorterCreate},     {"sorterDestroy", SorterDestroy}, {"sorterUploadCenters", SorterUploadCenters},

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsplat_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes table and header disagree"
-    assert lib.gs_abi_version() == 2
+    assert lib.gs_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.Camera) == 272
     assert C.sizeof(_lib.SceneParams) == 8 + 32 * (64 + 16 + 4 + 4 + 4 + 4)
     assert C.sizeof(_lib.GatherParams) == 160 and C.sizeof(_lib.TreeInfo) == 64
-    assert C.sizeof(_lib.RenderStats) == 72
+    assert C.sizeof(_lib.RenderStats) == 80
     assert _lib.RenderStats.tile_entries.offset == 24
 
 

@@ -431,6 +431,41 @@ def test_range_uploads_like_update_data_textures_from_base_data(ctx):
     once.dispose()
 
 
+def test_a_range_upload_that_leaves_a_hole_draws_like_zero_filled_textures(ctx):
+    """gs_mesh_upload accepts any range, so the FIRST upload may be [a, b) with a > 0: splats [0, a) then are what the
+    reference's zero-filled data textures hold (centre 0, covariance 0, alpha 0: SplatMesh.js:686-697) - defined planes, a
+    bijective storage permutation, nothing drawn.  The frame must equal the one of a mesh whose hole was uploaded as
+    zeros, with the full index list naming the never-uploaded splats as well."""
+    n, a = 5000, 1800
+    scene = helpers.small_scene(n, 2, seed=93)
+    cam = camera.demo_camera("garden", 320, 200)
+    zeroed = helpers.small_scene(n, 2, seed=93)
+    for name in ("centers", "cov", "rgba", "sh"):
+        getattr(zeroed, name)[:a] = 0
+    order = sorted_order(zeroed, cam)
+    want_mesh = build_mesh(ctx, zeroed)
+    want_mesh.set_camera(cam)
+    want_mesh.update_render_indexes(order, n)
+    want = want_mesh.render()[0]
+    holed = SplatMesh(ctx, n, 2)
+    holed.build(scene.centers[a:], scene.cov[a:], scene.rgba[a:], scene.sh[a:], start=a)     # [0, a) never uploaded
+    holed.set_camera(cam)
+    holed.update_render_indexes(order, n)
+    got, st = holed.render()
+    np.testing.assert_array_equal(got, want)
+    assert got[..., 3].any()
+    # the hole filled later: the ordinary frame
+    holed.build(scene.centers[:a], scene.cov[:a], scene.rgba[:a], scene.sh[:a], start=0)
+    full_order = sorted_order(scene, cam)
+    holed.update_render_indexes(full_order, n)
+    once = build_mesh(ctx, scene)
+    once.set_camera(cam)
+    once.update_render_indexes(full_order, n)
+    np.testing.assert_array_equal(holed.render()[0], once.render()[0])
+    for m in (want_mesh, holed, once):
+        m.dispose()
+
+
 def test_out_of_range_indexes_are_harmless(ctx):
     """A stale or wrong index list must neither fault the GPU nor read foreign memory (WebGL's out-of-range texelFetch is
     harmless too): the mesh draws nothing for entries >= the uploaded splat count, the sorter clamps them."""

@@ -149,18 +149,83 @@ def _free_port():
     return port
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and wait for them."""
+def spawn_ranks(n, timeout_s=None, poll_s=0.2):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, each the leader of a process
+    group of its own) and wait for ALL of them.  The first rank that fails - or the deadline ($GS_BENCH_RANK_TIMEOUT, default
+    1500 s: a rank that died inside ncclCommInitRank leaves the others waiting for ever) - takes the others down with it, so no
+    orphan keeps a GPU; returns the first non-zero exit code (124 on a timeout)."""
     port = os.environ.get("MASTER_PORT") or str(_free_port())
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("GS_BENCH_RANK_TIMEOUT", "1500"))
     procs = []
     for r in range(n):
         env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = rc or p.wait()
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      start_new_session=True))
+
+    def stop(p, sig):
+        try:
+            os.killpg(p.pid, sig)                         # the rank and anything it started
+        except (ProcessLookupError, PermissionError, AttributeError):
+            try:
+                p.send_signal(sig)
+            except Exception:
+                pass
+
+    import signal
+    deadline = time.monotonic() + timeout_s
+    rc, codes = 0, [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        timed_out = time.monotonic() > deadline
+        if failed or timed_out:
+            rc = failed[0] if failed else 124
+            live = [p for i, p in enumerate(procs) if codes[i] is None]
+            for p in live:
+                stop(p, signal.SIGTERM)
+            t_kill = time.monotonic() + 5.0
+            while live and time.monotonic() < t_kill:
+                live = [p for p in live if p.poll() is None]
+                time.sleep(poll_s)
+            for p in live:
+                stop(p, signal.SIGKILL)
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except Exception:
+                    pass
+            print(f"bench.py: {'a rank failed' if failed else 'timeout'} (exit codes {codes}); the other ranks were stopped",
+                  file=sys.stderr)
+            return rc
+        time.sleep(poll_s)
     return rc
+
+
+class Watchdog:
+    """Ends THIS rank if a collective set-up does not return (ncclCommInitRank blocks until every rank has called it: a peer
+    that died before it would hang the rest until the driver's own limit)."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.what, self.seconds = what, seconds
+
+    def _fire(self):
+        print(f"bench.py: {self.what} did not finish within {self.seconds:.0f} s - giving up", file=sys.stderr, flush=True)
+        os._exit(86)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 
 
 def parse_args():
@@ -168,14 +233,18 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C3T"])
+    ap.add_argument("--config", default=None, choices=["C1", "C2", "C3", "C4", "C5", "C3T", "C3S"],
+                    help="default: C3 (BASELINE.json's metric configuration) on one GPU; C5 with a second C3 object when "
+                         "--gpus N > 1 (BASELINE.json configs[4]: the 8-GPU configuration is garden at 7680x4320)")
     ap.add_argument("--splats", type=int, default=0, help="override the splat count (debug only; invalid as a result)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cull", action="store_true",
-                    help="skip the secondary columns (orbit, octree cull, fused frustum cull, translucent scene)")
+                    help="skip the secondary columns (orbit, octree cull, fused frustum cull, translucent / capture-like scenes)")
     ap.add_argument("--only-headline", action="store_true",
                     help="probe + warm-up + the timed frames and nothing else (profiler runs: every frame is a headline frame)")
+    ap.add_argument("--median-frames", type=int, default=50,
+                    help="frames of the hipEvent-bracketed median (SURVEY.md 8d: >= 50); 0 = skip")
     return ap.parse_args()
 
 
@@ -194,6 +263,10 @@ class Rig:
         self.mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
         self.mesh.set_camera(cam)
         self.frames = 0
+
+    def set_view(self, cam):
+        self.cam, self.mvp = cam, cam.sort_mvp()
+        self.mesh.set_camera(cam)
 
     def probe(self, out_ptr):
         """Untimed full-frame draws: grow the entry buffer if needed, settle the list-bin size, return the statistics."""
@@ -232,6 +305,23 @@ class Rig:
         enq = time.perf_counter() - t0
         torch.cuda.synchronize()
         return time.perf_counter() - t0, enq
+
+    def event_frames(self, frames, stream, out_ptr, tile_rows=None, after=None):
+        """SURVEY.md 8d's form of the metric: every frame bracketed by a pair of HIP events on the frame's own stream (the
+        context was created on `stream`, so torch's events see its kernels); returns the per-frame device milliseconds.
+        The two event records per frame are barrier packets (~3 us each), which is why `value` is taken from the
+        unbracketed region and this median is reported beside it."""
+        torch = self.torch
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(frames)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record(stream)
+            self.frame(out_ptr, tile_rows)
+            if after:
+                after()
+            b.record(stream)
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in evs]
 
     def close(self):
         self.worker.terminate()
@@ -274,12 +364,145 @@ def bench_c1(args):
     return 0 if r.get("identical") in (True, None) else 1
 
 
+class Env:
+    """What every measurement of this process shares: torch, the process group, one context on one stream, one rig."""
+    pass
+
+
+def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frames=50, dump=None):
+    """One workload (a BASELINE.json configuration = viewport + pose of the scene the rig holds) on `world` ranks: probe,
+    strips, warm-up, the timed region (barrier + synchronize on both sides, MAX over ranks), the hipEvent-bracketed median,
+    the k_project clock and (stages) the per-stage times.  world = 1 on a multi-rank job = rank 0 alone, the others wait."""
+    torch, dist, rig, stream, device = env.torch, env.dist, env.rig, env.stream, env.device
+    from gaussiansplats3d_amd import camera, scenes
+    from gaussiansplats3d_amd import dist as gdist
+    cfg = scenes.CONFIGS[cfg_name]
+    W, H = cfg["width"], cfg["height"]
+    cam = camera.demo_camera(cfg["pose"], W, H)
+    rig.set_view(cam)
+    worker, mesh = rig.worker, rig.mesh
+    rows_total = (H + 15) // 16
+    m = {"cfg": cfg_name, "W": W, "H": H, "cam": cam, "world": world}
+    with torch.cuda.stream(stream):
+        worker.set_visibility_cull(False)
+        full = torch.zeros((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+        probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
+        m["st_probe"] = rig.probe(probe.data_ptr())
+        row_cost = mesh.tile_row_costs()
+        strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
+        my = strips[rank]
+        y0, y1 = gdist.strip_pixel_rows(my, H)
+        strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
+        del probe
+        tile_rows = my if world > 1 else None
+        gather, gather_kind = None, None
+        if world > 1:
+            # every rank keys all splats but sorts / bins / blends only what reaches its strip
+            worker.set_visibility_cull(True)
+            if env.group is not None:
+                gather_kind = "gs_group_gather_strips (RCCL grouped send/recv behind the C ABI)"
+                full_ptr = full.data_ptr() if rank == 0 else 0
+                gather = lambda: env.group.gather_strips(strip.data_ptr(), full_ptr, W, strips, H)      # noqa: E731
+            else:
+                gather_kind = f"torch.distributed batch_isend_irecv ({env.backend})"
+                gather = lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)            # noqa: E731
+        for _ in range(warmup):
+            rig.frame(strip.data_ptr(), tile_rows)
+            if gather:
+                gather()
+        stream.synchronize()
+        torch.cuda.synchronize()
+        mesh.kernel_time(0, reset=True)                       # start the per-launch k_project clock
+        if world > 1:
+            dist.barrier()
+        elapsed, t_enqueued = rig.timed(steps, strip.data_ptr(), tile_rows, gather)
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if env.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if dump and rank == 0:                                # tests: the frame the timed steps left on rank 0
+            np.save(dump, full.cpu().numpy())
+        m["proj_ms_sum"], m["proj_launches"] = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
+        st_timed = mesh.last_stats()                          # the list-bin size the timed frames used, and their entries
+        m["list_px"], m["D32"] = int(st_timed.list_bin_px), int(st_timed.tile_entries)
+        m["ms_per_step"] = elapsed / steps * 1e3
+        m["enqueue_ms"] = t_enqueued / steps * 1e3
+        m["strips"], m["gather_kind"] = strips, gather_kind
+
+        # SURVEY.md 8d: median of >= 50 frames, hipEvents around the whole frame on its one stream (MAX over ranks of
+        # the ranks' medians; each frame includes the gather)
+        m["median_ms"], m["median_frames"], m["frame_ms_min"], m["frame_ms_p90"] = None, 0, None, None
+        if median_frames > 0:
+            if world > 1:
+                dist.barrier()
+            ev_ms = rig.event_frames(median_frames, stream, strip.data_ptr(), tile_rows, gather)
+            med = float(np.median(ev_ms))
+            if world > 1:
+                t = torch.tensor([med], dtype=torch.float64, device=device if env.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                med = float(t.item())
+            m["median_ms"], m["median_frames"] = med, median_frames
+            m["frame_ms_min"], m["frame_ms_p90"] = float(np.min(ev_ms)), float(np.percentile(ev_ms, 90))
+
+        m["stage_ms"], m["latency"] = {}, []
+        if stages:
+            # per-stage device times (HIP events recorded by the library), one synchronised frame at a time
+            stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
+            env.ctx.set_stage_timing(True)    # off in the timed region: an event record per stage costs ~10% of the frame
+            for _ in range(min(steps, 10)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rig.frame(strip.data_ptr(), tile_rows)
+                torch.cuda.synchronize()
+                m["latency"].append((time.perf_counter() - t1) * 1e3)
+                rs = mesh.last_stats()
+                ss, _ = worker.last_stats()
+                stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
+                stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
+            m["stage_ms"] = {k: float(np.median(v)) for k, v in stage.items()}
+            env.ctx.set_stage_timing(False)
+        m["strip_tensor"], m["full"] = strip, full
+    return m
+
+
+def brief(m, N):
+    """The short form of one measurement (secondary objects of the line)."""
+    return {"workload": m["cfg"], "width": m["W"], "height": m["H"], "n_gpus": m["world"],
+            "ms_per_step": round(m["ms_per_step"], 4), "value": round(N / (m["ms_per_step"] * 1e-3) / 1e6, 2), "unit": "Msplats/s",
+            "median_ms_per_step": round(m["median_ms"], 4) if m["median_ms"] else None, "median_frames": m["median_frames"],
+            "strips": m["strips"] if m["world"] > 1 else None,
+            "visible_splats": int(m["st_probe"].visible_splats), "tiles16_D": int(m["st_probe"].tiles16),
+            "list_entries": m["D32"], "list_bin_px": m["list_px"],
+            "stage_ms_isolated_frame": {k: round(v, 4) for k, v in m["stage_ms"].items()} or None}
+
+
+def blend_lane_fractions(cfg_name, timeout_s=240):
+    """What fraction of the blend's evaluated pixel lanes pass the fragment shader's A <= 8 test: measured in this run by
+    tools/blend_lanes.py on the lane-counting build of the same kernel (csrc/libgsplat_hip_blendprof.so, built by
+    __graft_entry__.build()), in a process of its own.  None if that build is not there."""
+    from gaussiansplats3d_amd import _lib
+    if not os.path.exists(_lib.BLENDPROF_LIB_PATH):
+        return None
+    try:
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "blend_lanes.py"), cfg_name],
+                                      env=dict(os.environ, GSPLAT_HIP_LIB=_lib.BLENDPROF_LIB_PATH), text=True,
+                                      stderr=subprocess.DEVNULL, timeout=timeout_s)
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception as e:                                   # a measurement aid must not take the bench line down
+        print(f"bench.py: blend_lanes.py failed: {e}", file=sys.stderr)
+        return None
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     if args.config == "C1":
         sys.exit(bench_c1(args))
+
+    # the live k_project clock (gs_mesh_kernel_time) samples every n-th launch: at least 8 samples in the timed region
+    os.environ.setdefault("GSPLAT_KERNEL_SAMPLE", str(max(1, min(8, args.steps // 8))))
 
     import torch
     import torch.distributed as dist
@@ -301,225 +524,217 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with Watchdog(float(os.environ.get("GS_BENCH_INIT_TIMEOUT", "600")), "init_process_group"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = scenes.CONFIGS[args.config]
+    # N = 1: BASELINE.json's metric configuration (C3).  N > 1: its 8-GPU configuration (configs[4] = C5, the same scene at
+    # 7680x4320) is the headline and C3 rides along as a second object - strips of a 0.29 ms 1080p frame cannot scale
+    # (DESIGN.md 7), so a scaling run on C3 alone would measure the configuration that was never meant to be sharded.
+    headline = args.config or ("C5" if world > 1 else "C3")
+    second_cfg = "C3" if (world > 1 and args.config is None) else None
+    cfg = scenes.CONFIGS[headline]
     W, H = cfg["width"], cfg["height"]
     t_gen = time.perf_counter()
-    scene = scenes.make_config_scene(args.config, args.splats or None)
+    scene = scenes.make_config_scene(headline, args.splats or None)
     cam = camera.demo_camera(cfg["pose"], W, H)
     N = scene.count
     t_gen = time.perf_counter() - t_gen
     extras = world == 1 and not args.no_cull and not args.only_headline
 
-    stream = torch.cuda.Stream(device=device)
-    ctx = Context(local_rank, stream.cuda_stream, single_stream=True)     # §8d: the whole frame on one stream
-    rig = Rig(ctx, scene, cam, device, torch)
+    env = Env()
+    env.torch, env.dist, env.device, env.backend, env.group = torch, dist, device, backend, None
+    env.stream = stream = torch.cuda.Stream(device=device)
+    env.ctx = ctx = Context(local_rank, stream.cuda_stream, single_stream=True)     # §8d: the whole frame on one stream
+    env.rig = rig = Rig(ctx, scene, cam, device, torch)
     worker, mesh, mvp = rig.worker, rig.mesh, rig.mvp
-    rows_total = (H + 15) // 16
-    with torch.cuda.stream(stream):
-        full = torch.zeros((H, W, 4), dtype=torch.uint8, device=device) if rank == 0 else None
-        probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
-        st_probe = rig.probe(probe.data_ptr())
-        row_cost = mesh.tile_row_costs()
-        strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
-        my = strips[rank]
-        y0, y1 = gdist.strip_pixel_rows(my, H)
-        strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
-        del probe
-        tile_rows = my if world > 1 else None
-        gather, gather_kind, group = None, None, None
-        if world > 1:
-            # every rank keys all splats but sorts / bins / blends only what reaches its strip
-            worker.set_visibility_cull(True)
-            if backend == "nccl" and os.environ.get("GS_BENCH_GATHER", "capi") == "capi":
-                try:
-                    group = gdist.StripGroup(ctx, rank, world, dist)          # RCCL behind the C ABI (gs_group_*)
-                    gather_kind = "gs_group_gather_strips (RCCL grouped send/recv behind the C ABI)"
-                    full_ptr = full.data_ptr() if rank == 0 else 0
-                    gather = lambda: group.gather_strips(strip.data_ptr(), full_ptr, W, strips, H)      # noqa: E731
-                except Exception as e:                                       # fall back to torch.distributed P2P
-                    print(f"bench.py rank {rank}: gs_group unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
-                # every rank must take the same path: one rank without its communicator sends all of them to the fallback
-                ok = torch.tensor([1 if gather is not None else 0], dtype=torch.int32, device=device)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0:
-                    if group is not None:
-                        group.close()
-                    group, gather = None, None
-            if gather is None:
-                gather_kind = f"torch.distributed batch_isend_irecv ({backend})"
-                gather = lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)            # noqa: E731
+    if world > 1 and backend == "nccl" and os.environ.get("GS_BENCH_GATHER", "capi") == "capi":
+        try:
+            with Watchdog(float(os.environ.get("GS_BENCH_INIT_TIMEOUT", "600")), "gs_group_create (ncclCommInitRank)"):
+                env.group = gdist.StripGroup(ctx, rank, world, dist)          # RCCL behind the C ABI (gs_group_*)
+        except Exception as e:                                       # fall back to torch.distributed P2P
+            print(f"bench.py rank {rank}: gs_group unavailable ({e}); gathering through torch.distributed", file=sys.stderr)
+        # every rank must take the same path: one rank without its communicator sends all of them to the fallback
+        ok = torch.tensor([1 if env.group is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and env.group is not None:
+            env.group.close()
+            env.group = None
 
-        for _ in range(args.warmup):
-            rig.frame(strip.data_ptr(), tile_rows)
-            if gather:
-                gather()
-        stream.synchronize()
-        torch.cuda.synchronize()
-        mesh.kernel_time(0, reset=True)                       # start the per-launch k_project clock
-        if world > 1:
-            dist.barrier()
-        elapsed, t_enqueued = rig.timed(args.steps, strip.data_ptr(), tile_rows, gather)
-        if world > 1:
-            dist.barrier()
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        if os.environ.get("GS_BENCH_DUMP") and rank == 0:      # tests: the frame the timed steps left on rank 0
-            np.save(os.environ["GS_BENCH_DUMP"], full.cpu().numpy())
-        proj_ms_sum, proj_launches = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
-        st_timed = mesh.last_stats()                          # the list-bin size the timed frames used, and their entries
-        list_px_timed, D32 = int(st_timed.list_bin_px), int(st_timed.tile_entries)
-        frames_headline = rig.frames
-
-        stage_ms, latency, orbit, cull, fused, translucent, pipelined, vis_fused = {}, [], None, None, None, None, None, None
-        if not args.only_headline:
-            # per-stage device times (HIP events recorded by the library), one synchronised frame at a time
-            stage = {"sort": [], "project": [], "bin": [], "entry_sort": [], "blend": []}
-            ctx.set_stage_timing(True)        # off in the timed region: an event record per stage costs ~10% of the frame
-            for _ in range(min(args.steps, 10)):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                rig.frame(strip.data_ptr(), tile_rows)
-                torch.cuda.synchronize()
-                latency.append((time.perf_counter() - t1) * 1e3)
-                rs = mesh.last_stats()
-                ss, _ = worker.last_stats()
-                stage["sort"].append(ss.device_ms); stage["project"].append(rs.project_ms); stage["bin"].append(rs.bin_ms)
-                stage["entry_sort"].append(rs.tile_sort_ms); stage["blend"].append(rs.blend_ms)
-            stage_ms = {k: float(np.median(v)) for k, v in stage.items()}
-            ctx.set_stage_timing(False)
-
-        if world == 1 and not args.only_headline:
-            # the engine's default shape: sorter and vertex stage on streams of their own (the reference sorts in a Web
-            # Worker concurrently with drawing); every frame still waits for ITS OWN sort before it bins
-            ctx2 = Context(local_rank, stream.cuda_stream, single_stream=False)
-            rig2 = Rig(ctx2, scene, cam, device, torch)
-            rig2.probe(strip.data_ptr())
-            for _ in range(args.warmup):
-                rig2.frame(strip.data_ptr())
-            p_el, p_enq = rig2.timed(args.steps, strip.data_ptr())
-            pipelined = {"ms_per_step": round(p_el / args.steps * 1e3, 4),
-                         "Msplats_per_s": round(N / (p_el / args.steps) / 1e6, 1),
-                         "host_enqueue_ms_per_frame": round(p_enq / args.steps * 1e3, 4),
-                         "note": "sorter + vertex stage on their own HIP streams: the sort of frame k+1 overlaps the tail "
-                                 "of frame k's draw (same camera); throughput of whole frames, not the §8d metric"}
-            rig2.close()
-            ctx2.close()
-
-        if extras:
-            # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the
-            # headline stays the fixed demo pose so rounds remain comparable)
-            ms, vis = [], []
-            for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
-                mesh.set_camera(oc)
-                o_mvp = oc.sort_mvp()
-                worker.sort_on_device(o_mvp, N)                # untimed: this draw may grow the entry buffer
-                _, o_st = mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                worker.sort_on_device(o_mvp, N)
-                mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
-                torch.cuda.synchronize()
-                ms.append((time.perf_counter() - t1) * 1e3)
-                vis.append(int(o_st.visible_splats))
-            mesh.set_camera(cam)
-            orbit = {"poses": 60, "frame_latency_ms_median": round(float(np.median(ms)), 4),
-                     "frame_latency_ms_min": round(float(np.min(ms)), 4), "frame_latency_ms_max": round(float(np.max(ms)), 4),
-                     "visible_splats_median": int(np.median(vis)), "visible_splats_max": int(np.max(vis)),
-                     "note": "isolated (synchronised) frames, so compare with frame_latency_ms, not ms_per_step"}
-
-            # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
-            from gaussiansplats3d_amd import SplatTree
-            t_tree = time.perf_counter()
-            tree = SplatTree(ctx, 8, 1000).process_splat_mesh(scene.centers, alphas=scene.rgba[:, 3])
-            t_tree = time.perf_counter() - t_tree
-
-            def cull_frame():
-                r = tree.gather_scene_nodes_for_sort(cam, sort_worker=worker, to_host=False)   # 4-byte read-back inside
-                worker.sort_gathered(mvp, keep_on_device=True)
-                mesh.use_sorter_result(worker, r["splatRenderCount"])
-                mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
-                return r["splatRenderCount"]
-
-            for _ in range(3):
-                Rc = cull_frame()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                cull_frame()
-            torch.cuda.synchronize()
-            cull_ms = (time.perf_counter() - t1) / 20 * 1e3
-            cull = {"render_count": int(Rc), "leaves": int(tree.info().leaves), "ms_per_frame": round(cull_ms, 4),
-                    "Msplats_per_s_scene": round(N / (cull_ms * 1e-3) / 1e6, 1),
-                    "Msplats_per_s_rendered": round(Rc / (cull_ms * 1e-3) / 1e6, 1), "tree_build_s": round(t_tree, 2),
-                    "note": "gather + sort + draw of the frustum-culled list; scene = all N splats per frame, "
-                            "rendered = R kept by the cull"}
-            tree.dispose()
-            mesh.use_sorter_result(worker, N)
-
-            # third column: the per-splat frustum cull fused into pass 0 of the sort (gs_sorter_set_frustum_cull).  Keys,
-            # range and buckets still span all N splats, so the frame must be bit-identical to the headline path's
-            rig.frame(strip.data_ptr())
-            torch.cuda.synchronize()
-            ref_img = strip.clone()
-            worker.set_frustum_cull(True)
-            for _ in range(3):
-                rig.frame(strip.data_ptr())
-            f_el, f_enq = rig.timed(args.steps, strip.data_ptr())
-            f_ms = f_el / args.steps * 1e3
-            fs = rig.timed_sort_stats(strip.data_ptr())
-            fused = {"kept": int(fs.result_count), "ms_per_frame": round(f_ms, 4),
-                     "Msplats_per_s_scene": round(N / (f_ms * 1e-3) / 1e6, 1),
-                     "host_enqueue_ms_per_frame": round(f_enq / args.steps * 1e3, 4), "sort_ms_last": round(float(fs.device_ms), 4),
-                     "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
-                     "note": "keys + min/max over all N, then pass 0 of the radix sort drops the splats whose centre is "
-                             "outside 1.25x the clip volume; the list is the full sort's list minus those splats"}
-            worker.set_frustum_cull(False)
-
-            # the exact version, and what every rank of a multi-GPU run does with its strip: vertex stage first, then the
-            # sort keeps only the splats that survived it (gs_sorter_set_visibility_cull)
-            worker.set_visibility_cull(True)
-            for _ in range(3):
-                rig.frame(strip.data_ptr())
-            v_el, v_enq = rig.timed(args.steps, strip.data_ptr())
-            v_ms = v_el / args.steps * 1e3
-            vs = rig.timed_sort_stats(strip.data_ptr())
-            vis_fused = {"kept": int(vs.result_count), "ms_per_frame": round(v_ms, 4),
-                         "Msplats_per_s_scene": round(N / (v_ms * 1e-3) / 1e6, 1), "sort_ms_last": round(float(vs.device_ms), 4),
-                         "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
-                         "note": "project -> sort (keys + min/max over all N, radix passes over the visible splats only) -> "
-                                 "bin -> blend: the per-rank frame of a multi-GPU run, here with the whole screen as the strip"}
+    detailed = not args.only_headline
+    M = measure(env, headline, args.steps, args.warmup, world, rank, stages=detailed, median_frames=args.median_frames,
+                dump=os.environ.get("GS_BENCH_DUMP"))
+    st_probe, strips, strip = M["st_probe"], M["strips"], M["strip_tensor"]
+    frames_headline = rig.frames
+    second, solo, c5_one = None, None, None
+    if world > 1 and detailed:
+        if second_cfg:
+            second = measure(env, second_cfg, args.steps, args.warmup, world, rank, stages=True, median_frames=args.median_frames)
+        # the same configuration on ONE GPU of this node, in this run: rank 0 draws the whole frame alone while the others
+        # wait, so the line carries its own N = 1 reference for the strong-scaling ratio
+        dist.barrier()
+        if rank == 0:
+            solo = measure(env, headline, min(args.steps, 20), 3, 1, 0, stages=True, median_frames=min(args.median_frames, 50))
+        dist.barrier()
+    pipelined, orbit, cull, fused, vis_fused, translucent, capture, lanes = None, None, None, None, None, None, None, None
+    if world == 1:
+        with torch.cuda.stream(stream):
             worker.set_visibility_cull(False)
-            del ref_img
+            if detailed:
+                # the engine's default shape: sorter and vertex stage on streams of their own (the reference sorts in a Web
+                # Worker concurrently with drawing); every frame still waits for ITS OWN sort before it bins
+                ctx2 = Context(local_rank, stream.cuda_stream, single_stream=False)
+                rig2 = Rig(ctx2, scene, cam, device, torch)
+                rig2.probe(strip.data_ptr())
+                for _ in range(args.warmup):
+                    rig2.frame(strip.data_ptr())
+                p_el, p_enq = rig2.timed(args.steps, strip.data_ptr())
+                pipelined = {"ms_per_step": round(p_el / args.steps * 1e3, 4),
+                             "Msplats_per_s": round(N / (p_el / args.steps) / 1e6, 1),
+                             "host_enqueue_ms_per_frame": round(p_enq / args.steps * 1e3, 4),
+                             "note": "sorter + vertex stage on their own HIP streams: the sort of frame k+1 overlaps the tail "
+                                     "of frame k's draw (same camera); throughput of whole frames, not the §8d metric"}
+                rig2.close()
+                ctx2.close()
 
-        if extras and args.config == "C3":
-            # fourth column: the same geometry with translucent splats.  The stand-in's pixels saturate after ~90 splats
-            # (the blend reads ~2 % of its lists); here they do not, so the blend walks its lists
-            rig.close()
-            t_scene = scenes.make_config_scene("C3T")
-            rig_t = Rig(ctx, t_scene, cam, device, torch)
-            st_t = rig_t.probe(strip.data_ptr())
-            for _ in range(3):
-                rig_t.frame(strip.data_ptr())
-            t_el, _ = rig_t.timed(min(args.steps, 20), strip.data_ptr())
-            t_ms = t_el / min(args.steps, 20) * 1e3
-            _, st_t = rig_t.mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
-            translucent = {"workload": scenes.CONFIGS["C3T"]["label"], "ms_per_frame": round(t_ms, 4),
-                           "Msplats_per_s": round(N / (t_ms * 1e-3) / 1e6, 1), "blend_ms": round(float(st_t.blend_ms), 4),
+            if extras:
+                # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the
+                # headline stays the fixed demo pose so rounds remain comparable)
+                ms, vis = [], []
+                for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
+                    mesh.set_camera(oc)
+                    o_mvp = oc.sort_mvp()
+                    worker.sort_on_device(o_mvp, N)                # untimed: this draw may grow the entry buffer
+                    _, o_st = mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    worker.sort_on_device(o_mvp, N)
+                    mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                    torch.cuda.synchronize()
+                    ms.append((time.perf_counter() - t1) * 1e3)
+                    vis.append(int(o_st.visible_splats))
+                mesh.set_camera(cam)
+                orbit = {"poses": 60, "frame_latency_ms_median": round(float(np.median(ms)), 4),
+                         "frame_latency_ms_min": round(float(np.min(ms)), 4), "frame_latency_ms_max": round(float(np.max(ms)), 4),
+                         "visible_splats_median": int(np.median(vis)), "visible_splats_max": int(np.max(vis)),
+                         "note": "isolated (synchronised) frames, so compare with frame_latency_ms, not ms_per_step"}
+
+                # second column: cull ON = the reference's octree + gatherSceneNodesForSort in front of the sort
+                from gaussiansplats3d_amd import SplatTree
+                t_tree = time.perf_counter()
+                tree = SplatTree(ctx, 8, 1000).process_splat_mesh(scene.centers, alphas=scene.rgba[:, 3])
+                t_tree = time.perf_counter() - t_tree
+
+                def cull_frame():
+                    r = tree.gather_scene_nodes_for_sort(cam, sort_worker=worker, to_host=False)   # 4-byte read-back inside
+                    worker.sort_gathered(mvp, keep_on_device=True)
+                    mesh.use_sorter_result(worker, r["splatRenderCount"])
+                    mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                    return r["splatRenderCount"]
+
+                for _ in range(3):
+                    Rc = cull_frame()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    cull_frame()
+                torch.cuda.synchronize()
+                cull_ms = (time.perf_counter() - t1) / 20 * 1e3
+                cull = {"render_count": int(Rc), "leaves": int(tree.info().leaves), "ms_per_frame": round(cull_ms, 4),
+                        "Msplats_per_s_scene": round(N / (cull_ms * 1e-3) / 1e6, 1),
+                        "Msplats_per_s_rendered": round(Rc / (cull_ms * 1e-3) / 1e6, 1), "tree_build_s": round(t_tree, 2),
+                        "note": "gather + sort + draw of the frustum-culled list; scene = all N splats per frame, "
+                                "rendered = R kept by the cull"}
+                tree.dispose()
+                mesh.use_sorter_result(worker, N)
+
+                # third column: the per-splat frustum cull fused into pass 0 of the sort (gs_sorter_set_frustum_cull).  Keys,
+                # range and buckets still span all N splats, so the frame must be bit-identical to the headline path's
+                rig.frame(strip.data_ptr())
+                torch.cuda.synchronize()
+                ref_img = strip.clone()
+                worker.set_frustum_cull(True)
+                for _ in range(3):
+                    rig.frame(strip.data_ptr())
+                f_el, f_enq = rig.timed(args.steps, strip.data_ptr())
+                f_ms = f_el / args.steps * 1e3
+                fs = rig.timed_sort_stats(strip.data_ptr())
+                fused = {"kept": int(fs.result_count), "ms_per_frame": round(f_ms, 4),
+                         "Msplats_per_s_scene": round(N / (f_ms * 1e-3) / 1e6, 1),
+                         "host_enqueue_ms_per_frame": round(f_enq / args.steps * 1e3, 4), "sort_ms_last": round(float(fs.device_ms), 4),
+                         "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
+                         "note": "keys + min/max over all N, then pass 0 of the radix sort drops the splats whose centre is "
+                                 "outside 1.25x the clip volume; the list is the full sort's list minus those splats"}
+                worker.set_frustum_cull(False)
+
+                # the exact version, and what every rank of a multi-GPU run does with its strip: vertex stage first, then the
+                # sort keeps only the splats that survived it (gs_sorter_set_visibility_cull)
+                worker.set_visibility_cull(True)
+                for _ in range(3):
+                    rig.frame(strip.data_ptr())
+                v_el, v_enq = rig.timed(args.steps, strip.data_ptr())
+                v_ms = v_el / args.steps * 1e3
+                vs = rig.timed_sort_stats(strip.data_ptr())
+                vis_fused = {"kept": int(vs.result_count), "ms_per_frame": round(v_ms, 4),
+                             "Msplats_per_s_scene": round(N / (v_ms * 1e-3) / 1e6, 1), "sort_ms_last": round(float(vs.device_ms), 4),
+                             "frame_identical_to_full_sort": bool(torch.equal(ref_img, strip)),
+                             "note": "project -> sort (keys + min/max over all N, radix passes over the visible splats only) -> "
+                                     "bin -> blend: the per-rank frame of a multi-GPU run, here with the whole screen as the strip"}
+                worker.set_visibility_cull(False)
+                del ref_img
+
+            if extras and headline == "C3":
+                # BASELINE.json configs[4]'s viewport on this one GPU: the N = 1 reference of a scaling run's headline
+                c5_one = brief(measure(env, "C5", min(args.steps, 20), 3, 1, 0, stages=True, median_frames=0), N)
+                rig.set_view(cam)
+                # secondary scenes, same pose and viewport: (a) the same geometry with translucent splats - the stand-in's
+                # pixels saturate after ~90 splats (the blend reads ~2 % of its lists), here they do not, so the blend walks
+                # its lists; (b) a stand-in that resembles a trained capture: surfels on a ground disc / an object / a backdrop,
+                # bimodal opacity, the camera outside the object (scenes.capture_like) - it brackets the headline from the
+                # honest side: most splats are inside the frustum and low-alpha splats lengthen every pixel's list
+                rig.close()
+                rig = env.rig = None
+                out_ptr = strip.data_ptr()
+                for key in ("C3T", "C3S"):
+                    sc = scenes.make_config_scene(key)
+                    rg = Rig(ctx, sc, cam, device, torch)
+                    rg.probe(out_ptr)
+                    for _ in range(3):
+                        rg.frame(out_ptr)
+                    k_steps = min(args.steps, 20)
+                    t_el, _ = rg.timed(k_steps, out_ptr)
+                    t_ms = t_el / k_steps * 1e3
+                    ev = rg.event_frames(max(min(args.median_frames, 50), 1), stream, out_ptr)
+                    _, st_t = rg.mesh.render(out_device_ptr=out_ptr, to_host=False, want_stats=True)
+                    ss_t = rg.timed_sort_stats(out_ptr)
+                    obj = {"workload": scenes.CONFIGS[key]["label"], "ms_per_frame": round(t_ms, 4),
+                           "median_ms_per_frame": round(float(np.median(ev)), 4),
+                           "Msplats_per_s": round(sc.count / (t_ms * 1e-3) / 1e6, 1),
+                           "sort_ms": round(float(ss_t.device_ms), 4), "project_ms": round(float(st_t.project_ms), 4),
+                           "bin_ms": round(float(st_t.bin_ms), 4), "entry_sort_ms": round(float(st_t.tile_sort_ms), 4),
+                           "blend_ms": round(float(st_t.blend_ms), 4),
+                           "visible_splats": int(st_t.visible_splats), "V_over_N": round(int(st_t.visible_splats) / sc.count, 4),
+                           "tiles16_D": int(st_t.tiles16), "D_over_R": round(int(st_t.tiles16) / sc.count, 3),
                            "list_entries": int(st_t.tile_entries), "list_bin_px": int(st_t.list_bin_px),
                            "entries_scanned": int(st_t.entries_scanned), "splats_walked": int(st_t.splats_walked),
-                           "visible_splats": int(st_t.visible_splats),
-                           "note": "opacity ~ sigmoid(N(-2,1)): pixels do not saturate early, the blend scans and walks "
-                                   "its entry lists (compare entries_scanned / splats_walked with the `blend` object)"}
-            rig_t.close()
-            rig = None
+                           "halves_evaluated": int(st_t.halves_evaluated)}
+                    if key == "C3T":
+                        obj["note"] = ("opacity ~ sigmoid(N(-2,1)): pixels do not saturate early, the blend scans and walks "
+                                       "its entry lists (compare entries_scanned / splats_walked with the `blend` object)")
+                        translucent = obj
+                    else:
+                        obj["note"] = ("not a BASELINE.json configuration: surfels on 2-D manifolds, one axis 5-20x thinner, 40 % "
+                                       "of the splats with alpha < 0.1, the demo camera outside the object looking in "
+                                       "(demo/garden.html:38-43 for the pose)")
+                        capture = obj
+                    rg.close()
+                    del sc, rg
+            if extras:
+                lanes = blend_lane_fractions(headline)       # own process, the lane-counting build of k_tile_blend
 
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = M["ms_per_step"]
     D16 = int(st_probe.tiles16)
     visible = int(st_probe.visible_splats)
     if rank == 0:
@@ -528,36 +743,49 @@ def main():
         B = frame_algorithmic_bytes(R, Rs, D16, P, scene.sh_degree, scene.cov_half)
         frame_gbs = B / (ms_per_step * 1e-3) / 1e9
         kb = project_algorithmic_bytes(N, visible, scene.sh_degree, scene.cov_half)
+        proj_ms_sum, proj_launches = M["proj_ms_sum"], M["proj_launches"]
         if not proj_launches:
             raise SystemExit("bench.py: no k_project launch was timed (GSPLAT_KERNEL_SAMPLE=0?)")
         k_ms = proj_ms_sum / proj_launches
         k_gbs = kb / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("k_project", args.config)
-        frame_traffic, frame_traffic_src = pmc_frame_traffic(args.config) if world == 1 else (None, None)
-        walked, scanned = int(st_probe.splats_walked), int(st_probe.entries_scanned)
+        roof_note = None
+        if world > 1:
+            # a rank projects all N centres but only its strip's survivors: the kernel's algorithmic bytes are the rank's
+            # own; reported for rank 0
+            roof_note = "rank 0's launch: all N centres, the survivors of its own strip (visible_splats is the full frame's)"
+        traffic, traffic_src = pmc_traffic("k_project", headline) if world == 1 else (None, None)
+        frame_traffic, frame_traffic_src = pmc_frame_traffic(headline) if world == 1 else (None, None)
+        walked, scanned, halves = int(st_probe.splats_walked), int(st_probe.entries_scanned), int(st_probe.halves_evaluated)
+        stage_ms = M["stage_ms"]
         blend_ms = stage_ms.get("blend")
-        blend_tflops = (walked * 256 * BLEND_FLOPS_PER_PIXEL_SPLAT / (blend_ms * 1e-3) / 1e12) if blend_ms else None
-        valu, valu_src = pmc_valu("k_tile_blend", args.config)
-        proj_valu, _ = pmc_valu("k_project", args.config)
+        # fp32 operations the blend really executed: 128 pixel lanes per evaluated half tile
+        blend_tflops = (halves * 128 * BLEND_FLOPS_PER_PIXEL_SPLAT / (blend_ms * 1e-3) / 1e12) if (blend_ms and world == 1) else None
+        valu, valu_src = pmc_valu("k_tile_blend", headline)
+        proj_valu, _ = pmc_valu("k_project", headline)
         out = {
-            "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if args.config == "C3"
+            "metric": "Msplats/s sorted+rasterized at 1920x1080 SH-2" if headline == "C3"
                       else f"Msplats/s sorted+rasterized ({cfg['label']})",
             "value": round(N / (ms_per_step * 1e-3) / 1e6, 2), "unit": "Msplats/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # SURVEY.md 8d's own form: median of >= 50 frames, each bracketed by HIP events on the frame's stream
+            "median_ms_per_step": round(M["median_ms"], 4) if M["median_ms"] else None, "median_frames": M["median_frames"],
+            "median_value": round(N / (M["median_ms"] * 1e-3) / 1e6, 2) if M["median_ms"] else None,
+            "frame_ms_min": round(M["frame_ms_min"], 4) if M["frame_ms_min"] else None,
+            "frame_ms_p90": round(M["frame_ms_p90"], 4) if M["frame_ms_p90"] else None,
             "fps": round(1e3 / ms_per_step, 2),
-            "frame_latency_ms": round(float(np.median(latency)), 4) if latency else None,
-            "host_enqueue_ms_per_frame": round(t_enqueued / args.steps * 1e3, 4),
+            "frame_latency_ms": round(float(np.median(M["latency"])), 4) if M["latency"] else None,
+            "host_enqueue_ms_per_frame": round(M["enqueue_ms"], 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 keys / f32 raster",
-            "data": "synthetic" if scene.name == args.config else f"file:{scene.name}",
-            "config": {"workload": f"{args.config}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
+            "data": "synthetic" if scene.name in (headline, "C3") else f"file:{scene.name}",
+            "config": {"workload": f"{headline}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
                        "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
                        "strips": strips if world > 1 else None, "backend": backend if world > 1 else None,
                        "sort": "full list (R = N)" if world == 1 else "per rank: keys over all N, radix passes over the splats "
                                "its strip draws (gs_sorter_set_visibility_cull)",
-                       "gather": gather_kind,
+                       "gather": M["gather_kind"],
                        "dry_run_shared_gpu": dry_run if world > 1 else None},
             # the largest HBM-bound kernel: the vertex stage (the largest kernel overall is the blend, which is VALU-bound:
             # see `blend`)
@@ -568,13 +796,18 @@ def main():
                          "launches_in_timed_region": args.steps,
                          # the vertex stage is co-limited: its SIMDs issue vector instructions most of the launch as well
                          "valu_busy_frac": proj_valu.get("valu_busy_frac") if proj_valu else None,
-                         "visible_splats": visible},
+                         "visible_splats": visible, "note": roof_note},
             # the largest kernel of the frame
             "blend": {"kernel": "k_tile_blend", "bound": "valu", "ms": round(blend_ms, 4) if blend_ms else None,
-                      "splats_walked": walked, "entries_scanned": scanned, "list_entries": D32,
+                      "splats_walked": walked, "halves_evaluated": halves, "entries_scanned": scanned, "list_entries": M["D32"],
                       "flops_per_pixel_splat": BLEND_FLOPS_PER_PIXEL_SPLAT,
                       "tflops": round(blend_tflops, 2) if blend_tflops else None,
                       "frac_of_157TF": round(blend_tflops / FP32_PEAK_TFLOPS, 4) if blend_tflops else None,
+                      # of the pixel lanes the kernel evaluates (128 per half tile), the fraction that passes A <= 8
+                      "lanes_kept_frac": lanes.get("lanes_kept_frac") if lanes else None,
+                      "lanes_useful_frac": lanes.get("lanes_useful_frac") if lanes else None,
+                      "lanes_kept_frac_of_whole_quadrants": lanes.get("lanes_kept_frac_of_whole_quadrants") if lanes else None,
+                      "lanes_source": "tools/blend_lanes.py on libgsplat_hip_blendprof.so, this run" if lanes else None,
                       "valu_busy_frac": valu.get("valu_busy_frac") if valu else None,
                       "valu_insts_per_launch": valu.get("SQ_INSTS_VALU") if valu else None, "counter_source": valu_src},
             # whole frame: SURVEY.md §8d's formula, and what the counters say the engine really moves
@@ -584,14 +817,22 @@ def main():
                       "counter_GBps": round(frame_traffic / (ms_per_step * 1e-3) / 1e9, 1) if frame_traffic else None,
                       "counter_frac_of_hbm_peak": round(frame_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                       if frame_traffic else None,
-                      "tiles16_D": D16, "D_per_splat": round(D16 / R, 3), "list_entries": D32, "list_bin_px": list_px_timed,
+                      "tiles16_D": D16, "D_per_splat": round(D16 / R, 3), "list_entries": M["D32"], "list_bin_px": M["list_px"],
                       "stage_ms_isolated_frame": {k: round(v, 4) for k, v in stage_ms.items()}},
+            # N > 1: BASELINE.json's metric configuration on the same ranks, and the headline configuration on one GPU of this
+            # node (rank 0 alone) - the line's own strong-scaling reference
+            "c3": brief(second, N) if second else None,
+            "same_config_1gpu": brief(solo, N) if solo else None,
+            "speedup_vs_same_config_1gpu": round(solo["ms_per_step"] / ms_per_step, 3) if solo else None,
+            # N = 1: configs[4]'s viewport on this one GPU
+            "c5_1gpu": c5_one,
             "pipelined": pipelined,
             "orbit": orbit,
             "cull_on": cull,
             "frustum_cull_fused": fused,
             "visibility_cull_fused": vis_fused,
             "translucent": translucent,
+            "capture_like": capture,
             "cpu_baseline": None,
             "frames_drawn_before_timing_ended": frames_headline,
             "scene_gen_s": round(t_gen, 1),
@@ -599,13 +840,13 @@ def main():
         if world == 1 and not args.no_cpu and not args.only_headline:
             out["cpu_baseline"] = cpu_baseline(scene, mvp, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if group is not None:
-        group.close()
+    if env.group is not None:
+        env.group.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rig is not None:
-        rig.close()
+    if env.rig is not None:
+        env.rig.close()
     ctx.close()
 
 

@@ -12,6 +12,7 @@ import weakref
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GSPLAT_HIP_LIB") or os.path.join(CSRC, "libgsplat_hip.so")   # override: A/B of builds
+BLENDPROF_LIB_PATH = os.path.join(CSRC, "libgsplat_hip_blendprof.so")   # -DGS_BLEND_PROFILE build (tools/blend_lanes.py)
 
 GS_OK, GS_WARN_KEY_CLAMPED, GS_WARN_FRAME_TRUNCATED = 0, 1, 2
 GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
@@ -130,7 +131,7 @@ _lib = None
 
 def build(force=False):
     """Compile csrc/*.hip for gfx950 into csrc/libgsplat_hip.so (hipcc cross-compiles without a GPU)."""
-    args = ["make", "-C", CSRC, "-j8"]
+    args = ["make", "-C", CSRC, "-j8", "all", "blendprof"]     # + the lane-counting measurement build of the blend
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(args, stdout=subprocess.DEVNULL)

@@ -243,7 +243,8 @@ class SplatMesh:
         return cnt.reshape(b1 - b0, bins_x)
 
     def blend_bin_stats(self):
-        """Per 32-px blend bin of the last FULL-frame draw: (entries staged, (splat, tile) pairs walked), [bin_rows, bins_x, 2]."""
+        """Per 32-px blend bin of the last FULL-frame draw: (entries staged, (splat, 16x8-px half tile) pairs evaluated),
+        [bin_rows, bins_x, 2]."""
         cam = self._cam
         bx, by = (cam.width + L.GS_BIN - 1) // L.GS_BIN, (cam.height + L.GS_BIN - 1) // L.GS_BIN
         out = np.zeros((by * bx, 2), dtype=np.uint32)
@@ -253,14 +254,15 @@ class SplatMesh:
     def tile_row_costs(self):
         """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips).  The blend is
         what a strip mostly pays for and its cost is what it WALKS before its pixels saturate, not the length of its lists:
-        per 32-px bin row, walked (splat, tile) pairs + an eighth of the entries it staged; binning / entry sorting add the
-        list entries of the row (a quarter each).  Rows inherit an even share of the bin / list-bin row they lie in."""
+        per 32-px bin row, the half tiles it evaluated (0.55 of a whole-tile walk each) + an eighth of the entries it staged;
+        binning / entry sorting add the list entries of the row (a quarter each).  Rows inherit an even share of the bin /
+        list-bin row they lie in."""
         cam = self._cam
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
         ratio = int(self.last_stats().list_bin_px) // L.GS_TILE
         entries = np.repeat(self.bin_entry_counts().sum(axis=1).astype(np.float64) / ratio, ratio)[:rows_total]
         st = self.blend_bin_stats().astype(np.float64).sum(axis=1)          # [bin_rows, 2]
-        blend = np.repeat((st[:, 1] + st[:, 0] / 8.0) / 2.0, 2)[:rows_total]
+        blend = np.repeat((0.55 * st[:, 1] + st[:, 0] / 8.0) / 2.0, 2)[:rows_total]
         if blend.shape[0] < rows_total:
             blend = np.pad(blend, (0, rows_total - blend.shape[0]))
         return blend + 0.25 * entries

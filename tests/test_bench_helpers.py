@@ -1,5 +1,7 @@
 """CPU tier: the arithmetic behind bench.py's JSON line (SURVEY.md 8d formulas), the PMC look-up and the CPU baseline leg."""
 import importlib.util
+import sys
+import time
 import json
 import os
 
@@ -54,16 +56,48 @@ def test_self_spawn_sets_up_one_rank_per_gpu(monkeypatch):
     started = []
 
     class P:
+        pid = -1
+
         def __init__(self, cmd, env):
             started.append((cmd, env))
 
-        def wait(self):
+        def poll(self):
             return 0
 
-    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None: P(cmd, env))
+        def wait(self, timeout=None):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None, **kw: P(cmd, env))
     monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
     assert bench.spawn_ranks(4) == 0
     assert [e["RANK"] for _, e in started] == ["0", "1", "2", "3"]
     assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["LOCAL_RANK"] == e["RANK"] for _, e in started)
     assert len({e["MASTER_PORT"] for _, e in started}) == 1
     assert all(c[-4:] == ["--gpus", "4", "--steps", "2"] for c, _ in started)
+
+
+def test_a_failing_rank_takes_the_others_down(monkeypatch, tmp_path):
+    """One rank exits non-zero while the others would run for ever (a peer stuck in ncclCommInitRank): spawn_ranks stops
+    them all, waits for them and returns the failing rank's code; a deadline does the same with 124."""
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+                      "time.sleep(600)\n")
+    procs = []
+    real_popen = bench.subprocess.Popen
+
+    def popen(cmd, env=None, **kw):
+        p = real_popen([sys.executable, str(script)], env=env, **kw)
+        procs.append(p)
+        return p
+
+    monkeypatch.setattr(bench.subprocess, "Popen", popen)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "3"])
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(3, poll_s=0.05) == 7
+    assert time.monotonic() - t0 < 30 and len(procs) == 3 and all(p.poll() is not None for p in procs)
+    # the deadline
+    script.write_text("import time\ntime.sleep(600)\n")
+    procs.clear()
+    assert bench.spawn_ranks(2, timeout_s=1.0, poll_s=0.05) == 124
+    assert all(p.poll() is not None for p in procs)

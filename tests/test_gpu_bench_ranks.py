@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(tmp_path, gpus):
-    dump = str(tmp_path / f"frame_{gpus}.npy")
+def _run(tmp_path, gpus, config="C3"):
+    dump = str(tmp_path / f"frame_{gpus}_{config}.npy")
     env = dict(os.environ, GS_BENCH_DUMP=dump)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3",
-                                   "--warmup", "1", "--no-cpu", "--no-cull", "--splats", "300000"], env=env, text=True,
-                                  timeout=600)
+                                   "--warmup", "1", "--no-cpu", "--no-cull", "--splats", "300000", "--median-frames", "5"] +
+                                  (["--config", config] if config else []), env=env, text=True, timeout=600)
     line = [l for l in out.splitlines() if l.startswith('{"metric"')]
     assert len(line) == 1, out
     return json.loads(line[0]), np.load(dump)
@@ -32,3 +32,17 @@ def test_two_ranks_gather_the_single_gpu_frame(tmp_path):
     assert frame1.shape == frame2.shape == (1080, 1920, 4) and frame1.any()
     np.testing.assert_array_equal(frame1, frame2)
     assert two["value"] > 0 and two["ms_per_step"] > 0
+
+
+def test_a_multi_gpu_run_headlines_the_8k_configuration(tmp_path):
+    """`bench.py --gpus N` as the driver runs it (no --config): BASELINE.json configs[4] (garden at 7680x4320) is the headline,
+    the metric configuration C3 rides along on the same ranks, and rank 0 alone supplies the N = 1 reference of the headline
+    configuration; the gathered 8K frame equals the one-GPU 8K frame."""
+    two, frame2 = _run(tmp_path, 2, config=None)
+    one, frame1 = _run(tmp_path, 1, config="C5")
+    assert two["n_gpus"] == 2 and two["config"]["width"] == 7680 and two["config"]["workload"].startswith("C5")
+    assert two["c3"]["width"] == 1920 and two["c3"]["n_gpus"] == 2 and two["c3"]["ms_per_step"] > 0
+    assert two["same_config_1gpu"]["n_gpus"] == 1 and two["same_config_1gpu"]["width"] == 7680
+    assert two["speedup_vs_same_config_1gpu"] > 0 and two["median_ms_per_step"] > 0 and two["median_frames"] == 5
+    assert frame1.shape == frame2.shape == (4320, 7680, 4) and frame1.any()
+    np.testing.assert_array_equal(frame1, frame2)

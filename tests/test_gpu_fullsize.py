@@ -1,6 +1,7 @@
-"""-m gpu: BASELINE.json full sizes through size-independent properties (the fp32 oracle cannot rasterise 5.8 M splats at
-1080p in test time): storage-order invariance, bound-sorter vs host-index equivalence, strips == full frame, idempotence,
-statistics consistency."""
+"""-m gpu: INVARIANTS of the engine at BASELINE.json's full sizes - NOT parity.  Every test here compares the engine with
+itself: storage-order invariance, bound-sorter vs host-index equivalence, strips == full frame, idempotence, statistics
+consistency.  They would pass for an engine that is consistently wrong; parity against the oracle at these sizes is
+tests/test_gpu_crops.py (oracle-rendered windows of the same frames) and, bit-exact for the sort, tests/test_gpu_sort.py."""
 import numpy as np
 import pytest
 

@@ -69,6 +69,16 @@ __device__ __forceinline__ uint32_t quadrant_mask(uint2 r16, uint32_t bx, uint32
 #ifndef GS_BLEND_EXACT
 #define GS_BLEND_EXACT 1
 #endif
+// Skipping the half of a quadrant a splat cannot reach (task 3) was built and measured, and is OFF: the lane
+// counters (tools/blend_lanes.py, profiles/r03b_blend_lanes.txt) say 93 % (C3), 97 % (C5), 70 % (C3T), 65 % (C2) of the
+// evaluated pixel lanes pass `A <= 8` - the splats a quadrant walks before it saturates are the large near ones, only 3 % /
+// 12 % / 13 % of the halves are skippable there - and the branches cost more than they save (same-box r03b, blend ms with
+// whole-quadrant masks / half masks + skip: C3 0.070 / 0.076-0.083, C3T 0.477 / 0.507-0.585, C2 0.190 / 0.203-0.226).  Even
+// on the capture-like C3S scene (19 % of the lanes kept, 36 % of the halves skippable) it gains nothing (4.38 / 4.30 ms):
+// that frame is bound by a few bins with very long lists, not by VALU slots.
+#ifndef GS_BLEND_HALF_SKIP
+#define GS_BLEND_HALF_SKIP 0          // 1: skip the half (16 x 8 px) of a reached quadrant the ellipse does not enter
+#endif
 __device__ __forceinline__ uint32_t spread_quadrants(uint32_t qm) {          // 4 quadrant bits -> both half bits of each
     const uint32_t s = (qm & 1u) | ((qm & 2u) << 1) | ((qm & 4u) << 2) | ((qm & 8u) << 3);
     return s | (s << 1);
@@ -83,10 +93,13 @@ __device__ __forceinline__ uint32_t exact_halves(uint32_t qm, const uint4 lo, co
 #ifndef BLEND_EXACT_UNROLL
 #define BLEND_EXACT_UNROLL 4
 #endif
+#ifndef GS_BLEND_EXACT_HALVES
+#define GS_BLEND_EXACT_HALVES GS_BLEND_HALF_SKIP   // 0: test whole quadrants (16 x 16); both half bits of a reached one are set
+#endif
     const float Xq[2] = {(float)(bx * GS_BIN) + 0.5f - cx, (float)(bx * GS_BIN + GS_TILE) + 0.5f - cx};
 #pragma unroll BLEND_EXACT_UNROLL
-    for (uint32_t r = 0; r < 4u; r++) {                                   // band r = rows 8r .. 8r+7 of the 32-px bin
-        const float Y0 = (float)(by * GS_BIN + r * 8u) + 0.5f - cy, Y1 = Y0 + 7.0f;
+    for (uint32_t r = 0; r < 4u; r += GS_BLEND_EXACT_HALVES ? 1u : 2u) {   // band r = rows 8r .. 8r+7 of the 32-px bin
+        const float Y0 = (float)(by * GS_BIN + r * 8u) + 0.5f - cy, Y1 = Y0 + (GS_BLEND_EXACT_HALVES ? 7.0f : 15.0f);
         const float yb = Y0 > 0.0f ? Y0 : (Y1 < 0.0f ? Y1 : 0.0f);     // bound between the box and the centre, 0 = none
 #pragma unroll
         for (uint32_t c = 0; c < 2u; c++) {                               // column c = x 16c .. 16c+15
@@ -103,7 +116,7 @@ __device__ __forceinline__ uint32_t exact_halves(uint32_t qm, const uint4 lo, co
                 qmin = fminf(q1, q2);
             }
             // quadrant q = c + 2 * (r >> 1), half h = r & 1
-            if (!(qmin > limit)) out |= 1u << (2u * (c + 2u * (r >> 1)) + (r & 1u));   // NaN keeps the half
+            if (!(qmin > limit)) out |= (GS_BLEND_EXACT_HALVES ? 1u : 3u) << (2u * (c + 2u * (r >> 1)) + (r & 1u));   // NaN keeps the half
         }
     }
     return qm & out;
@@ -141,8 +154,8 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef BLEND_OCC
 #define BLEND_OCC 6
 #endif
-#ifndef GS_BLEND_HALF_SKIP
-#define GS_BLEND_HALF_SKIP 1          // 0: always evaluate both halves of a quadrant the splat reaches (A/B)
+#ifndef GS_BLEND_BRANCH_STYLE
+#define GS_BLEND_BRANCH_STYLE 1       // 0: two independent ifs, 1: both / first / second as three blocks (A/B)
 #endif
 __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
@@ -287,9 +300,26 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                         const v2f t_new = T[h] - wgt;
                         T[h] = t_new * pk_fma_sat(t_new, v2f{GS_HUGE, GS_HUGE}, v2f{-GS_T_EPS * GS_HUGE, -GS_T_EPS * GS_HUGE});
                     };
+                    // (both halves as ONE straight-line block: the scheduler interleaves the two independent chains exactly as
+                    // before there was anything to skip - the common case for large splats; r03a: with two separately
+                    // branched blocks the C3 blend went 0.066 -> 0.080 ms while only 3 % of its halves could be skipped)
                     const bool do0 = !GS_BLEND_HALF_SKIP || ((mh0 >> bit) & 1ull), do1 = !GS_BLEND_HALF_SKIP || ((mh1 >> bit) & 1ull);
+#if GS_BLEND_BRANCH_STYLE == 0
                     if (do0) { half(0); halves++; }
                     if (do1) { half(1); halves++; }
+#else
+                    if (do0 && do1) {
+                        half(0);
+                        half(1);
+                        halves += 2u;
+                    } else if (do0) {
+                        half(0);
+                        halves++;
+                    } else {
+                        half(1);
+                        halves++;
+                    }
+#endif
                     if (++since_check == 16u || m == 0ull) {
                         // retire the wave when its whole quadrant is saturated
                         since_check = 0;

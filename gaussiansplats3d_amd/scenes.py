@@ -116,8 +116,8 @@ def _surfel_covariances(rng, nrm, spacing, chunk=1 << 20):
 def capture_like(n, sh_degree, seed, pose="garden", name=""):
     """A stand-in that resembles a trained capture (the "C3S" scene): splats lie ON 2-D manifolds instead of filling a
     volume, they are flat, and their opacities are bimodal.
-      * 35 %: a ground disc of radius 6 under the demo's look-at point (normal = the demo's up vector), denser towards
-              the middle;
+      * 35 %: a ground disc of radius 6 under the demo's look-at point (normal = the demo's up vector), half of it
+              uniform, half a 2-D Gaussian about the object (splat sizes follow the local spacing);
       * 35 %: the object: a table-like box (2.0 x 0.9 x 1.2) standing on the ground at the look-at point with three balls on
               its top;
       * 30 %: 96 planar background patches (3..8 units across) tangent to spheres of radius 7..15 about the look-at point,
@@ -142,15 +142,16 @@ def capture_like(n, sh_degree, seed, pose="garden", name=""):
         pts.append(p); nrm.append(nn); spc.append(np.broadcast_to(spacing, (p.shape[0],)).astype(np.float64))
         col.append(np.clip(np.asarray(base_rgb)[None, :] + rng.normal(0.0, 18.0, size=(p.shape[0], 3)), 0, 255))
 
-    # ground: half uniform over the disc, half concentrated under the object
+    # ground: half uniform over the disc, half a 2-D Gaussian (sigma 1.6) about the object - denser where a capture has more views
     G = look - 0.6 * u
-    R_g = 6.0
+    R_g, sig = 6.0, 1.6
     h = n_ground // 2
-    r = np.concatenate([R_g * np.sqrt(rng.uniform(size=h)), np.minimum(np.abs(rng.normal(0.0, 1.6, size=n_ground - h)), R_g)])
+    r_c = sig * np.sqrt(-2.0 * np.log(1.0 - rng.uniform(size=n_ground - h) * (1.0 - np.exp(-0.5 * (R_g / sig) ** 2))))   # Rayleigh, cut at R_g
+    r = np.concatenate([R_g * np.sqrt(rng.uniform(size=h)), r_c])
     th = rng.uniform(0.0, 2.0 * np.pi, size=n_ground)
     p = G + (r * np.cos(th))[:, None] * e1 + (r * np.sin(th))[:, None] * e2 + rng.normal(0.0, 0.01, size=(n_ground, 1)) * u
-    # local spacing from the local density of the two populations
-    dens = h / (np.pi * R_g ** 2) + (n_ground - h) * np.exp(-0.5 * (r / 1.6) ** 2) / (2.0 * np.pi * 1.6 ** 2) / np.maximum(r / 1.6, 0.25) * 0.8
+    # local spacing from the local areal density of the two populations
+    dens = h / (np.pi * R_g ** 2) + (n_ground - h) * np.exp(-0.5 * (r / sig) ** 2) / (2.0 * np.pi * sig ** 2)
     add(p, np.broadcast_to(u, p.shape).copy(), 1.0 / np.sqrt(dens), (96, 120, 64))
 
     # object: box faces by area + three balls

@@ -205,8 +205,11 @@ struct gs_sorter {
     gs_mesh* bound_mesh = nullptr;     // gs_sorter_bind_mesh: results are positions in this mesh's storage order
     gs_mesh* result_mesh = nullptr;    // ... as it was when the last sort ran (nullptr = plain splat indexes)
     const uint32_t* result_unmap = nullptr;
-    uint32_t gathered = 0;             // splatRenderCount of the list gs_tree_gather left in idx_in
+    uint32_t gathered = 0;             // splatRenderCount of the list gs_tree_gather left in idx_in (an upper bound when
+                                       // gathered_on_device: the asynchronous gather leaves the real count in gathered_dev)
     bool has_gathered = false;
+    bool gathered_on_device = false;
+    DevBuf gathered_dev;               // uint32: splatRenderCount of that list, written by k_tree_plan
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
     bool last_identity = true;
     bool has_result = false;

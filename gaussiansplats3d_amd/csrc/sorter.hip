@@ -162,7 +162,11 @@ __global__ __launch_bounds__(256) void k_depth_key(KeyParams p) {
             }
         }
     } else {
-        for (uint32_t i = p.sort_start + t; i < p.render_count; i += stride) {
+        // the list's length may live on the device (an asynchronous gs_tree_gather): the sorted result then has that length,
+        // published where the consumers of a culled sort look for it
+        const uint32_t R = p.count_dev ? min(*p.count_dev, p.render_count) : p.render_count;
+        if (p.count_dev && t == 0) p.frame->kept = R;
+        for (uint32_t i = p.sort_start + t; i < R; i += stride) {
             const uint32_t g = p.idx_in ? min(p.idx_in[i], p.last_splat) : i;
             const int32_t k = depth_key_one(p, g);
             p.keys_out[i] = k;
@@ -236,7 +240,8 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
         p.next_frame->kept = 0;
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t R = p.render_count;                             // sort_start == 0 in this variant
+    // sort_start == 0 in this variant; the length of a gathered list may live on the device (asynchronous gs_tree_gather)
+    const uint32_t R = (!VEC4 && p.count_dev) ? min(*p.count_dev, p.render_count) : p.render_count;
     if (VEC4) {
         const uint32_t nvec = (R + 3u) / 4u, full = R / 4u, padded = (nvec + 63u) & ~63u;
         const uint4* x4 = reinterpret_cast<const uint4*>(p.cx);
@@ -691,7 +696,7 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
 
 static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* indexes_to_sort, bool device_list,
                             uint32_t sort_count, uint32_t render_count, const void* precomputed, const float* transforms,
-                            uint32_t* sorted_out, gs_sort_stats* stats) {
+                            uint32_t* sorted_out, gs_sort_stats* stats, const uint32_t* list_count_dev = nullptr) {
     GS_REQUIRE(s && mvp, "sorter / mvp == NULL");
     // SortWorker.js:100-101 clamps both counts to the uploaded splat count
     if (render_count > s->uploaded) render_count = s->uploaded;
@@ -699,8 +704,11 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     GS_REQUIRE(sort_count <= render_count, "splatSortCount > splatRenderCount");
     const bool dynamic = (s->flags & GS_SORT_DYNAMIC) != 0;
     GS_REQUIRE(!dynamic || transforms, "dynamic sorter needs transforms");
-    const bool vis_cull = s->visibility_cull;
+    const bool vis_cull = s->visibility_cull && !list_count_dev;   // (sorts the identity list: not combinable with a gathered one)
     const bool cull = s->frustum_cull && !vis_cull;        // the frustum cull's keep-mask path; the visibility cull compacts instead
+    // list_count_dev: the list's real length lives on the device (asynchronous gs_tree_gather); render_count bounds it
+    GS_REQUIRE(!list_count_dev || (device_list && sort_count == render_count && !dynamic && !precomputed),
+               "a gathered list whose length lives on the device needs a full sort of a static scene without precomputed distances");
     GS_REQUIRE(!(cull || vis_cull) || (sort_count == render_count && !dynamic && !precomputed),
                "a per-splat cull needs a full sort (splatSortCount == splatRenderCount) of a static scene without precomputed distances");
     gs_context* ctx = s->ctx;
@@ -782,6 +790,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         kp.keep = s->keep_mask.as<unsigned long long>();
         memcpy(kp.mvp, mvp, sizeof(kp.mvp));
     }
+    if (list_count_dev) kp.count_dev = list_count_dev;
 
     s->timed_sort = stats != nullptr || ctx->stage_events;
     if (s->timed_sort) GS_HIP(hipEventRecord(s->ev0, st));
@@ -825,7 +834,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         dl.render_count = R;
         dl.range = 1u << s->precision;
         dl.last_splat = kp.last_splat;
-        dl.n_dev = vis_cull ? &kp.frame->kept : nullptr;
+        dl.n_dev = vis_cull ? &kp.frame->kept : list_count_dev;
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
         const bool wide = s->precision > 16;
@@ -836,11 +845,12 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             const int shift = 8 * (int)p;
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
-            const uint32_t* n_dev = (cull || vis_cull) ? &kp.frame->kept : nullptr;
+            const uint32_t* n_dev = (cull || vis_cull || list_count_dev) ? &kp.frame->kept : nullptr;
             if (p == 0 && cull) {
                 DepthLoaderCull dc = {};
                 dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
                 dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;
+                dc.n_dev = dl.n_dev;
                 DepthLoaderCull h = dc;
                 h.count_clamps = 1;
                 if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
@@ -871,7 +881,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     s->last_sort = Rs;
     s->last_passes = passes;
     s->last_identity = (idx_dev == nullptr);
-    s->last_culled = (cull || vis_cull) && Rs > 0;
+    s->last_culled = (cull || vis_cull || list_count_dev) && Rs > 0;   // the result's length lives in result_frame->kept
     s->last_vis_culled = vis_cull && Rs > 0;
     s->result_frame = kp.frame;
     s->result_mesh = map ? s->bound_mesh : nullptr;
@@ -913,6 +923,12 @@ int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count,
                             const float* transforms, uint32_t* sorted_out, gs_sort_stats* stats) {
     GS_REQUIRE(s != nullptr, "sorter == NULL");
     GS_REQUIRE(s->has_gathered, "no gs_tree_gather has filled this sorter's index list");
+    if (s->gathered_on_device) {                                  // s->gathered = the tree's splat count, an upper bound
+        GS_REQUIRE(sort_count >= s->gathered, "after an asynchronous gs_tree_gather only the whole list can be sorted: the "
+                                              "partial-sort schedule needs splatRenderCount on the host (pass render_count)");
+        return sorter_sort_impl(s, mvp, nullptr, true, s->gathered, s->gathered, precomputed, transforms, sorted_out, stats,
+                                s->gathered_dev.as<uint32_t>());
+    }
     if (sort_count > s->gathered) sort_count = s->gathered;       // Math.min(queuedSorts.shift(), splatRenderCount)
     return sorter_sort_impl(s, mvp, nullptr, true, sort_count, s->gathered, precomputed, transforms, sorted_out, stats);
 }

@@ -35,8 +35,8 @@ struct gs_tree {
     std::vector<uint32_t> indexes;
     // device mirror
     DevBuf d_center, d_size, d_begin, d_count, d_indexes;
-    DevBuf d_bucket;            // uint32 [hist 65536 | fill 65536 | start 65537]
-    DevBuf d_key, d_cnt, d_rank, d_sorted_cnt, d_sorted_leaf, d_offset, d_total, d_out;
+    DevBuf d_bucket;            // uint32 [hist 65536 | fill 65536 | start 65537]; hist / fill are zero between gathers
+    DevBuf d_key, d_rank, d_sorted_cnt, d_sorted_leaf, d_offset, d_total, d_out;   // d_total: {splats gathered, leaves kept}
 };
 
 namespace {
@@ -120,14 +120,8 @@ constexpr uint32_t TREE_BUCKETS = 1u << 16;
 // bucket of a distance key: top 16 bits of (float)key, monotonic in key; any bit pattern stays below TREE_BUCKETS
 __device__ __forceinline__ uint32_t tree_bucket(double key) { return __float_as_uint((float)key) >> 16; }
 
-// Viewer.js:2010-2035 for one leaf
-__global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double* __restrict__ center,
-                                                   const double* __restrict__ size, const uint32_t* __restrict__ count,
-                                                   double* __restrict__ key, uint32_t* __restrict__ cnt,
-                                                   uint32_t* __restrict__ bucket_hist) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= p.leaves) return;
-    const double x = center[3 * (size_t)i], y = center[3 * (size_t)i + 1], z = center[3 * (size_t)i + 2];
+// Viewer.js:2010-2035 for one leaf: the sort key (distance, or +inf when the leaf is culled)
+__device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x, double y, double z, double size) {
     const double* e = p.mv;
     // Vector3.applyMatrix4 (three r160)
     const double w = 1.0 / (e[3] * x + e[7] * y + e[11] * z + e[15]);
@@ -146,106 +140,124 @@ __global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double*
     const double xz_z = vz * (1.0 / (lxz != 0.0 ? lxz : 1.0));
     const double dot_xz = -xz_z, dot_yz = -yz_z;                           // forward.dot(v) = -v.z
     const bool out_y = dot_yz < p.thr_y, out_x = dot_xz < p.thr_x;
-    const bool skip = !p.gather_all && ((out_x || out_y) && dist > size[i]);
-    const double k = skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;   // +inf sorts behind every kept leaf
-    key[i] = k;
-    cnt[i] = skip ? 0u : count[i];
-    if (!skip) atomicAdd(&bucket_hist[tree_bucket(k)], 1u);   // culled leaves take no part in the ranking (their count is 0)
+    const bool skip = !p.gather_all && ((out_x || out_y) && dist > size);
+    return skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;         // +inf: the leaf takes no part in the ranking
 }
 
-// Rank of leaf i in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2) (26 k leaves: ~0.15 ms);
-// instead the leaves are bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa
-// bits, i.e. 0.8 % wide buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number -
-// only against the members of its own bucket.  The result is the same total order; only the work is smaller.
-// one workgroup: exclusive scan of the bucket histogram (thread t owns 64 consecutive buckets)
-__global__ __launch_bounds__(1024) void k_tree_bucket_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
-    __shared__ uint32_t s_wave[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t CH = TREE_BUCKETS / 1024u;
-    uint32_t v[CH], sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < CH; k += 4) {
-        const uint4 q = *reinterpret_cast<const uint4*>(hist + tid * CH + k);
-        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
-        sum += q.x + q.y + q.z + q.w;
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-#pragma unroll
-    for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < CH; k++) {
-        start[tid * CH + k] = run;
-        run += v[k];
-    }
-    if (tid == 1023u) start[TREE_BUCKETS] = run;
-}
-
-__global__ __launch_bounds__(256) void k_tree_fill(const double* __restrict__ key, uint32_t n, const uint32_t* __restrict__ start,
-                                                   uint32_t* __restrict__ fill, uint32_t* __restrict__ members) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const double k = key[i];
-    if (k == __longlong_as_double(0x7FF0000000000000ll)) return;          // culled
-    const uint32_t b = tree_bucket(k);
-    members[start[b] + atomicAdd(&fill[b], 1u)] = i;       // order inside a bucket is arbitrary: the rank below is exact
-}
-
-__global__ __launch_bounds__(256) void k_tree_rank_place(const unsigned long long* __restrict__ key, uint32_t n,
-                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ members,
-                                                         const uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted_cnt,
-                                                         uint32_t* __restrict__ sorted_leaf) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long mine = key[i];                // non-negative doubles order like their bit patterns
-    if (mine == 0x7FF0000000000000ull) return;             // culled: sorted_cnt stays 0 behind the kept leaves
-    const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
-    const uint32_t lo = start[b], hi = start[b + 1];
-    uint32_t r = lo;
-    for (uint32_t p = lo; p < hi; p++) {
-        const uint32_t m = members[p];
-        const unsigned long long k = key[m];
-        r += (k < mine || (k == mine && m < i)) ? 1u : 0u;
-    }
-    sorted_cnt[r] = cnt[i];
-    sorted_leaf[r] = i;
-}
-
-// one workgroup: offset[r] = total - inclusive_prefix(sorted_cnt)[r]  (nearest leaf, r = 0, ends the buffer:
-// Viewer.js:2046-2055 copies from the END backwards).  Thread t owns the contiguous ranks [t*per, (t+1)*per).
-__global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restrict__ sorted_cnt, uint32_t n,
-                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ total_out) {
+// The whole plan of a gather in ONE workgroup (r02: six launches + two memsets, ~0.22 ms of launch-bound kernels for 26 k
+// leaves): node test -> bucket histogram -> scan -> bucket fill -> exact rank -> suffix offsets, phases separated by
+// workgroup barriers (one workgroup = one L1, so its own global writes are visible to it after a barrier).
+// Rank of a leaf in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2); instead the leaves are
+// bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa bits, i.e. 0.8 % wide
+// buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number - only against the
+// members of its own bucket.  The result is the same total order; only the work is smaller.
+// offset[r] = total - inclusive_prefix(counts by rank)[r]: the nearest leaf, r = 0, ends the buffer (Viewer.js:2046-2055
+// copies from the END backwards).  `hist` / `fill` are zero on entry and are left zero; kept_out = ranked (kept) leaves.
+constexpr uint32_t PLAN_THREADS = 1024;
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, const double* __restrict__ center,
+                                                            const double* __restrict__ size, const uint32_t* __restrict__ count,
+                                                            unsigned long long* __restrict__ key, uint32_t* __restrict__ hist,
+                                                            uint32_t* __restrict__ fill, uint32_t* __restrict__ start,
+                                                            uint32_t* __restrict__ members, uint32_t* __restrict__ sorted_cnt,
+                                                            uint32_t* __restrict__ sorted_leaf, uint32_t* __restrict__ offset,
+                                                            uint32_t* __restrict__ totals /* {splats, kept leaves} */,
+                                                            uint32_t* __restrict__ count_out /* nullable: the sorter's copy */) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t CH = 16;                            // values per thread and round, all loads in flight together
-    // pass 1: total
+    const uint32_t L = p.leaves;
+    const unsigned long long INF = 0x7FF0000000000000ull;
+    // 1. test every leaf, count the kept ones per bucket
+    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
+        const double k = tree_leaf_key(p, center[3 * (size_t)i], center[3 * (size_t)i + 1], center[3 * (size_t)i + 2], size[i]);
+        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);   // non-negative doubles order like their bits
+        key[i] = kb;
+        if (kb != INF) atomicAdd(&hist[tree_bucket(k)], 1u);
+    }
+    __syncthreads();
+    // 2. exclusive scan of the histogram (thread t owns 64 consecutive buckets); the histogram is handed back zeroed
+    {
+        constexpr uint32_t CH = TREE_BUCKETS / PLAN_THREADS;
+        uint32_t v[CH], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k += 4) {
+            uint4* hp = reinterpret_cast<uint4*>(hist + tid * CH + k);
+            const uint4 q = *hp;
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+            sum += q.x + q.y + q.z + q.w;
+            if (q.x | q.y | q.z | q.w) *hp = make_uint4(0u, 0u, 0u, 0u);
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < CH; k++) {
+            start[tid * CH + k] = run;
+            run += v[k];
+        }
+        if (tid == PLAN_THREADS - 1u) start[TREE_BUCKETS] = run;
+    }
+    __syncthreads();
+    const uint32_t K = start[TREE_BUCKETS];                  // kept leaves
+    // 3. members of every bucket (order inside a bucket is arbitrary: the rank below is exact)
+    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
+        const unsigned long long kb = key[i];
+        if (kb == INF) continue;
+        const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
+        members[start[b] + atomicAdd(&fill[b], 1u)] = i;
+    }
+    __syncthreads();
+    // 4. exact rank inside the bucket -> the leaf and its count at their rank; the fill counters are handed back zeroed
+    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
+        const unsigned long long mine = key[i];
+        if (mine == INF) continue;
+        const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
+        const uint32_t lo = start[b], hi = start[b + 1];
+        uint32_t r = lo;
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint32_t m = members[q];
+            const unsigned long long k = key[m];
+            r += (k < mine || (k == mine && m < i)) ? 1u : 0u;
+        }
+        sorted_cnt[r] = count[i];
+        sorted_leaf[r] = i;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
+        const unsigned long long kb = key[i];
+        if (kb != INF) fill[tree_bucket(__longlong_as_double((long long)kb))] = 0u;      // same value from every member
+    }
+    // 5. total and suffix offsets over the K ranks; thread t owns CH consecutive ranks per round
+    constexpr uint32_t CH = 16;
     uint32_t sum = 0;
-    for (uint32_t i = tid; i < n; i += 1024u) sum += sorted_cnt[i];
+    for (uint32_t i = tid; i < K; i += PLAN_THREADS) sum += sorted_cnt[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    __syncthreads();                                         // s_wave of the scan above consumed
     if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
     uint32_t total = 0;
 #pragma unroll
     for (int w = 0; w < 16; w++) total += s_wave[w];
     if (tid == 0) {
-        *total_out = total;
+        totals[0] = total;
+        totals[1] = K;
+        if (count_out) *count_out = total;
         s_carry = 0;
     }
-    // pass 2: rounds of 16384 ranks, thread t owns CH consecutive ones
-    for (uint32_t base = 0; base < n; base += 1024u * CH) {
+    for (uint32_t base = 0; base < K; base += PLAN_THREADS * CH) {
         const uint32_t b = base + tid * CH;
         uint32_t v[CH];
 #pragma unroll
-        for (uint32_t k = 0; k < CH; k++) v[k] = b + k < n ? sorted_cnt[b + k] : 0u;
+        for (uint32_t k = 0; k < CH; k++) v[k] = b + k < K ? sorted_cnt[b + k] : 0u;
         uint32_t mine = 0;
 #pragma unroll
         for (uint32_t k = 0; k < CH; k++) mine += v[k];
@@ -269,23 +281,27 @@ __global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restric
 #pragma unroll
         for (uint32_t k = 0; k < CH; k++) {
             run += v[k];
-            if (b + k < n) offset[b + k] = total - run;
+            if (b + k < K) offset[b + k] = total - run;
         }
         __syncthreads();
         if (tid == 0) s_carry += chunk;
     }
 }
 
-// one wave per rank: coalesced copy of the leaf's index list (<= ~1000 indexes) to its place in indexesToSort
-__global__ __launch_bounds__(64) void k_tree_copy(const uint32_t* __restrict__ sorted_leaf, const uint32_t* __restrict__ sorted_cnt,
-                                                   const uint32_t* __restrict__ offset, const uint32_t* __restrict__ leaf_begin,
-                                                   const uint32_t* __restrict__ leaf_indexes, uint32_t* __restrict__ out) {
-    const uint32_t r = blockIdx.x;
-    const uint32_t n = sorted_cnt[r];
-    if (n == 0) return;
-    const uint32_t* src = leaf_indexes + leaf_begin[sorted_leaf[r]];
-    uint32_t* dst = out + offset[r];
-    for (uint32_t t = threadIdx.x; t < n; t += 64u) dst[t] = src[t];
+// Coalesced copy of the kept leaves' index lists (<= ~1000 indexes each) to their places in indexesToSort: one wave per
+// rank, four ranks per workgroup; ranks >= the kept count (read on the device) have nothing to copy.
+constexpr uint32_t COPY_WAVES = 4;
+__global__ __launch_bounds__(64 * COPY_WAVES) void k_tree_copy(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ sorted_leaf,
+                                                                const uint32_t* __restrict__ sorted_cnt, const uint32_t* __restrict__ offset,
+                                                                const uint32_t* __restrict__ leaf_begin,
+                                                                const uint32_t* __restrict__ leaf_indexes, uint32_t* __restrict__ out) {
+    const uint32_t K = totals[1], lane = threadIdx.x & 63u;
+    for (uint32_t r = blockIdx.x * COPY_WAVES + (threadIdx.x >> 6); r < K; r += gridDim.x * COPY_WAVES) {
+        const uint32_t n = sorted_cnt[r];
+        const uint32_t* src = leaf_indexes + leaf_begin[sorted_leaf[r]];
+        uint32_t* dst = out + offset[r];
+        for (uint32_t t = lane; t < n; t += 64u) dst[t] = src[t];
+    }
 }
 
 extern "C" {
@@ -345,7 +361,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         auto A = [&](DevBuf& buf, size_t bytes) { if (st == GS_OK) st = buf.alloc(bytes); };
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
         A(t->d_indexes, 4 * t->indexes.size() + 4);
-        A(t->d_key, 8 * L + 8); A(t->d_cnt, 4 * L + 4); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
+        A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
         A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4); A(t->d_total, 16);
         if (st != GS_OK) {
             delete t;
@@ -358,6 +374,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         };
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
         UP(t->d_count, cnt.data(), 4 * L); UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // k_tree_plan keeps them zero
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
             gs_set_error("uploading the splat tree failed: %s", hipGetErrorString(e));
@@ -411,7 +428,8 @@ int gs_tree_read(gs_tree* t, double* bounds, double* centers, uint32_t* depths, 
 }
 
 int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint32_t* render_count, uint32_t* indexes_out_host) {
-    GS_REQUIRE(t && gp && render_count, "tree / params / render_count == NULL");
+    GS_REQUIRE(t && gp, "tree / params == NULL");
+    GS_REQUIRE(render_count || (dst && !indexes_out_host), "render_count == NULL (asynchronous gather) needs a sorter and no host copy");
     GS_REQUIRE(t->ctx != nullptr, "host-only tree (created without a context) cannot gather");
     GS_REQUIRE(!dst || dst->ctx == t->ctx, "sorter lives on another context");
     GS_REQUIRE(!dst || dst->max_count >= t->indexes.size(), "sorter is smaller than the tree");
@@ -427,9 +445,9 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
         GS_TRY(t->d_out.ensure(4 * t->indexes.size() + 4));
         out_dev = t->d_out.as<uint32_t>();
     }
-    *render_count = 0;
+    if (render_count) *render_count = 0;
     if (L == 0) {
-        if (dst) dst->gathered = 0, dst->has_gathered = true;
+        if (dst) dst->gathered = 0, dst->gathered_on_device = false, dst->has_gathered = true;
         return GS_OK;
     }
     GatherParams p;
@@ -442,23 +460,32 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     p.thr_y = cos(fov_y2) - .6;
     p.gather_all = gp->gather_all ? 1u : 0u;
     p.leaves = L;
-    const dim3 g((L + 255u) / 256u), b(256);
     uint32_t* bhist = t->d_bucket.as<uint32_t>();
     uint32_t* bfill = bhist + TREE_BUCKETS;
     uint32_t* bstart = bfill + TREE_BUCKETS;
-    GS_HIP(hipMemsetAsync(bhist, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, st));
-    GS_HIP(hipMemsetAsync(t->d_sorted_cnt.p, 0, sizeof(uint32_t) * L, st));
-    hipLaunchKernelGGL(k_tree_test, g, b, 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(), t->d_count.as<uint32_t>(),
-                       t->d_key.as<double>(), t->d_cnt.as<uint32_t>(), bhist);
-    hipLaunchKernelGGL(k_tree_bucket_scan, dim3(1), dim3(1024), 0, st, bhist, bstart);
-    hipLaunchKernelGGL(k_tree_fill, g, b, 0, st, t->d_key.as<double>(), L, bstart, bfill, t->d_rank.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_rank_place, g, b, 0, st, t->d_key.as<unsigned long long>(), L, bstart, t->d_rank.as<uint32_t>(),
-                       t->d_cnt.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_offsets, dim3(1), dim3(1024), 0, st, t->d_sorted_cnt.as<uint32_t>(), L, t->d_offset.as<uint32_t>(),
-                       t->d_total.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_copy, dim3(L), dim3(64), 0, st, t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(),
-                       t->d_offset.as<uint32_t>(), t->d_begin.as<uint32_t>(), t->d_indexes.as<uint32_t>(), out_dev);
+    // two launches: the plan (one workgroup) and the copy; the sorter gets the list's length on the device as well
+    uint32_t* count_dev = nullptr;
+    if (dst) {
+        GS_TRY(dst->gathered_dev.ensure(16));
+        count_dev = dst->gathered_dev.as<uint32_t>();
+    }
+    hipLaunchKernelGGL(k_tree_plan, dim3(1), dim3(PLAN_THREADS), 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(),
+                       t->d_count.as<uint32_t>(), t->d_key.as<unsigned long long>(), bhist, bfill, bstart, t->d_rank.as<uint32_t>(),
+                       t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>(), t->d_offset.as<uint32_t>(),
+                       t->d_total.as<uint32_t>(), count_dev);
+    const uint32_t copy_grid = (L + COPY_WAVES - 1u) / COPY_WAVES;
+    hipLaunchKernelGGL(k_tree_copy, dim3(copy_grid < 8192u ? copy_grid : 8192u), dim3(64 * COPY_WAVES), 0, st, t->d_total.as<uint32_t>(),
+                       t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(), t->d_offset.as<uint32_t>(),
+                       t->d_begin.as<uint32_t>(), t->d_indexes.as<uint32_t>(), out_dev);
     GS_HIP(hipGetLastError());
+    if (!render_count) {
+        // asynchronous: nothing returns to the host, splatRenderCount stays on the device next to the list; the sorter takes
+        // both from there (gs_sorter_sort_gathered), the draw takes the sorted list's length from the sorter
+        dst->gathered = (uint32_t)t->indexes.size();          // upper bound: sizes grids and buffers
+        dst->gathered_on_device = true;
+        dst->has_gathered = true;
+        return GS_OK;
+    }
     uint32_t total = 0;
     GS_HIP(hipMemcpyAsync(&total, t->d_total.p, 4, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));                      // the Viewer needs splatRenderCount on the host
@@ -469,6 +496,7 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     }
     if (dst) {
         dst->gathered = total;
+        dst->gathered_on_device = false;
         dst->has_gathered = true;
     }
     return GS_OK;

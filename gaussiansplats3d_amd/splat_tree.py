@@ -24,6 +24,7 @@ class SplatTree:
         self.max_centers_per_node = int(max_centers_per_node)
         self.handle = C.c_void_p()
         self.splat_count = 0
+        self._splats = None           # splats held by the leaves (info().splats), cached for asynchronous gathers
         if context is not None:
             context._adopt(self)
 
@@ -39,6 +40,7 @@ class SplatTree:
                                         keep.ctypes.data if keep is not None else None, c.shape[0], int(first_index),
                                         self.max_depth, self.max_centers_per_node, C.byref(self.handle)))
         self.splat_count = c.shape[0]
+        self._splats = None
         return self
 
     def info(self):
@@ -58,9 +60,11 @@ class SplatTree:
         return bounds, centers, depths, offsets, indexes
 
     def gather_scene_nodes_for_sort(self, camera, sort_worker=None, gather_all_nodes=False, mesh_world=None,
-                                    fov_deg=cam_math.THREE_FOV_DEG, to_host=True, model_view=None):
+                                    fov_deg=cam_math.THREE_FOV_DEG, to_host=True, model_view=None, asynchronous=False):
         """Viewer.gatherSceneNodesForSort: returns {'splatRenderCount', 'shouldSortAll', 'indexesToSort'}.  With a
-        sort worker the list is written into its device buffer (``sort_worker.sort_gathered`` consumes it)."""
+        sort worker the list is written into its device buffer (``sort_worker.sort_gathered`` consumes it).
+        asynchronous=True (needs a sort worker, no host list): nothing returns to the host - splatRenderCount stays on the
+        device next to the list and the reply carries the tree's splat count as its upper bound."""
         gp = L.GatherParams()
         if model_view is not None:        # inverse(camera.matrixWorld) * splatMesh.matrixWorld, already multiplied (fp64)
             mv = np.asarray(model_view, np.float64)
@@ -71,6 +75,12 @@ class SplatTree:
         gp.render_width, gp.render_height = float(camera.width), float(camera.height)
         gp.gather_all = 1 if gather_all_nodes else 0
         count = C.c_uint32(0)
+        if asynchronous:
+            if self._splats is None:
+                self._splats = int(self.info().splats)
+            L.check(self.lib.gs_tree_gather(self.handle, C.byref(gp), sort_worker.handle, None, None))
+            sort_worker.gathered_count = self._splats
+            return {"splatRenderCount": self._splats, "shouldSortAll": False, "indexesToSort": None, "countOnDevice": True}
         out = np.empty(self.info().splats, dtype=np.uint32) if to_host else None
         L.check(self.lib.gs_tree_gather(self.handle, C.byref(gp), sort_worker.handle if sort_worker is not None else None,
                                         C.byref(count), out.ctypes.data if out is not None else None))

@@ -188,10 +188,14 @@ typedef struct gs_gather_params {
     uint32_t pad;
 } gs_gather_params;
 /* Tests every leaf, orders the kept ones by distance and lays their index lists out far -> near (the nearest leaf
- * ends the buffer), on the device.
+ * ends the buffer), on the device (two launches: a one-workgroup plan, a copy).
  *   dst               sorter whose device-side indexesToSort buffer receives the list (then call
  *                     gs_sorter_sort_gathered), or NULL
- *   render_count      out: splatRenderCount
+ *   render_count      out: splatRenderCount (this waits for the device); or NULL = asynchronous: nothing returns to the host,
+ *                     the count stays on the device next to the list (needs dst, no host copy).  A following
+ *                     gs_sorter_sort_gathered(dst, ..., sort_count >= the tree's splat count) then sorts the whole list
+ *                     without ever learning its length on the host, and gs_mesh_render(..., sorter = dst, render_count =
+ *                     the tree's splat count) draws it: the frame needs no host round trip at all
  *   indexes_out_host  uint32[tree splats] host copy of the list, or NULL */
 int gs_tree_gather(gs_tree* t, const gs_gather_params* params, gs_sorter* dst, uint32_t* render_count,
                    uint32_t* indexes_out_host);

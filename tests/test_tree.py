@@ -252,3 +252,62 @@ def test_gather_then_sort_on_device_matches_reference_pipeline(ctx):
         np.testing.assert_array_equal(reply["sortedIndexes"], expect)
     w.terminate()
     tree.dispose()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frustum_cull", [False, True])
+def test_asynchronous_gather_sorts_and_draws_without_a_host_round_trip(ctx, frustum_cull):
+    """gs_tree_gather(render_count = NULL): splatRenderCount never reaches the host - the plan kernel leaves it on the device,
+    the sort takes the list's length from there, the draw takes the sorted list's length from the sort.  The sorted list
+    (its real length from the sort's statistics) equals the reference sorter on the oracle's gathered list, the frame
+    equals the frame of the synchronous path; with the per-splat frustum cull on top the list is the same one minus the
+    splats the cull drops, and the frame does not change."""
+    import oracle
+    from oracle import tree_oracle
+    import helpers
+    from gaussiansplats3d_amd import SplatMesh, create_sort_worker
+    scene = helpers.small_scene(30000, 1, seed=61)
+    c, n = scene.centers, scene.count
+    ci = util.integer_centers(c)
+    cam = camera.demo_camera("garden", 640, 360)
+    tree = SplatTree(ctx, 8, 200).process_splat_mesh(c)
+    w = create_sort_worker(ctx, n)
+    w.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+    mesh = SplatMesh(ctx, n, 1).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(cam)
+    leaves, _ = tree_oracle.build_tree(c, None, 8, 200)
+    idx = tree_oracle.gather(leaves, cam.view, 50.0, 640, 360)
+    assert 0 < len(idx) < n, "the case should cull something"
+    expect = oracle.sort_indexes(idx, ci, cam.sort_mvp())
+    # synchronous path: the frame to reproduce
+    r = tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False)
+    assert r["splatRenderCount"] == len(idx)
+    w.sort_gathered(cam.sort_mvp(), keep_on_device=True)
+    mesh.use_sorter_result(w, r["splatRenderCount"])
+    want = mesh.render()[0]
+    assert want[..., 3].any()
+    # asynchronous path
+    w.set_frustum_cull(frustum_cull)
+    for _ in range(2):                                       # twice: the device-side tables must be left clean
+        r = tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False, asynchronous=True)
+        assert r["countOnDevice"] and r["splatRenderCount"] == int(tree.info().splats) >= len(idx)
+        w.sort_gathered(cam.sort_mvp(), keep_on_device=True)
+        mesh.use_sorter_result(w, r["splatRenderCount"])
+        got = mesh.render()[0]
+        np.testing.assert_array_equal(got, want)
+    st, _ = w.last_stats()
+    got_list = w.debug_read(2, int(tree.info().splats))[:st.result_count]
+    if frustum_cull:
+        kept_sorted, keep = oracle.culled_sort(idx, ci, cam.sort_mvp())
+        np.testing.assert_array_equal(got_list, kept_sorted)
+        assert st.result_count == int(keep.sum()) < len(idx)
+    else:
+        assert st.result_count == len(idx)
+        np.testing.assert_array_equal(got_list, expect)
+    with pytest.raises(Exception):                           # a partial sort needs splatRenderCount on the host
+        tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False, asynchronous=True)
+        w.sort_gathered(cam.sort_mvp(), 100, keep_on_device=True)
+    w.set_frustum_cull(False)
+    w.terminate()
+    mesh.dispose()
+    tree.dispose()

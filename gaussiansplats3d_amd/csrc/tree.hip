@@ -2,10 +2,13 @@
 //
 //   build   /root/reference/src/splattree/SplatTree.js:132-271 (createSplatTreeWorker: buildSubTree +
 //           processSplatTreeNode), driven by SplatMesh.buildSplatTree (src/splatmesh/SplatMesh.js:231-280: depth 8,
-//           1000 centres per node, alpha filter).  One-off, host side, native C++ (the reference runs it in a Web
-//           Worker).  The arithmetic is the reference's: fp32 centres widened to double, child boxes from
-//           min + (max-min)*0.5 in double, INCLUSIVE containment so a point on a split plane enters several children,
-//           first leaf in depth-first order keeps it, leaves sorted ascending, leaf order = depth-first.
+//           1000 centres per node, alpha filter).  One-off (the reference runs it in a Web Worker).  The arithmetic is the
+//           reference's: fp32 centres widened to double, child boxes from min + (max-min)*0.5 in double, INCLUSIVE
+//           containment so a point on a split plane enters several children, first leaf in depth-first order keeps it,
+//           leaves sorted ascending, leaf order = depth-first.  With a context the build runs ON THE DEVICE, level by level
+//           (tree_build_device below): the kernels only compare centres with split planes and move memberships, every
+//           fp64 box is computed by the same host code as the host builder, so the leaves are the reference's bit for
+//           bit; without a context (or under GSPLAT_TREE_HOST_BUILD=1) the recursive host builder runs.
 //   gather  Viewer.gatherSceneNodesForSort (src/Viewer.js:1969-2077): per leaf, centre -> view space (three.js
 //           Vector3.applyMatrix4 / normalize, fp64, same operation order), keep unless outside fov-0.6 AND farther than
 //           its own diagonal, order kept leaves by distance, lay their index lists out far -> near.  The reference does
@@ -14,8 +17,9 @@
 // Built with -ffp-contract=off: every fp64 product and sum rounds once, like the JS engine's.
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 
-#include "gs_internal.hpp"
+#include "radix.hpp"
 
 // ---------------------------------------------------------------------------------------------------
 // host-side build
@@ -30,6 +34,7 @@ struct gs_tree {
     gs_context* ctx = nullptr;
     uint32_t max_depth = 8, max_centers = 1000;
     uint32_t all_leaves = 0, nodes = 0;
+    bool built_on_device = false;
     double scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     std::vector<TreeLeaf> leaves;          // nodesWithIndexes order
     std::vector<uint32_t> indexes;
@@ -103,6 +108,297 @@ void process_node(BuildCtx& b, const Box& box, uint32_t depth, std::vector<uint3
     }
     std::vector<uint32_t>().swap(list);                                                // node.data = {} :213
     for (int j = 0; j < 8; j++) process_node(b, child[j], depth + 1, lists[j]);        // :214-216
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// device-side build
+// ---------------------------------------------------------------------------------------------------
+// processSplatTreeNode is a recursion over NODES whose only per-point work is "which of the 8 child boxes contain this
+// centre" (inclusive, so possibly several, possibly none: c - half may round above the parent's min).  Level by level, with
+// one MEMBERSHIP (point, node) per list element of the recursion:
+//   k_tree_split   every membership of a node that splits at this level is tested against the node's 9 split planes
+//                  (x0 x1 x2 | y0 y1 y2 | z0 z1 z2, doubles computed on the host by the reference's own expressions) and
+//                  moves to the first child that contains the point; further children get appended memberships, no child
+//                  = the membership dies (the reference drops the point from that subtree too).  Children count their
+//                  list lengths (duplicates included, as `list.size()` does at SplatTree.js:135).
+//   host           reads the 8 * (split nodes) counts, decides leaf / split for the next level (count >= maxCentres and
+//                  depth <= maxDepth), computes the next split planes and child boxes.
+//   k_tree_claim   `addedIndexes` (first leaf VISITED wins, SplatTree.js:136-143): depth-first visiting order of the leaves is
+//                  the order of their child-index paths; every point takes the minimum over its surviving memberships.
+//   radix sort     (final leaf number, point index): stable, so every leaf's list is ascending (SplatTree.js:144-147).
+constexpr uint32_t TREE_DEAD = 0xFFFFFFFFu;
+
+template <bool LDS_COUNTS>
+__global__ __launch_bounds__(256) void k_tree_split(const float* __restrict__ pts, uint32_t* __restrict__ mem_point,
+                                                    uint32_t* __restrict__ mem_node, uint32_t M, uint32_t cap,
+                                                    uint32_t* __restrict__ tail, uint32_t lvl_base, uint32_t lvl_nodes,
+                                                    const uint32_t* __restrict__ lvl_rank, const double* __restrict__ planes,
+                                                    uint32_t child_base, uint32_t* __restrict__ child_count, uint32_t n_child,
+                                                    uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t s_cnt[LDS_COUNTS ? 4096 : 1];
+    if (LDS_COUNTS) {
+        for (uint32_t k = threadIdx.x; k < n_child; k += 256u) s_cnt[k] = 0u;
+        __syncthreads();
+    }
+    for (uint32_t m = blockIdx.x * 256u + threadIdx.x; m < M; m += gridDim.x * 256u) {
+        const uint32_t id = mem_node[m];
+        if (id - lvl_base >= lvl_nodes) continue;             // a final leaf of an earlier level, or dead
+        const uint32_t r = lvl_rank[id - lvl_base];
+        if (r == TREE_DEAD) continue;                         // a leaf of this level
+        const uint32_t i = mem_point[m];
+        const double px = (double)pts[3 * (size_t)i], py = (double)pts[3 * (size_t)i + 1], pz = (double)pts[3 * (size_t)i + 2];
+        const double* pl = planes + 9 * (size_t)r;
+        // Box3.containsPoint, inclusive on both sides; false for NaN
+        const bool xl = px >= pl[0] && px <= pl[1], xh = px >= pl[1] && px <= pl[2];
+        const bool yl = py >= pl[3] && py <= pl[4], yh = py >= pl[4] && py <= pl[5];
+        const bool zl = pz >= pl[6] && pz <= pl[7], zh = pz >= pl[7] && pz <= pl[8];
+        // child order of SplatTree.js:162-182: (x lo, y hi, z lo) (x hi, y hi, z lo) (x hi, y hi, z hi) (x lo, y hi, z hi)
+        //                                       (x lo, y lo, z lo) (x hi, y lo, z lo) (x hi, y lo, z hi) (x lo, y lo, z hi)
+        const bool in[8] = {xl && yh && zl, xh && yh && zl, xh && yh && zh, xl && yh && zh,
+                            xl && yl && zl, xh && yl && zl, xh && yl && zh, xl && yl && zh};
+        bool first = true;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            if (!in[j]) continue;
+            const uint32_t c = 8u * r + j;
+            if (LDS_COUNTS) atomicAdd(&s_cnt[c], 1u);
+            else atomicAdd(&child_count[c], 1u);
+            if (first) {
+                mem_node[m] = child_base + c;
+                first = false;
+            } else {
+                const uint32_t slot = atomicAdd(tail, 1u);
+                if (slot < cap) {
+                    mem_point[slot] = i;
+                    mem_node[slot] = child_base + c;
+                } else {
+                    *overflow = 1u;
+                }
+            }
+        }
+        if (first) mem_node[m] = TREE_DEAD;
+    }
+    if (LDS_COUNTS) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < n_child; k += 256u)
+            if (s_cnt[k]) atomicAdd(&child_count[k], s_cnt[k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tree_root(uint32_t* __restrict__ mem_point, uint32_t* __restrict__ mem_node,
+                                                   const uint32_t* __restrict__ root_list, uint32_t M) {
+    for (uint32_t m = blockIdx.x * 256u + threadIdx.x; m < M; m += gridDim.x * 256u) {
+        mem_point[m] = root_list ? root_list[m] : m;
+        mem_node[m] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tree_claim(const uint32_t* __restrict__ mem_point, const uint32_t* __restrict__ mem_node,
+                                                    uint32_t M, const uint32_t* __restrict__ dfs_rank, uint32_t* __restrict__ best) {
+    for (uint32_t m = blockIdx.x * 256u + threadIdx.x; m < M; m += gridDim.x * 256u) {
+        const uint32_t id = mem_node[m];
+        if (id != TREE_DEAD) atomicMin(&best[mem_point[m]], dfs_rank[id]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tree_claimed_count(const uint32_t* __restrict__ best, uint32_t n, uint32_t* __restrict__ rank_count) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        if (best[i] != TREE_DEAD) atomicAdd(&rank_count[best[i]], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_tree_keys(const uint32_t* __restrict__ best, uint32_t n, const uint32_t* __restrict__ final_of_rank,
+                                                   uint32_t n_final, uint32_t first_index, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        keys[i] = best[i] != TREE_DEAD ? final_of_rank[best[i]] : n_final;     // unclaimed points sort behind the last leaf
+        vals[i] = first_index + i;
+    }
+}
+
+namespace {
+
+struct BuildNode {
+    double mn[3], mx[3];
+    uint32_t depth, count, first_child;        // first_child = global id of child 0, 0 = leaf
+};
+
+inline uint32_t grid_of(uint32_t n) {
+    uint32_t g = (n + 255u) / 256u;
+    return g < 1u ? 1u : (g > 4096u ? 4096u : g);
+}
+
+// returns GS_OK and fills t->leaves / indexes / d_indexes; GS_ERR_CAPACITY when the membership buffer overflowed (a degenerate
+// scene whose points sit on split planes by the million: the caller falls back to the host builder)
+int tree_build_device(gs_tree* t, gs_context* ctx, const float* centers, const std::vector<uint32_t>& root, uint32_t count,
+                      uint32_t first_index) {
+    ScopedDevice sd(ctx->device);
+    hipStream_t st = ctx->stream;
+    const uint32_t M0 = (uint32_t)root.size();
+    const uint64_t cap64 = 2ull * M0 + (1ull << 21);
+    if (cap64 > 0x7FFFFFFFull) return GS_ERR_CAPACITY;
+    const uint32_t cap = (uint32_t)cap64;
+    DevBuf pts, mem_point, mem_node, scalars, lvl_rank, planes, child_count, rank_tab, best, root_dev;
+    GS_TRY(pts.alloc((size_t)count * 12));
+    GS_TRY(mem_point.alloc((size_t)cap * 4));
+    GS_TRY(mem_node.alloc((size_t)cap * 4));
+    GS_TRY(scalars.alloc(64));                                // [0] tail, [1] overflow
+    GS_HIP(hipMemcpyAsync(pts.p, centers, (size_t)count * 12, hipMemcpyHostToDevice, st));
+    const bool filtered = M0 != count;
+    if (filtered) {
+        GS_TRY(root_dev.alloc((size_t)M0 * 4));
+        GS_HIP(hipMemcpyAsync(root_dev.p, root.data(), (size_t)M0 * 4, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_tree_root, dim3(grid_of(M0)), dim3(256), 0, st, mem_point.as<uint32_t>(), mem_node.as<uint32_t>(),
+                       filtered ? root_dev.as<uint32_t>() : nullptr, M0);
+    uint32_t init[2] = {M0, 0u};
+    GS_HIP(hipMemcpyAsync(scalars.p, init, 8, hipMemcpyHostToDevice, st));
+
+    std::vector<BuildNode> nodes(1);
+    for (int k = 0; k < 3; k++) { nodes[0].mn[k] = t->scene_min[k]; nodes[0].mx[k] = t->scene_max[k]; }
+    nodes[0].depth = 0; nodes[0].count = M0; nodes[0].first_child = 0;
+    uint32_t lvl_base = 0, lvl_nodes = 1, M = M0;
+    std::vector<uint32_t> rank_host, counts_host;
+    std::vector<double> planes_host;
+    for (;;) {
+        // which nodes of this level split (SplatTree.js:135), their planes and children (:152-182)
+        rank_host.assign(lvl_nodes, TREE_DEAD);
+        planes_host.clear();
+        uint32_t n_split = 0;
+        const uint32_t child_base = lvl_base + lvl_nodes;
+        for (uint32_t k = 0; k < lvl_nodes; k++) {
+            BuildNode nd = nodes[lvl_base + k];               // by value: `nodes` grows below
+            if (nd.count < t->max_centers || nd.depth > t->max_depth) continue;
+            rank_host[k] = n_split;
+            double dim[3], half[3], c[3];
+            for (int a = 0; a < 3; a++) {
+                dim[a] = nd.mx[a] - nd.mn[a];
+                half[a] = dim[a] * 0.5;
+                c[a] = nd.mn[a] + half[a];
+            }
+            double pl[9];
+            for (int a = 0; a < 3; a++) { pl[3 * a] = c[a] - half[a]; pl[3 * a + 1] = c[a]; pl[3 * a + 2] = c[a] + half[a]; }
+            planes_host.insert(planes_host.end(), pl, pl + 9);
+            nodes[lvl_base + k].first_child = child_base + 8u * n_split;
+            static const int sel[8][3] = {{0, 1, 0}, {1, 1, 0}, {1, 1, 1}, {0, 1, 1}, {0, 0, 0}, {1, 0, 0}, {1, 0, 1}, {0, 0, 1}};
+            for (int j = 0; j < 8; j++) {
+                BuildNode ch;
+                for (int a = 0; a < 3; a++) { ch.mn[a] = pl[3 * a + sel[j][a]]; ch.mx[a] = pl[3 * a + sel[j][a] + 1]; }
+                ch.depth = nd.depth + 1; ch.count = 0; ch.first_child = 0;
+                nodes.push_back(ch);
+            }
+            n_split++;
+        }
+        if (n_split == 0) break;
+        const uint32_t n_child = 8u * n_split;
+        GS_TRY(lvl_rank.ensure((size_t)lvl_nodes * 4));
+        GS_TRY(planes.ensure((size_t)n_split * 72));
+        GS_TRY(child_count.ensure((size_t)n_child * 4));
+        GS_HIP(hipMemcpyAsync(lvl_rank.p, rank_host.data(), (size_t)lvl_nodes * 4, hipMemcpyHostToDevice, st));
+        GS_HIP(hipMemcpyAsync(planes.p, planes_host.data(), (size_t)n_split * 72, hipMemcpyHostToDevice, st));
+        GS_HIP(hipMemsetAsync(child_count.p, 0, (size_t)n_child * 4, st));
+        if (n_child <= 4096u)      // few, hot counters: per-workgroup LDS histograms (5.8 M atomics on 8 addresses would serialise)
+            hipLaunchKernelGGL(k_tree_split<true>, dim3(grid_of(M)), dim3(256), 0, st, pts.as<float>(), mem_point.as<uint32_t>(),
+                               mem_node.as<uint32_t>(), M, cap, scalars.as<uint32_t>(), lvl_base, lvl_nodes, lvl_rank.as<uint32_t>(),
+                               planes.as<double>(), child_base, child_count.as<uint32_t>(), n_child, scalars.as<uint32_t>() + 1);
+        else
+            hipLaunchKernelGGL(k_tree_split<false>, dim3(grid_of(M)), dim3(256), 0, st, pts.as<float>(), mem_point.as<uint32_t>(),
+                               mem_node.as<uint32_t>(), M, cap, scalars.as<uint32_t>(), lvl_base, lvl_nodes, lvl_rank.as<uint32_t>(),
+                               planes.as<double>(), child_base, child_count.as<uint32_t>(), n_child, scalars.as<uint32_t>() + 1);
+        GS_HIP(hipGetLastError());
+        counts_host.resize(n_child);
+        uint32_t sc[2];
+        GS_HIP(hipMemcpyAsync(counts_host.data(), child_count.p, (size_t)n_child * 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipMemcpyAsync(sc, scalars.p, 8, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (sc[1]) return GS_ERR_CAPACITY;
+        M = sc[0];
+        for (uint32_t k = 0; k < n_child; k++) nodes[child_base + k].count = counts_host[k];
+        lvl_base = child_base;
+        lvl_nodes = n_child;
+    }
+    // depth-first visiting order of the leaf nodes = processSplatTreeNode's recursion order (children 0..7)
+    const uint32_t n_nodes = (uint32_t)nodes.size();
+    std::vector<uint32_t> dfs_rank(n_nodes, TREE_DEAD), leaf_ids;
+    {
+        std::vector<uint32_t> stack(1, 0u);
+        while (!stack.empty()) {
+            const uint32_t id = stack.back();
+            stack.pop_back();
+            if (nodes[id].first_child == 0) {
+                dfs_rank[id] = (uint32_t)leaf_ids.size();
+                leaf_ids.push_back(id);
+            } else {
+                for (int j = 7; j >= 0; j--) stack.push_back(nodes[id].first_child + (uint32_t)j);
+            }
+        }
+    }
+    const uint32_t n_leaf_nodes = (uint32_t)leaf_ids.size();
+    t->nodes = n_nodes;
+    t->all_leaves = n_leaf_nodes;
+    // first visitor wins, then the claimed points per leaf
+    GS_TRY(rank_tab.alloc((size_t)n_nodes * 4));
+    GS_TRY(best.alloc((size_t)count * 4));
+    GS_TRY(child_count.ensure((size_t)n_leaf_nodes * 4));
+    GS_HIP(hipMemcpyAsync(rank_tab.p, dfs_rank.data(), (size_t)n_nodes * 4, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemsetAsync(best.p, 0xFF, (size_t)count * 4, st));
+    GS_HIP(hipMemsetAsync(child_count.p, 0, (size_t)n_leaf_nodes * 4, st));
+    hipLaunchKernelGGL(k_tree_claim, dim3(grid_of(M)), dim3(256), 0, st, mem_point.as<uint32_t>(), mem_node.as<uint32_t>(), M,
+                       rank_tab.as<uint32_t>(), best.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_claimed_count, dim3(grid_of(count)), dim3(256), 0, st, best.as<uint32_t>(), count, child_count.as<uint32_t>());
+    GS_HIP(hipGetLastError());
+    std::vector<uint32_t> claimed(n_leaf_nodes);
+    GS_HIP(hipMemcpyAsync(claimed.data(), child_count.p, (size_t)n_leaf_nodes * 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    // the leaves that keep at least one index (convertWorkerSubTree), in visiting order
+    std::vector<uint32_t> final_of_rank(n_leaf_nodes, 0u);
+    t->leaves.clear();
+    uint32_t total = 0;
+    for (uint32_t r = 0; r < n_leaf_nodes; r++) {
+        final_of_rank[r] = (uint32_t)t->leaves.size();
+        if (claimed[r] == 0) continue;
+        const BuildNode& nd = nodes[leaf_ids[r]];
+        TreeLeaf leaf;
+        for (int k = 0; k < 3; k++) {
+            leaf.mn[k] = nd.mn[k];
+            leaf.mx[k] = nd.mx[k];
+            leaf.center[k] = (nd.mx[k] - nd.mn[k]) * 0.5 + nd.mn[k];                // WorkerSplatTreeNode :121-123
+        }
+        leaf.depth = nd.depth;
+        leaf.begin = total;
+        leaf.count = claimed[r];
+        total += claimed[r];
+        t->leaves.push_back(leaf);
+    }
+    const uint32_t n_final = (uint32_t)t->leaves.size();
+    t->indexes.assign(total, 0u);
+    if (total == 0) return GS_OK;
+    // stable sort of (final leaf number, ascending point index): the leaves' index lists, concatenated in leaf order
+    DevBuf kA, kB, vA, vB;
+    RadixScratch scratch;
+    GS_TRY(scratch.init());
+    GS_TRY(kA.alloc((size_t)count * 4)); GS_TRY(kB.alloc((size_t)count * 4));
+    GS_TRY(vA.alloc((size_t)count * 4)); GS_TRY(vB.alloc((size_t)count * 4));
+    GS_HIP(hipMemcpyAsync(rank_tab.p, final_of_rank.data(), (size_t)n_leaf_nodes * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tree_keys, dim3(grid_of(count)), dim3(256), 0, st, best.as<uint32_t>(), count, rank_tab.as<uint32_t>(), n_final,
+                       first_index, kA.as<uint32_t>(), vA.as<uint32_t>());
+    GS_HIP(hipMemsetAsync(scratch.digit_total.p, 0, sizeof(uint32_t) * RADIX_TOTAL_WORDS, st));
+    uint32_t bits = 1;
+    while ((1ull << bits) <= n_final) bits++;                 // keys 0 .. n_final
+    const uint32_t passes = (bits + 7) / 8;
+    uint32_t* kbuf[2] = {kA.as<uint32_t>(), kB.as<uint32_t>()};
+    uint32_t* vbuf[2] = {vA.as<uint32_t>(), vB.as<uint32_t>()};
+    const RadixExec ex = {st, &scratch, ctx->lds_atomic_lane_order};
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        ArrayLoader<uint32_t> al = {kbuf[pass & 1], vbuf[pass & 1], nullptr, count};
+        GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ex, al, al, count, 8 * (int)pass, (int)pass, kbuf[(pass + 1) & 1],
+                                                                 vbuf[(pass + 1) & 1])));
+    }
+    GS_TRY(t->d_indexes.alloc(4 * (size_t)total + 4));
+    GS_HIP(hipMemcpyAsync(t->d_indexes.p, vbuf[passes & 1], (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+    GS_HIP(hipMemcpyAsync(t->indexes.data(), vbuf[passes & 1], (size_t)total * 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
 }
 
 }  // namespace
@@ -331,13 +627,28 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
             first = false;
             root.push_back(i);
         }
-        BuildCtx b = {centers, first_index, max_depth, max_centers_per_node, std::vector<uint8_t>(count, 0), t};
-        Box box;
-        for (int k = 0; k < 3; k++) {
-            box.mn[k] = t->scene_min[k];
-            box.mx[k] = t->scene_max[k];
+        // with a context: level-synchronous build on the device (same leaves, see tree_build_device); the recursive host
+        // builder serves host-only trees, empty inputs and the degenerate case of a membership buffer that overflows
+        int dev = GS_ERR_CAPACITY;
+        if (ctx && !root.empty() && !getenv("GSPLAT_TREE_HOST_BUILD")) {
+            dev = tree_build_device(t, ctx, centers, root, count, first_index);
+            if (dev < 0 && dev != GS_ERR_CAPACITY) {
+                delete t;
+                return dev;
+            }
         }
-        process_node(b, box, 0, root);
+        t->built_on_device = dev == GS_OK;
+        if (!t->built_on_device) {
+            t->leaves.clear(); t->indexes.clear();
+            t->nodes = t->all_leaves = 0;
+            BuildCtx b = {centers, first_index, max_depth, max_centers_per_node, std::vector<uint8_t>(count, 0), t};
+            Box box;
+            for (int k = 0; k < 3; k++) {
+                box.mn[k] = t->scene_min[k];
+                box.mx[k] = t->scene_max[k];
+            }
+            process_node(b, box, 0, root);
+        }
     } catch (const std::bad_alloc&) {
         delete t;
         gs_set_error("out of host memory while building the splat tree");
@@ -360,7 +671,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         int st = GS_OK;
         auto A = [&](DevBuf& buf, size_t bytes) { if (st == GS_OK) st = buf.alloc(bytes); };
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
-        A(t->d_indexes, 4 * t->indexes.size() + 4);
+        if (!t->built_on_device) A(t->d_indexes, 4 * t->indexes.size() + 4);      // the device build left them there
         A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
         A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4); A(t->d_total, 16);
         if (st != GS_OK) {
@@ -373,7 +684,8 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
             if (e == hipSuccess && bytes) e = hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, s);
         };
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
-        UP(t->d_count, cnt.data(), 4 * L); UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
+        UP(t->d_count, cnt.data(), 4 * L);
+        if (!t->built_on_device) UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
         if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // k_tree_plan keeps them zero
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {

@@ -311,3 +311,45 @@ def test_asynchronous_gather_sorts_and_draws_without_a_host_round_trip(ctx, frus
     w.terminate()
     mesh.dispose()
     tree.dispose()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", tree_cases.CASES)
+def test_device_builder_matches_the_reference_tree(ctx, name):
+    """gs_tree_create with a context builds the octree ON THE DEVICE (level-synchronous memberships, first-visitor claim,
+    stable sort): the same leaves as the reference's createSplatTreeWorker, bit for bit - bounds, centres, depths, index
+    lists, order, node and leaf counts (tests/golden/tree_kat.json), including centres on split planes (memberships in
+    several children), the depth limit and the 32768-leaf degenerate tree."""
+    case = tree_cases.make_case(name)
+    g = GOLD[name]
+    tree = SplatTree(ctx, case["max_depth"], case["max_centers"]).process_splat_mesh(case["centers"])
+    info = tree.info()
+    assert (info.leaves, info.all_leaves, info.splats) == (g["leaves"], g["all_leaves"], g["splats"])
+    assert _digest(_native_leaves(tree)) == g["sha256"]
+    tree.dispose()
+
+
+@pytest.mark.gpu
+def test_device_builder_equals_the_host_builder_on_a_large_filtered_scene(ctx, monkeypatch):
+    """300 k clustered centres, an alpha filter and a first_index: device build == host build (GSPLAT_TREE_HOST_BUILD=1),
+    every field; and the device gather works on the device-built tree."""
+    rng = np.random.default_rng(77)
+    k = rng.uniform(-4, 4, size=(200, 3))
+    c = (k[rng.integers(0, 200, 300000)] + rng.normal(size=(300000, 3)) * 0.15).astype(np.float32)
+    c[::1000] = np.round(c[::1000])                          # some centres on coarse planes
+    alphas = rng.integers(0, 256, 300000).astype(np.uint8)
+    dev = SplatTree(ctx, 8, 1000).process_splat_mesh(c, alphas=alphas, min_alpha=40, first_index=1234)
+    monkeypatch.setenv("GSPLAT_TREE_HOST_BUILD", "1")
+    host = SplatTree(ctx, 8, 1000).process_splat_mesh(c, alphas=alphas, min_alpha=40, first_index=1234)
+    monkeypatch.delenv("GSPLAT_TREE_HOST_BUILD")
+    a, b = dev.info(), host.info()
+    assert (a.leaves, a.all_leaves, a.nodes, a.splats) == (b.leaves, b.all_leaves, b.nodes, b.splats) and a.leaves > 100
+    for x, y in zip(dev.leaves(), host.leaves()):
+        np.testing.assert_array_equal(x, y)
+    cam = camera.demo_camera("garden", 1920, 1080)
+    ga = dev.gather_scene_nodes_for_sort(cam)
+    gb = host.gather_scene_nodes_for_sort(cam)
+    assert ga["splatRenderCount"] == gb["splatRenderCount"] > 0
+    np.testing.assert_array_equal(ga["indexesToSort"], gb["indexesToSort"])
+    dev.dispose()
+    host.dispose()

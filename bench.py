@@ -660,7 +660,7 @@ def main():
                         "ms_per_frame": round(cull_ms, 4), "max_abs_diff_vs_cull_off_frame_u8": cull_diff,
                         "Msplats_per_s_scene": round(N / (cull_ms * 1e-3) / 1e6, 1),
                         "Msplats_per_s_rendered": round(Rc / (cull_ms * 1e-3) / 1e6, 1), "tree_build_s": round(t_tree, 2),
-                        "note": "asynchronous gather (2 launches, no host round trip) + sort with the per-splat frustum cull on top "
+                        "note": "asynchronous gather (6 small launches, no memset, no host round trip) + sort with the per-splat frustum cull on top "
                                 "+ draw; render_count = R kept by the reference's leaf test, scene = all N splats per frame"}
                 tree.dispose()
                 mesh.use_sorter_result(worker, N)

@@ -556,9 +556,11 @@ __global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __
     }
 }
 
+// (positions beyond a culled / gathered result's length hold stale words: clamped, so a caller that reads too far gets
+// garbage indexes, never a fault)
 __global__ void k_unmap(const uint32_t* __restrict__ in, const uint32_t* __restrict__ unmap, uint32_t* __restrict__ out,
-                        uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = unmap[in[i]];
+                        uint32_t n, uint32_t last) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = unmap[min(in[i], last)];
 }
 
 __global__ void k_debug_buckets(DepthLoader ld, int32_t* out) {
@@ -901,7 +903,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         if (unmap) {                               // the host always sees the caller's splat indexes
             GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
             hipLaunchKernelGGL(k_unmap, dim3(grid_for(out_count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(), unmap,
-                               s->debug.as<uint32_t>(), out_count);
+                               s->debug.as<uint32_t>(), out_count, s->uploaded - 1u);
             GS_HIP(hipGetLastError());
             src = s->debug.p;
         }
@@ -976,7 +978,7 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
         if (alive && s->result_unmap && count) {
             GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
             hipLaunchKernelGGL(k_unmap, dim3(grid_for(count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(),
-                               s->result_unmap, s->debug.as<uint32_t>(), count);
+                               s->result_unmap, s->debug.as<uint32_t>(), count, s->uploaded ? s->uploaded - 1u : 0u);
             GS_HIP(hipGetLastError());
             src = s->debug.p;
         }

@@ -440,104 +440,112 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
     return skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;         // +inf: the leaf takes no part in the ranking
 }
 
-// The whole plan of a gather in ONE workgroup (r02: six launches + two memsets, ~0.22 ms of launch-bound kernels for 26 k
-// leaves): node test -> bucket histogram -> scan -> bucket fill -> exact rank -> suffix offsets, phases separated by
-// workgroup barriers (one workgroup = one L1, so its own global writes are visible to it after a barrier).
 // Rank of a leaf in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2); instead the leaves are
 // bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa bits, i.e. 0.8 % wide
 // buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number - only against the
 // members of its own bucket.  The result is the same total order; only the work is smaller.
-// offset[r] = total - inclusive_prefix(counts by rank)[r]: the nearest leaf, r = 0, ends the buffer (Viewer.js:2046-2055
-// copies from the END backwards).  `hist` / `fill` are zero on entry and are left zero; kept_out = ranked (kept) leaves.
-constexpr uint32_t PLAN_THREADS = 1024;
-__global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, const double* __restrict__ center,
-                                                            const double* __restrict__ size, const uint32_t* __restrict__ count,
-                                                            unsigned long long* __restrict__ key, uint32_t* __restrict__ hist,
-                                                            uint32_t* __restrict__ fill, uint32_t* __restrict__ start,
-                                                            uint32_t* __restrict__ members, uint32_t* __restrict__ sorted_cnt,
-                                                            uint32_t* __restrict__ sorted_leaf, uint32_t* __restrict__ offset,
-                                                            uint32_t* __restrict__ totals /* {splats, kept leaves} */,
-                                                            uint32_t* __restrict__ count_out /* nullable: the sorter's copy */) {
+// Six small launches per gather, no memset and no host round trip: `hist` and `fill` are zero between gathers (whoever
+// reads a counter last zeroes it).  (Tried in r03: the whole plan in ONE workgroup of 1024 threads - two launches per
+// gather - was 1.3 ms: 26 k leaves x ~55 bucket members are a serial chain of dependent L2 loads per thread, and one
+// workgroup has 1024 of them in flight where the grid has 26 k.)
+__global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double* __restrict__ center,
+                                                   const double* __restrict__ size, unsigned long long* __restrict__ key,
+                                                   uint32_t* __restrict__ bucket_hist) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.leaves) return;
+    const double k = tree_leaf_key(p, center[3 * (size_t)i], center[3 * (size_t)i + 1], center[3 * (size_t)i + 2], size[i]);
+    const unsigned long long kb = (unsigned long long)__double_as_longlong(k);       // non-negative doubles order like their bits
+    key[i] = kb;
+    if (kb != 0x7FF0000000000000ull) atomicAdd(&bucket_hist[tree_bucket(k)], 1u);   // culled leaves take no part in the ranking
+}
+
+// one workgroup: exclusive scan of the bucket histogram (thread t owns 64 consecutive buckets); the histogram is handed
+// back zeroed
+__global__ __launch_bounds__(1024) void k_tree_bucket_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+    __shared__ uint32_t s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t CH = TREE_BUCKETS / 1024u;
+    uint32_t v[CH], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CH; k += 4) {
+        uint4* hp = reinterpret_cast<uint4*>(hist + tid * CH + k);
+        const uint4 q = *hp;
+        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        sum += q.x + q.y + q.z + q.w;
+        if (q.x | q.y | q.z | q.w) *hp = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < CH; k++) {
+        start[tid * CH + k] = run;
+        run += v[k];
+    }
+    if (tid == 1023u) start[TREE_BUCKETS] = run;             // = the number of kept leaves
+}
+
+__global__ __launch_bounds__(256) void k_tree_fill(const unsigned long long* __restrict__ key, uint32_t n, const uint32_t* __restrict__ start,
+                                                   uint32_t* __restrict__ fill, uint32_t* __restrict__ members) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long kb = key[i];
+    if (kb == 0x7FF0000000000000ull) return;               // culled
+    const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
+    members[start[b] + atomicAdd(&fill[b], 1u)] = i;       // order inside a bucket is arbitrary: the rank below is exact
+}
+
+// exact rank inside the bucket -> the leaf and its count at their rank.  The bucket's members are read eight at a time (two
+// rounds of independent loads instead of a chain of 2 x members dependent ones); the fill counters are handed back zeroed.
+__global__ __launch_bounds__(256) void k_tree_rank_place(const unsigned long long* __restrict__ key, uint32_t n,
+                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ members,
+                                                         uint32_t* __restrict__ fill, const uint32_t* __restrict__ count,
+                                                         uint32_t* __restrict__ sorted_cnt, uint32_t* __restrict__ sorted_leaf) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long mine = key[i];
+    if (mine == 0x7FF0000000000000ull) return;             // culled: has no rank
+    const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
+    const uint32_t lo = start[b], hi = start[b + 1];
+    uint32_t r = lo;
+    for (uint32_t q = lo; q < hi; q += 8u) {
+        uint32_t m[8];
+        unsigned long long k[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) m[j] = q + j < hi ? members[q + j] : i;      // padding = the leaf itself: counts 0
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) k[j] = key[m[j]];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) r += (k[j] < mine || (k[j] == mine && m[j] < i)) ? 1u : 0u;
+    }
+    sorted_cnt[r] = count[i];
+    sorted_leaf[r] = i;
+    fill[b] = 0u;                                          // (every member writes the same value; nobody reads it in this kernel)
+}
+
+// one workgroup: offset[r] = total - inclusive_prefix(counts by rank)[r] over the kept ranks (the nearest leaf, r = 0, ends
+// the buffer: Viewer.js:2046-2055 copies from the END backwards).  Thread t owns CH consecutive ranks per round.
+// totals = {splats gathered, leaves kept}; count_out = the sorter's own copy of splatRenderCount (nullable).
+__global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restrict__ sorted_cnt, const uint32_t* __restrict__ start,
+                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ totals,
+                                                       uint32_t* __restrict__ count_out) {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t L = p.leaves;
-    const unsigned long long INF = 0x7FF0000000000000ull;
-    // 1. test every leaf, count the kept ones per bucket
-    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
-        const double k = tree_leaf_key(p, center[3 * (size_t)i], center[3 * (size_t)i + 1], center[3 * (size_t)i + 2], size[i]);
-        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);   // non-negative doubles order like their bits
-        key[i] = kb;
-        if (kb != INF) atomicAdd(&hist[tree_bucket(k)], 1u);
-    }
-    __syncthreads();
-    // 2. exclusive scan of the histogram (thread t owns 64 consecutive buckets); the histogram is handed back zeroed
-    {
-        constexpr uint32_t CH = TREE_BUCKETS / PLAN_THREADS;
-        uint32_t v[CH], sum = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < CH; k += 4) {
-            uint4* hp = reinterpret_cast<uint4*>(hist + tid * CH + k);
-            const uint4 q = *hp;
-            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
-            sum += q.x + q.y + q.z + q.w;
-            if (q.x | q.y | q.z | q.w) *hp = make_uint4(0u, 0u, 0u, 0u);
-        }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += t;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < CH; k++) {
-            start[tid * CH + k] = run;
-            run += v[k];
-        }
-        if (tid == PLAN_THREADS - 1u) start[TREE_BUCKETS] = run;
-    }
-    __syncthreads();
-    const uint32_t K = start[TREE_BUCKETS];                  // kept leaves
-    // 3. members of every bucket (order inside a bucket is arbitrary: the rank below is exact)
-    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
-        const unsigned long long kb = key[i];
-        if (kb == INF) continue;
-        const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
-        members[start[b] + atomicAdd(&fill[b], 1u)] = i;
-    }
-    __syncthreads();
-    // 4. exact rank inside the bucket -> the leaf and its count at their rank; the fill counters are handed back zeroed
-    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
-        const unsigned long long mine = key[i];
-        if (mine == INF) continue;
-        const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
-        const uint32_t lo = start[b], hi = start[b + 1];
-        uint32_t r = lo;
-        for (uint32_t q = lo; q < hi; q++) {
-            const uint32_t m = members[q];
-            const unsigned long long k = key[m];
-            r += (k < mine || (k == mine && m < i)) ? 1u : 0u;
-        }
-        sorted_cnt[r] = count[i];
-        sorted_leaf[r] = i;
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < L; i += PLAN_THREADS) {
-        const unsigned long long kb = key[i];
-        if (kb != INF) fill[tree_bucket(__longlong_as_double((long long)kb))] = 0u;      // same value from every member
-    }
-    // 5. total and suffix offsets over the K ranks; thread t owns CH consecutive ranks per round
-    constexpr uint32_t CH = 16;
+    const uint32_t K = start[TREE_BUCKETS];
+    constexpr uint32_t CH = 16;                            // values per thread and round, all loads in flight together
     uint32_t sum = 0;
-    for (uint32_t i = tid; i < K; i += PLAN_THREADS) sum += sorted_cnt[i];
+    for (uint32_t i = tid; i < K; i += 1024u) sum += sorted_cnt[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    __syncthreads();                                         // s_wave of the scan above consumed
     if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
     uint32_t total = 0;
@@ -549,7 +557,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, cons
         if (count_out) *count_out = total;
         s_carry = 0;
     }
-    for (uint32_t base = 0; base < K; base += PLAN_THREADS * CH) {
+    for (uint32_t base = 0; base < K; base += 1024u * CH) {
         const uint32_t b = base + tid * CH;
         uint32_t v[CH];
 #pragma unroll
@@ -686,7 +694,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
         UP(t->d_count, cnt.data(), 4 * L);
         if (!t->built_on_device) UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
-        if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // k_tree_plan keeps them zero
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // the gather kernels keep them zero
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
             gs_set_error("uploading the splat tree failed: %s", hipGetErrorString(e));
@@ -775,15 +783,20 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     uint32_t* bhist = t->d_bucket.as<uint32_t>();
     uint32_t* bfill = bhist + TREE_BUCKETS;
     uint32_t* bstart = bfill + TREE_BUCKETS;
-    // two launches: the plan (one workgroup) and the copy; the sorter gets the list's length on the device as well
+    // the sorter gets the list's length on the device as well
     uint32_t* count_dev = nullptr;
     if (dst) {
         GS_TRY(dst->gathered_dev.ensure(16));
         count_dev = dst->gathered_dev.as<uint32_t>();
     }
-    hipLaunchKernelGGL(k_tree_plan, dim3(1), dim3(PLAN_THREADS), 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(),
-                       t->d_count.as<uint32_t>(), t->d_key.as<unsigned long long>(), bhist, bfill, bstart, t->d_rank.as<uint32_t>(),
-                       t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>(), t->d_offset.as<uint32_t>(),
+    const dim3 g((L + 255u) / 256u), b(256);
+    unsigned long long* key = t->d_key.as<unsigned long long>();
+    hipLaunchKernelGGL(k_tree_test, g, b, 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(), key, bhist);
+    hipLaunchKernelGGL(k_tree_bucket_scan, dim3(1), dim3(1024), 0, st, bhist, bstart);
+    hipLaunchKernelGGL(k_tree_fill, g, b, 0, st, key, L, bstart, bfill, t->d_rank.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_rank_place, g, b, 0, st, key, L, bstart, t->d_rank.as<uint32_t>(), bfill, t->d_count.as<uint32_t>(),
+                       t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
+    hipLaunchKernelGGL(k_tree_offsets, dim3(1), dim3(1024), 0, st, t->d_sorted_cnt.as<uint32_t>(), bstart, t->d_offset.as<uint32_t>(),
                        t->d_total.as<uint32_t>(), count_dev);
     const uint32_t copy_grid = (L + COPY_WAVES - 1u) / COPY_WAVES;
     hipLaunchKernelGGL(k_tree_copy, dim3(copy_grid < 8192u ? copy_grid : 8192u), dim3(64 * COPY_WAVES), 0, st, t->d_total.as<uint32_t>(),

@@ -296,7 +296,7 @@ def test_asynchronous_gather_sorts_and_draws_without_a_host_round_trip(ctx, frus
         got = mesh.render()[0]
         np.testing.assert_array_equal(got, want)
     st, _ = w.last_stats()
-    got_list = w.debug_read(2, int(tree.info().splats))[:st.result_count]
+    got_list = w.debug_read(2, int(st.result_count))       # (positions beyond the result's length are undefined)
     if frustum_cull:
         kept_sorted, keep = oracle.culled_sort(idx, ci, cam.sort_mvp())
         np.testing.assert_array_equal(got_list, kept_sorted)

@@ -422,7 +422,8 @@ static napi_value MeshUploadShU8(napi_env env, napi_callback_info info) {
     if (!get_bytes(env, argv[3], &p, &b) || !p) { napi_throw_type_error(env, NULL, "meshUploadShU8: bad buffer"); return NULL; }
     const uint32_t count = get_u32(env, argv[2]);
     if (b < (size_t)count * 9) { napi_throw_range_error(env, NULL, "meshUploadShU8: buffer shorter than count"); return NULL; }
-    int st = gs_mesh_upload_sh_u8((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint8_t*)p);
+    int st;
+    LOCKED(st = gs_mesh_upload_sh_u8((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1]), count, (const uint8_t*)p));
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
@@ -628,6 +629,35 @@ static napi_value TreeInfo(napi_env env, napi_callback_info info) {
     set(env, r, "splats", ti.splats);
     return r;
 }
+/* treeRead(tree) -> {bounds Float64Array(6L) = min xyz | max xyz, centers Float64Array(3L), depths Uint32Array(L),
+ *                    offsets Uint32Array(L+1), indexes Uint32Array(S)}: the leaves in nodesWithIndexes order (gs_tree_read) */
+static napi_value TreeRead(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    gs_tree* t = (gs_tree*)get_external(env, argv[0]);
+    gs_tree_info ti;
+    int st;
+    LOCKED(st = gs_tree_get_info(t, &ti));
+    if (st < 0) return throw_gs(env, st);
+    const size_t L = ti.leaves, S = ti.splats;
+    void *bnd, *ctr, *dep, *off, *idx;
+    napi_value ab[5], ta[5], r;
+    NAPI_OK(napi_create_arraybuffer(env, 48 * L, &bnd, &ab[0]));
+    NAPI_OK(napi_create_arraybuffer(env, 24 * L, &ctr, &ab[1]));
+    NAPI_OK(napi_create_arraybuffer(env, 4 * L, &dep, &ab[2]));
+    NAPI_OK(napi_create_arraybuffer(env, 4 * (L + 1), &off, &ab[3]));
+    NAPI_OK(napi_create_arraybuffer(env, 4 * S, &idx, &ab[4]));
+    LOCKED(st = gs_tree_read(t, (double*)bnd, (double*)ctr, (uint32_t*)dep, (uint32_t*)off, (uint32_t*)idx));
+    if (st < 0) return throw_gs(env, st);
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, 6 * L, ab[0], 0, &ta[0]));
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, 3 * L, ab[1], 0, &ta[1]));
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, L, ab[2], 0, &ta[2]));
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, L + 1, ab[3], 0, &ta[3]));
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, S, ab[4], 0, &ta[4]));
+    NAPI_OK(napi_create_object(env, &r));
+    static const char* names[5] = {"bounds", "centers", "depths", "offsets", "indexes"};
+    for (int k = 0; k < 5; k++) NAPI_OK(napi_set_named_property(env, r, names[k], ta[k]));
+    return r;
+}
 /* treeGather(tree, modelView Float64Array(16), fovYDeg, renderWidth, renderHeight, gatherAll, sorter|null,
  *            out Uint32Array|null) -> splatRenderCount */
 static napi_value TreeGather(napi_env env, napi_callback_info info) {
@@ -711,7 +741,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"meshUploadSceneIndexes", MeshUploadSceneIndexes},                   {"meshSetScenes", MeshSetScenes},
         {"sorterBindMesh", SorterBindMesh}, {"sorterSetFrustumCull", SorterSetFrustumCull}, {"sorterSortGathered", SorterSortGathered},
         {"treeCreate", TreeCreate},         {"treeDestroy", TreeDestroy},     {"treeInfo", TreeInfo},
-        {"treeGather", TreeGather},         {"assetLoad", AssetLoad},
+        {"treeGather", TreeGather},         {"treeRead", TreeRead},         {"assetLoad", AssetLoad},
         {"meshProject", MeshProject},       {"sorterSetVisibilityCull", SorterSetVisibilityCull},
         {"groupUniqueId", GroupUniqueId},   {"groupCreate", GroupCreate},     {"groupDestroy", GroupDestroy},
         {"groupRenderGather", GroupRenderGather},

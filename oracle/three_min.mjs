@@ -81,6 +81,7 @@ export class Quaternion {
   set(x, y, z, w) { this._x = x; this._y = y; this._z = z; this._w = w; return this; }
   clone() { return new Quaternion(this._x, this._y, this._z, this._w); }
   copy(q) { this._x = q.x; this._y = q.y; this._z = q.z; this._w = q.w; return this; }
+  fromArray(array, offset = 0) { this._x = array[offset]; this._y = array[offset + 1]; this._z = array[offset + 2]; this._w = array[offset + 3]; return this; }
   length() { return Math.sqrt(this._x * this._x + this._y * this._y + this._z * this._z + this._w * this._w); }
   normalize() {
     let l = this.length();

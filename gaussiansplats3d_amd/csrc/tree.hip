@@ -35,6 +35,7 @@ struct gs_tree {
     uint32_t max_depth = 8, max_centers = 1000;
     uint32_t all_leaves = 0, nodes = 0;
     bool built_on_device = false;
+    uint32_t barrier_epoch = 0;     // launches of k_tree_plan so far (its grid barriers count arrivals on one monotonic word)
     double scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     std::vector<TreeLeaf> leaves;          // nodesWithIndexes order
     std::vector<uint32_t> indexes;
@@ -444,151 +445,147 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
 // bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa bits, i.e. 0.8 % wide
 // buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number - only against the
 // members of its own bucket.  The result is the same total order; only the work is smaller.
-// Six small launches per gather, no memset and no host round trip: `hist` and `fill` are zero between gathers (whoever
-// reads a counter last zeroes it).  (Tried in r03: the whole plan in ONE workgroup of 1024 threads - two launches per
-// gather - was 1.3 ms: 26 k leaves x ~55 bucket members are a serial chain of dependent L2 loads per thread, and one
-// workgroup has 1024 of them in flight where the grid has 26 k.)
-__global__ __launch_bounds__(256) void k_tree_test(GatherParams p, const double* __restrict__ center,
-                                                   const double* __restrict__ size, unsigned long long* __restrict__ key,
-                                                   uint32_t* __restrict__ bucket_hist) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= p.leaves) return;
-    const double k = tree_leaf_key(p, center[3 * (size_t)i], center[3 * (size_t)i + 1], center[3 * (size_t)i + 2], size[i]);
-    const unsigned long long kb = (unsigned long long)__double_as_longlong(k);       // non-negative doubles order like their bits
-    key[i] = kb;
-    if (kb != 0x7FF0000000000000ull) atomicAdd(&bucket_hist[tree_bucket(k)], 1u);   // culled leaves take no part in the ranking
-}
+//
+// ONE launch plans the whole gather: PLAN_GRID workgroups (one per CU, all resident) pass through six phases separated by
+// grid-wide barriers (a monotonic arrival counter in global memory; no workgroup waits for anything but "everybody has
+// arrived", and every workgroup is resident, so there is no circular wait).  The phases are a handful of microseconds of
+// latency-bound work each; as separate launches they cost 8-60 us apiece (r03f profile: test 12, a one-workgroup scan of
+// the 65536 counters 44, fill 13, rank 31, a one-workgroup offset scan 62 = 181 us per gather with the copy), and as ONE
+// workgroup of 1024 threads the ranking alone was 1.3 ms (26 k leaves x ~55 bucket members = a serial chain of dependent L2
+// loads per thread).
+//   1 test     every leaf: distance key (or +inf when culled), one atomic on its bucket's counter
+//   2 scan     workgroup g owns buckets [256 g, 256 g + 256): exclusive scan inside the chunk -> start_local, chunk total;
+//              the histogram is handed back zeroed
+//   3 fill     chunk bases = scan of the 256 chunk totals (every workgroup, in LDS); members[base + start_local + fill++]
+//   4 rank     exact rank inside the bucket (its members read eight at a time) -> leaf and count at their rank
+//   5 sums     workgroup g owns a contiguous run of ranks: its count total
+//   6 offsets  offset[r] = total - inclusive_prefix(counts by rank)[r]: the nearest leaf, r = 0, ends the buffer
+//              (Viewer.js:2046-2055 copies from the END backwards); totals = {splats gathered, leaves kept}; count_out =
+//              the sorter's own copy of splatRenderCount (nullable); the fill counters are handed back zeroed
+constexpr uint32_t PLAN_GRID = 256, PLAN_THREADS = 256;
+constexpr uint32_t PLAN_BARRIERS = 5;      // grid barriers per launch: the arrival counter advances by exactly PLAN_BARRIERS * PLAN_GRID
+static_assert(TREE_BUCKETS == PLAN_GRID * PLAN_THREADS, "one bucket per thread of the plan grid");
 
-// one workgroup: exclusive scan of the bucket histogram (thread t owns 64 consecutive buckets); the histogram is handed
-// back zeroed
-__global__ __launch_bounds__(1024) void k_tree_bucket_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
-    __shared__ uint32_t s_wave[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t CH = TREE_BUCKETS / 1024u;
-    uint32_t v[CH], sum = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < CH; k += 4) {
-        uint4* hp = reinterpret_cast<uint4*>(hist + tid * CH + k);
-        const uint4 q = *hp;
-        v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
-        sum += q.x + q.y + q.z + q.w;
-        if (q.x | q.y | q.z | q.w) *hp = make_uint4(0u, 0u, 0u, 0u);
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += t;
-    }
-    if (lane == 63) s_wave[wave] = incl;
+__device__ __forceinline__ void plan_grid_barrier(uint32_t* counter, uint32_t target) {
     __syncthreads();
-    uint32_t run = incl - sum;
-#pragma unroll
-    for (int w = 0; w < 16; w++) run += ((uint32_t)w < wave) ? s_wave[w] : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < CH; k++) {
-        start[tid * CH + k] = run;
-        run += v[k];
+    if (threadIdx.x == 0) {
+        __threadfence();                                    // this workgroup's writes are visible before it arrives
+        atomicAdd(counter, 1u);
+        while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+        __threadfence();                                    // ... and the others' writes before anybody here reads them
     }
-    if (tid == 1023u) start[TREE_BUCKETS] = run;             // = the number of kept leaves
-}
-
-__global__ __launch_bounds__(256) void k_tree_fill(const unsigned long long* __restrict__ key, uint32_t n, const uint32_t* __restrict__ start,
-                                                   uint32_t* __restrict__ fill, uint32_t* __restrict__ members) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long kb = key[i];
-    if (kb == 0x7FF0000000000000ull) return;               // culled
-    const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
-    members[start[b] + atomicAdd(&fill[b], 1u)] = i;       // order inside a bucket is arbitrary: the rank below is exact
-}
-
-// exact rank inside the bucket -> the leaf and its count at their rank.  The bucket's members are read eight at a time (two
-// rounds of independent loads instead of a chain of 2 x members dependent ones); the fill counters are handed back zeroed.
-__global__ __launch_bounds__(256) void k_tree_rank_place(const unsigned long long* __restrict__ key, uint32_t n,
-                                                         const uint32_t* __restrict__ start, const uint32_t* __restrict__ members,
-                                                         uint32_t* __restrict__ fill, const uint32_t* __restrict__ count,
-                                                         uint32_t* __restrict__ sorted_cnt, uint32_t* __restrict__ sorted_leaf) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long mine = key[i];
-    if (mine == 0x7FF0000000000000ull) return;             // culled: has no rank
-    const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
-    const uint32_t lo = start[b], hi = start[b + 1];
-    uint32_t r = lo;
-    for (uint32_t q = lo; q < hi; q += 8u) {
-        uint32_t m[8];
-        unsigned long long k[8];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) m[j] = q + j < hi ? members[q + j] : i;      // padding = the leaf itself: counts 0
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) k[j] = key[m[j]];
-#pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) r += (k[j] < mine || (k[j] == mine && m[j] < i)) ? 1u : 0u;
-    }
-    sorted_cnt[r] = count[i];
-    sorted_leaf[r] = i;
-    fill[b] = 0u;                                          // (every member writes the same value; nobody reads it in this kernel)
-}
-
-// one workgroup: offset[r] = total - inclusive_prefix(counts by rank)[r] over the kept ranks (the nearest leaf, r = 0, ends
-// the buffer: Viewer.js:2046-2055 copies from the END backwards).  Thread t owns CH consecutive ranks per round.
-// totals = {splats gathered, leaves kept}; count_out = the sorter's own copy of splatRenderCount (nullable).
-__global__ __launch_bounds__(1024) void k_tree_offsets(const uint32_t* __restrict__ sorted_cnt, const uint32_t* __restrict__ start,
-                                                       uint32_t* __restrict__ offset, uint32_t* __restrict__ totals,
-                                                       uint32_t* __restrict__ count_out) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t K = start[TREE_BUCKETS];
-    constexpr uint32_t CH = 16;                            // values per thread and round, all loads in flight together
-    uint32_t sum = 0;
-    for (uint32_t i = tid; i < K; i += 1024u) sum += sorted_cnt[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    if (lane == 0) s_wave[wave] = sum;
     __syncthreads();
-    uint32_t total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) total += s_wave[w];
-    if (tid == 0) {
-        totals[0] = total;
-        totals[1] = K;
-        if (count_out) *count_out = total;
-        s_carry = 0;
+}
+
+struct PlanBuffers {
+    const double* center; const double* size; const uint32_t* count;      // per leaf
+    unsigned long long* key;                                              // per leaf: sortable bits of the distance
+    uint32_t* hist; uint32_t* fill; uint32_t* start_local;                // per bucket
+    uint32_t* chunk_sum;                                                  // [2][PLAN_GRID]: bucket chunks | rank chunks
+    uint32_t* members; uint32_t* sorted_cnt; uint32_t* sorted_leaf; uint32_t* offset;   // per kept leaf / rank
+    uint32_t* totals; uint32_t* count_out; uint32_t* barrier;
+};
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, PlanBuffers B, uint32_t barrier_base) {
+    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_base[PLAN_GRID];
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, L = p.leaves;
+    const uint32_t gid = wg * PLAN_THREADS + tid, stride = PLAN_GRID * PLAN_THREADS;
+    const unsigned long long INF = 0x7FF0000000000000ull;
+    uint32_t phase = 0;
+    auto barrier = [&]() { plan_grid_barrier(B.barrier, barrier_base + (++phase) * PLAN_GRID); };
+    // 1. test
+    for (uint32_t i = gid; i < L; i += stride) {
+        const double k = tree_leaf_key(p, B.center[3 * (size_t)i], B.center[3 * (size_t)i + 1], B.center[3 * (size_t)i + 2], B.size[i]);
+        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);   // non-negative doubles order like their bits
+        B.key[i] = kb;
+        if (kb != INF) atomicAdd(&B.hist[tree_bucket(k)], 1u);                      // culled leaves take no part in the ranking
     }
-    for (uint32_t base = 0; base < K; base += 1024u * CH) {
-        const uint32_t b = base + tid * CH;
-        uint32_t v[CH];
-#pragma unroll
-        for (uint32_t k = 0; k < CH; k++) v[k] = b + k < K ? sorted_cnt[b + k] : 0u;
-        uint32_t mine = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < CH; k++) mine += v[k];
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += t;
-        }
-        __syncthreads();                                   // s_wave / s_carry of the previous round consumed
-        if (lane == 63) s_wave[wave] = incl;
+    barrier();
+    // 2. scan inside this workgroup's chunk of 256 buckets
+    {
+        const uint32_t c = B.hist[gid];
+        if (c) B.hist[gid] = 0u;
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(c, s_tmp, &total);
+        B.start_local[gid] = excl;
+        if (tid == 0) B.chunk_sum[wg] = total;
+    }
+    barrier();
+    // 3. chunk bases (every workgroup scans the 256 chunk totals), then the members of every bucket
+    uint32_t K;
+    {
+        const uint32_t c = B.chunk_sum[tid];
+        const uint32_t excl = block_excl_scan_256(c, s_tmp, &K);       // K = kept leaves
+        s_base[tid] = excl;
         __syncthreads();
-        uint32_t wbase = 0, chunk = 0;
+    }
+    for (uint32_t i = gid; i < L; i += stride) {
+        const unsigned long long kb = B.key[i];
+        if (kb == INF) continue;
+        const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
+        B.members[s_base[b >> 8] + B.start_local[b] + atomicAdd(&B.fill[b], 1u)] = i;   // order inside a bucket is arbitrary
+    }
+    barrier();
+    // 4. exact rank inside the bucket -> the leaf and its count at their rank
+    for (uint32_t i = gid; i < L; i += stride) {
+        const unsigned long long mine = B.key[i];
+        if (mine == INF) continue;                             // culled: has no rank
+        const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
+        const uint32_t lo = s_base[b >> 8] + B.start_local[b], hi = lo + B.fill[b];
+        uint32_t r = lo;
+        for (uint32_t q = lo; q < hi; q += 8u) {
+            uint32_t m[8];
+            unsigned long long k[8];
 #pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const uint32_t c = s_wave[w];
-            wbase += ((uint32_t)w < wave) ? c : 0u;
-            chunk += c;
-        }
-        uint32_t run = s_carry + wbase + incl - mine;
+            for (uint32_t j = 0; j < 8u; j++) m[j] = q + j < hi ? B.members[q + j] : i;   // padding = the leaf itself: counts 0
 #pragma unroll
-        for (uint32_t k = 0; k < CH; k++) {
-            run += v[k];
-            if (b + k < K) offset[b + k] = total - run;
+            for (uint32_t j = 0; j < 8u; j++) k[j] = B.key[m[j]];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) r += (k[j] < mine || (k[j] == mine && m[j] < i)) ? 1u : 0u;
         }
+        B.sorted_cnt[r] = B.count[i];
+        B.sorted_leaf[r] = i;
+    }
+    barrier();
+    // 5. this workgroup's run of ranks [r0, r1): its total
+    const uint32_t per = (K + PLAN_GRID - 1u) / PLAN_GRID;
+    const uint32_t r0 = min(wg * per, K), r1 = min(r0 + per, K);
+    {
+        uint32_t sum = 0;
+        for (uint32_t r = r0 + tid; r < r1; r += PLAN_THREADS) sum += B.sorted_cnt[r];
+        uint32_t total;
+        (void)block_excl_scan_256(sum, s_tmp, &total);
+        if (tid == 0) B.chunk_sum[PLAN_GRID + wg] = total;
+    }
+    barrier();
+    // (phase == PLAN_BARRIERS here)
+    // 6. offsets of this workgroup's ranks; the fill counters go back to zero (nobody reads them any more)
+    {
+        const uint32_t c = B.chunk_sum[PLAN_GRID + tid];
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(c, s_tmp, &total);
         __syncthreads();
-        if (tid == 0) s_carry += chunk;
+        s_base[tid] = excl;
+        __syncthreads();
+        uint32_t run = s_base[wg];
+        if (gid == 0) {
+            B.totals[0] = total;
+            B.totals[1] = K;
+            if (B.count_out) *B.count_out = total;
+        }
+        for (uint32_t rb = r0; rb < r1; rb += PLAN_THREADS) {
+            const uint32_t r = rb + tid;
+            const uint32_t v = r < r1 ? B.sorted_cnt[r] : 0u;
+            uint32_t round_total;
+            const uint32_t ex = block_excl_scan_256(v, s_tmp, &round_total);
+            if (r < r1) B.offset[r] = total - (run + ex + v);
+            run += round_total;
+        }
+        for (uint32_t i = gid; i < L; i += stride) {
+            const unsigned long long kb = B.key[i];
+            if (kb != INF) B.fill[tree_bucket(__longlong_as_double((long long)kb))] = 0u;    // same value from every member
+        }
     }
 }
 
@@ -681,7 +678,8 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
         if (!t->built_on_device) A(t->d_indexes, 4 * t->indexes.size() + 4);      // the device build left them there
         A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
-        A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4); A(t->d_total, 16);
+        A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4);
+        A(t->d_total, 16 + 8 * PLAN_GRID);        // {splats, kept leaves, barrier word, pad} + the plan's two chunk-total tables
         if (st != GS_OK) {
             delete t;
             return st;
@@ -694,6 +692,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
         UP(t->d_count, cnt.data(), 4 * L);
         if (!t->built_on_device) UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_total.p, 0, 16 + 8 * PLAN_GRID, s);
         if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // the gather kernels keep them zero
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
@@ -789,15 +788,17 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
         GS_TRY(dst->gathered_dev.ensure(16));
         count_dev = dst->gathered_dev.as<uint32_t>();
     }
-    const dim3 g((L + 255u) / 256u), b(256);
-    unsigned long long* key = t->d_key.as<unsigned long long>();
-    hipLaunchKernelGGL(k_tree_test, g, b, 0, st, p, t->d_center.as<double>(), t->d_size.as<double>(), key, bhist);
-    hipLaunchKernelGGL(k_tree_bucket_scan, dim3(1), dim3(1024), 0, st, bhist, bstart);
-    hipLaunchKernelGGL(k_tree_fill, g, b, 0, st, key, L, bstart, bfill, t->d_rank.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_rank_place, g, b, 0, st, key, L, bstart, t->d_rank.as<uint32_t>(), bfill, t->d_count.as<uint32_t>(),
-                       t->d_sorted_cnt.as<uint32_t>(), t->d_sorted_leaf.as<uint32_t>());
-    hipLaunchKernelGGL(k_tree_offsets, dim3(1), dim3(1024), 0, st, t->d_sorted_cnt.as<uint32_t>(), bstart, t->d_offset.as<uint32_t>(),
-                       t->d_total.as<uint32_t>(), count_dev);
+    PlanBuffers pb;
+    pb.center = t->d_center.as<double>(); pb.size = t->d_size.as<double>(); pb.count = t->d_count.as<uint32_t>();
+    pb.key = t->d_key.as<unsigned long long>();
+    pb.hist = bhist; pb.fill = bfill; pb.start_local = bstart;
+    pb.chunk_sum = t->d_total.as<uint32_t>() + 4;
+    pb.members = t->d_rank.as<uint32_t>(); pb.sorted_cnt = t->d_sorted_cnt.as<uint32_t>();
+    pb.sorted_leaf = t->d_sorted_leaf.as<uint32_t>(); pb.offset = t->d_offset.as<uint32_t>();
+    pb.totals = t->d_total.as<uint32_t>(); pb.count_out = count_dev; pb.barrier = t->d_total.as<uint32_t>() + 2;
+    // PLAN_BARRIERS grid barriers per launch on one monotonic counter (wrap-safe: compared by difference)
+    hipLaunchKernelGGL(k_tree_plan, dim3(PLAN_GRID), dim3(PLAN_THREADS), 0, st, p, pb, t->barrier_epoch * PLAN_BARRIERS * PLAN_GRID);
+    t->barrier_epoch++;
     const uint32_t copy_grid = (L + COPY_WAVES - 1u) / COPY_WAVES;
     hipLaunchKernelGGL(k_tree_copy, dim3(copy_grid < 8192u ? copy_grid : 8192u), dim3(64 * COPY_WAVES), 0, st, t->d_total.as<uint32_t>(),
                        t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(), t->d_offset.as<uint32_t>(),

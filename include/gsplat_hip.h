@@ -188,7 +188,7 @@ typedef struct gs_gather_params {
     uint32_t pad;
 } gs_gather_params;
 /* Tests every leaf, orders the kept ones by distance and lays their index lists out far -> near (the nearest leaf
- * ends the buffer), on the device (six small launches, no memset).
+ * ends the buffer), on the device (two launches: the plan - one grid-synchronised kernel - and the copy).
  *   dst               sorter whose device-side indexesToSort buffer receives the list (then call
  *                     gs_sorter_sort_gathered), or NULL
  *   render_count      out: splatRenderCount (this waits for the device); or NULL = asynchronous: nothing returns to the host,

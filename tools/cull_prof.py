@@ -13,10 +13,16 @@ w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from"
 mesh = SplatMesh(ctx, N, scene.sh_degree).build(scene.centers, scene.cov, scene.rgba, scene.sh)
 mesh.set_camera(cam)
 tree = SplatTree(ctx, 8, 1000).process_splat_mesh(scene.centers, alphas=scene.rgba[:, 3])
-for _ in range(12):
-    r = tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False)
+import time
+w.set_frustum_cull(True)                                     # as bench.py's cull_on column: the per-splat cull on top
+splats = int(tree.info().splats)
+FRAMES = 40
+for k in range(FRAMES + 4):
+    if k == 4:
+        ctx.synchronize(); t0 = time.perf_counter()
+    tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False, asynchronous=True)
     w.sort_gathered(cam.sort_mvp(), keep_on_device=True)
-    mesh.use_sorter_result(w, r["splatRenderCount"])
+    mesh.use_sorter_result(w, splats)
     mesh.render(to_host=False, want_stats=False)
 ctx.synchronize()
-print("R =", r["splatRenderCount"])
+print("cull-on frame: %.4f ms (%d frames, asynchronous gather + fused frustum cull)" % ((time.perf_counter() - t0) / FRAMES * 1e3, FRAMES))

@@ -413,9 +413,12 @@ struct GatherParams {
     uint32_t gather_all, leaves;
 };
 
-constexpr uint32_t TREE_BUCKETS = 1u << 16;
-// bucket of a distance key: top 16 bits of (float)key, monotonic in key; any bit pattern stays below TREE_BUCKETS
-__device__ __forceinline__ uint32_t tree_bucket(double key) { return __float_as_uint((float)key) >> 16; }
+// bucket of a distance key: top 20 bits of (float)key (8 exponent + 11 mantissa bits: 0.05 % wide), monotonic in key; any bit
+// pattern stays below TREE_BUCKETS.  (r03g: with 16-bit buckets - 0.8 % wide - the leaves 10 units from the camera share a
+// bucket by the hundred and the slowest thread's exact ranking, a chain of dependent loads, set the plan's length: 113 us.)
+constexpr uint32_t TREE_BUCKET_BITS = 20;
+constexpr uint32_t TREE_BUCKETS = 1u << TREE_BUCKET_BITS;
+__device__ __forceinline__ uint32_t tree_bucket(double key) { return __float_as_uint((float)key) >> (32u - TREE_BUCKET_BITS); }
 
 // Viewer.js:2010-2035 for one leaf: the sort key (distance, or +inf when the leaf is culled)
 __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x, double y, double z, double size) {
@@ -442,7 +445,7 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
 }
 
 // Rank of a leaf in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2); instead the leaves are
-// bucketed by the top 16 bits of (float)distance (monotonic in the distance: 8 exponent + 7 mantissa bits, i.e. 0.8 % wide
+// bucketed by the top 20 bits of (float)distance (monotonic in the distance: 8 exponent + 11 mantissa bits, i.e. 0.05 % wide
 // buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number - only against the
 // members of its own bucket.  The result is the same total order; only the work is smaller.
 //
@@ -454,7 +457,7 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
 // workgroup of 1024 threads the ranking alone was 1.3 ms (26 k leaves x ~55 bucket members = a serial chain of dependent L2
 // loads per thread).
 //   1 test     every leaf: distance key (or +inf when culled), one atomic on its bucket's counter
-//   2 scan     workgroup g owns buckets [256 g, 256 g + 256): exclusive scan inside the chunk -> start_local, chunk total;
+//   2 scan     workgroup g owns a chunk of 4096 buckets: exclusive scan inside the chunk -> start_local, chunk total;
 //              the histogram is handed back zeroed
 //   3 fill     chunk bases = scan of the 256 chunk totals (every workgroup, in LDS); members[base + start_local + fill++]
 //   4 rank     exact rank inside the bucket (its members read eight at a time) -> leaf and count at their rank
@@ -464,7 +467,9 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
 //              the sorter's own copy of splatRenderCount (nullable); the fill counters are handed back zeroed
 constexpr uint32_t PLAN_GRID = 256, PLAN_THREADS = 256;
 constexpr uint32_t PLAN_BARRIERS = 5;      // grid barriers per launch: the arrival counter advances by exactly PLAN_BARRIERS * PLAN_GRID
-static_assert(TREE_BUCKETS == PLAN_GRID * PLAN_THREADS, "one bucket per thread of the plan grid");
+constexpr uint32_t PLAN_CHUNK = TREE_BUCKETS / PLAN_GRID;          // buckets per workgroup of the plan
+constexpr uint32_t PLAN_PER_THREAD = PLAN_CHUNK / PLAN_THREADS;    // ... and per thread: 16 consecutive ones
+static_assert(PLAN_PER_THREAD * PLAN_THREADS * PLAN_GRID == TREE_BUCKETS && PLAN_PER_THREAD % 4 == 0, "plan geometry");
 
 __device__ __forceinline__ void plan_grid_barrier(uint32_t* counter, uint32_t target) {
     __syncthreads();
@@ -502,13 +507,29 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, Plan
         if (kb != INF) atomicAdd(&B.hist[tree_bucket(k)], 1u);                      // culled leaves take no part in the ranking
     }
     barrier();
-    // 2. scan inside this workgroup's chunk of 256 buckets
+    // 2. scan inside this workgroup's chunk of buckets (thread t owns PLAN_PER_THREAD consecutive ones, 16-byte accesses)
     {
-        const uint32_t c = B.hist[gid];
-        if (c) B.hist[gid] = 0u;
+        uint4* hp = reinterpret_cast<uint4*>(B.hist + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
+        uint4* sp = reinterpret_cast<uint4*>(B.start_local + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
+        uint32_t v[PLAN_PER_THREAD], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PLAN_PER_THREAD / 4; k++) {
+            const uint4 q = hp[k];
+            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            sum += q.x + q.y + q.z + q.w;
+            if (q.x | q.y | q.z | q.w) hp[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
         uint32_t total;
-        const uint32_t excl = block_excl_scan_256(c, s_tmp, &total);
-        B.start_local[gid] = excl;
+        uint32_t run = block_excl_scan_256(sum, s_tmp, &total);
+#pragma unroll
+        for (uint32_t k = 0; k < PLAN_PER_THREAD / 4; k++) {
+            uint4 o;
+            o.x = run; run += v[4 * k];
+            o.y = run; run += v[4 * k + 1];
+            o.z = run; run += v[4 * k + 2];
+            o.w = run; run += v[4 * k + 3];
+            sp[k] = o;
+        }
         if (tid == 0) B.chunk_sum[wg] = total;
     }
     barrier();
@@ -524,7 +545,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, Plan
         const unsigned long long kb = B.key[i];
         if (kb == INF) continue;
         const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
-        B.members[s_base[b >> 8] + B.start_local[b] + atomicAdd(&B.fill[b], 1u)] = i;   // order inside a bucket is arbitrary
+        B.members[s_base[b / PLAN_CHUNK] + B.start_local[b] + atomicAdd(&B.fill[b], 1u)] = i;   // order inside a bucket is arbitrary
     }
     barrier();
     // 4. exact rank inside the bucket -> the leaf and its count at their rank
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, Plan
         const unsigned long long mine = B.key[i];
         if (mine == INF) continue;                             // culled: has no rank
         const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
-        const uint32_t lo = s_base[b >> 8] + B.start_local[b], hi = lo + B.fill[b];
+        const uint32_t lo = s_base[b / PLAN_CHUNK] + B.start_local[b], hi = lo + B.fill[b];
         uint32_t r = lo;
         for (uint32_t q = lo; q < hi; q += 8u) {
             uint32_t m[8];

@@ -471,12 +471,18 @@ constexpr uint32_t PLAN_CHUNK = TREE_BUCKETS / PLAN_GRID;          // buckets pe
 constexpr uint32_t PLAN_PER_THREAD = PLAN_CHUNK / PLAN_THREADS;    // ... and per thread: 16 consecutive ones
 static_assert(PLAN_PER_THREAD * PLAN_THREADS * PLAN_GRID == TREE_BUCKETS && PLAN_PER_THREAD % 4 == 0, "plan geometry");
 
-__device__ __forceinline__ void plan_grid_barrier(uint32_t* counter, uint32_t target) {
+// arrivals count on `counter`; the last one to arrive publishes the target in `flag` (another cache line), which is what the
+// others poll - 255 pollers on the counter's own line would queue in front of the remaining arrivals' atomics
+__device__ __forceinline__ void plan_grid_barrier(uint32_t* counter, uint32_t* flag, uint32_t target) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();                                    // this workgroup's writes are visible before it arrives
-        atomicAdd(counter, 1u);
-        while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+        const uint32_t prev = atomicAdd(counter, 1u);
+        if (prev + 1u == target) {
+            __hip_atomic_store(flag, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
+        }
         __threadfence();                                    // ... and the others' writes before anybody here reads them
     }
     __syncthreads();
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, Plan
     const uint32_t gid = wg * PLAN_THREADS + tid, stride = PLAN_GRID * PLAN_THREADS;
     const unsigned long long INF = 0x7FF0000000000000ull;
     uint32_t phase = 0;
-    auto barrier = [&]() { plan_grid_barrier(B.barrier, barrier_base + (++phase) * PLAN_GRID); };
+    auto barrier = [&]() { plan_grid_barrier(B.barrier, B.barrier + 32, barrier_base + (++phase) * PLAN_GRID); };
     // 1. test
     for (uint32_t i = gid; i < L; i += stride) {
         const double k = tree_leaf_key(p, B.center[3 * (size_t)i], B.center[3 * (size_t)i + 1], B.center[3 * (size_t)i + 2], B.size[i]);
@@ -700,7 +706,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         if (!t->built_on_device) A(t->d_indexes, 4 * t->indexes.size() + 4);      // the device build left them there
         A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
         A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4);
-        A(t->d_total, 16 + 8 * PLAN_GRID);        // {splats, kept leaves, barrier word, pad} + the plan's two chunk-total tables
+        A(t->d_total, 16 + 8 * PLAN_GRID + 512);  // {splats, kept leaves, pad} + the plan's two chunk-total tables + its barrier words
         if (st != GS_OK) {
             delete t;
             return st;
@@ -713,7 +719,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
         UP(t->d_count, cnt.data(), 4 * L);
         if (!t->built_on_device) UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
-        if (e == hipSuccess) e = hipMemsetAsync(t->d_total.p, 0, 16 + 8 * PLAN_GRID, s);
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_total.p, 0, 16 + 8 * PLAN_GRID + 512, s);
         if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // the gather kernels keep them zero
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
@@ -816,7 +822,8 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     pb.chunk_sum = t->d_total.as<uint32_t>() + 4;
     pb.members = t->d_rank.as<uint32_t>(); pb.sorted_cnt = t->d_sorted_cnt.as<uint32_t>();
     pb.sorted_leaf = t->d_sorted_leaf.as<uint32_t>(); pb.offset = t->d_offset.as<uint32_t>();
-    pb.totals = t->d_total.as<uint32_t>(); pb.count_out = count_dev; pb.barrier = t->d_total.as<uint32_t>() + 2;
+    pb.totals = t->d_total.as<uint32_t>(); pb.count_out = count_dev;
+    pb.barrier = t->d_total.as<uint32_t>() + 4 + 2 * PLAN_GRID + 32;      // arrival counter; its release flag 128 bytes further
     // PLAN_BARRIERS grid barriers per launch on one monotonic counter (wrap-safe: compared by difference)
     hipLaunchKernelGGL(k_tree_plan, dim3(PLAN_GRID), dim3(PLAN_THREADS), 0, st, p, pb, t->barrier_epoch * PLAN_BARRIERS * PLAN_GRID);
     t->barrier_epoch++;

@@ -275,6 +275,7 @@ struct ProjectParams {
     uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
+    uint32_t block_cull;           // 1: whole 256-splat storage blocks are tested first (project.hip); 0 for per-scene transforms
     float mv_row_norm[3];          // |row r of mat3(view)| * (1 + 1e-6): bounds |T0|, |T1| of the strip pre-test (project.hip)
 };
 
@@ -290,6 +291,8 @@ struct gs_mesh {
     DevBuf cov_bound;          // float: an upper bound of the covariance's spectral radius (largest absolute row sum), written
                                // at upload; lets a rank of a multi-GPU draw drop splats that cannot reach its strip before it
                                // fetches their covariance
+    DevBuf block_box;          // float [ceil(n/256)][8]: per storage block {min xyz, max xyz of the centres, max cov_bound, -}:
+                               // lets k_project drop a whole block (frustum, strip) without reading its centres
     DevBuf rgba;               // uint32
     DevBuf sh0, sh1, sh2;      // fp16: uint4 planes (SH2: 3 planes; SH1: sh0 = uint4, sh1 = uint)
                                // u8  : sh0 = uint4 (bytes 0..15), sh1 = uint2 (bytes 16..23, SH2 only)
@@ -297,6 +300,7 @@ struct gs_mesh {
     DevBuf inv_perm;           // uint32 [n]: internal position -> original splat index
     std::vector<std::pair<uint32_t, uint32_t>> slotted;   // [begin, end) ranges of splats that own storage slots (disjoint, sorted)
     bool reorder = true;
+    bool no_block_cull = false;    // GSPLAT_NO_BLOCK_CULL=1 (A/B and tests)
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
     DevBuf scene_dev;          // gs_scene_params on the device

@@ -165,6 +165,49 @@ __global__ __launch_bounds__(256) void k_split_sh_u8(const uint8_t* __restrict__
     }
 }
 
+// Per storage block of 256 splats: the box of its centres and its largest covariance bound (NaN centres / bounds are left out
+// of the box: such splats draw nothing; a NaN covariance bound keeps the block's strip test from ever culling it).
+__global__ __launch_bounds__(256) void k_block_boxes(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                     const float* __restrict__ cov_bound, uint32_t n, uint32_t first_block,
+                                                     float* __restrict__ boxes) {
+    __shared__ float s_red[4][7];
+    const uint32_t block = first_block + blockIdx.x, i = block * 256u + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, cb = 0.0f;
+    bool cb_nan = false;
+    if (i < n) {
+        const float c[3] = {px[i], py[i], pz[i]};
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], c[k]); hi[k] = fmaxf(hi[k], c[k]); }
+        const float b = cov_bound[i];
+        cb_nan = b != b;
+        cb = cb_nan ? 0.0f : b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64)); }
+        cb = fmaxf(cb, __shfl_xor(cb, o, 64));
+    }
+    const bool any_nan = __ballot(cb_nan) != 0ull;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0u) {
+        for (int k = 0; k < 3; k++) { s_red[wave][k] = lo[k]; s_red[wave][3 + k] = hi[k]; }
+        s_red[wave][6] = any_nan ? NAN : cb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8u) {
+        const uint32_t k = threadIdx.x;
+        float v = 0.0f;
+        if (k < 3u) v = fminf(fminf(s_red[0][k], s_red[1][k]), fminf(s_red[2][k], s_red[3][k]));
+        else if (k < 6u) v = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+        else if (k == 6u) {
+            v = fmaxf(fmaxf(s_red[0][6], s_red[1][6]), fmaxf(s_red[2][6], s_red[3][6]));
+            if (s_red[0][6] != s_red[0][6] || s_red[1][6] != s_red[1][6] || s_red[2][6] != s_red[2][6] || s_red[3][6] != s_red[3][6]) v = NAN;
+        }
+        boxes[8u * (size_t)block + k] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_iota2(uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = b[i] = i;
 }
@@ -216,7 +259,9 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     }
     A(m->scene_dev, sizeof(gs_scene_params));
     A(m->cov_bound, n * 4);
+    A(m->block_box, ((n + 255) / 256) * 32 + 32);
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
+    m->no_block_cull = getenv("GSPLAT_NO_BLOCK_CULL") != nullptr;
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
     if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
@@ -236,6 +281,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
         hipError_t e = hipSuccess;
         auto Z = [&](DevBuf& b) { if (e == hipSuccess && b.p) e = hipMemsetAsync(b.p, 0, b.bytes, ctx->stream); };
         Z(m->px); Z(m->py); Z(m->pz); Z(m->covA); Z(m->covB); Z(m->cov_bound); Z(m->rgba); Z(m->sh0); Z(m->sh1); Z(m->sh2);
+        Z(m->block_box);                                      // boxes of never-uploaded blocks: the origin (their zero centres)
         if (e == hipSuccess && m->reorder) {
             hipLaunchKernelGGL(k_iota2, dim3(up_grid(max_splat_count)), dim3(256), 0, ctx->stream, m->perm.as<uint32_t>(),
                                m->inv_perm.as<uint32_t>(), max_splat_count);
@@ -374,6 +420,11 @@ static int mesh_upload_segment(gs_mesh* m, uint32_t from, uint32_t count, const 
     if (ncoef)
         hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, perm, ncoef, m->sh0.as<uint4>(),
                            m->sh1.p, m->sh2.as<uint4>());
+    {   // the boxes of the storage blocks this segment touches (its splats own the slots [from, from + count))
+        const uint32_t b0 = from / 256u, b1 = (from + count + 255u) / 256u;
+        hipLaunchKernelGGL(k_block_boxes, dim3(b1 - b0), dim3(256), 0, st, m->px.as<float>(), m->py.as<float>(), m->pz.as<float>(),
+                           m->cov_bound.as<float>(), m->max_count, b0, m->block_box.as<float>());
+    }
     GS_HIP(hipGetLastError());
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;
@@ -633,6 +684,8 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     if (pp.row_begin == 0 && pp.row_end == 0) pp.row_end = pp.tiles_y;
     GS_REQUIRE(pp.row_begin <= pp.row_end && pp.row_end <= pp.tiles_y, "tile row range outside the viewport");
     pp.count = m->uploaded;
+    // whole-block tests assume one modelView for every splat of a block: off under per-scene transforms (and GSPLAT_NO_BLOCK_CULL)
+    pp.block_cull = (!(cam->flags & GS_CAM_DYNAMIC) && !m->no_block_cull) ? 1u : 0u;
 
     // pixel rows covered by this rank's strip, and the 32-px bins that cover them
     const uint32_t y0 = pp.row_begin * GS_TILE;

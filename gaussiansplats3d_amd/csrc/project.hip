@@ -22,6 +22,7 @@ struct MeshPlanes {
     const void* __restrict__ covA;      // fp32: float4 (c0..c3)   | fp16: uint2 (c0..c3)
     const void* __restrict__ covB;      // fp32: float2 (c4,c5)    | fp16: uint  (c4,c5)
     const float* __restrict__ cov_bound;   // spectral-radius bound of the covariance (mesh.hip, cov_spectral_bound)
+    const float* __restrict__ block_box;   // per 256-splat storage block: {min xyz, max xyz, max cov_bound, -} (mesh.hip, k_block_boxes)
     const uint32_t* __restrict__ rgba;
     const uint4* __restrict__ sh0;      // halfs 0..7
     const void* __restrict__ sh1;       // SH2: uint4 halfs 8..15 | SH1: uint (half 8)
@@ -116,6 +117,74 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    // Block-level cull.  Storage order is Morton order, so a block of 256 splats is a small box in space; its eight corners
+    // (one lane each, wave 0) decide whether EVERY splat inside must fail the vertex stage - then nothing of the block is
+    // read: not even its centres (12 bytes x 256), which is all a rank of a multi-GPU draw still paid for the ~85 % of the
+    // scene that cannot reach its strip, and what the 75 % of a scene outside the frustum cost a single GPU.
+    //  * frustum: each reject of SplatMaterial.js:160-164 (x > 1.2 w, x < -1.2 w, the same for y, z < -1.2 w; w < 0 fails them
+    //    all) is a linear inequality in the position, so if all eight corners satisfy ONE of them - with a margin far above
+    //    the fp32 rounding of either evaluation - so does every point of the box;
+    //  * strip (tile_row_begin / end): with every corner in front of the camera the box projects into the hull of its corners;
+    //    the reach of any splat inside is bounded as in the per-splat pre-test below, from the block's largest covariance
+    //    bound, its nearest depth and its largest |x|, |y| in view space.
+    // A dead block publishes empty masks and returns; the frame cannot change (every splat it skips would have been rejected).
+    if (pp.block_cull) {
+        __shared__ uint32_t s_dead;
+        if (threadIdx.x < 64u) {
+            const uint32_t c = threadIdx.x & 7u;
+            const float* bb = mp.block_box + 8u * (size_t)blockIdx.x;
+            const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
+            const float* MV = pp.view;
+            const float* P = pp.proj;
+            float v[4], q[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[r] = MV[r] * x + MV[4 + r] * y + MV[8 + r] * z + MV[12 + r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
+            const float clip = 1.2f * q[3], tol = 1e-4f * (fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(clip) + 1.0f);
+            const unsigned long long lanes8 = 0xFFull;
+            const bool dead_frustum = (__ballot(q[0] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[0] - clip > tol) & lanes8) == lanes8 ||
+                                      (__ballot(q[1] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[1] - clip > tol) & lanes8) == lanes8 ||
+                                      (__ballot(-q[2] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[3] > tol) & lanes8) == lanes8;
+            bool dead = dead_frustum;
+            const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
+            if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC)) {
+                // every corner properly in front of the camera (w > 0 and view-space z < 0)?
+                const bool front = q[3] > 1e-6f && v[2] < -1e-6f;
+                float ypx = (q[1] / q[3] * 0.5f + 0.5f) * pp.height;
+                float ymin = ypx, ymax = ypx, zmin = -v[2], axmax = fabsf(v[0]), aymax = fabsf(v[1]);
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    ymin = fminf(ymin, __shfl_xor(ymin, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+                    zmin = fminf(zmin, __shfl_xor(zmin, o, 64));
+                    axmax = fmaxf(axmax, __shfl_xor(axmax, o, 64)); aymax = fmaxf(aymax, __shfl_xor(aymax, o, 64));
+                }
+                if ((__ballot(front) & lanes8) == lanes8) {
+                    const float ks = fabsf(pp.splat_scale * pp.inv_focal_adj);
+                    float reach = pp.max_splat_px * ks * 1.001f + 2.0f;
+                    const float iz = 1.0f / zmin, s2 = iz * iz;
+                    const float t0 = fabsf(pp.focal_x) * iz * pp.mv_row_norm[0] + fabsf(pp.focal_x) * axmax * s2 * pp.mv_row_norm[2];
+                    const float t1 = fabsf(pp.focal_y) * iz * pp.mv_row_norm[1] + fabsf(pp.focal_y) * aymax * s2 * pp.mv_row_norm[2];
+                    const float t = fmaxf(t0, t1) * 1.001f;
+                    float l = bb[6] * t * t + pp.kernel2d + 0.3163f;
+                    if (pp.flags & GS_CAM_POINT_CLOUD) l = fmaxf(l, 0.2f);
+                    const float tight = ks * sqrtf(8.0f * l) * 1.002f + 2.0f;
+                    if (tight < reach) reach = tight;                     // false for NaN: the cap stays
+                    const float slack = 0.05f + 1e-5f * pp.height;       // the corners' own fp32 projection
+                    dead = ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
+                }
+            }
+            if (threadIdx.x == 0u) s_dead = dead ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_dead) {                                         // nothing of this block draws: empty masks, no records
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            if (lane == 0u) vis_mask[blockIdx.x * 4u + wave] = 0ull;
+            if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blockIdx.x * 256u);
+            if (threadIdx.x == 0u) block_any[blockIdx.x] = 0;
+            return;
+        }
+    }
     bool visible = false;
     SplatRec rec;
     rec.cx = rec.cy = rec.ax = rec.ay = rec.bx = rec.by = 0.0f;
@@ -360,6 +429,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     mp.px = m->px.as<float>(); mp.py = m->py.as<float>(); mp.pz = m->pz.as<float>();
     mp.covA = m->covA.p; mp.covB = m->covB.p;
     mp.cov_bound = m->cov_bound.as<float>();
+    mp.block_box = m->block_box.as<float>();
     mp.rgba = m->rgba.as<uint32_t>();
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
     mp.scene_idx = m->scene_idx.as<uint32_t>();

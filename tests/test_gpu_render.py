@@ -4,7 +4,7 @@ import pytest
 
 import helpers
 import oracle
-from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, util
+from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util
 
 pytestmark = pytest.mark.gpu
 K_POWER = np.float32(2.4022448)
@@ -505,3 +505,38 @@ def test_out_of_range_indexes_are_harmless(ctx):
     worker.terminate()
     for m in (mesh, mesh2):
         m.dispose()
+
+
+def test_block_level_cull_changes_nothing(ctx, monkeypatch):
+    """k_project drops whole 256-splat storage blocks whose box fails the frustum (or cannot reach the rank's strip) before it
+    reads their centres.  Same frames, same visible counts and the same per-splat visibility masks as with the block test off
+    (GSPLAT_NO_BLOCK_CULL=1), for the demo pose, orbit poses that look away from most of the cloud, a camera inside it, and
+    strips of a multi-GPU draw; and the test must really fire (most of the scene is outside the frustum)."""
+    n = 120000
+    scene = scenes.scene_like(n, 1, 4242)
+    W, H = 640, 360
+    cams = [camera.demo_camera("garden", W, H)] + camera.orbit_cameras("garden", W, H, 6)[1:4] + \
+           [camera.PerspectiveCamera(W, H, (0.1, 0.2, -0.3), (3.0, 1.0, 2.0), (0.0, -1.0, 0.0))]
+    on = build_mesh(ctx, scene)
+    monkeypatch.setenv("GSPLAT_NO_BLOCK_CULL", "1")
+    off = build_mesh(ctx, scene)
+    monkeypatch.delenv("GSPLAT_NO_BLOCK_CULL")
+    rows = (H + 15) // 16
+    for cam in cams:
+        order = sorted_order(scene, cam)
+        frames = []
+        for m in (on, off):
+            m.set_camera(cam)
+            m.update_render_indexes(order, n)
+            f, st = m.render()
+            vis = m.debug_records(n)[2]
+            strips = [m.render(tile_rows=r)[0] for r in ((0, 5), (5, 6), (6, rows))]
+            frames.append((f, int(st.visible_splats), vis, strips))
+        np.testing.assert_array_equal(frames[0][0], frames[1][0])
+        assert frames[0][1] == frames[1][1] and 0 < frames[0][1] < n // 2
+        np.testing.assert_array_equal(frames[0][2], frames[1][2])
+        for a, b in zip(frames[0][3], frames[1][3]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(np.concatenate(frames[0][3], axis=0), frames[0][0])
+    on.dispose()
+    off.dispose()

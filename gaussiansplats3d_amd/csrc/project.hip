@@ -13,8 +13,6 @@
 //
 // Outputs per splat: SplatRec (32 B, what the blend gathers) and a tile rect (8 B, what the binner gathers).
 // Built with -ffp-contract=off and written in the oracle's operation order so accept/reject decisions agree.
-#include <stdlib.h>
-
 #include "gs_internal.hpp"
 
 struct MeshPlanes {
@@ -113,13 +111,23 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
 // EXT = false: the static perspective scene with fp16 SH (the benchmark path).  EXT = true adds the reference's shader
 // permutations: orthographic J, per-scene transforms (dynamicMode), per-scene opacity / visibility
 // (enableOptionalEffects), 8-bit SH, distance fade-in.
+// PROJECT_BLOCKS 256-splat blocks per workgroup (four waves each, independent of one another but for the barriers): a dead
+// block costs a quarter of a workgroup launch.  One block per workgroup had a floor of 20 us for 22.6 k blocks with
+// EVERYTHING culled (r03 tools/project_floor.py) - the dispatch rate of 256-thread workgroups - and a fixed grid of workgroups
+// looping over the blocks was slower still (76 VGPRs instead of 46: 56 -> 72 us for the full frame).
+#ifndef PROJECT_BLOCKS
+#define PROJECT_BLOCKS 4
+#endif
 template <bool EXT>
-__device__ __forceinline__ void project_block(const ProjectParams& pp, const MeshPlanes& mp, SplatRec* __restrict__ recs,
-                                              uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
-                                              uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
-                                              const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any,
-                                              const uint32_t blk, uint32_t* s_dead_slot, uint32_t* s_cnt) {
-    const uint32_t i = blk * 256u + threadIdx.x;
+__global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
+                                                 uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
+                                                 uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
+                                                 const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any) {
+    constexpr uint32_t PB = EXT ? 1u : (uint32_t)PROJECT_BLOCKS;               // (the extended shader needs 98 VGPRs: one block)
+    const uint32_t sub = threadIdx.x >> 8, tid = threadIdx.x & 255u;           // block of this workgroup, thread of the block
+    const uint32_t blk = blockIdx.x * PB + sub;
+    const uint32_t i = blk * 256u + tid;
+    if (blk * 256u >= pp.count) return;                       // the last workgroup's spare blocks (ended waves leave the barriers)
     // Block-level cull.  Storage order is Morton order, so a block of 256 splats is a small box in space; its eight corners
     // (one lane each, wave 0) decide whether EVERY splat inside must fail the vertex stage - then nothing of the block is
     // read: not even its centres (12 bytes x 256), which is all a rank of a multi-GPU draw still paid for the ~85 % of the
@@ -132,8 +140,9 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     //    bound, its nearest depth and its largest |x|, |y| in view space.
     // A dead block publishes empty masks and returns; the frame cannot change (every splat it skips would have been rejected).
     if (pp.block_cull) {
-        if (threadIdx.x < 64u) {
-            const uint32_t c = threadIdx.x & 7u;
+        __shared__ uint32_t s_dead[PB];
+        if (tid < 64u) {
+            const uint32_t c = tid & 7u;
             const float* bb = mp.block_box + 8u * (size_t)blk;
             const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
             const float* MV = pp.view;
@@ -176,15 +185,15 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
                     dead = ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
                 }
             }
-            if (threadIdx.x == 0u) *s_dead_slot = dead ? 1u : 0u;
+            if (tid == 0u) s_dead[sub] = dead ? 1u : 0u;
         }
         __syncthreads();
-        if (*s_dead_slot) {                                   // nothing of this block draws: empty masks, no records
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        if (s_dead[sub]) {                                    // nothing of this block draws: empty masks, no records
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
             if (lane == 0u) vis_mask[blk * 4u + wave] = 0ull;
             if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blk * 256u);
-            if (threadIdx.x == 0u) block_any[blk] = 0;
-            return;
+            if (tid == 0u) block_any[blk] = 0;
+            return;                                           // (ended waves no longer take part in the workgroup's barriers)
         }
     }
     bool visible = false;
@@ -392,7 +401,9 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     //  - one wave per 256-splat block in four rounds, centres of all rounds fetched up front, no LDS / barriers: 55 -> 64 us
     //    (71 VGPRs -> 7 waves per SIMD, and a wave's four rounds run back to back instead of on four waves at once).
     // 252 MB in 55 us is 4.6 TB/s of mixed read / write traffic against the 6.3 TB/s a pure copy reaches.
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_cnt_all[PB][4];
+    uint32_t* s_cnt = s_cnt_all[sub];
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     const unsigned long long vis = __ballot(visible);
     if (lane == 0u) {
         s_cnt[wave] = (uint32_t)__popcll(vis);
@@ -401,7 +412,7 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     __syncthreads();
     // one byte per block: does ANY of its 256 splats reach the frame?  Morton order makes most blocks all-or-nothing, and the
     // binner tests this (from LDS) before it spends an L2 gather on a splat's visibility word
-    if (threadIdx.x == 0) block_any[blk] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
+    if (tid == 0) block_any[blk] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
     const uint32_t block_base = blk * 256u;
     uint32_t wave_base = block_base;
 #pragma unroll
@@ -423,37 +434,6 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
             atomicOr(&vis_orig[orig >> 5], 1u << (orig & 31u));
         }
     }
-}
-
-// workgroups resident per CU (the persistent loop needs 76 / 120 VGPRs for the static / extended shader: forcing 8 per CU
-// spills 9 / 61 of them)
-#ifndef PROJECT_OCC
-#define PROJECT_OCC 6
-#endif
-#ifndef PROJECT_OCC_EXT
-#define PROJECT_OCC_EXT 4
-#endif
-static uint32_t project_grid_cap(int cu_count, bool ext) {
-    static const char* e = getenv("GSPLAT_PROJECT_WGS_PER_CU");         // A/B knob
-    const uint32_t per_cu = (e && atoi(e) > 0) ? (uint32_t)atoi(e) : (ext ? PROJECT_OCC_EXT : PROJECT_OCC);
-    return (uint32_t)(cu_count > 0 ? cu_count : 256) * per_cu;
-}
-
-// A fixed grid of workgroups walks the 256-splat blocks (block b, b + grid, ...): a dead block costs its wave-0 test and a few
-// stores instead of a workgroup launch - one workgroup per block had a floor of 20 us for 22.6 k blocks with EVERYTHING
-// culled (r03 tools/project_floor.py), which is what every rank of a multi-GPU draw paid.  The two shared slots of the block
-// verdict alternate, so a fast wave's next verdict never overwrites the one a slow wave still reads.
-template <bool EXT>
-__global__ __launch_bounds__(256, EXT ? PROJECT_OCC_EXT : PROJECT_OCC) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
-                                                 uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
-                                                 uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
-                                                 const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any) {
-    __shared__ uint32_t s_dead[2];
-    __shared__ uint32_t s_cnt[2][4];
-    const uint32_t blocks = (pp.count + 255u) / 256u;
-    uint32_t it = 0;
-    for (uint32_t blk = blockIdx.x; blk < blocks; blk += gridDim.x, it ^= 1u)
-        project_block<EXT>(pp, mp, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, blk, &s_dead[it], s_cnt[it]);
 }
 
 int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
@@ -482,15 +462,12 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;
     const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
-    const uint32_t blocks = (pp.count + 255u) / 256u;
-    const uint32_t max_grid = project_grid_cap(m->ctx->cu_count, ext);
-    const uint32_t grid = blocks < max_grid ? blocks : max_grid;
     if (ext)
-        hipLaunchKernelGGL(k_project<true>, dim3(grid), dim3(256), 0, m->ctx->aux, pp, mp,
+        hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
                            vis_orig, inv_perm, m->block_any.as<uint8_t>());
     else
-        hipLaunchKernelGGL(k_project<false>, dim3(grid), dim3(256), 0, m->ctx->aux, pp, mp,
+        hipLaunchKernelGGL(k_project<false>, dim3(((pp.count + 255u) / 256u + PROJECT_BLOCKS - 1u) / PROJECT_BLOCKS), dim3(256 * PROJECT_BLOCKS), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
                            vis_orig, inv_perm, m->block_any.as<uint8_t>());
     GS_HIP(hipGetLastError());

@@ -111,23 +111,12 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
 // EXT = false: the static perspective scene with fp16 SH (the benchmark path).  EXT = true adds the reference's shader
 // permutations: orthographic J, per-scene transforms (dynamicMode), per-scene opacity / visibility
 // (enableOptionalEffects), 8-bit SH, distance fade-in.
-// PROJECT_BLOCKS 256-splat blocks per workgroup (four waves each, independent of one another but for the barriers): a dead
-// block costs a quarter of a workgroup launch.  One block per workgroup had a floor of 20 us for 22.6 k blocks with
-// EVERYTHING culled (r03 tools/project_floor.py) - the dispatch rate of 256-thread workgroups - and a fixed grid of workgroups
-// looping over the blocks was slower still (76 VGPRs instead of 46: 56 -> 72 us for the full frame).
-#ifndef PROJECT_BLOCKS
-#define PROJECT_BLOCKS 4
-#endif
 template <bool EXT>
-__global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
+__global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any) {
-    constexpr uint32_t PB = EXT ? 1u : (uint32_t)PROJECT_BLOCKS;               // (the extended shader needs 98 VGPRs: one block)
-    const uint32_t sub = threadIdx.x >> 8, tid = threadIdx.x & 255u;           // block of this workgroup, thread of the block
-    const uint32_t blk = blockIdx.x * PB + sub;
-    const uint32_t i = blk * 256u + tid;
-    if (blk * 256u >= pp.count) return;                       // the last workgroup's spare blocks (ended waves leave the barriers)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     // Block-level cull.  Storage order is Morton order, so a block of 256 splats is a small box in space; its eight corners
     // (one lane each, wave 0) decide whether EVERY splat inside must fail the vertex stage - then nothing of the block is
     // read: not even its centres (12 bytes x 256), which is all a rank of a multi-GPU draw still paid for the ~85 % of the
@@ -139,11 +128,16 @@ __global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(Pr
     //    the reach of any splat inside is bounded as in the per-splat pre-test below, from the block's largest covariance
     //    bound, its nearest depth and its largest |x|, |y| in view space.
     // A dead block publishes empty masks and returns; the frame cannot change (every splat it skips would have been rejected).
+    // What it buys (r03, tools/project_floor.py, C3): full frame 59.8 -> 56.5 us, one strip of eight 39.7 -> 38.8 us, a camera
+    // that sees nothing 26.0 -> 20.2 us: the floor is now the dispatch of 22.6 k workgroups, not their memory traffic.  Both
+    // ways around that floor were built and measured slower: a fixed grid of workgroups looping over the blocks (the loop needs
+    // 76 VGPRs instead of 46: 72.5 / 51.9 / 25.4 us) and four blocks per 1024-thread workgroup (92.7 / 71.9 / 36.1 us: sixteen
+    // waves have to find room at once and wait for each other at the barrier).
     if (pp.block_cull) {
-        __shared__ uint32_t s_dead[PB];
-        if (tid < 64u) {
-            const uint32_t c = tid & 7u;
-            const float* bb = mp.block_box + 8u * (size_t)blk;
+        __shared__ uint32_t s_dead;
+        if (threadIdx.x < 64u) {
+            const uint32_t c = threadIdx.x & 7u;
+            const float* bb = mp.block_box + 8u * (size_t)blockIdx.x;
             const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
             const float* MV = pp.view;
             const float* P = pp.proj;
@@ -185,15 +179,15 @@ __global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(Pr
                     dead = ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
                 }
             }
-            if (tid == 0u) s_dead[sub] = dead ? 1u : 0u;
+            if (threadIdx.x == 0u) s_dead = dead ? 1u : 0u;
         }
         __syncthreads();
-        if (s_dead[sub]) {                                    // nothing of this block draws: empty masks, no records
-            const uint32_t lane = tid & 63u, wave = tid >> 6;
-            if (lane == 0u) vis_mask[blk * 4u + wave] = 0ull;
-            if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blk * 256u);
-            if (tid == 0u) block_any[blk] = 0;
-            return;                                           // (ended waves no longer take part in the workgroup's barriers)
+        if (s_dead) {                                         // nothing of this block draws: empty masks, no records
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            if (lane == 0u) vis_mask[blockIdx.x * 4u + wave] = 0ull;
+            if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blockIdx.x * 256u);
+            if (threadIdx.x == 0u) block_any[blockIdx.x] = 0;
+            return;
         }
     }
     bool visible = false;
@@ -401,9 +395,8 @@ __global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(Pr
     //  - one wave per 256-splat block in four rounds, centres of all rounds fetched up front, no LDS / barriers: 55 -> 64 us
     //    (71 VGPRs -> 7 waves per SIMD, and a wave's four rounds run back to back instead of on four waves at once).
     // 252 MB in 55 us is 4.6 TB/s of mixed read / write traffic against the 6.3 TB/s a pure copy reaches.
-    __shared__ uint32_t s_cnt_all[PB][4];
-    uint32_t* s_cnt = s_cnt_all[sub];
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned long long vis = __ballot(visible);
     if (lane == 0u) {
         s_cnt[wave] = (uint32_t)__popcll(vis);
@@ -412,8 +405,8 @@ __global__ __launch_bounds__(256 * (EXT ? 1 : PROJECT_BLOCKS)) void k_project(Pr
     __syncthreads();
     // one byte per block: does ANY of its 256 splats reach the frame?  Morton order makes most blocks all-or-nothing, and the
     // binner tests this (from LDS) before it spends an L2 gather on a splat's visibility word
-    if (tid == 0) block_any[blk] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
-    const uint32_t block_base = blk * 256u;
+    if (threadIdx.x == 0) block_any[blockIdx.x] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
+    const uint32_t block_base = blockIdx.x * 256u;
     uint32_t wave_base = block_base;
 #pragma unroll
     for (uint32_t w = 0; w < 3; w++) wave_base += (w < wave) ? s_cnt[w] : 0u;
@@ -467,7 +460,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
                            vis_orig, inv_perm, m->block_any.as<uint8_t>());
     else
-        hipLaunchKernelGGL(k_project<false>, dim3(((pp.count + 255u) / 256u + PROJECT_BLOCKS - 1u) / PROJECT_BLOCKS), dim3(256 * PROJECT_BLOCKS), 0, m->ctx->aux, pp, mp,
+        hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
                            vis_orig, inv_perm, m->block_any.as<uint8_t>());
     GS_HIP(hipGetLastError());

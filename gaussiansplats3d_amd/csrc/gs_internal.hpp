@@ -313,6 +313,8 @@ struct gs_mesh {
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
     DevBuf block_any;          // uint8 [ceil(n/256)]      1 = some splat of the 256-splat block survived the vertex stage
     DevBuf vis32;              // uint2 [8*ceil(n/256)]   {the same mask per 32 splats, slot of its first visible splat}
+    DevBuf prect;              // uint2 [n]: per splat POSITION of a live block {x0:12|y0:12|slot in block:8, x1:12|y1:12|visible:1}:
+                               //            the binner's one gather per sorted index (project.hip)
     DevBuf vis_orig;           // uint32 [ceil(n/32)]     the mask by ORIGINAL splat index (gs_mesh_project only: feeds the
                                //                         visibility-culled sort)
     DevBuf cidx;               // uint32 [render_count] record slots of the visible splats in traversal order (compacted per workgroup)

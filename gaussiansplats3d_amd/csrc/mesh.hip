@@ -268,6 +268,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->vis32, ((n + 255) / 256) * 64 + 64);
+    A(m->prect, ((n + 255) / 256) * 256 * 8 + 64);
     A(m->block_any, ((n + 255) / 256 + 127) & ~(size_t)63);
     A(m->bin_sums, 4 * 3 * 2048 + 64);               // uint32 [3][BIN_MAX_BLOCKS] + the batches-per-workgroup of the last count
     A(m->frame, sizeof(RenderFrame));
@@ -645,8 +646,8 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
 
 // gs_camera -> the kernels' parameter block (shared by gs_mesh_project and gs_mesh_render)
 static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
-    GS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 65535u * GS_TILE && cam->height <= 65535u * GS_TILE,
-               "viewport size");
+    GS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 4096u * GS_TILE && cam->height <= 4096u * GS_TILE,
+               "viewport size (at most 65536 x 65536 px: tile coordinates travel as 12-bit fields)");
     GS_REQUIRE(cam->sh_degree <= 2, "sphericalHarmonicsDegree > 2");
     memset(&pp, 0, sizeof(pp));
     memcpy(pp.view, cam->view, sizeof(pp.view));

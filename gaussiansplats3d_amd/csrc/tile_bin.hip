@@ -78,8 +78,8 @@ extern "C" int gs_debug_bin_prof(void* dst) {
 __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
                                                            const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
-                                                           const uint2* __restrict__ vis32,
-                                                           const uint2* __restrict__ rects, uint32_t* __restrict__ cidx,
+                                                           const uint2* __restrict__ prect,
+                                                           uint32_t* __restrict__ cidx,
                                                            uint2* __restrict__ crect, uint32_t* __restrict__ coff,
                                                            uint32_t* __restrict__ block_sums,
                                                            uint32_t* __restrict__ digit_total,
@@ -148,22 +148,24 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
             for (int k = 0; k < BIN_PER_LANE; k++) idx[k] = perm[idx[k]];
         }
-        // k_project compacts survivors inside their 256-splat block and leaves, per 32 splats, {visibility mask, slot of
-        // the first visible one}: one 8-byte look-up in an L2-resident table gives both the filter and the slot
+        // k_project compacts survivors inside their 256-splat block and leaves, per position of a live block, one 8-byte word
+        // {visible, slot in the block, tile rect}: a single gather gives the filter, the slot and the rect
         if (coarse) {
 #pragma unroll
             for (int k = 0; k < BIN_PER_LANE; k++) keep[k] = keep[k] && ((s_any[idx[k] >> 13] >> ((idx[k] >> 8) & 31u)) & 1u);
+        } else if (block_any) {                            // more blocks than the LDS bitmap holds: the flag byte itself
+#pragma unroll
+            for (int k = 0; k < BIN_PER_LANE; k++) keep[k] = keep[k] && block_any[idx[k] >> 8] != 0;
         }
         uint32_t slot[BIN_PER_LANE];
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) {
-            const uint2 m = keep[k] ? vis32[idx[k] >> 5] : make_uint2(0u, 0u);
-            const uint32_t bit = idx[k] & 31u;
-            keep[k] = keep[k] && ((m.x >> bit) & 1u);
-            slot[k] = m.y + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
+            const uint2 w = keep[k] ? prect[idx[k]] : make_uint2(0u, 0u);
+            keep[k] = keep[k] && ((w.y >> 24) & 1u);
+            slot[k] = (idx[k] & ~255u) + (w.x >> 24);
+            r[k] = keep[k] ? make_uint2((w.x & 0xFFFu) | (((w.x >> 12) & 0xFFFu) << 16), (w.y & 0xFFFu) | (((w.y >> 12) & 0xFFFu) << 16))
+                           : make_uint2(0xFFFFu, 0u);
         }
-#pragma unroll
-        for (int k = 0; k < BIN_PER_LANE; k++) r[k] = keep[k] ? rects[slot[k]] : make_uint2(0xFFFFu, 0u);
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) t16 += rect_tiles(r[k]);
         uint32_t n[BIN_PER_LANE], cnt = 0, ent = 0;
@@ -444,11 +446,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const uint32_t cap = m->entry_capacity;
     const uint32_t* R_dev = (sorter && sorter->last_culled) ? &sorter->result_frame->kept : nullptr;
     hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
-                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->vis32.as<uint2>(),
-                       m->rects.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
+                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(),
                        m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
-                       getenv("GSPLAT_NO_COARSE_VIS") ? nullptr : m->block_any.as<uint8_t>());
+                       m->block_any.as<uint8_t>());
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;

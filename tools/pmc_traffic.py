@@ -20,7 +20,7 @@ import json
 import re
 import sys
 
-UPLOAD = ("k_split", "k_aos4", "k_morton", "k_perm_from", "k_scatter_u32", "k_selftest", "k_debug", "k_unmap")
+UPLOAD = ("k_split", "k_aos4", "k_morton", "k_perm_from", "k_scatter_u32", "k_selftest", "k_debug", "k_unmap", "k_block_boxes", "k_iota2")
 
 root, out = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -835,7 +835,7 @@ def main():
             # node (rank 0 alone) - the line's own strong-scaling reference
             "c3": brief(second, N) if second else None,
             "same_config_1gpu": brief(solo, N) if solo else None,
-            "speedup_vs_same_config_1gpu": round(solo["ms_per_step"] / ms_per_step, 3) if solo else None,
+            "speedup_vs_same_config_1gpu": round(solo["ms_per_step"] / ms_per_step, 4) if solo else None,
             # N = 1: configs[4]'s viewport on this one GPU
             "c5_1gpu": c5_one,
             "pipelined": pipelined,

@@ -85,6 +85,10 @@ constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
 constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
 constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
+// Depth slabs (GS_CAM_DEPTH_SLABS, tile_blend.hip): a list entry's slab travels in the top bits of its payload (record slots
+// need 28 bits: max_splat_count <= 2^28) and as the low bits of its sort key, so every (list, slab) gets a range of its own
+constexpr uint32_t GS_SLAB_BITS = 4, GS_SLABS = 1u << GS_SLAB_BITS;
+constexpr uint32_t GS_SLOT_MASK = (1u << 28) - 1u;
 
 #ifndef RADIX_TILE_CFG
 #define RADIX_TILE_CFG 4096
@@ -275,6 +279,7 @@ struct ProjectParams {
     uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
+    uint32_t slabs;                // 1: GS_CAM_DEPTH_SLABS: entries carry depth slabs, the blend is the two-level fold
     uint32_t block_cull;           // 1: whole 256-splat storage blocks are tested first (project.hip); 0 for per-scene transforms
     float mv_row_norm[3];          // |row r of mat3(view)| * (1 + 1e-6): bounds |T0|, |T1| of the strip pre-test (project.hip)
 };
@@ -329,6 +334,9 @@ struct gs_mesh {
     DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, half quadrants evaluated}, then
                                // uint32 [the same]: (splat, quadrant) pairs walked
     uint32_t blend_bins = 0, blend_row_begin = 0, blend_width = 0;    // the bins the last draw blended
+    DevBuf slab_partial;       // float4 [bins * GS_SLABS][1024]: the slabs' partial composites (slab mode)
+    DevBuf slab_flags;         // uint32 [bins] opaque_upto | uint32 [bins * GS_SLABS] partial written
+    DevBuf slab_end;           // uint32 [GS_SLABS]: near -> far list positions where the slabs end (from the sort's last digit)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
     bool blend_order_valid = false;
     RadixScratch radix;

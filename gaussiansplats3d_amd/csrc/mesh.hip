@@ -622,7 +622,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     hipStream_t st = ctx->stream, aux = ctx->aux;
     timed = timed || ctx->stage_events;
     m->timed_draw = timed;
-    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin) * (pp.slabs ? GS_SLABS : 1u);  // one entry list per list bin (and depth slab)
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     if (!projected) GS_TRY(mesh_project(m, pp, false, timed));   // else gs_mesh_project already ran it for this camera
     else if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
@@ -687,6 +687,7 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     pp.count = m->uploaded;
     // whole-block tests assume one modelView for every splat of a block: off under per-scene transforms (and GSPLAT_NO_BLOCK_CULL)
     pp.block_cull = (!(cam->flags & GS_CAM_DYNAMIC) && !m->no_block_cull) ? 1u : 0u;
+    pp.slabs = (cam->flags & GS_CAM_DEPTH_SLABS) ? 1u : 0u;
 
     // pixel rows covered by this rank's strip, and the 32-px bins that cover them
     const uint32_t y0 = pp.row_begin * GS_TILE;

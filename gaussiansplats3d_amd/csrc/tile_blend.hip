@@ -157,18 +157,38 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef GS_BLEND_BRANCH_STYLE
 #define GS_BLEND_BRANCH_STYLE 1       // 0: two independent ifs, 1: both / first / second as three blocks (A/B)
 #endif
+// DEPTH SLABS (GS_CAM_DEPTH_SLABS, SLAB = true).  A pixel's composite is sequential in its list, so a bin whose list is tens of
+// thousands of entries deep and does not saturate (a surface seen at a grazing angle, a pile of translucent splats) runs on
+// four waves for milliseconds while the rest of the GPU idles (the capture-like C3S scene: 8 bins of 2040 take > 4 ms,
+// profiles/r03c_blend_profile_C3S.txt).  In slab mode the composite is DEFINED as a two-level fold: the depth sort's buckets are
+// cut into GS_SLABS slabs (a splat's slab is a property of the splat and the camera: the top bits of its sort bucket), every
+// (bin, slab) composites its own splats from T = 1 on a workgroup of its own - partial (C, T) per pixel - and k_slab_fold
+// merges the partials in slab order: C += T * C_s, T *= T_s.  A slab that holds nothing for a pixel is exactly neutral, a slab
+// behind a fully opaque one contributes exactly nothing (0 * C_s), so the result does not depend on which workgroups ran,
+// which lists the entries travelled in or which strip of the screen a rank draws: strips of a multi-GPU draw in slab mode
+// equal the full slab-mode frame bit for bit.  It differs from the single-fold frame by fp32 rounding only (both are held
+// to the same tolerance against the oracle); draws from host-supplied index lists have no buckets and fold as one slab.
+struct SlabArgs {
+    float4* partial;            // [bins * GS_SLABS][1024]: {C.r, C.g, C.b, T} per pixel of the bin
+    uint32_t* opaque_upto;      // [bins]: smallest slab whose own composite saturated every pixel of the bin (0xFFFFFFFF: none)
+    uint32_t* valid;            // [bins * GS_SLABS]: the partial was written
+};
+
+template <bool SLAB>
 __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
                                                               const uint4* __restrict__ recs, const uint2* __restrict__ rects,
                                                               uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
                                                               uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
                                                               uint32_t list_row_begin, uint32_t list_shift,
                                                               uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
-                                                              const uint32_t* __restrict__ bin_order) {
+                                                              const uint32_t* __restrict__ bin_order, SlabArgs sa) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
+    __shared__ uint32_t s_abort;
     __shared__ uint32_t s_walked[4], s_halves[4];
-    const uint32_t bin = bin_order ? bin_order[blockIdx.x] : blockIdx.x;       // heaviest bins of the previous draw first (k_bin_emit)
+    const uint32_t slab = SLAB ? blockIdx.x % GS_SLABS : 0u;
+    const uint32_t bin = SLAB ? blockIdx.x / GS_SLABS : (bin_order ? bin_order[blockIdx.x] : blockIdx.x);   // heaviest bins first (k_bin_emit)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
     const uint32_t qx0 = bx * GS_BIN + (wave & 1u) * GS_TILE, qy0 = by * GS_BIN + (wave >> 1) * GS_TILE;   // quadrant origin
@@ -187,7 +207,9 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
 #endif
     // the entry list of the list bin this 32-px bin lies in
     const uint32_t per_list = list_shift - GS_BIN_SHIFT;
-    const uint2 range = ranges[((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list)];
+    const uint32_t list_id = ((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list);
+    const uint2 range = ranges[SLAB ? list_id * GS_SLABS + slab : list_id];
+    if (SLAB && !(range.y > range.x)) return;              // nothing of this slab reaches the list: no partial (the fold skips it)
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
 
     // a quadrant outside the viewport / this rank's strip of pixel rows has nothing to draw
@@ -212,14 +234,14 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     uint32_t v_next = 0;
     if (BLEND_PREFETCH) {
         if (tid < n) {
-            const uint32_t slot = vals[begin + tid];
+            const uint32_t slot = vals[begin + tid] & GS_SLOT_MASK;       // (top bits: the entry's depth slab)
             rect = rects[slot];
             lo = recs[2 * (size_t)slot];
             hi = recs[2 * (size_t)slot + 1];
         }
-        if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid];
+        if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid] & GS_SLOT_MASK;
     } else if (tid < n) {
-        v_next = vals[begin + tid];
+        v_next = vals[begin + tid] & GS_SLOT_MASK;
     }
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
@@ -236,13 +258,17 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                 hi = recs[2 * (size_t)v_next + 1];
             }
             const uint32_t nx = base + BLEND_THREADS + tid;
-            if (nx < n) v_next = vals[begin + nx];
+            if (nx < n) v_next = vals[begin + nx] & GS_SLOT_MASK;
         }
         uint32_t qm = tid < cnt ? spread_quadrants(quadrant_mask(rect, bx, by)) : 0u;   // bit 2q + h: half h of quadrant q
         if (GS_BLEND_EXACT && qm) qm = exact_halves(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi);
-        if (tid == 0) s_live = 0u;
+        if (tid == 0) {
+            s_live = 0u;
+            // a nearer slab of this bin has saturated every pixel by itself: whatever this one composites is multiplied by 0
+            if (SLAB) s_abort = __hip_atomic_load(&sa.opaque_upto[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slab ? 1u : 0u;
+        }
         const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
         if (BLEND_PREFETCH) {
             if (nxt < n) {
@@ -250,9 +276,10 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                 lo = recs[2 * (size_t)v_next];
                 hi = recs[2 * (size_t)v_next + 1];
             }
-            if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS];
+            if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS] & GS_SLOT_MASK;
         }
         __syncthreads();
+        if (SLAB && s_abort) return;                       // (uniform: no partial is written, the fold never gets this far)
         if (live_wave) {
             uint32_t since_check = 0;
             for (uint32_t g0 = 0; g0 < cnt && live_wave; g0 += 64) {
@@ -370,6 +397,24 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     // multi-GPU strips), and the (splat, quadrant) pairs in a plane of their own behind them
     if (lane == 0u) { s_walked[wave] = walked; s_halves[wave] = halves; }
     __syncthreads();
+    if (SLAB) {
+        // this slab's composite of the bin: {C, T} per pixel (pixels it never touched keep the neutral (0, 0, 0, 1)); the fold
+        // (k_slab_fold) merges the slabs in order and writes the frame.  s_live == 0 after the last batch: every quadrant of the
+        // bin is saturated (or clipped) by this slab alone - farther slabs need not finish.
+        float4* part = sa.partial + (size_t)blockIdx.x * 1024u + wave * 256u + lane;
+#pragma unroll
+        for (int g = 0; g < 4; g++) part[64 * g] = make_float4(Cr[g >> 1][g & 1], Cg[g >> 1][g & 1], Cb[g >> 1][g & 1], T[g >> 1][g & 1]);
+        if (tid == 0u) {
+            atomicAdd(&bin_stats[bin].x, scanned);
+            atomicAdd(&bin_stats[bin].y, s_halves[0] + s_halves[1] + s_halves[2] + s_halves[3]);
+            atomicAdd(&bin_pairs[bin], s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3]);
+            if (s_live == 0u) atomicMin(&sa.opaque_upto[bin], slab);
+        }
+        __threadfence();                                    // the partial is visible before its flag
+        __syncthreads();
+        if (tid == 0u) __hip_atomic_store(&sa.valid[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (tid == 0u) {
         bin_stats[bin] = make_uint2(scanned, s_halves[0] + s_halves[1] + s_halves[2] + s_halves[3]);
         bin_pairs[bin] = s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3];
@@ -388,17 +433,76 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     }
 }
 
+// The second level of the slab-mode composite: per pixel, the slabs' partials merged near -> far,
+//     C += T * C_s ;  T *= T_s  (frozen to 0 at T <= 1e-4, like the per-splat rule)
+// with fp32 multiply-adds in exactly this order whatever produced the partials.  A (bin, slab) whose list range is empty has no
+// partial and is skipped (exactly neutral); one whose partial is missing can only lie behind a slab that saturated the whole
+// bin (its workgroup gave up because of that), where T is 0 for every pixel: the fold stops there.
+__global__ __launch_bounds__(BLEND_THREADS) void k_slab_fold(const uint2* __restrict__ ranges, SlabArgs sa, uint32_t* __restrict__ out,
+                                                              uint32_t width, uint32_t y0, uint32_t y1, uint32_t bins_x,
+                                                              uint32_t bin_row_begin, uint32_t lists_x, uint32_t list_row_begin,
+                                                              uint32_t list_shift) {
+    const uint32_t bin = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
+    const uint32_t px = bx * GS_BIN + (wave & 1u) * GS_TILE + (lane & 15u), py0 = by * GS_BIN + (wave >> 1) * GS_TILE + (lane >> 4);
+    const uint32_t per_list = list_shift - GS_BIN_SHIFT;
+    const uint32_t list_id = ((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list);
+    float T[4] = {1.0f, 1.0f, 1.0f, 1.0f}, C[4][3] = {};
+    for (uint32_t s = 0; s < GS_SLABS; s++) {
+        const uint2 range = ranges[list_id * GS_SLABS + s];
+        if (!(range.y > range.x)) continue;
+        if (__hip_atomic_load(&sa.valid[bin * GS_SLABS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+        const float4* part = sa.partial + ((size_t)bin * GS_SLABS + s) * 1024u + wave * 256u + lane;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 p = part[64 * g];
+            C[g][0] = __builtin_fmaf(T[g], p.x, C[g][0]);
+            C[g][1] = __builtin_fmaf(T[g], p.y, C[g][1]);
+            C[g][2] = __builtin_fmaf(T[g], p.z, C[g][2]);
+            const float t = T[g] * p.w;
+            T[g] = t > GS_T_EPS ? t : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t py = py0 + 4u * g;
+        if (px < width && py >= y0 && py < y1) {
+            const float a = 1.0f - T[g];
+            const uint32_t r8 = (uint32_t)(fminf(fmaxf(C[g][0], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t g8 = (uint32_t)(fminf(fmaxf(C[g][1], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t b8 = (uint32_t)(fminf(fmaxf(C[g][2], 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t a8 = (uint32_t)(fminf(fmaxf(a, 0.0f), 1.0f) * 255.0f + 0.5f);
+            out[(size_t)(py - y0) * width + px] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+        }
+    }
+}
+
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
     if (bins == 0) return GS_OK;
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     GS_TRY(m->blend_stats.ensure((size_t)bins * 12));     // uint2 [bins] {staged, halves} | uint32 [bins] pairs
     m->blend_bins = bins;
-    hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
-                       m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
-                       pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                       m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins,
-                       m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr);
+    SlabArgs sa = {nullptr, nullptr, nullptr};
+    if (pp.slabs) {
+        // (the buffers were sized and reset by the binner's launch: gs_launch_binning)
+        sa.partial = m->slab_partial.as<float4>();
+        sa.opaque_upto = m->slab_flags.as<uint32_t>();
+        sa.valid = m->slab_flags.as<uint32_t>() + bins;
+        hipLaunchKernelGGL(k_tile_blend<true>, dim3(bins * GS_SLABS), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
+                           m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
+                           pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
+                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins, (const uint32_t*)nullptr, sa);
+        hipLaunchKernelGGL(k_slab_fold, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), sa,
+                           reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0, pp.y1, pp.bins_x, pp.bin_row_begin,
+                           pp.lists_x, pp.list_row_begin, pp.list_shift);
+    } else {
+        hipLaunchKernelGGL(k_tile_blend<false>, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
+                           m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
+                           pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
+                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins,
+                           m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr, sa);
+    }
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;
     GS_HIP(hipGetLastError());

@@ -19,7 +19,7 @@ class SplatMesh:
     def __init__(self, context, max_splat_count, spherical_harmonics_degree=0, half_precision_covariances=False,
                  antialiased=False, kernel_2d_size=0.3, max_screen_space_splat_size=1024.0, splat_scale=1.0,
                  point_cloud_mode=False, spherical_harmonics_8bit=False, dynamic_mode=False,
-                 enable_optional_effects=False):
+                 enable_optional_effects=False, depth_slabs=False):
         self.ctx = context
         self.lib = context.lib
         self.max_splat_count = int(max_splat_count)
@@ -33,6 +33,7 @@ class SplatMesh:
         self.sh_8bit = bool(spherical_harmonics_8bit)          # sphericalHarmonics8BitMode (compression level 2)
         self.dynamic_mode = bool(dynamic_mode)
         self.enable_optional_effects = bool(enable_optional_effects)
+        self.depth_slabs = bool(depth_slabs)                   # GS_CAM_DEPTH_SLABS: the two-level composite for very deep lists
         self.fade_in = None                                    # (sceneCenter, visibleRegionFadeStartRadius) or None
         self.splat_count = 0
         self.render_count = 0
@@ -138,7 +139,7 @@ class SplatMesh:
         cam.flags = ((L.GS_CAM_ANTIALIASED if self.antialiased else 0) | (L.GS_CAM_POINT_CLOUD if self.point_cloud_mode else 0) |
                      (L.GS_CAM_ORTHOGRAPHIC if orthographic_mode else 0) | (L.GS_CAM_DYNAMIC if self.dynamic_mode else 0) |
                      (L.GS_CAM_SCENE_EFFECTS if self.enable_optional_effects else 0) |
-                     (L.GS_CAM_FADE_IN if self.fade_in is not None else 0))
+                     (L.GS_CAM_FADE_IN if self.fade_in is not None else 0) | (L.GS_CAM_DEPTH_SLABS if self.depth_slabs else 0))
         if self.fade_in is not None:
             cam.scene_center[:] = self.fade_in[0].tolist()
             cam.fade_start_radius = self.fade_in[1]
@@ -165,6 +166,14 @@ class SplatMesh:
 
     def set_point_cloud_mode_enabled(self, enabled):
         self.point_cloud_mode = bool(enabled)
+
+    def set_depth_slabs(self, enabled):
+        """GS_CAM_DEPTH_SLABS for the draws that follow (takes effect with the next set_camera / update_uniforms)."""
+        self.depth_slabs = bool(enabled)
+        if enabled:
+            self._cam.flags |= L.GS_CAM_DEPTH_SLABS
+        else:
+            self._cam.flags &= ~L.GS_CAM_DEPTH_SLABS
 
     # -- the draw -----------------------------------------------------------------------------------------
     def strip_shape(self, tile_rows=None):

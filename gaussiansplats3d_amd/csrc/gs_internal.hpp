@@ -89,6 +89,11 @@ constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
 // need 28 bits: max_splat_count <= 2^28) and as the low bits of its sort key, so every (list, slab) gets a range of its own
 constexpr uint32_t GS_SLAB_BITS = 4, GS_SLABS = 1u << GS_SLAB_BITS;
 constexpr uint32_t GS_SLOT_MASK = (1u << 28) - 1u;
+// slab-mode flag words of a draw (gs_mesh::slab_flags): opaque_upto [DEEP_MAX] | partial written [DEEP_MAX * SLABS] |
+// deep_list [DEEP_MAX] | deep_count (+3 pad) | deep_of [bins]
+constexpr uint32_t GS_DEEP_MAX_BINS = 256;
+constexpr uint32_t GS_FLAG_VALID = GS_DEEP_MAX_BINS, GS_FLAG_LIST = GS_DEEP_MAX_BINS * (1u + GS_SLABS),
+                   GS_FLAG_COUNT = GS_DEEP_MAX_BINS * (2u + GS_SLABS), GS_FLAG_OF = GS_FLAG_COUNT + 4u;
 
 #ifndef RADIX_TILE_CFG
 #define RADIX_TILE_CFG 4096
@@ -334,8 +339,8 @@ struct gs_mesh {
     DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, half quadrants evaluated}, then
                                // uint32 [the same]: (splat, quadrant) pairs walked
     uint32_t blend_bins = 0, blend_row_begin = 0, blend_width = 0;    // the bins the last draw blended
-    DevBuf slab_partial;       // float4 [bins * GS_SLABS][1024]: the slabs' partial composites (slab mode)
-    DevBuf slab_flags;         // uint32 [bins] opaque_upto | uint32 [bins * GS_SLABS] partial written
+    DevBuf slab_partial;       // float4 [GS_DEEP_MAX_BINS * GS_SLABS][1024]: the deep bins' partial composites (slab mode)
+    DevBuf slab_flags;         // uint32 words, layout above (GS_FLAG_*)
     DevBuf slab_end;           // uint32 [GS_SLABS]: near -> far list positions where the slabs end (from the sort's last digit)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
     bool blend_order_valid = false;

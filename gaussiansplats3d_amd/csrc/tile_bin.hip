@@ -142,10 +142,11 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
         for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
         for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
-        if (SLABS) {                                       // slab mode: nothing saturated yet, no partial written, statistics summed atomically
-            for (uint32_t w = t; w < blend_bins; w += stride) slab_flags[w] = 0xFFFFFFFFu;
-            for (uint32_t w = t; w < blend_bins * GS_SLABS; w += stride) slab_flags[blend_bins + w] = 0u;
-            for (uint32_t w = t; w < 3u * blend_bins; w += stride) blend_stats[w] = 0u;
+        if (SLABS) {                                       // slab mode: no slab saturated, no partial written, no deep bins (k_bin_emit names them)
+            for (uint32_t w = t; w < GS_DEEP_MAX_BINS; w += stride) slab_flags[w] = 0xFFFFFFFFu;
+            for (uint32_t w = t; w < GS_DEEP_MAX_BINS * GS_SLABS; w += stride) slab_flags[GS_FLAG_VALID + w] = 0u;
+            if (t == 0) slab_flags[GS_FLAG_COUNT] = 0u;
+            for (uint32_t w = t; w < blend_bins; w += stride) slab_flags[GS_FLAG_OF + w] = 0xFFFFFFFFu;
         }
     }
     __shared__ uint32_t s_send[GS_SLABS];                  // (LDS, not registers: the kernel runs at 8 waves per SIMD)
@@ -288,7 +289,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           uint32_t* __restrict__ vals_out, uint32_t list_shift,
                                                           volatile uint32_t* __restrict__ mirror, uint32_t serial,
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
-                                                          uint32_t* __restrict__ blend_order, uint32_t slabs) {
+                                                          uint32_t* __restrict__ blend_order, uint32_t slabs,
+                                                          uint32_t* __restrict__ slab_flags, uint32_t* __restrict__ blend_stats_w) {
     __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
     __shared__ unsigned long long s_wsum[4], s_t16[4];
@@ -339,6 +341,27 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
         s_cost[threadIdx.x] = start;
         __syncthreads();
         sweep([&](uint32_t i, uint32_t c) { blend_order[atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u)] = i; });
+        if (slabs) {
+            // Slab mode: the bins whose previous draw cost far more than the mean are drawn slab-parallel (one workgroup per depth
+            // slab + a fold) instead of by one workgroup - same pixels either way (tile_blend.hip), so this is scheduling only.
+            // Their statistics are summed atomically by up to GS_SLABS workgroups: zeroed here.
+            __shared__ uint32_t s_deep_n;
+            if (threadIdx.x == 0) s_deep_n = 0u;
+            __syncthreads();
+            const uint32_t mean = total_walked / max(blend_bins, 1u), thr = max(4u * mean, 8192u);
+            sweep([&](uint32_t i, uint32_t c) {
+                if (c > thr) {
+                    const uint32_t k = atomicAdd(&s_deep_n, 1u);
+                    if (k < GS_DEEP_MAX_BINS) {
+                        slab_flags[GS_FLAG_LIST + k] = i;
+                        slab_flags[GS_FLAG_OF + i] = k;
+                        blend_stats_w[2u * i] = 0u; blend_stats_w[2u * i + 1u] = 0u; blend_stats_w[2u * blend_bins + i] = 0u;
+                    }
+                }
+            });
+            __syncthreads();
+            if (threadIdx.x == 0) slab_flags[GS_FLAG_COUNT] = min(s_deep_n, GS_DEEP_MAX_BINS);
+        }
         BIN_PROF(1, 1, wall_clock64());
         BIN_PROF(1, 2, wall_clock64());
         return;
@@ -495,8 +518,8 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         // where the depth slabs end in the near -> far walk, from the top digit of the sort that produced this list (a full sort
         // of a sorter-fed draw; anything else folds as one slab), and the slab-mode blend's buffers
         GS_TRY(m->slab_end.ensure(GS_SLABS * 4));
-        GS_TRY(m->slab_flags.ensure((size_t)blend_bins * (1 + GS_SLABS) * 4));
-        GS_TRY(m->slab_partial.ensure((size_t)blend_bins * GS_SLABS * 1024 * sizeof(float4)));
+        GS_TRY(m->slab_flags.ensure(((size_t)GS_FLAG_OF + blend_bins) * 4 + 64));
+        GS_TRY(m->slab_partial.ensure((size_t)GS_DEEP_MAX_BINS * GS_SLABS * 1024 * sizeof(float4)));
         GS_TRY(m->blend_stats.ensure((size_t)blend_bins * 12));
         slab_end = m->slab_end.as<uint32_t>();
         const bool have = sorter && sorter->last_passes > 0 && sorter->last_sort == sorter->last_render && order_dev == sorter->sorted.as<uint32_t>();
@@ -519,7 +542,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
     // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
     // backfilling, and ordering them in one workgroup would cost more than it gives)
-    const bool order_ok = !pp.slabs && blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
+    const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
     // (+ one workgroup that only orders the blend's bins)
@@ -527,7 +550,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr,
-                       pp.slabs);
+                       pp.slabs, m->slab_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>());
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
     if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));

@@ -157,38 +157,58 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef GS_BLEND_BRANCH_STYLE
 #define GS_BLEND_BRANCH_STYLE 1       // 0: two independent ifs, 1: both / first / second as three blocks (A/B)
 #endif
-// DEPTH SLABS (GS_CAM_DEPTH_SLABS, SLAB = true).  A pixel's composite is sequential in its list, so a bin whose list is tens of
-// thousands of entries deep and does not saturate (a surface seen at a grazing angle, a pile of translucent splats) runs on
-// four waves for milliseconds while the rest of the GPU idles (the capture-like C3S scene: 8 bins of 2040 take > 4 ms,
+// DEPTH SLABS (GS_CAM_DEPTH_SLABS).  A pixel's composite is sequential in its list, so a bin whose list is tens of thousands
+// of entries deep and does not saturate (a surface seen at a grazing angle, a pile of translucent splats) runs on four waves
+// for milliseconds while the rest of the GPU idles (the capture-like C3S scene: 8 bins of 2040 take > 4 ms,
 // profiles/r03c_blend_profile_C3S.txt).  In slab mode the composite is DEFINED as a two-level fold: the depth sort's buckets are
-// cut into GS_SLABS slabs (a splat's slab is a property of the splat and the camera: the top bits of its sort bucket), every
-// (bin, slab) composites its own splats from T = 1 on a workgroup of its own - partial (C, T) per pixel - and k_slab_fold
-// merges the partials in slab order: C += T * C_s, T *= T_s.  A slab that holds nothing for a pixel is exactly neutral, a slab
-// behind a fully opaque one contributes exactly nothing (0 * C_s), so the result does not depend on which workgroups ran,
-// which lists the entries travelled in or which strip of the screen a rank draws: strips of a multi-GPU draw in slab mode
-// equal the full slab-mode frame bit for bit.  It differs from the single-fold frame by fp32 rounding only (both are held
-// to the same tolerance against the oracle); draws from host-supplied index lists have no buckets and fold as one slab.
+// cut into GS_SLABS slabs (a splat's slab is a property of the splat and the camera: the top bits of its sort bucket); inside a
+// slab a pixel composites its splats from T = 1, and the slabs are merged near -> far with
+//     C = fma(T, C_s, C) ;  T = T * T_s  (frozen to 0 at T <= 1e-4, like the per-splat rule).
+// A slab that holds nothing for a pixel is exactly neutral and a slab behind T = 0 contributes exactly nothing, so the value of
+// a pixel depends only on its own ordered splats and their slabs - not on lists, strips or on WHO executes the fold:
+//   MODE_SEQ   one workgroup per bin walks its list as before and closes a slab (merges, resets) whenever the next splat of a
+//              wave belongs to another one; early termination works across slabs (running T == 0);
+//   MODE_PART  the bins the previous draw found very deep (k_bin_emit's ordering workgroup: cost > 8x the mean) are drawn by
+//              one workgroup per (bin, slab) instead, each from T = 1 into a partial {C, T} per pixel, merged by k_slab_fold.
+// Both give the same bits (tests/test_gpu_slabs.py), so the choice is pure scheduling.  The frame differs from the default
+// single fold by fp32 rounding only (same tolerance against the oracle); draws from host-supplied index lists have no buckets
+// and fold as one slab.  (First cut, r03l: EVERY (bin, slab) on a workgroup of its own - early termination across slabs is
+// lost, deeper slabs walk what nearer ones already hide: C3 0.30 -> 2.3 ms, C3S 4.6 -> 6.9 ms.  Hence the two modes.)
+constexpr int MODE_DEFAULT = 0, MODE_SEQ = 1, MODE_PART = 2;
+constexpr uint32_t GS_DEEP_MAX = GS_DEEP_MAX_BINS;        // bins drawn slab-parallel per draw, at most
+constexpr uint32_t GS_DEEP_NONE = 0xFFFFFFFFu;
 struct SlabArgs {
-    float4* partial;            // [bins * GS_SLABS][1024]: {C.r, C.g, C.b, T} per pixel of the bin
-    uint32_t* opaque_upto;      // [bins]: smallest slab whose own composite saturated every pixel of the bin (0xFFFFFFFF: none)
-    uint32_t* valid;            // [bins * GS_SLABS]: the partial was written
+    float4* partial;            // [GS_DEEP_MAX * GS_SLABS][1024]: {C.r, C.g, C.b, T} per pixel of a deep bin and slab
+    uint32_t* opaque_upto;      // [GS_DEEP_MAX]: smallest slab whose own composite saturated every pixel of the bin
+    uint32_t* valid;            // [GS_DEEP_MAX * GS_SLABS]: the partial was written
+    const uint32_t* deep_list;  // [GS_DEEP_MAX]: the deep bins of this draw
+    const uint32_t* deep_count;
+    const uint32_t* deep_of;    // [bins]: index in deep_list, or GS_DEEP_NONE
 };
 
-template <bool SLAB>
-__global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
-                                                              const uint4* __restrict__ recs, const uint2* __restrict__ rects,
-                                                              uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
-                                                              uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
-                                                              uint32_t list_row_begin, uint32_t list_shift,
-                                                              uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
-                                                              const uint32_t* __restrict__ bin_order, SlabArgs sa) {
+template <int MODE>
+__device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
+                                           const uint4* __restrict__ recs, const uint2* __restrict__ rects,
+                                           uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
+                                           uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
+                                           uint32_t list_row_begin, uint32_t list_shift,
+                                           uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
+                                           const uint32_t* __restrict__ bin_order, const SlabArgs& sa, const uint32_t wg) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
     __shared__ uint32_t s_abort;
     __shared__ uint32_t s_walked[4], s_halves[4];
-    const uint32_t slab = SLAB ? blockIdx.x % GS_SLABS : 0u;
-    const uint32_t bin = SLAB ? blockIdx.x / GS_SLABS : (bin_order ? bin_order[blockIdx.x] : blockIdx.x);   // heaviest bins first (k_bin_emit)
+    constexpr bool SLAB = MODE == MODE_PART;                // one workgroup per (deep bin, slab), from T = 1 into a partial
+    const uint32_t slab = SLAB ? wg % GS_SLABS : 0u;
+    uint32_t bin;
+    if (SLAB) {
+        if (wg / GS_SLABS >= *sa.deep_count) return;
+        bin = sa.deep_list[wg / GS_SLABS];
+    } else {
+        bin = bin_order ? bin_order[wg] : wg;             // heaviest bins of the previous draw first (k_bin_emit)
+        if (MODE == MODE_SEQ && sa.deep_of[bin] != GS_DEEP_NONE) return;   // drawn slab-parallel (MODE_PART + k_slab_fold)
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
     const uint32_t qx0 = bx * GS_BIN + (wave & 1u) * GS_TILE, qy0 = by * GS_BIN + (wave >> 1) * GS_TILE;   // quadrant origin
@@ -208,7 +228,21 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     // the entry list of the list bin this 32-px bin lies in
     const uint32_t per_list = list_shift - GS_BIN_SHIFT;
     const uint32_t list_id = ((by >> per_list) - list_row_begin) * lists_x + (bx >> per_list);
-    const uint2 range = ranges[SLAB ? list_id * GS_SLABS + slab : list_id];
+    uint2 range;
+    if (MODE == MODE_SEQ) {
+        // the list's GS_SLABS per-slab ranges lie back to back in the sorted entries (keys list * GS_SLABS + slab): their union
+        __shared__ uint32_t s_rng[2];
+        if (tid == 0u) { s_rng[0] = 0xFFFFFFFFu; s_rng[1] = 0u; }
+        __syncthreads();
+        if (tid < GS_SLABS) {
+            const uint2 r = ranges[list_id * GS_SLABS + tid];
+            if (r.y > r.x) { atomicMin(&s_rng[0], r.x); atomicMax(&s_rng[1], r.y); }
+        }
+        __syncthreads();
+        range = make_uint2(s_rng[0], s_rng[1]);
+    } else {
+        range = ranges[SLAB ? list_id * GS_SLABS + slab : list_id];
+    }
     if (SLAB && !(range.y > range.x)) return;              // nothing of this slab reaches the list: no partial (the fold skips it)
     const uint32_t begin = range.x, n = range.y > range.x ? range.y - range.x : 0u;   // untouched bins keep (~0, 0)
 
@@ -219,6 +253,23 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     v2f T[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
     v2f Cr[2] = {{0, 0}, {0, 0}}, Cg[2] = {{0, 0}, {0, 0}}, Cb[2] = {{0, 0}, {0, 0}};
     const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
+    // MODE_SEQ: T / C above are the CURRENT slab's composite (from T = 1); these are the fold of the slabs closed so far
+    v2f Tr[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+    v2f Rr[2] = {{0, 0}, {0, 0}}, Rg[2] = {{0, 0}, {0, 0}}, Rb[2] = {{0, 0}, {0, 0}};
+    uint32_t cur_slab = 0;                                  // wave-uniform
+    auto close_slab = [&]() {                               // the arithmetic of k_slab_fold, component by component
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            Rr[h].x = __builtin_fmaf(Tr[h].x, Cr[h].x, Rr[h].x); Rr[h].y = __builtin_fmaf(Tr[h].y, Cr[h].y, Rr[h].y);
+            Rg[h].x = __builtin_fmaf(Tr[h].x, Cg[h].x, Rg[h].x); Rg[h].y = __builtin_fmaf(Tr[h].y, Cg[h].y, Rg[h].y);
+            Rb[h].x = __builtin_fmaf(Tr[h].x, Cb[h].x, Rb[h].x); Rb[h].y = __builtin_fmaf(Tr[h].y, Cb[h].y, Rb[h].y);
+            const float tx = Tr[h].x * T[h].x, ty = Tr[h].y * T[h].y;
+            Tr[h].x = tx > GS_T_EPS ? tx : 0.0f;
+            Tr[h].y = ty > GS_T_EPS ? ty : 0.0f;
+            T[h] = v2f{1.0f, 1.0f};
+            Cr[h] = v2f{0, 0}; Cg[h] = v2f{0, 0}; Cb[h] = v2f{0, 0};
+        }
+    };
 
     // entry payload = record slot (k_bin_emit); the slot also names the splat's tile rect, which says whether and where the
     // splat touches THIS bin - most entries of a 128-px list do not, and only the others are expanded into LDS.
@@ -232,16 +283,19 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     uint2 rect = make_uint2(0xFFFFu, 0u);              // empty
     uint32_t v_next = 0;
+    uint32_t v_slab = 0, v_slab_next = 0;              // slab of the entry in (lo, hi) / of the entry word in v_next (MODE_SEQ)
     if (BLEND_PREFETCH) {
         if (tid < n) {
-            const uint32_t slot = vals[begin + tid] & GS_SLOT_MASK;       // (top bits: the entry's depth slab)
+            const uint32_t raw = vals[begin + tid];                    // (top bits: the entry's depth slab)
+            const uint32_t slot = raw & GS_SLOT_MASK;
+            v_slab = raw >> 28;
             rect = rects[slot];
             lo = recs[2 * (size_t)slot];
             hi = recs[2 * (size_t)slot + 1];
         }
-        if (BLEND_THREADS + tid < n) v_next = vals[begin + BLEND_THREADS + tid] & GS_SLOT_MASK;
+        if (BLEND_THREADS + tid < n) { const uint32_t raw = vals[begin + BLEND_THREADS + tid]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
     } else if (tid < n) {
-        v_next = vals[begin + tid] & GS_SLOT_MASK;
+        const uint32_t raw = vals[begin + tid]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28;
     }
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
@@ -256,18 +310,20 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                 rect = rects[v_next];
                 lo = recs[2 * (size_t)v_next];
                 hi = recs[2 * (size_t)v_next + 1];
+                v_slab = v_slab_next;
             }
             const uint32_t nx = base + BLEND_THREADS + tid;
-            if (nx < n) v_next = vals[begin + nx] & GS_SLOT_MASK;
+            if (nx < n) { const uint32_t raw = vals[begin + nx]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
         }
         uint32_t qm = tid < cnt ? spread_quadrants(quadrant_mask(rect, bx, by)) : 0u;   // bit 2q + h: half h of quadrant q
         if (GS_BLEND_EXACT && qm) qm = exact_halves(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi);
+        if (MODE == MODE_SEQ && qm) s_batch[tid].pad0 = __uint_as_float(v_slab);       // the entry's depth slab (payload's top bits)
         if (tid == 0) {
             s_live = 0u;
             // a nearer slab of this bin has saturated every pixel by itself: whatever this one composites is multiplied by 0
-            if (SLAB) s_abort = __hip_atomic_load(&sa.opaque_upto[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slab ? 1u : 0u;
+            if (SLAB) s_abort = __hip_atomic_load(&sa.opaque_upto[wg / GS_SLABS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < slab ? 1u : 0u;
         }
         const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
         if (BLEND_PREFETCH) {
@@ -275,8 +331,9 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                 rect = rects[v_next];
                 lo = recs[2 * (size_t)v_next];
                 hi = recs[2 * (size_t)v_next + 1];
+                v_slab = v_slab_next;
             }
-            if (nxt + BLEND_THREADS < n) v_next = vals[begin + nxt + BLEND_THREADS] & GS_SLOT_MASK;
+            if (nxt + BLEND_THREADS < n) { const uint32_t raw = vals[begin + nxt + BLEND_THREADS]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
         }
         __syncthreads();
         if (SLAB && s_abort) return;                       // (uniform: no partial is written, the fold never gets this far)
@@ -295,6 +352,20 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
                     const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].cx);
                     const float4 q1 = *reinterpret_cast<const float4*>(&s_batch[j].bx);
                     const float4 q2 = *reinterpret_cast<const float4*>(&s_batch[j].r);
+                    if (MODE == MODE_SEQ) {
+                        const uint32_t sj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.z));
+                        if (sj != cur_slab) {              // this wave's next splat opens another slab: merge the finished one
+                            close_slab();
+                            cur_slab = sj;
+                            bool open = false;
+#pragma unroll
+                            for (int h = 0; h < 2; h++) open = open || (Tr[h].x > 0.0f) || (Tr[h].y > 0.0f);
+                            if (__ballot(open) == 0ull) {  // every pixel of the quadrant is saturated by the slabs merged so far
+                                live_wave = false;
+                                break;
+                            }
+                        }
+                    }
                     const float dx = fx - q0.x;
                     const float adx = q0.z * dx, bdx = q1.x * dx;
                     // The four 16x4 strips of a lane are two packed pairs (v_pk_*_f32 does two fp32 lanes per VALU slot): pair
@@ -401,19 +472,24 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
         // this slab's composite of the bin: {C, T} per pixel (pixels it never touched keep the neutral (0, 0, 0, 1)); the fold
         // (k_slab_fold) merges the slabs in order and writes the frame.  s_live == 0 after the last batch: every quadrant of the
         // bin is saturated (or clipped) by this slab alone - farther slabs need not finish.
-        float4* part = sa.partial + (size_t)blockIdx.x * 1024u + wave * 256u + lane;
+        float4* part = sa.partial + (size_t)wg * 1024u + wave * 256u + lane;
 #pragma unroll
         for (int g = 0; g < 4; g++) part[64 * g] = make_float4(Cr[g >> 1][g & 1], Cg[g >> 1][g & 1], Cb[g >> 1][g & 1], T[g >> 1][g & 1]);
         if (tid == 0u) {
             atomicAdd(&bin_stats[bin].x, scanned);
             atomicAdd(&bin_stats[bin].y, s_halves[0] + s_halves[1] + s_halves[2] + s_halves[3]);
             atomicAdd(&bin_pairs[bin], s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3]);
-            if (s_live == 0u) atomicMin(&sa.opaque_upto[bin], slab);
+            if (s_live == 0u) atomicMin(&sa.opaque_upto[wg / GS_SLABS], slab);
         }
         __threadfence();                                    // the partial is visible before its flag
         __syncthreads();
-        if (tid == 0u) __hip_atomic_store(&sa.valid[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0u) __hip_atomic_store(&sa.valid[wg], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
+    }
+    if (MODE == MODE_SEQ) {                                 // the last open slab, then the frame comes from the fold
+        close_slab();
+#pragma unroll
+        for (int h = 0; h < 2; h++) { T[h] = Tr[h]; Cr[h] = Rr[h]; Cg[h] = Rg[h]; Cb[h] = Rb[h]; }
     }
     if (tid == 0u) {
         bin_stats[bin] = make_uint2(scanned, s_halves[0] + s_halves[1] + s_halves[2] + s_halves[3]);
@@ -433,16 +509,48 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const u
     }
 }
 
-// The second level of the slab-mode composite: per pixel, the slabs' partials merged near -> far,
-//     C += T * C_s ;  T *= T_s  (frozen to 0 at T <= 1e-4, like the per-splat rule)
-// with fp32 multiply-adds in exactly this order whatever produced the partials.  A (bin, slab) whose list range is empty has no
-// partial and is skipped (exactly neutral); one whose partial is missing can only lie behind a slab that saturated the whole
-// bin (its workgroup gave up because of that), where T is 0 for every pixel: the fold stops there.
+// the default frame: one workgroup per bin, the single fold
+__global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
+                                                              const uint4* __restrict__ recs, const uint2* __restrict__ rects,
+                                                              uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
+                                                              uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
+                                                              uint32_t list_row_begin, uint32_t list_shift,
+                                                              uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
+                                                              const uint32_t* __restrict__ bin_order) {
+    const SlabArgs none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    blend_body<MODE_DEFAULT>(ranges, vals, recs, rects, out, width, y0, y1, bins_x, bin_row_begin, lists_x, list_row_begin, list_shift,
+                             bin_stats, bin_pairs, bin_order, none, blockIdx.x);
+}
+
+// slab mode, one launch: the first GS_DEEP_MAX * GS_SLABS workgroups are the (deep bin, slab) slots - the long ones start
+// first -, the rest draw one bin each (and leave the deep bins alone).  5 workgroups per CU: the sequential mode carries the
+// merged {C, T} next to the open slab's (92 VGPRs).
+__global__ __launch_bounds__(BLEND_THREADS, 5) void k_tile_blend_slabs(const uint2* __restrict__ ranges, const uint32_t* __restrict__ vals,
+                                                              const uint4* __restrict__ recs, const uint2* __restrict__ rects,
+                                                              uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1,
+                                                              uint32_t bins_x, uint32_t bin_row_begin, uint32_t lists_x,
+                                                              uint32_t list_row_begin, uint32_t list_shift,
+                                                              uint2* __restrict__ bin_stats, uint32_t* __restrict__ bin_pairs,
+                                                              const uint32_t* __restrict__ bin_order, SlabArgs sa) {
+    if (blockIdx.x < GS_DEEP_MAX * GS_SLABS)
+        blend_body<MODE_PART>(ranges, vals, recs, rects, out, width, y0, y1, bins_x, bin_row_begin, lists_x, list_row_begin, list_shift,
+                              bin_stats, bin_pairs, nullptr, sa, blockIdx.x);
+    else
+        blend_body<MODE_SEQ>(ranges, vals, recs, rects, out, width, y0, y1, bins_x, bin_row_begin, lists_x, list_row_begin, list_shift,
+                             bin_stats, bin_pairs, bin_order, sa, blockIdx.x - GS_DEEP_MAX * GS_SLABS);
+}
+
+// The second level of the slab-mode composite for the deep bins: per pixel, the slabs' partials merged near -> far,
+//     C = fma(T, C_s, C) ;  T = T * T_s  (frozen to 0 at T <= 1e-4, like the per-splat rule)
+// exactly what MODE_SEQ does when it closes a slab.  A (bin, slab) whose list range is empty has no partial and is skipped
+// (exactly neutral); one whose partial is missing can only lie behind a slab that saturated the whole bin (its workgroup gave
+// up because of that), where T is 0 for every pixel: the fold stops there.
 __global__ __launch_bounds__(BLEND_THREADS) void k_slab_fold(const uint2* __restrict__ ranges, SlabArgs sa, uint32_t* __restrict__ out,
                                                               uint32_t width, uint32_t y0, uint32_t y1, uint32_t bins_x,
                                                               uint32_t bin_row_begin, uint32_t lists_x, uint32_t list_row_begin,
                                                               uint32_t list_shift) {
-    const uint32_t bin = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (blockIdx.x >= *sa.deep_count) return;
+    const uint32_t bin = sa.deep_list[blockIdx.x], tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
     const uint32_t px = bx * GS_BIN + (wave & 1u) * GS_TILE + (lane & 15u), py0 = by * GS_BIN + (wave >> 1) * GS_TILE + (lane >> 4);
     const uint32_t per_list = list_shift - GS_BIN_SHIFT;
@@ -451,8 +559,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_slab_fold(const uint2* __rest
     for (uint32_t s = 0; s < GS_SLABS; s++) {
         const uint2 range = ranges[list_id * GS_SLABS + s];
         if (!(range.y > range.x)) continue;
-        if (__hip_atomic_load(&sa.valid[bin * GS_SLABS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
-        const float4* part = sa.partial + ((size_t)bin * GS_SLABS + s) * 1024u + wave * 256u + lane;
+        if (__hip_atomic_load(&sa.valid[blockIdx.x * GS_SLABS + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;
+        const float4* part = sa.partial + ((size_t)blockIdx.x * GS_SLABS + s) * 1024u + wave * 256u + lane;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const float4 p = part[64 * g];
@@ -483,25 +591,29 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t* vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     GS_TRY(m->blend_stats.ensure((size_t)bins * 12));     // uint2 [bins] {staged, halves} | uint32 [bins] pairs
     m->blend_bins = bins;
-    SlabArgs sa = {nullptr, nullptr, nullptr};
+    const uint32_t* order = m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr;
     if (pp.slabs) {
-        // (the buffers were sized and reset by the binner's launch: gs_launch_binning)
+        // (the buffers were sized and reset by the binner's launches: gs_launch_binning)
+        uint32_t* flags = m->slab_flags.as<uint32_t>();      // layout: GS_FLAG_* in gs_internal.hpp
+        SlabArgs sa;
         sa.partial = m->slab_partial.as<float4>();
-        sa.opaque_upto = m->slab_flags.as<uint32_t>();
-        sa.valid = m->slab_flags.as<uint32_t>() + bins;
-        hipLaunchKernelGGL(k_tile_blend<true>, dim3(bins * GS_SLABS), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
-                           m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
-                           pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins, (const uint32_t*)nullptr, sa);
-        hipLaunchKernelGGL(k_slab_fold, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), sa,
+        sa.opaque_upto = flags;
+        sa.valid = flags + GS_FLAG_VALID;
+        sa.deep_list = flags + GS_FLAG_LIST;
+        sa.deep_count = flags + GS_FLAG_COUNT;
+        sa.deep_of = flags + GS_FLAG_OF;
+        hipLaunchKernelGGL(k_tile_blend_slabs, dim3(GS_DEEP_MAX * GS_SLABS + bins), dim3(BLEND_THREADS), 0, m->ctx->stream,
+                           m->tile_ranges.as<uint2>(), vals, m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev),
+                           (uint32_t)pp.width, pp.y0, pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
+                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins, order, sa);
+        hipLaunchKernelGGL(k_slab_fold, dim3(GS_DEEP_MAX), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), sa,
                            reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0, pp.y1, pp.bins_x, pp.bin_row_begin,
                            pp.lists_x, pp.list_row_begin, pp.list_shift);
     } else {
-        hipLaunchKernelGGL(k_tile_blend<false>, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
+        hipLaunchKernelGGL(k_tile_blend, dim3(bins), dim3(BLEND_THREADS), 0, m->ctx->stream, m->tile_ranges.as<uint2>(), vals,
                            m->recs.as<uint4>(), m->rects.as<uint2>(), reinterpret_cast<uint32_t*>(out_dev), (uint32_t)pp.width, pp.y0,
                            pp.y1, pp.bins_x, pp.bin_row_begin, pp.lists_x, pp.list_row_begin, pp.list_shift,
-                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins,
-                           m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr, sa);
+                           m->blend_stats.as<uint2>(), m->blend_stats.as<uint32_t>() + 2 * (size_t)bins, order);
     }
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;

@@ -260,6 +260,12 @@ class SplatMesh:
         L.check(self.lib.gs_mesh_debug_read(self.handle, 4, out.ctypes.data, by * bx))
         return out.reshape(by, bx, 2)
 
+    def deep_bins(self):
+        """Slab mode: the 32-px bins the last draw drew slab-parallel (chosen from the draw before it)."""
+        out = np.zeros(257, dtype=np.uint32)
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, 257))
+        return out[1:1 + int(out[0])].copy()
+
     def tile_row_costs(self):
         """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips).  The blend is
         what a strip mostly pays for and its cost is what it WALKS before its pixels saturate, not the length of its lists:

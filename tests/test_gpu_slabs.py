@@ -110,3 +110,40 @@ def test_host_index_lists_fold_as_one_slab(ctx):
         frames.append(mesh.render()[0])
         mesh.dispose()
     np.testing.assert_array_equal(frames[0], frames[1])
+
+
+def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold(ctx):
+    """The first slab-mode draw of a mesh has no statistics: every bin is folded by one workgroup (MODE_SEQ).  From the second
+    draw on the bins that cost far more than the mean are drawn by one workgroup per depth slab and merged by k_slab_fold
+    (MODE_PART).  Same arithmetic, different executors: the frames must be identical, and the scene must really have deep bins."""
+    W, H = 480, 270
+    cam = camera.demo_camera("garden", W, H)
+    n = 260000
+    scene = _deep_pile(n, 33)
+    rng = np.random.default_rng(9)
+    pos, look = np.array(camera.DEMO_POSES["garden"][1]), np.array(camera.DEMO_POSES["garden"][2])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    k = n // 2                                              # half of the splats in a thin translucent column: a few very deep bins
+    scene.centers[-k:] = (pos + fwd * rng.uniform(1.5, 9.0, size=(k, 1)) + rng.normal(size=(k, 3)) * 0.03).astype(np.float32)
+    mesh = SplatMesh(ctx, n, scene.sh_degree, depth_slabs=True).build(scene.centers, scene.cov, scene.rgba, scene.sh)
+    mesh.set_camera(cam)
+    w = create_sort_worker(ctx, n)
+    w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": n - 1, "count": n}})
+    mesh.use_sorter_result(w, n)
+    frames, deep = [], []
+    for _ in range(4):
+        w.sort_on_device(cam.sort_mvp(), n)
+        frames.append(mesh.render()[0])
+        deep.append(len(mesh.deep_bins()))
+    assert deep[0] == 0 and deep[1] > 0 and deep[2] > 0, deep
+    for f in frames[1:]:
+        np.testing.assert_array_equal(f, frames[0])
+    # ... and strips of that state still reproduce it
+    rows = (H + 15) // 16
+    strips = []
+    for r in ((0, 7), (7, rows)):
+        w.sort_on_device(cam.sort_mvp(), n)
+        strips.append(mesh.render(tile_rows=r)[0])
+    np.testing.assert_array_equal(np.concatenate(strips, axis=0), frames[0])
+    w.terminate()
+    mesh.dispose()

@@ -1,0 +1,56 @@
+"""Default composite vs GS_CAM_DEPTH_SLABS on the same box: one-stream frame time and isolated stage medians per config.
+usage: python tools/slab_ab.py "C3S C3T C3 C2" [frames]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util
+
+names = (sys.argv[1] if len(sys.argv) > 1 else "C3S").split()
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ctx = Context(0, single_stream=True)
+for name in names:
+    cfg = scenes.CONFIGS[name]
+    scene = scenes.make_config_scene("C3" if name == "C5" else name)
+    cam = camera.demo_camera(cfg["pose"], cfg["width"], cfg["height"])
+    N = scene.count
+    w = create_sort_worker(ctx, N)
+    w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
+    mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half).build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+    mesh.set_camera(cam)
+    mesh.use_sorter_result(w, N)
+    mvp = cam.sort_mvp()
+    ref = None
+    for slabs in (False, True, False, True):
+        mesh.set_depth_slabs(slabs)
+        for _ in range(3):
+            w.sort_on_device(mvp, N)
+            img, _ = mesh.render(to_host=slabs is not None, want_stats=True)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            w.sort_on_device(mvp, N)
+            mesh.render(to_host=False, want_stats=False)
+        ctx.synchronize()
+        ms = (time.perf_counter() - t0) / frames * 1e3
+        st = {"bin": [], "esort": [], "blend": []}
+        ctx.set_stage_timing(True)
+        for _ in range(7):
+            w.sort_on_device(mvp, N)
+            _, r = mesh.render(to_host=False, want_stats=True)
+            st["bin"].append(r.bin_ms); st["esort"].append(r.tile_sort_ms); st["blend"].append(r.blend_ms)
+        ctx.set_stage_timing(False)
+        diff = ""
+        if not slabs:
+            ref = img
+        elif ref is not None:
+            d = np.abs(ref.astype(int) - img.astype(int))
+            diff = " | vs default frame: max %d LSB, %.4f %% of channel values differ" % (d.max(), 100.0 * (d > 0).mean())
+        print("%-4s %-8s frame %.4f ms = %7.1f Msplats/s | bin %.4f esort %.4f blend %.4f | entries %d walked %d%s" %
+              (name, "slabs" if slabs else "default", ms, N / ms / 1e3, np.median(st["bin"]), np.median(st["esort"]),
+               np.median(st["blend"]), r.tile_entries, r.splats_walked, diff), flush=True)
+    w.terminate(); mesh.dispose()
+    del scene

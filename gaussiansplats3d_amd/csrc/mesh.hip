@@ -688,6 +688,7 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     // whole-block tests assume one modelView for every splat of a block: off under per-scene transforms (and GSPLAT_NO_BLOCK_CULL)
     pp.block_cull = (!(cam->flags & GS_CAM_DYNAMIC) && !m->no_block_cull) ? 1u : 0u;
     pp.slabs = (cam->flags & GS_CAM_DEPTH_SLABS) ? 1u : 0u;
+    GS_REQUIRE(!pp.slabs || m->max_count <= (1u << GS_SLAB_SHIFT), "GS_CAM_DEPTH_SLABS: the mesh holds more than 2^26 splats");
 
     // pixel rows covered by this rank's strip, and the 32-px bins that cover them
     const uint32_t y0 = pp.row_begin * GS_TILE;

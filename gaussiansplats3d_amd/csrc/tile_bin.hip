@@ -237,10 +237,11 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         for (int k = 0; k < BIN_PER_LANE; k++) {
             if (SLABS && keep[k]) {                        // the splat's depth slab rides in the payload's top bits
                 const uint32_t q = q0 + (uint32_t)k;
-                uint32_t sl = 0;
+                uint32_t sl = 0;                           // number of slab ends <= q (the ends ascend): binary search
 #pragma unroll
-                for (uint32_t j = 0; j < GS_SLABS - 1u; j++) sl += s_send[j] <= q ? 1u : 0u;
-                slot[k] |= sl << 28;
+                for (uint32_t step = GS_SLABS / 2u; step > 0u; step >>= 1)
+                    if (s_send[sl + step - 1u] <= q) sl += step;
+                slot[k] |= sl << GS_SLAB_SHIFT;
             }
             if (keep[k]) {
                 cidx[o] = slot[k];                         // what the blend gathers records by
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     const uint32_t units = bin_grid * per;
     auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
         if (e >= D) return;                                  // dropped by an overflowing draw (it is redone)
-        keys_out[e] = (KeyT)(slabs ? key * GS_SLABS + (idx >> 28) : key);   // slab mode: one list per (list bin, depth slab)
+        keys_out[e] = (KeyT)(slabs ? key * GS_SLABS + (idx >> GS_SLAB_SHIFT) : key);   // slab mode: one list per (list bin, depth slab)
         vals_out[e] = idx;
     };
     uint32_t emitted = 0;

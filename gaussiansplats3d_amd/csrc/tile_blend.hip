@@ -287,15 +287,15 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
     if (BLEND_PREFETCH) {
         if (tid < n) {
             const uint32_t raw = vals[begin + tid];                    // (top bits: the entry's depth slab)
-            const uint32_t slot = raw & GS_SLOT_MASK;
-            v_slab = raw >> 28;
+            const uint32_t slot = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK;
+            v_slab = raw >> GS_SLAB_SHIFT;
             rect = rects[slot];
             lo = recs[2 * (size_t)slot];
             hi = recs[2 * (size_t)slot + 1];
         }
-        if (BLEND_THREADS + tid < n) { const uint32_t raw = vals[begin + BLEND_THREADS + tid]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
+        if (BLEND_THREADS + tid < n) { const uint32_t raw = vals[begin + BLEND_THREADS + tid]; v_next = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK; v_slab_next = raw >> GS_SLAB_SHIFT; }
     } else if (tid < n) {
-        const uint32_t raw = vals[begin + tid]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28;
+        const uint32_t raw = vals[begin + tid]; v_next = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK; v_slab_next = raw >> GS_SLAB_SHIFT;
     }
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
@@ -313,7 +313,7 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                 v_slab = v_slab_next;
             }
             const uint32_t nx = base + BLEND_THREADS + tid;
-            if (nx < n) { const uint32_t raw = vals[begin + nx]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
+            if (nx < n) { const uint32_t raw = vals[begin + nx]; v_next = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK; v_slab_next = raw >> GS_SLAB_SHIFT; }
         }
         uint32_t qm = tid < cnt ? spread_quadrants(quadrant_mask(rect, bx, by)) : 0u;   // bit 2q + h: half h of quadrant q
         if (GS_BLEND_EXACT && qm) qm = exact_halves(qm, lo, hi, bx, by);
@@ -333,7 +333,7 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                 hi = recs[2 * (size_t)v_next + 1];
                 v_slab = v_slab_next;
             }
-            if (nxt + BLEND_THREADS < n) { const uint32_t raw = vals[begin + nxt + BLEND_THREADS]; v_next = raw & GS_SLOT_MASK; v_slab_next = raw >> 28; }
+            if (nxt + BLEND_THREADS < n) { const uint32_t raw = vals[begin + nxt + BLEND_THREADS]; v_next = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK; v_slab_next = raw >> GS_SLAB_SHIFT; }
         }
         __syncthreads();
         if (SLAB && s_abort) return;                       // (uniform: no partial is written, the fold never gets this far)

@@ -306,11 +306,12 @@ typedef struct gs_camera {
 #define GS_CAM_FADE_IN 8u        /* fadeInComplete == 0: distance fade-in, SplatMaterial.js:347-363             */
 #define GS_CAM_SCENE_EFFECTS 16u /* enableOptionalEffects: per-scene opacity / visibility, SplatMaterial.js:129 */
 #define GS_CAM_DYNAMIC 32u       /* dynamicMode: per-scene transforms, SplatMaterial.js:140-144,179-183         */
-#define GS_CAM_DEPTH_SLABS 64u   /* composite as a two-level fold over 16 depth slabs (a splat's slab = the top bits of its sort
-                                    bucket): bins with very deep lists are drawn by up to 16 workgroups instead of one.  The frame
-                                    differs from the default single fold by fp32 rounding only; strips of a multi-GPU draw still
-                                    equal the full frame bit for bit when every rank sets the flag.  Needs a sorter-fed draw of a
-                                    full sort; other draws fold as one slab.                                          */
+#define GS_CAM_DEPTH_SLABS 64u   /* composite as a two-level fold over 64 depth slabs (a splat's slab = the top bits of its sort
+                                    bucket): the bins the previous draw found very deep are drawn by one workgroup per slab
+                                    instead of one per bin.  The frame differs from the default single fold by fp32 rounding
+                                    only; strips of a multi-GPU draw still equal the full frame bit for bit when every rank
+                                    sets the flag.  Needs a sorter-fed draw of a full sort (other draws fold as one slab) and
+                                    a mesh of at most 2^26 splats.                                                      */
 #define GS_TILE 16u
 
 typedef struct gs_render_stats {

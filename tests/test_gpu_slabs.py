@@ -125,6 +125,7 @@ def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold(ctx):
     fwd = (look - pos) / np.linalg.norm(look - pos)
     k = n // 2                                              # half of the splats in a thin translucent column: a few very deep bins
     scene.centers[-k:] = (pos + fwd * rng.uniform(1.5, 9.0, size=(k, 1)) + rng.normal(size=(k, 3)) * 0.03).astype(np.float32)
+    scene.rgba[-k:, 3] = 2                                  # alpha 2/255: thousands of them before a pixel saturates
     mesh = SplatMesh(ctx, n, scene.sh_degree, depth_slabs=True).build(scene.centers, scene.cov, scene.rgba, scene.sh)
     mesh.set_camera(cam)
     w = create_sort_worker(ctx, n)

@@ -49,8 +49,12 @@ for name in names:
         elif ref is not None:
             d = np.abs(ref.astype(int) - img.astype(int))
             diff = " | vs default frame: max %d LSB, %.4f %% of channel values differ" % (d.max(), 100.0 * (d > 0).mean())
+        extra = ""
+        if slabs:
+            bs = mesh.blend_bin_stats()[..., 1].astype(np.int64)
+            extra = " | deep bins %d (cost mean %d max %d)" % (len(mesh.deep_bins()), bs.mean(), bs.max())
         print("%-4s %-8s frame %.4f ms = %7.1f Msplats/s | bin %.4f esort %.4f blend %.4f | entries %d walked %d%s" %
               (name, "slabs" if slabs else "default", ms, N / ms / 1e3, np.median(st["bin"]), np.median(st["esort"]),
-               np.median(st["blend"]), r.tile_entries, r.splats_walked, diff), flush=True)
+               np.median(st["blend"]), r.tile_entries, r.splats_walked, diff + extra), flush=True)
     w.terminate(); mesh.dispose()
     del scene

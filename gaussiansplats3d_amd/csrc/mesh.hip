@@ -888,7 +888,7 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
         GS_REQUIRE(count <= m->blend_bins, "count exceeds the blend bins of the last draw");
         if (count) GS_HIP(hipMemcpyAsync(dst, m->blend_stats.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
     } else if (what == 5) {   // slab mode: {number of bins the last draw drew slab-parallel, then their bin numbers}; count = words
-        GS_REQUIRE(m->slab_flags.p && count >= 1 && count <= 1u + GS_DEEP_MAX_BINS, "no slab-mode draw / count outside 1 .. 257");
+        GS_REQUIRE(m->slab_flags.p && count >= 1 && count <= 1u + GS_DEEP_MAX_BINS, "no slab-mode draw / count outside 1 .. 1 + GS_DEEP_MAX_BINS");
         GS_HIP(hipMemcpyAsync(dst, m->slab_flags.as<uint32_t>() + GS_FLAG_COUNT, 4, hipMemcpyDeviceToHost, st));
         if (count > 1) GS_HIP(hipMemcpyAsync(static_cast<uint32_t*>(dst) + 1, m->slab_flags.as<uint32_t>() + GS_FLAG_LIST, (size_t)(count - 1) * 4, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");

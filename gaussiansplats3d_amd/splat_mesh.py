@@ -262,8 +262,8 @@ class SplatMesh:
 
     def deep_bins(self):
         """Slab mode: the 32-px bins the last draw drew slab-parallel (chosen from the draw before it)."""
-        out = np.zeros(257, dtype=np.uint32)
-        L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, 257))
+        out = np.zeros(129, dtype=np.uint32)                   # count + at most GS_DEEP_MAX_BINS = 128 bins
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, 129))
         return out[1:1 + int(out[0])].copy()
 
     def tile_row_costs(self):

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           volatile uint32_t* __restrict__ mirror, uint32_t serial,
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
                                                           uint32_t* __restrict__ blend_order, uint32_t slabs,
-                                                          uint32_t* __restrict__ slab_flags, uint32_t* __restrict__ blend_stats_w) {
+                                                          uint32_t* __restrict__ slab_flags, uint32_t* __restrict__ blend_stats_w,
+                                                          uint32_t deep_factor, uint32_t deep_min) {
     __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
     __shared__ unsigned long long s_wsum[4], s_t16[4];
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
             __shared__ uint32_t s_deep_n;
             if (threadIdx.x == 0) s_deep_n = 0u;
             __syncthreads();
-            const uint32_t mean = total_walked / max(blend_bins, 1u), thr = max(4u * mean, 8192u);
+            const uint32_t mean = total_walked / max(blend_bins, 1u), thr = max(deep_factor * mean, deep_min);
             sweep([&](uint32_t i, uint32_t c) {
                 if (c > thr) {
                     const uint32_t k = atomicAdd(&s_deep_n, 1u);
@@ -543,6 +544,9 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
     // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
     // backfilling, and ordering them in one workgroup would cost more than it gives)
+    // slab mode: a bin is drawn slab-parallel when its previous cost (half tiles evaluated) exceeds both limits
+    static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 4u;
+    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 8192u;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
@@ -551,7 +555,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr,
-                       pp.slabs, m->slab_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>());
+                       pp.slabs, m->slab_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_factor, deep_min);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
     if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));

@@ -4,6 +4,8 @@ the slab-mode frame meets the SAME tolerance against the fp32 oracle as the defa
 is reproduced bit for bit by strips (with the visibility-culled sort every rank of a multi-GPU draw uses), does not depend on
 the list-bin size, survives deep non-saturating piles (many slabs per bin) and fully opaque near slabs (farther slabs give up),
 and degrades to one slab for host-supplied index lists."""
+import os
+
 import numpy as np
 import pytest
 
@@ -112,10 +114,20 @@ def test_host_index_lists_fold_as_one_slab(ctx):
     np.testing.assert_array_equal(frames[0], frames[1])
 
 
-def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold(ctx):
+def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold():
     """The first slab-mode draw of a mesh has no statistics: every bin is folded by one workgroup (MODE_SEQ).  From the second
     draw on the bins that cost far more than the mean are drawn by one workgroup per depth slab and merged by k_slab_fold
     (MODE_PART).  Same arithmetic, different executors: the frames must be identical, and the scene must really have deep bins."""
+    import subprocess
+    import sys
+    # (the limits are read once per process: a child with a low bar, so that this small scene has "deep" bins)
+    env = dict(os.environ, GSPLAT_DEEP_FACTOR="2", GSPLAT_DEEP_MIN="1000", GS_SLAB_CHILD="1")
+    if not os.environ.get("GS_SLAB_CHILD"):
+        out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__ + "::test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold"],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+        return
+    ctx = Context(0)
     W, H = 480, 270
     cam = camera.demo_camera("garden", W, H)
     n = 260000
@@ -131,12 +143,14 @@ def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold(ctx):
     w = create_sort_worker(ctx, n)
     w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": n - 1, "count": n}})
     mesh.use_sorter_result(w, n)
-    frames, deep = [], []
+    frames, deep, cost = [], [], []
     for _ in range(4):
         w.sort_on_device(cam.sort_mvp(), n)
         frames.append(mesh.render()[0])
         deep.append(len(mesh.deep_bins()))
-    assert deep[0] == 0 and deep[1] > 0 and deep[2] > 0, deep
+        c = mesh.blend_bin_stats()[..., 1].astype(np.int64)
+        cost.append((int(c.mean()), int(c.max())))
+    assert deep[0] == 0 and deep[1] > 0 and deep[2] > 0, (deep, cost)
     for f in frames[1:]:
         np.testing.assert_array_equal(f, frames[0])
     # ... and strips of that state still reproduce it
@@ -148,3 +162,4 @@ def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold(ctx):
     np.testing.assert_array_equal(np.concatenate(strips, axis=0), frames[0])
     w.terminate()
     mesh.dispose()
+    ctx.close()

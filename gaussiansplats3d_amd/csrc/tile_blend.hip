@@ -34,10 +34,13 @@ __device__ __forceinline__ v2f pk_fma_sat(v2f a, v2f b, v2f c) {
     return d;
 }
 
+// A staged splat, relative to the origin of the 32-px bin that staged it: the two rows of the pixel -> ellipse-space map are
+//     u = ax * x + ay * y + cu ,  w = bx * x + by * y + cw      (x, y = pixel centre - bin origin, |x|, |y| < 32)
+// with cu = -(ax * cx' + ay * cy'), (cx', cy') = splat centre - bin origin, so the inner loop never forms pixel - centre.
 struct __attribute__((aligned(16))) LdsSplat {
-    float cx, cy, ax, ay;
-    float bx, by, pad0, pad1;      // 48-byte stride keeps the three reads of a splat 16-byte aligned
-    float r, g, b, a;
+    float ax, ay, cu, slab;        // slab: the entry's depth slab (MODE_SEQ), as raw bits
+    float bx, by, cw, a;           // 48-byte stride keeps the three reads of a splat 16-byte aligned
+    float r, g, b, pad;
 };
 
 // which of the 2x2 tiles of the 32-px bin (bx, by) the splat's 16-px tile rect touches: bit (qx + 2*qy).  The rect is the
@@ -123,12 +126,14 @@ __device__ __forceinline__ uint32_t exact_halves(uint32_t qm, const uint4 lo, co
 }
 
 // expands one record
-__device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi) {
+__device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi, float bin_x0, float bin_y0, uint32_t slab) {
     LdsSplat s;
-    s.cx = __uint_as_float(lo.x); s.cy = __uint_as_float(lo.y);
+    const float cx = __uint_as_float(lo.x) - bin_x0, cy = __uint_as_float(lo.y) - bin_y0;
     s.ax = __uint_as_float(lo.z); s.ay = __uint_as_float(lo.w);
     s.bx = __uint_as_float(hi.x); s.by = __uint_as_float(hi.y);
-    s.pad0 = 0.0f; s.pad1 = 0.0f;
+    s.cu = -__builtin_fmaf(s.ax, cx, s.ay * cy);
+    s.cw = -__builtin_fmaf(s.bx, cx, s.by * cy);
+    s.slab = __uint_as_float(slab); s.pad = 0.0f;
     s.r = (float)(hi.z & 0xFFFFu) * (1.0f / 65535.0f);
     s.g = (float)(hi.z >> 16) * (1.0f / 65535.0f);
     s.b = (float)(hi.w & 0xFFFFu) * (1.0f / 65535.0f);
@@ -153,6 +158,9 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 // into whatever CU frees up first
 #ifndef BLEND_OCC
 #define BLEND_OCC 6
+#endif
+#ifndef GS_BLEND_CHECK
+#define GS_BLEND_CHECK 4u             // default mode: a wave tests its quadrant for saturation after every 4th walked splat
 #endif
 #ifndef GS_BLEND_BRANCH_STYLE
 #define GS_BLEND_BRANCH_STYLE 1       // 0: two independent ifs, 1: both / first / second as three blocks (A/B)
@@ -200,6 +208,7 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
     __shared__ uint32_t s_abort;
     __shared__ uint32_t s_walked[4], s_halves[4];
     constexpr bool SLAB = MODE == MODE_PART;                // one workgroup per (deep bin, slab), from T = 1 into a partial
+    constexpr bool FREEZE = MODE != MODE_DEFAULT;           // per-pixel freeze at saturation (see the inner loop)
     const uint32_t slab = SLAB ? wg % GS_SLABS : 0u;
     uint32_t bin;
     if (SLAB) {
@@ -209,19 +218,24 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
         bin = bin_order ? bin_order[wg] : wg;             // heaviest bins of the previous draw first (k_bin_emit)
         if (MODE == MODE_SEQ && sa.deep_of[bin] != GS_DEEP_NONE) return;   // drawn slab-parallel (MODE_PART + k_slab_fold)
     }
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));     // wave-uniform, and known to be
     const uint32_t bx = bin % bins_x, by = bin / bins_x + bin_row_begin;
     const uint32_t qx0 = bx * GS_BIN + (wave & 1u) * GS_TILE, qy0 = by * GS_BIN + (wave >> 1) * GS_TILE;   // quadrant origin
     const uint32_t px = qx0 + (lane & 15u);
     const uint32_t py0 = qy0 + (lane >> 4);
-    const float fx = (float)px + 0.5f;
-    const float fy0 = (float)py0 + 0.5f;
+    // pixel centres relative to the bin's origin (what the staged splats are expressed in)
+    const float bin_x0 = (float)(bx * GS_BIN), bin_y0 = (float)(by * GS_BIN);
+    const float fx = (float)((wave & 1u) * GS_TILE + (lane & 15u)) + 0.5f;
+    const float fy0 = (float)((wave >> 1) * GS_TILE + (lane >> 4)) + 0.5f;
 
 #ifdef GS_BLEND_PROFILE
     const unsigned long long t_start = wall_clock64();
     uint32_t batches = 0;
 #endif
     uint32_t walked = 0, halves = 0, scanned = 0;      // statistics: wave-uniform, kept in scalar registers
+    uint32_t since_check = 0;                          // splats walked since the last saturation test (default mode: never reset
+                                                       // by a batch or group boundary - see the test)
 #ifdef GS_BLEND_PROFILE
     uint32_t p_kept = 0, p_useful = 0;
 #endif
@@ -318,8 +332,7 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
         uint32_t qm = tid < cnt ? spread_quadrants(quadrant_mask(rect, bx, by)) : 0u;   // bit 2q + h: half h of quadrant q
         if (GS_BLEND_EXACT && qm) qm = exact_halves(qm, lo, hi, bx, by);
         s_qmask[tid] = qm;
-        if (qm) stage_entry(&s_batch[tid], lo, hi);
-        if (MODE == MODE_SEQ && qm) s_batch[tid].pad0 = __uint_as_float(v_slab);       // the entry's depth slab (payload's top bits)
+        if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0, v_slab);           // (v_slab: the payload's top bits)
         if (tid == 0) {
             s_live = 0u;
             // a nearer slab of this bin has saturated every pixel by itself: whatever this one composites is multiplied by 0
@@ -336,9 +349,9 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
             if (nxt + BLEND_THREADS < n) { const uint32_t raw = vals[begin + nxt + BLEND_THREADS]; v_next = MODE == MODE_DEFAULT ? raw : raw & GS_SLOT_MASK; v_slab_next = raw >> GS_SLAB_SHIFT; }
         }
         __syncthreads();
-        if (SLAB && s_abort) return;                       // (uniform: no partial is written, the fold never gets this far)
+        if (SLAB && __builtin_amdgcn_readfirstlane((int)s_abort)) return;                       // (uniform: no partial is written, the fold never gets this far)
         if (live_wave) {
-            uint32_t since_check = 0;
+            if (FREEZE) since_check = 0;
             for (uint32_t g0 = 0; g0 < cnt && live_wave; g0 += 64) {
                 // this wave's survivors among staged entries [g0, g0+64), per half of its quadrant (wave-uniform masks)
                 const uint32_t mine = s_qmask[g0 + lane] >> (2u * wave);
@@ -349,11 +362,11 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                     const uint32_t j = g0 + bit;
                     m &= m - 1ull;
                     walked++;
-                    const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].cx);
+                    const float4 q0 = *reinterpret_cast<const float4*>(&s_batch[j].ax);
                     const float4 q1 = *reinterpret_cast<const float4*>(&s_batch[j].bx);
                     const float4 q2 = *reinterpret_cast<const float4*>(&s_batch[j].r);
                     if (MODE == MODE_SEQ) {
-                        const uint32_t sj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q1.z));
+                        const uint32_t sj = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(q0.w));
                         if (sj != cur_slab) {              // this wave's next splat opens another slab: merge the finished one
                             close_slab();
                             cur_slab = sj;
@@ -366,17 +379,15 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                             }
                         }
                     }
-                    const float dx = fx - q0.x;
-                    const float adx = q0.z * dx, bdx = q1.x * dx;
+                    const float ux = __builtin_fmaf(q0.x, fx, q0.z), wx = __builtin_fmaf(q1.x, fx, q1.z);
                     // The four 16x4 strips of a lane are two packed pairs (v_pk_*_f32 does two fp32 lanes per VALU slot): pair
                     // h = rows 8h .. 8h+7 of the quadrant, and a pair the splat cannot reach is skipped with a scalar branch.
                     // `if (A > 8.0) discard` and the freeze are saturated multiply-adds instead of compare + select pairs
                     // (which do not pack and stall on VCC): keep = sat((CUT - pw) * 2^100) is exactly 1 for pw < CUT and 0
                     // for pw >= CUT - fp32 cannot represent a positive difference below 2^-100 here.
                     auto half = [&](const int h) {
-                        const v2f dy = fy[h] - q0.y;
-                        const v2f u = q0.w * dy + adx;                       // contracted to v_pk_fma_f32
-                        const v2f w = q1.y * dy + bdx;
+                        const v2f u = q0.y * fy[h] + ux;                     // contracted to v_pk_fma_f32
+                        const v2f w = q1.y * fy[h] + wx;
                         const v2f pw = w * w + u * u;
                         v2f e;
                         e.x = __builtin_amdgcn_exp2f(-pw.x);
@@ -387,16 +398,16 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                         p_useful += (uint32_t)__popcll(__ballot(keep.x > 0.0f && T[h].x > 0.0f)) +
                                     (uint32_t)__popcll(__ballot(keep.y > 0.0f && T[h].y > 0.0f));
 #endif
-                        const v2f alpha = e * (q2.w * keep);
+                        const v2f alpha = e * (q1.w * keep);
                         const v2f wgt = T[h] * alpha;
                         Cr[h] += wgt * q2.x;
                         Cg[h] += wgt * q2.y;
                         Cb[h] += wgt * q2.z;
-                        // a pixel freezes the moment it saturates (T <= 1e-4 -> 0), so its value depends only on its own
-                        // ordered list of contributing splats - not on how lists are batched (strips of a multi-GPU draw
-                        // stay bit-exact)
                         const v2f t_new = T[h] - wgt;
-                        T[h] = t_new * pk_fma_sat(t_new, v2f{GS_HUGE, GS_HUGE}, v2f{-GS_T_EPS * GS_HUGE, -GS_T_EPS * GS_HUGE});
+                        // slab modes: a pixel freezes the moment it saturates (T <= 1e-4 -> 0), so that its value depends only
+                        // on its own ordered splats and their slabs, whoever executes the fold
+                        if (FREEZE) T[h] = t_new * pk_fma_sat(t_new, v2f{GS_HUGE, GS_HUGE}, v2f{-GS_T_EPS * GS_HUGE, -GS_T_EPS * GS_HUGE});
+                        else T[h] = t_new;
                     };
                     // (both halves as ONE straight-line block: the scheduler interleaves the two independent chains exactly as
                     // before there was anything to skip - the common case for large splats; r03a: with two separately
@@ -418,23 +429,30 @@ __device__ __forceinline__ void blend_body(const uint2* __restrict__ ranges, con
                         halves++;
                     }
 #endif
-                    if (++since_check == 16u || m == 0ull) {
-                        // retire the wave when its whole quadrant is saturated
+                    // Retire the wave when its whole quadrant is saturated (every T <= 1e-4).  Default mode: tested after every
+                    // GS_BLEND_CHECK-th splat the wave walks and nowhere else, so a quadrant composites exactly the first K of its
+                    // own ordered survivors (K = the first multiple of GS_BLEND_CHECK at which all 256 pixels are saturated) - a
+                    // function of that sequence alone, not of how the list is batched: strips of a multi-GPU draw reproduce the
+                    // full frame bit for bit WITHOUT a per-pixel freeze in the chain (r03: two packed VALU slots per half).
+                    if (++since_check == (FREEZE ? 16u : GS_BLEND_CHECK) || (FREEZE && m == 0ull)) {
                         since_check = 0;
-                        bool live = false;
-#pragma unroll
-                        for (int h = 0; h < 2; h++) live = live || (T[h].x > 0.0f) || (T[h].y > 0.0f);
-                        if (__ballot(live) == 0ull) {
+                        const float thr = FREEZE ? 0.0f : GS_T_EPS;
+                        const float tmax = fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y));
+                        if (__ballot(tmax > thr) == 0ull) {
                             live_wave = false;
                             break;
                         }
                     }
                 }
             }
-            if (live_wave && lane == 0u) atomicAdd(&s_live, 1u);
+            // (every lane stores the same word: a `lane == 0` guard here makes live_wave - and with it every counter and branch of
+            // the loops above - divergent in the compiler's eyes: exec-mask bookkeeping and VALU counters in the inner loop)
+            if (live_wave) s_live = 1u;
         }
         __syncthreads();
-        if (s_live == 0u) break;                       // every quadrant saturated (or clipped): skip the rest of the list
+        // (LDS words read through readfirstlane: the compiler cannot know they are wave-uniform, and one divergent-looking exit
+        // turns every counter of these loops into a VGPR and every branch into exec-mask bookkeeping)
+        if (__builtin_amdgcn_readfirstlane((int)s_live) == 0) break;   // every quadrant saturated (or clipped): skip the rest of the list
     }
 #ifdef GS_BLEND_PROFILE
     __shared__ unsigned int s_prof[3];

@@ -4,7 +4,7 @@
 set -e
 NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-SRC=$ROOT/gaussiansplats3d_amd/csrc
+SRC=${GS_VARIANT_SRC:-$ROOT/gaussiansplats3d_amd/csrc}     # (GS_VARIANT_SRC: another source tree, e.g. a checkout of an older commit)
 OUT=$ROOT/gpurun_ab; OBJ=/tmp/gsvar_$NAME
 mkdir -p $OUT $OBJ
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $*"

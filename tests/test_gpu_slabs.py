@@ -99,7 +99,9 @@ def test_slab_mode_strips_equal_the_full_frame_bit_for_bit(ctx, monkeypatch):
 
 
 def test_host_index_lists_fold_as_one_slab(ctx):
-    """No sorter, no buckets: every entry is slab 0 and the frame equals the default composite exactly."""
+    """No sorter, no buckets: every entry is slab 0, the fold is the single fold.  The slab executors freeze a pixel at
+    saturation (T <= 1e-4 -> 0) while the default kernel lets it run until its quadrant retires: fp32 rounding below 1e-4 of
+    full scale, i.e. at most one 8-bit step on a rounding boundary."""
     W, H = 320, 200
     cam = camera.demo_camera("garden", W, H)
     scene = helpers.small_scene(8000, 1, seed=5)
@@ -111,7 +113,8 @@ def test_host_index_lists_fold_as_one_slab(ctx):
         mesh.update_render_indexes(order, scene.count)
         frames.append(mesh.render()[0])
         mesh.dispose()
-    np.testing.assert_array_equal(frames[0], frames[1])
+    d = np.abs(frames[0].astype(np.int32) - frames[1].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (int(d.max()), float((d > 0).mean()))
 
 
 def test_slab_parallel_bins_give_the_same_bits_as_the_sequential_fold():

@@ -732,19 +732,20 @@ def main():
                            "list_entries": int(st_t.tile_entries), "list_bin_px": int(st_t.list_bin_px),
                            "entries_scanned": int(st_t.entries_scanned), "splats_walked": int(st_t.splats_walked),
                            "halves_evaluated": int(st_t.halves_evaluated)}
+                    info = rg.mesh.deep_pass_info()
+                    obj["deep_pass"] = {"bins": int(len(info["bins"])), "bins_over_threshold": info["candidates"],
+                                        "chunks_closed_by_bin_workgroups": info["chunks_closed_by_bins"],
+                                        "pool_exhausted": info["pool_exhausted"]}
                     if key == "C3S":
-                        # the same scene through the two-level composite (GS_CAM_DEPTH_SLABS): correct and strip-exact, and - as
-                        # measured - no faster here: the deep bins keep their entries within two or three of the 64 depth slabs
-                        rg.mesh.set_depth_slabs(True)
+                        # the same frames with every bin on one workgroup (the deep pass off): same pixels, the tail of a few very
+                        # deep bins back on four waves each
+                        rg.mesh.set_deep_pass(False)
                         for _ in range(3):
                             rg.frame(out_ptr)
                         s_el, _ = rg.timed(k_steps, out_ptr)
                         _, st_s = rg.mesh.render(out_device_ptr=out_ptr, to_host=False, want_stats=True)
-                        obj["depth_slabs"] = {"ms_per_frame": round(s_el / k_steps * 1e3, 4), "blend_ms": round(float(st_s.blend_ms), 4),
-                                              "entry_sort_ms": round(float(st_s.tile_sort_ms), 4),
-                                              "bins_drawn_slab_parallel": int(len(rg.mesh.deep_bins())),
-                                              "splats_walked": int(st_s.splats_walked)}
-                        rg.mesh.set_depth_slabs(False)
+                        obj["deep_pass"]["off"] = {"ms_per_frame": round(s_el / k_steps * 1e3, 4), "blend_ms": round(float(st_s.blend_ms), 4)}
+                        rg.mesh.set_deep_pass(True)
                     if key == "C3T":
                         obj["note"] = ("opacity ~ sigmoid(N(-2,1)): pixels do not saturate early, the blend scans and walks "
                                        "its entry lists (compare entries_scanned / splats_walked with the `blend` object)")

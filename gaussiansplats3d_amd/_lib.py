@@ -19,7 +19,6 @@ GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = 
 GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
-GS_CAM_DEPTH_SLABS = 64
 GS_CTX_SINGLE_STREAM, GS_CTX_STAGE_TIMING = 1, 2
 GS_TILE = 16
 GS_BIN = 32          # blend workgroups are per 32-px bin (2x2 tiles); entry lists per list bin (RenderStats.list_bin_px)
@@ -123,6 +122,7 @@ SYMBOLS = {
     "gs_group_render_gather": (C.c_int, [_VP, _VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.c_uint32, _VP]),
     "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_mesh_set_deep_pass": (C.c_int, [_VP, C.c_int]),
     "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),
     "gs_mesh_kernel_time": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }

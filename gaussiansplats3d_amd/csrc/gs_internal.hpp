@@ -85,19 +85,29 @@ constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
 constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
 constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
-// Depth slabs (GS_CAM_DEPTH_SLABS, tile_blend.hip): a list entry's slab travels in the top bits of its payload (slab-mode
-// meshes hold at most 2^26 splats) and as the low bits of its sort key, so every (list, slab) gets a range of its own.
-// 64 slabs: the sort's buckets are linear in depth over the WHOLE scene, and a bin that is deep because it looks along a
-// surface keeps its entries within a few units of depth - with 16 slabs they shared one or two (r03: 100 deep bins split,
-// blend 4.3 ms either way).
-constexpr uint32_t GS_SLAB_BITS = 6, GS_SLABS = 1u << GS_SLAB_BITS;
-constexpr uint32_t GS_SLAB_SHIFT = 32u - GS_SLAB_BITS;
-constexpr uint32_t GS_SLOT_MASK = (1u << GS_SLAB_SHIFT) - 1u;
-// slab-mode flag words of a draw (gs_mesh::slab_flags): opaque_upto [DEEP_MAX] | partial written [DEEP_MAX * SLABS] |
-// deep_list [DEEP_MAX] | deep_count (+3 pad) | deep_of [bins]
-constexpr uint32_t GS_DEEP_MAX_BINS = 128;
-constexpr uint32_t GS_FLAG_VALID = GS_DEEP_MAX_BINS, GS_FLAG_LIST = GS_DEEP_MAX_BINS * (1u + GS_SLABS),
-                   GS_FLAG_COUNT = GS_DEEP_MAX_BINS * (2u + GS_SLABS), GS_FLAG_OF = GS_FLAG_COUNT + 4u;
+// CHUNKED COMPOSITE (tile_blend.hip).  The value of a pixel is DEFINED per 16x16 quadrant as a two-level fold: the quadrant's
+// ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks of GS_CHUNK, each
+// chunk is composited front to back from T = 1, C = 0, and the chunks are merged near -> far (C = fma(T, C_c, C); T = T * T_c).
+// A quadrant with <= GS_CHUNK survivors (every quadrant of the BASELINE configurations) is one chunk and the merge is exact, so
+// this IS the plain front-to-back composite there; a quadrant that is thousands of splats deep and does not saturate (a surface
+// seen at a grazing angle) can be composited by many waves at once - the "over" operator is associative - and the frame does not
+// depend on who did it.  The last chunk (index GS_CHUNKS_MAX - 1) is unbounded.
+constexpr uint32_t GS_CHUNK = 1024, GS_CHUNKS_MAX = 32;
+// The deep pass: the <= GS_DEEP_MAX_BINS bins that cost most in the previous draw (and more than a threshold) are scanned once
+// (k_deep_scan: exact quadrant masks of every list entry + survivor counts per GS_DEEP_RLEN entries) and composited by one wave per
+// (bin, quadrant, chunk); k_deep_fold merges.  Lists longer than GS_DEEP_LIST_CAP stay with the one-workgroup-per-bin kernel, which
+// closes chunks itself (partials in a pool).
+constexpr uint32_t GS_DEEP_MAX_BINS = 256, GS_DEEP_LIST_CAP = 65536, GS_DEEP_RLEN = 1024, GS_DEEP_RANGES = GS_DEEP_LIST_CAP / GS_DEEP_RLEN;
+constexpr uint32_t GS_DEEP_SCAN_WGS = 8;                    // k_deep_scan workgroups per deep bin (each strides over the ranges)
+constexpr uint32_t GS_DEEP_UNITS = GS_DEEP_MAX_BINS * 4u * GS_CHUNKS_MAX;   // (bin, quadrant, chunk) waves of the deep pass
+constexpr uint32_t GS_POOL_SLOTS = 8192;                    // chunk partials (4 KB each) the per-bin kernel may close per draw
+constexpr uint32_t GS_ENT_SLOT_MASK = (1u << 28) - 1u;     // deep_ent word = record slot | quadrant mask << 28
+constexpr uint32_t GS_DEEP_NONE = 0xFFFFFFFFu;
+// flag words of a draw (gs_mesh::deep_flags): [0] deep bins of this draw  [1] bins over the threshold (mirrored to the host: the
+// NEXT draw launches the deep pass when this is non-zero)  [2] next pool slot  [3] pool exhausted  | deep_list [DEEP_MAX] |
+// deep_of [bins]
+constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, GS_FLAG_POOL_OVER = 3, GS_FLAG_LIST = 8,
+                   GS_FLAG_OF = GS_FLAG_LIST + GS_DEEP_MAX_BINS;
 
 #ifndef RADIX_TILE_CFG
 #define RADIX_TILE_CFG 4096
@@ -288,7 +298,6 @@ struct ProjectParams {
     uint32_t list_row_begin, list_row_end;
     uint32_t y0, y1;               // pixel rows [y0, y1) of this rank's strip
     uint32_t count;
-    uint32_t slabs;                // 1: GS_CAM_DEPTH_SLABS: entries carry depth slabs, the blend is the two-level fold
     uint32_t block_cull;           // 1: whole 256-splat storage blocks are tested first (project.hip); 0 for per-scene transforms
     float mv_row_norm[3];          // |row r of mat3(view)| * (1 + 1e-6): bounds |T0|, |T1| of the strip pre-test (project.hip)
 };
@@ -343,9 +352,13 @@ struct gs_mesh {
     DevBuf blend_stats;        // uint2 [blend workgroups of the last draw]: {entries staged, half quadrants evaluated}, then
                                // uint32 [the same]: (splat, quadrant) pairs walked
     uint32_t blend_bins = 0, blend_row_begin = 0, blend_width = 0;    // the bins the last draw blended
-    DevBuf slab_partial;       // float4 [GS_DEEP_MAX_BINS * GS_SLABS][1024]: the deep bins' partial composites (slab mode)
-    DevBuf slab_flags;         // uint32 words, layout above (GS_FLAG_*)
-    DevBuf slab_end;           // uint32 [GS_SLABS]: near -> far list positions where the slabs end (from the sort's last digit)
+    DevBuf deep_flags;         // uint32 words, layout above (GS_FLAG_*)
+    DevBuf chunk_pool;         // float4 [GS_POOL_SLOTS][256]: chunk partials closed by the per-bin kernel
+    DevBuf deep_ent;           // uint32 [GS_DEEP_MAX_BINS][GS_DEEP_LIST_CAP]: slot | quadrant mask << 28 per list entry (deep pass)
+    DevBuf deep_cnt;           // uint32 [GS_DEEP_MAX_BINS][GS_DEEP_RANGES][4]: survivors per range and quadrant
+    DevBuf deep_partial;       // float4 [GS_DEEP_UNITS][256]: {C, T} of every (deep bin, quadrant, chunk)
+    bool no_deep = false;      // GSPLAT_NO_DEEP: never launch the deep pass (the per-bin kernel draws everything)
+    bool deep_pass = false;    // this draw runs the deep pass (decided in gs_launch_binning)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
     bool blend_order_valid = false;
     RadixScratch radix;

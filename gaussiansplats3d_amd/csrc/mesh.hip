@@ -262,6 +262,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->block_box, ((n + 255) / 256) * 32 + 32);
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
     m->no_block_cull = getenv("GSPLAT_NO_BLOCK_CULL") != nullptr;
+    m->no_deep = getenv("GSPLAT_NO_DEEP") != nullptr;
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
     if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
@@ -622,7 +623,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     hipStream_t st = ctx->stream, aux = ctx->aux;
     timed = timed || ctx->stage_events;
     m->timed_draw = timed;
-    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin) * (pp.slabs ? GS_SLABS : 1u);  // one entry list per list bin (and depth slab)
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     if (!projected) GS_TRY(mesh_project(m, pp, false, timed));   // else gs_mesh_project already ran it for this camera
     else if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
@@ -687,8 +688,7 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     pp.count = m->uploaded;
     // whole-block tests assume one modelView for every splat of a block: off under per-scene transforms (and GSPLAT_NO_BLOCK_CULL)
     pp.block_cull = (!(cam->flags & GS_CAM_DYNAMIC) && !m->no_block_cull) ? 1u : 0u;
-    pp.slabs = (cam->flags & GS_CAM_DEPTH_SLABS) ? 1u : 0u;
-    GS_REQUIRE(!pp.slabs || m->max_count <= (1u << GS_SLAB_SHIFT), "GS_CAM_DEPTH_SLABS: the mesh holds more than 2^26 splats");
+    GS_REQUIRE(m->max_count <= GS_ENT_SLOT_MASK, "the mesh holds more than 2^28 - 1 splats");
 
     // pixel rows covered by this rank's strip, and the 32-px bins that cover them
     const uint32_t y0 = pp.row_begin * GS_TILE;
@@ -863,6 +863,12 @@ int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32
     return GS_OK;
 }
 
+int gs_mesh_set_deep_pass(gs_mesh* m, int enabled) {
+    GS_REQUIRE(m, "mesh == NULL");
+    m->no_deep = !enabled;
+    return GS_OK;
+}
+
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     GS_REQUIRE(m && dst, "mesh / dst == NULL");
     GS_REQUIRE(m->has_draw && (what >= 2 || count <= m->last_count), "no draw / count too large");
@@ -887,10 +893,11 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     } else if (what == 4) {   // per 32-px blend bin of the last draw: {entries staged, (splat, tile) pairs walked}
         GS_REQUIRE(count <= m->blend_bins, "count exceeds the blend bins of the last draw");
         if (count) GS_HIP(hipMemcpyAsync(dst, m->blend_stats.p, (size_t)count * 8, hipMemcpyDeviceToHost, st));
-    } else if (what == 5) {   // slab mode: {number of bins the last draw drew slab-parallel, then their bin numbers}; count = words
-        GS_REQUIRE(m->slab_flags.p && count >= 1 && count <= 1u + GS_DEEP_MAX_BINS, "no slab-mode draw / count outside 1 .. 1 + GS_DEEP_MAX_BINS");
-        GS_HIP(hipMemcpyAsync(dst, m->slab_flags.as<uint32_t>() + GS_FLAG_COUNT, 4, hipMemcpyDeviceToHost, st));
-        if (count > 1) GS_HIP(hipMemcpyAsync(static_cast<uint32_t*>(dst) + 1, m->slab_flags.as<uint32_t>() + GS_FLAG_LIST, (size_t)(count - 1) * 4, hipMemcpyDeviceToHost, st));
+    } else if (what == 5) {   // the last draw's deep pass: {bins it drew, bins over the threshold, chunk partials the per-bin kernel closed,
+                              // pool exhausted, then the bin numbers}; count = words (4 .. 4 + GS_DEEP_MAX_BINS)
+        GS_REQUIRE(m->deep_flags.p && count >= 4 && count <= 4u + GS_DEEP_MAX_BINS, "no draw yet / count outside 4 .. 4 + GS_DEEP_MAX_BINS");
+        GS_HIP(hipMemcpyAsync(dst, m->deep_flags.as<uint32_t>(), 16, hipMemcpyDeviceToHost, st));
+        if (count > 4) GS_HIP(hipMemcpyAsync(static_cast<uint32_t*>(dst) + 4, m->deep_flags.as<uint32_t>() + GS_FLAG_LIST, (size_t)(count - 4) * 4, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;

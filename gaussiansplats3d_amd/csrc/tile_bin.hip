@@ -70,37 +70,11 @@ extern "C" int gs_debug_bin_prof(void* dst) {
 #define BIN_PROF(k, slot, v) do { } while (0)
 #endif
 
-// Depth slabs (GS_CAM_DEPTH_SLABS): where, in the near -> far walk of the sorted list, each slab ends.  The list is sorted by
-// key' (far -> near ascending with the position); the LAST radix pass of the depth sort counted its top digit per group of
-// workgroups (RadixScratch::digit_total, still intact: the next sort zeroes it), so the positions where the top digit changes
-// are prefix sums of 256 counts.  Slab s (0 = nearest) = the digits whose top GS_SLAB_BITS equal (max - s).  No sorter / a
-// partial sort: every position is slab 0 (all ends = 0xFFFFFFFF).
-__global__ __launch_bounds__(256) void k_slab_bounds(const uint32_t* __restrict__ digit_total /* [groups][256] of the last pass, nullable */,
-                                                     uint32_t groups, uint32_t digit_bits, uint32_t* __restrict__ slab_end) {
-    __shared__ uint32_t s_cnt[256];
-    const uint32_t d = threadIdx.x;
-    uint32_t c = 0;
-    if (digit_total)
-        for (uint32_t g = 0; g < groups; g++) c += digit_total[g * RADIX_BINS + d];
-    s_cnt[d] = c;
-    __syncthreads();
-    if (d < GS_SLABS) {
-        if (!digit_total) { slab_end[d] = 0xFFFFFFFFu; return; }
-        const uint32_t dmax = (1u << digit_bits) - 1u;
-        const uint32_t shift = digit_bits > GS_SLAB_BITS ? digit_bits - GS_SLAB_BITS : 0u;     // digits per slab = 1 << shift
-        uint32_t end = 0;
-        for (uint32_t v = 0; v <= dmax; v++)
-            if (((dmax - v) >> shift) <= d) end += s_cnt[v];                    // every digit of slabs 0 .. d
-        slab_end[d] = (d + 1u == GS_SLABS || (d + 1u) << shift > dmax) ? 0xFFFFFFFFu : end;   // the last slab takes the rest
-    }
-}
-
 // (waves_per_eu 8: at 62 VGPRs the compiler reports 8 waves per SIMD, yet only 7 workgroups per CU became resident and the last
 // 256 of the 2048 started 10 us late - r02v timeline; with the attribute all start together: span 35.4 -> 33.0 us.
 // Dealing spans of 1024 positions round-robin instead of one contiguous chunk per workgroup, with a scan kernel between count
 // and emit, was tried as well: the entries per workgroup even out (max 1841 vs 3681) but the body time does not - 24.6 us max
 // either way, it is a chain of loaded memory round trips - and the extra kernel makes the C3 frame 3 us slower.)
-template <bool SLABS>
 __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
                                                            const uint32_t* __restrict__ R_dev /* nullable */,
                                                            const uint32_t* __restrict__ perm,
@@ -111,9 +85,7 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                                                            uint32_t* __restrict__ digit_total,
                                                            uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift,
                                                            uint32_t splat_count, const uint8_t* __restrict__ block_any,
-                                                           const uint32_t* __restrict__ slab_end /* nullable: no slabs */,
-                                                           uint32_t* __restrict__ slab_flags, uint32_t blend_bins,
-                                                           uint32_t* __restrict__ blend_stats) {
+                                                           uint32_t* __restrict__ deep_flags, uint32_t blend_bins) {
     __shared__ unsigned long long s_w[4];
     // Coarse visibility, one bit per 256-splat storage block, in LDS.  75 % of a scene's splats draw nothing and, stored along
     // a Morton curve, mostly whole blocks of them; an LDS bit test spares those list positions the 8-byte L2 gather of their
@@ -142,16 +114,10 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
         for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
         for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
-        if (SLABS) {                                       // slab mode: no slab saturated, no partial written, no deep bins (k_bin_emit names them)
-            for (uint32_t w = t; w < GS_DEEP_MAX_BINS; w += stride) slab_flags[w] = 0xFFFFFFFFu;
-            for (uint32_t w = t; w < GS_DEEP_MAX_BINS * GS_SLABS; w += stride) slab_flags[GS_FLAG_VALID + w] = 0u;
-            if (t == 0) slab_flags[GS_FLAG_COUNT] = 0u;
-            for (uint32_t w = t; w < blend_bins; w += stride) slab_flags[GS_FLAG_OF + w] = 0xFFFFFFFFu;
-        }
+        // the chunked composite's per-draw words: no deep bins (k_bin_emit names them), an empty partial pool
+        if (t < GS_FLAG_LIST) deep_flags[t] = 0u;
+        for (uint32_t w = t; w < blend_bins; w += stride) deep_flags[GS_FLAG_OF + w] = GS_DEEP_NONE;
     }
-    __shared__ uint32_t s_send[GS_SLABS];                  // (LDS, not registers: the kernel runs at 8 waves per SIMD)
-    if (SLABS && threadIdx.x < GS_SLABS) s_send[threadIdx.x] = slab_end[threadIdx.x];
-    if (SLABS) __syncthreads();
     // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
     // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
     const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
@@ -235,14 +201,6 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         uint32_t e = sum + (uint32_t)excl;
 #pragma unroll
         for (int k = 0; k < BIN_PER_LANE; k++) {
-            if (SLABS && keep[k]) {                        // the splat's depth slab rides in the payload's top bits
-                const uint32_t q = q0 + (uint32_t)k;
-                uint32_t sl = 0;                           // number of slab ends <= q (the ends ascend): binary search
-#pragma unroll
-                for (uint32_t step = GS_SLABS / 2u; step > 0u; step >>= 1)
-                    if (s_send[sl + step - 1u] <= q) sl += step;
-                slot[k] |= sl << GS_SLAB_SHIFT;
-            }
             if (keep[k]) {
                 cidx[o] = slot[k];                         // what the blend gathers records by
                 crect[o] = r[k];
@@ -290,9 +248,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           uint32_t* __restrict__ vals_out, uint32_t list_shift,
                                                           volatile uint32_t* __restrict__ mirror, uint32_t serial,
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
-                                                          uint32_t* __restrict__ blend_order, uint32_t slabs,
-                                                          uint32_t* __restrict__ slab_flags, uint32_t* __restrict__ blend_stats_w,
-                                                          uint32_t deep_factor, uint32_t deep_min) {
+                                                          uint32_t* __restrict__ blend_order, uint32_t deep,
+                                                          uint32_t* __restrict__ deep_flags, uint32_t* __restrict__ blend_stats_w,
+                                                          uint32_t deep_min) {
     __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
     __shared__ unsigned long long s_wsum[4], s_t16[4];
@@ -343,26 +301,31 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
         s_cost[threadIdx.x] = start;
         __syncthreads();
         sweep([&](uint32_t i, uint32_t c) { blend_order[atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u)] = i; });
-        if (slabs) {
-            // Slab mode: the bins whose previous draw cost far more than the mean are drawn slab-parallel (one workgroup per depth
-            // slab + a fold) instead of by one workgroup - same pixels either way (tile_blend.hip), so this is scheduling only.
-            // Their statistics are summed atomically by up to GS_SLABS workgroups: zeroed here.
-            __shared__ uint32_t s_deep_n;
-            if (threadIdx.x == 0) s_deep_n = 0u;
-            __syncthreads();
-            const uint32_t mean = total_walked / max(blend_bins, 1u), thr = max(deep_factor * mean, deep_min);
-            sweep([&](uint32_t i, uint32_t c) {
-                if (c > thr) {
-                    const uint32_t k = atomicAdd(&s_deep_n, 1u);
-                    if (k < GS_DEEP_MAX_BINS) {
-                        slab_flags[GS_FLAG_LIST + k] = i;
-                        slab_flags[GS_FLAG_OF + i] = k;
-                        blend_stats_w[2u * i] = 0u; blend_stats_w[2u * i + 1u] = 0u; blend_stats_w[2u * blend_bins + i] = 0u;
-                    }
+        // The deep pass (tile_blend.hip): among the GS_DEEP_MAX_BINS costliest bins (the head of the order just written), the ones
+        // whose previous draw walked >= deep_min (splat, quadrant) pairs are composited by one wave per (quadrant, chunk) + a fold
+        // instead of by one workgroup - same pixels either way, so this is scheduling only.  Their count goes to the host (the NEXT
+        // draw launches the deep pass when it is non-zero); they are only named when THIS draw runs the pass.  Their statistics
+        // are then summed atomically by many waves: zeroed here.
+        __shared__ uint32_t s_deep_n;
+        if (threadIdx.x == 0) s_deep_n = 0u;
+        __threadfence_block();
+        __syncthreads();                                   // blend_order complete (and visible to this workgroup)
+        for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
+            const uint32_t i = __hip_atomic_load(&blend_order[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i < blend_bins && prev_blend_stats[i].y >= 2u * deep_min) {        // .y = half quadrants evaluated = 2 per pair
+                const uint32_t k = atomicAdd(&s_deep_n, 1u);
+                if (deep) {
+                    deep_flags[GS_FLAG_LIST + k] = i;
+                    deep_flags[GS_FLAG_OF + i] = k;
+                    blend_stats_w[2u * i] = 0u; blend_stats_w[2u * i + 1u] = 0u; blend_stats_w[2u * blend_bins + i] = 0u;
                 }
-            });
-            __syncthreads();
-            if (threadIdx.x == 0) slab_flags[GS_FLAG_COUNT] = min(s_deep_n, GS_DEEP_MAX_BINS);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            deep_flags[GS_FLAG_CAND] = s_deep_n;
+            if (deep) deep_flags[GS_FLAG_COUNT] = s_deep_n;
+            if (mirror) mirror[4] = s_deep_n;
         }
         BIN_PROF(1, 1, wall_clock64());
         BIN_PROF(1, 2, wall_clock64());
@@ -458,7 +421,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     const uint32_t units = bin_grid * per;
     auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
         if (e >= D) return;                                  // dropped by an overflowing draw (it is redone)
-        keys_out[e] = (KeyT)(slabs ? key * GS_SLABS + (idx >> GS_SLAB_SHIFT) : key);   // slab mode: one list per (list bin, depth slab)
+        keys_out[e] = (KeyT)key;
         vals_out[e] = idx;
     };
     uint32_t emitted = 0;
@@ -515,28 +478,15 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const uint32_t cap = m->entry_capacity;
     const uint32_t* R_dev = (sorter && sorter->last_culled) ? &sorter->result_frame->kept : nullptr;
     const uint32_t blend_bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
-    uint32_t* slab_end = nullptr;
-    if (pp.slabs) {
-        // where the depth slabs end in the near -> far walk, from the top digit of the sort that produced this list (a full sort
-        // of a sorter-fed draw; anything else folds as one slab), and the slab-mode blend's buffers
-        GS_TRY(m->slab_end.ensure(GS_SLABS * 4));
-        GS_TRY(m->slab_flags.ensure(((size_t)GS_FLAG_OF + blend_bins) * 4 + 64));
-        GS_TRY(m->slab_partial.ensure((size_t)GS_DEEP_MAX_BINS * GS_SLABS * 1024 * sizeof(float4)));
-        GS_TRY(m->blend_stats.ensure((size_t)blend_bins * 12));
-        slab_end = m->slab_end.as<uint32_t>();
-        const bool have = sorter && sorter->last_passes > 0 && sorter->last_sort == sorter->last_render && order_dev == sorter->sorted.as<uint32_t>();
-        const uint32_t last = have ? sorter->last_passes - 1u : 0u;
-        const uint32_t digit_bits = have ? sorter->precision - 8u * last : 8u;
-        hipLaunchKernelGGL(k_slab_bounds, dim3(1), dim3(256), 0, st,
-                           have ? sorter->radix.digit_total.as<uint32_t>() + (size_t)last * RADIX_MAX_GROUPS * RADIX_BINS : nullptr,
-                           (uint32_t)RADIX_MAX_GROUPS, digit_bits, slab_end);
-    }
-    auto* count_kernel = pp.slabs ? k_bin_count<true> : k_bin_count<false>;
-    hipLaunchKernelGGL(count_kernel, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
+    // the chunked composite's per-draw words and the pool the per-bin kernel closes chunks into (reset by k_bin_count)
+    GS_TRY(m->deep_flags.ensure(((size_t)GS_FLAG_OF + blend_bins) * 4 + 64));
+    GS_TRY(m->chunk_pool.ensure((size_t)GS_POOL_SLOTS * 256 * sizeof(float4)));
+    GS_TRY(m->blend_stats.ensure((size_t)blend_bins * 12));
+    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
                        m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
                        m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(),
                        m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
-                       m->block_any.as<uint8_t>(), slab_end, m->slab_flags.as<uint32_t>(), blend_bins, m->blend_stats.as<uint32_t>());
+                       m->block_any.as<uint8_t>(), m->deep_flags.as<uint32_t>(), blend_bins);
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
@@ -544,18 +494,25 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
     // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
     // backfilling, and ordering them in one workgroup would cost more than it gives)
-    // slab mode: a bin is drawn slab-parallel when its previous cost (half tiles evaluated) exceeds both limits
-    static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 4u;
-    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 8192u;
+    // deep pass: a bin qualifies when its previous draw walked >= deep_min (splat, quadrant) pairs (3 chunks' worth by default)
+    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 3u * GS_CHUNK;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
+    // The deep pass runs when the last draw whose verdict has arrived (mapped host word, no synchronisation) left bins over the
+    // threshold - the decision only moves work between executors, the pixels do not depend on it (tile_blend.hip)
+    m->deep_pass = order_ok && !m->no_deep && m->mirror_host && ((volatile uint32_t*)m->mirror_host)[4] > 0u;
+    if (m->deep_pass) {
+        GS_TRY(m->deep_ent.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_LIST_CAP * 4));
+        GS_TRY(m->deep_cnt.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_RANGES * 4 * 4));
+        GS_TRY(m->deep_partial.ensure((size_t)GS_DEEP_UNITS * 256 * sizeof(float4)));
+    }
     // (+ one workgroup that only orders the blend's bins)
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_ok ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr,
-                       pp.slabs, m->slab_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_factor, deep_min);
+                       m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
     if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));
@@ -582,7 +539,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
 }
 
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count) {
-    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin) * (pp.slabs ? GS_SLABS : 1u);   // one list per sort key
+    const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);   // one list per sort key
     if (tiles <= 65536u && !m->ctx->wide_entry_keys) return binning_typed<uint16_t>(m, pp, order_dev, sorter, render_count, tiles);
     return binning_typed<uint32_t>(m, pp, order_dev, sorter, render_count, tiles);
 }

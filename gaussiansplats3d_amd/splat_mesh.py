@@ -19,7 +19,7 @@ class SplatMesh:
     def __init__(self, context, max_splat_count, spherical_harmonics_degree=0, half_precision_covariances=False,
                  antialiased=False, kernel_2d_size=0.3, max_screen_space_splat_size=1024.0, splat_scale=1.0,
                  point_cloud_mode=False, spherical_harmonics_8bit=False, dynamic_mode=False,
-                 enable_optional_effects=False, depth_slabs=False):
+                 enable_optional_effects=False):
         self.ctx = context
         self.lib = context.lib
         self.max_splat_count = int(max_splat_count)
@@ -33,7 +33,6 @@ class SplatMesh:
         self.sh_8bit = bool(spherical_harmonics_8bit)          # sphericalHarmonics8BitMode (compression level 2)
         self.dynamic_mode = bool(dynamic_mode)
         self.enable_optional_effects = bool(enable_optional_effects)
-        self.depth_slabs = bool(depth_slabs)                   # GS_CAM_DEPTH_SLABS: the two-level composite for very deep lists
         self.fade_in = None                                    # (sceneCenter, visibleRegionFadeStartRadius) or None
         self.splat_count = 0
         self.render_count = 0
@@ -139,7 +138,7 @@ class SplatMesh:
         cam.flags = ((L.GS_CAM_ANTIALIASED if self.antialiased else 0) | (L.GS_CAM_POINT_CLOUD if self.point_cloud_mode else 0) |
                      (L.GS_CAM_ORTHOGRAPHIC if orthographic_mode else 0) | (L.GS_CAM_DYNAMIC if self.dynamic_mode else 0) |
                      (L.GS_CAM_SCENE_EFFECTS if self.enable_optional_effects else 0) |
-                     (L.GS_CAM_FADE_IN if self.fade_in is not None else 0) | (L.GS_CAM_DEPTH_SLABS if self.depth_slabs else 0))
+                     (L.GS_CAM_FADE_IN if self.fade_in is not None else 0))
         if self.fade_in is not None:
             cam.scene_center[:] = self.fade_in[0].tolist()
             cam.fade_start_radius = self.fade_in[1]
@@ -167,15 +166,6 @@ class SplatMesh:
     def set_point_cloud_mode_enabled(self, enabled):
         self.point_cloud_mode = bool(enabled)
 
-    def set_depth_slabs(self, enabled):
-        """GS_CAM_DEPTH_SLABS for the draws that follow (takes effect with the next set_camera / update_uniforms)."""
-        self.depth_slabs = bool(enabled)
-        if enabled:
-            self._cam.flags |= L.GS_CAM_DEPTH_SLABS
-        else:
-            self._cam.flags &= ~L.GS_CAM_DEPTH_SLABS
-
-    # -- the draw -----------------------------------------------------------------------------------------
     def strip_shape(self, tile_rows=None):
         cam = self._cam
         rows_total = (cam.height + L.GS_TILE - 1) // L.GS_TILE
@@ -252,7 +242,7 @@ class SplatMesh:
         return cnt.reshape(b1 - b0, bins_x)
 
     def blend_bin_stats(self):
-        """Per 32-px blend bin of the last FULL-frame draw: (entries staged, (splat, 16x8-px half tile) pairs evaluated),
+        """Per 32-px blend bin of the last FULL-frame draw: (entries scanned, 2 x (splat, quadrant) pairs composited),
         [bin_rows, bins_x, 2]."""
         cam = self._cam
         bx, by = (cam.width + L.GS_BIN - 1) // L.GS_BIN, (cam.height + L.GS_BIN - 1) // L.GS_BIN
@@ -260,11 +250,23 @@ class SplatMesh:
         L.check(self.lib.gs_mesh_debug_read(self.handle, 4, out.ctypes.data, by * bx))
         return out.reshape(by, bx, 2)
 
+    def set_deep_pass(self, enabled):
+        """Scheduling only (the pixels do not change): whether very deep bins may be composited by one wave per quadrant and
+        chunk instead of by one workgroup."""
+        L.check(self.lib.gs_mesh_set_deep_pass(self.handle, 1 if enabled else 0))
+
     def deep_bins(self):
-        """Slab mode: the 32-px bins the last draw drew slab-parallel (chosen from the draw before it)."""
-        out = np.zeros(129, dtype=np.uint32)                   # count + at most GS_DEEP_MAX_BINS = 128 bins
-        L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, 129))
-        return out[1:1 + int(out[0])].copy()
+        """The 32-px bins the last draw composited through the deep pass (one wave per quadrant and chunk; chosen from the
+        statistics of the draw before it)."""
+        return self.deep_pass_info()["bins"]
+
+    def deep_pass_info(self):
+        """{bins drawn by the deep pass, bins over its threshold, chunk partials the per-bin kernel closed itself, whether its
+        partial pool ran out} of the last draw."""
+        out = np.zeros(4 + 256, dtype=np.uint32)               # 4 words + at most GS_DEEP_MAX_BINS = 256 bins
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, out.size))
+        return {"bins": out[4:4 + int(out[0])].copy(), "candidates": int(out[1]), "chunks_closed_by_bins": int(out[2]),
+                "pool_exhausted": bool(out[3])}
 
     def tile_row_costs(self):
         """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips).  The blend is

@@ -306,12 +306,6 @@ typedef struct gs_camera {
 #define GS_CAM_FADE_IN 8u        /* fadeInComplete == 0: distance fade-in, SplatMaterial.js:347-363             */
 #define GS_CAM_SCENE_EFFECTS 16u /* enableOptionalEffects: per-scene opacity / visibility, SplatMaterial.js:129 */
 #define GS_CAM_DYNAMIC 32u       /* dynamicMode: per-scene transforms, SplatMaterial.js:140-144,179-183         */
-#define GS_CAM_DEPTH_SLABS 64u   /* composite as a two-level fold over 64 depth slabs (a splat's slab = the top bits of its sort
-                                    bucket): the bins the previous draw found very deep are drawn by one workgroup per slab
-                                    instead of one per bin.  The frame differs from the default single fold by fp32 rounding
-                                    only; strips of a multi-GPU draw still equal the full frame bit for bit when every rank
-                                    sets the flag.  Needs a sorter-fed draw of a full sort (other draws fold as one slab) and
-                                    a mesh of at most 2^26 splats.                                                      */
 #define GS_TILE 16u
 
 typedef struct gs_render_stats {
@@ -358,9 +352,21 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
  * rect {x0|y0<<16, x1|y1<<16} (0 and 1 are defined only for splats whose mask bit is set); 2 = per list bin (gs_render_stats.list_bin_px) of the
  * drawn strip the [begin,end) range of its entry list ((~0,0) = untouched); 3 = the visibility mask, 1 bit per
  * splat packed in uint64 words (count = number of words); 4 = per 32x32-px blend bin of the drawn strip (row-major,
- * bins_x = ceil(width / 32)) the pair {list entries staged, (splat, 16x8-px half tile) pairs evaluated}: the blend's real
- * cost, used to balance multi-GPU strips. */
+ * bins_x = ceil(width / 32)) the pair {list entries scanned, 2 x (splat, 16x16-px quadrant) pairs composited}: the blend's
+ * real cost, used to balance multi-GPU strips; 5 = the deep pass of the last draw: {bins it composited, bins over its threshold,
+ * chunk partials the per-bin kernel closed itself, 1 if that pool ran out}, then the bin numbers (count = 4 .. 4 + 256 words).
+ *
+ * The composite (csrc/tile_blend.hip).  Per 16x16-px quadrant, the ordered list entries whose ellipse reaches the quadrant are
+ * cut into chunks of 1024; a chunk is the plain front-to-back composite from T = 1, and the chunks are merged near -> far
+ * (C = fma(T, C_c, C); T = T * T_c).  Up to 1024 contributing splats per quadrant - every quadrant of the BASELINE
+ * configurations - that is exactly the single front-to-back composite; beyond, it differs from it by fp32 rounding, and it lets
+ * many waves composite one very deep quadrant at once (the "deep pass", chosen per bin from the previous draw's statistics).
+ * The frame does not depend on that choice, on list batching or on how a multi-GPU draw cuts its strips. */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
+
+/* Scheduling switch, 1 by default (0 also via $GSPLAT_NO_DEEP at gs_mesh_create): whether the draws that follow may composite
+ * very deep bins through the deep pass.  The frame is the same either way (see the composite above). */
+int gs_mesh_set_deep_pass(gs_mesh* m, int enabled);
 
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of
  * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams.

@@ -15,7 +15,7 @@ const addon = require(path.join(__dirname, 'gsplat_addon.node'));
 
 const Constants = { DefaultSplatSortDistanceMapPrecision: 16, BytesPerInt: 4, BytesPerFloat: 4, MaxScenes: 32 };
 const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_MESH_SH_U8 = 2;
-const GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2, GS_CAM_ORTHOGRAPHIC = 4, GS_CAM_FADE_IN = 8, GS_CAM_SCENE_EFFECTS = 16, GS_CAM_DYNAMIC = 32, GS_CAM_DEPTH_SLABS = 64;
+const GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2, GS_CAM_ORTHOGRAPHIC = 4, GS_CAM_FADE_IN = 8, GS_CAM_SCENE_EFFECTS = 16, GS_CAM_DYNAMIC = 32;
 
 let sharedContext = null;
 function getContext(device) {
@@ -183,7 +183,6 @@ class SplatMeshHIP {
     this.dynamicMode = !!options.dynamicMode;                               // per-scene transforms (SplatMesh dynamicMode)
     this.enableOptionalEffects = !!options.enableOptionalEffects;           // per-scene opacity / visibility
     this.sphericalHarmonics8Bit = !!options.sphericalHarmonics8Bit;         // .ksplat compression level 2 SH
-    this.depthSlabs = !!options.depthSlabs;                                 // GS_CAM_DEPTH_SLABS: two-level composite for very deep lists
     this.orthographicMode = false;
     this.fadeIn = false;
     this.handle = addon.meshCreate(this.ctx.handle, maxSplatCount, this.shDegree,
@@ -242,8 +241,7 @@ class SplatMeshHIP {
     c.splatScale = this.splatScale;
     c.flags = (this.antialiased ? GS_CAM_ANTIALIASED : 0) | (this.pointCloudModeEnabled ? GS_CAM_POINT_CLOUD : 0) |
       (this.orthographicMode ? GS_CAM_ORTHOGRAPHIC : 0) | (this.fadeIn ? GS_CAM_FADE_IN : 0) |
-      (this.enableOptionalEffects ? GS_CAM_SCENE_EFFECTS : 0) | (this.dynamicMode ? GS_CAM_DYNAMIC : 0) |
-      (this.depthSlabs ? GS_CAM_DEPTH_SLABS : 0);
+      (this.enableOptionalEffects ? GS_CAM_SCENE_EFFECTS : 0) | (this.dynamicMode ? GS_CAM_DYNAMIC : 0);
     return c;
   }
   // HIP-engine extras for a multi-GPU draw (no counterpart in the reference: one WebGL context).  One process per GPU:

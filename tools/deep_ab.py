@@ -1,5 +1,6 @@
-"""Default composite vs GS_CAM_DEPTH_SLABS on the same box: one-stream frame time and isolated stage medians per config.
-usage: python tools/slab_ab.py "C3S C3T C3 C2" [frames]"""
+"""The deep pass on / off on the same box (same pixels either way): one-stream frame time, isolated stage medians, the pass's own
+numbers, and a check that the two frames are identical.
+usage: python tools/deep_ab.py "C3S C3T C3 C2" [frames]"""
 import os
 import sys
 import time
@@ -24,11 +25,12 @@ for name in names:
     mesh.use_sorter_result(w, N)
     mvp = cam.sort_mvp()
     ref = None
-    for slabs in (False, True, False, True):
-        mesh.set_depth_slabs(slabs)
-        for _ in range(3):
+    for deep in (False, True, False, True):
+        mesh.set_deep_pass(deep)
+        for _ in range(4):
             w.sort_on_device(mvp, N)
-            img, _ = mesh.render(to_host=slabs is not None, want_stats=True)
+            img, _ = mesh.render(to_host=True, want_stats=True)
+        info = mesh.deep_pass_info()
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(frames):
@@ -44,17 +46,16 @@ for name in names:
             st["bin"].append(r.bin_ms); st["esort"].append(r.tile_sort_ms); st["blend"].append(r.blend_ms)
         ctx.set_stage_timing(False)
         diff = ""
-        if not slabs:
+        if ref is None:
             ref = img
-        elif ref is not None:
+        else:
             d = np.abs(ref.astype(int) - img.astype(int))
-            diff = " | vs default frame: max %d LSB, %.4f %% of channel values differ" % (d.max(), 100.0 * (d > 0).mean())
-        extra = ""
-        if slabs:
-            bs = mesh.blend_bin_stats()[..., 1].astype(np.int64)
-            extra = " | deep bins %d (cost mean %d max %d)" % (len(mesh.deep_bins()), bs.mean(), bs.max())
-        print("%-4s %-8s frame %.4f ms = %7.1f Msplats/s | bin %.4f esort %.4f blend %.4f | entries %d walked %d%s" %
-              (name, "slabs" if slabs else "default", ms, N / ms / 1e3, np.median(st["bin"]), np.median(st["esort"]),
-               np.median(st["blend"]), r.tile_entries, r.splats_walked, diff + extra), flush=True)
+            diff = " | vs the first frame: max %d LSB, %d channel values differ" % (d.max(), int((d > 0).sum()))
+        bs = mesh.blend_bin_stats()[..., 1].astype(np.int64) // 2
+        print("%-4s deep pass %-3s frame %.4f ms = %7.1f Msplats/s | bin %.4f esort %.4f blend %.4f | walked %d | bins in the pass %d "
+              "(over the threshold %d), chunks closed by per-bin workgroups %d, pool exhausted %s | pairs per bin mean %d max %d%s" %
+              (name, "on" if deep else "off", ms, N / ms / 1e3, np.median(st["bin"]), np.median(st["esort"]), np.median(st["blend"]),
+               r.splats_walked, len(info["bins"]), info["candidates"], info["chunks_closed_by_bins"], info["pool_exhausted"],
+               bs.mean(), bs.max(), diff), flush=True)
     w.terminate(); mesh.dispose()
     del scene

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One-box evidence set for a round tag: GPU tests, the bench line (and the lines of the other configs), rocprofv3 kernel
 # stats of the headline frames, the HBM and VALU counter passes (C3 and, HBM only, C4), the blend's lane counters, the
-# vertex stage's floors, the cull-on kernel table, the slab-mode A/B, the per-rank cost of strip-sharded frames and a 2-rank
+# vertex stage's floors, the cull-on kernel table, the per-rank cost of strip-sharded frames and a 2-rank
 # dry run.  Everything lands under gpurun_out/<tag>/; copy what should be judged into profiles/.   usage: tools/evidence.sh <tag>
 TAG=${1:-rXX}
 cd /root/repo; mkdir -p gpurun_out/$TAG
@@ -25,7 +25,6 @@ python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_C4 gpurun_out/$TAG/pmc_traffic
 (GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 400 python tools/blend_lanes.py C3 C3T C2 C5 C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_lanes.txt
 (python tools/project_floor.py C3; GSPLAT_NO_BLOCK_CULL=1 python tools/project_floor.py C3) 2>&1 | grep k_project > gpurun_out/$TAG/project_floor.txt
 (GSPLAT_SERIAL=1 bash tools/prof_script.sh ${TAG}_cull 44 /root/repo/tools/cull_prof.py; grep "cull-on" gpurun_out/${TAG}_cull/log.txt) > gpurun_out/$TAG/cull_on_serial_kstats.txt 2>&1
-(timeout 300 python tools/slab_ab.py "C3S C3T C3" 10 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/slab_ab.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 (timeout 400 python bench.py --gpus 2 --steps 10 --no-cpu --no-cull 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_2ranks_dry_run.json
 cp gpurun_out/crops_C*.json gpurun_out/$TAG/ 2>/dev/null

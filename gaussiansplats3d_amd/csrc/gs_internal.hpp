@@ -86,27 +86,40 @@ constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
 constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
 constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
 // CHUNKED COMPOSITE (tile_blend.hip).  The value of a pixel is DEFINED per 16x16 quadrant as a two-level fold: the quadrant's
-// ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks of GS_CHUNK, each
+// ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks (below), each
 // chunk is composited front to back from T = 1, C = 0, and the chunks are merged near -> far (C = fma(T, C_c, C); T = T * T_c).
-// A quadrant with <= GS_CHUNK survivors (every quadrant of the BASELINE configurations) is one chunk and the merge is exact, so
+// A quadrant with <= GS_CHUNK0 survivors (every quadrant of the BASELINE configurations) is one chunk and the merge is exact, so
 // this IS the plain front-to-back composite there; a quadrant that is thousands of splats deep and does not saturate (a surface
 // seen at a grazing angle) can be composited by many waves at once - the "over" operator is associative - and the frame does not
 // depend on who did it.  The last chunk (index GS_CHUNKS_MAX - 1) is unbounded.
-constexpr uint32_t GS_CHUNK = 1024, GS_CHUNKS_MAX = 32;
+constexpr uint32_t GS_CHUNK0 = 1024, GS_CHUNK = 1024, GS_CHUNKS_MAX = 32;
+// Chunk 0 holds the first GS_CHUNK0 survivors, every later chunk GS_CHUNK (both 1024 now; the code keeps them apart).  A chunk
+// stops by ITS OWN transmittance (that is what makes it independent of the chunks in front of it), and the merge stops at chunk
+// boundaries - so a quadrant that saturates inside a later chunk is composited up to that chunk's end.  Measured: 512 everywhere
+// made C3T (~450 survivors per quadrant, a few up to ~1500) walk 17 % more splats, 1024 makes it walk 0.15 % more; 2048 for chunk
+// 0 made the first unit of every deep quadrant the long pole of the deep pass; 512 for the later chunks left quadrants deeper than
+// 16 k survivors with an unbounded last chunk of thousands (1 ms on one wave).  32 x 1024 covers 32 k survivors per quadrant.
+__host__ __device__ constexpr uint32_t gs_chunk_first(uint32_t c) { return c ? GS_CHUNK0 + (c - 1u) * GS_CHUNK : 0u; }
+__host__ __device__ constexpr uint32_t gs_chunk_size(uint32_t c) { return c ? GS_CHUNK : GS_CHUNK0; }
+__host__ __device__ constexpr uint32_t gs_chunk_count(uint32_t survivors) {
+    return survivors <= GS_CHUNK0 ? (survivors ? 1u : 0u)
+                                  : (1u + (survivors - GS_CHUNK0 + GS_CHUNK - 1u) / GS_CHUNK < GS_CHUNKS_MAX ? 1u + (survivors - GS_CHUNK0 + GS_CHUNK - 1u) / GS_CHUNK : GS_CHUNKS_MAX);
+}
 // The deep pass: the <= GS_DEEP_MAX_BINS bins that cost most in the previous draw (and more than a threshold) are scanned once
 // (k_deep_scan: exact quadrant masks of every list entry + survivor counts per GS_DEEP_RLEN entries) and composited by one wave per
 // (bin, quadrant, chunk); k_deep_fold merges.  Lists longer than GS_DEEP_LIST_CAP stay with the one-workgroup-per-bin kernel, which
 // closes chunks itself (partials in a pool).
-constexpr uint32_t GS_DEEP_MAX_BINS = 256, GS_DEEP_LIST_CAP = 65536, GS_DEEP_RLEN = 1024, GS_DEEP_RANGES = GS_DEEP_LIST_CAP / GS_DEEP_RLEN;
-constexpr uint32_t GS_DEEP_SCAN_WGS = 8;                    // k_deep_scan workgroups per deep bin (each strides over the ranges)
+constexpr uint32_t GS_DEEP_MAX_BINS = 512, GS_DEEP_LIST_CAP = 65536, GS_DEEP_RLEN = 1024, GS_DEEP_RANGES = GS_DEEP_LIST_CAP / GS_DEEP_RLEN;
+constexpr uint32_t GS_DEEP_SCAN_WGS = 32;                   // k_deep_scan workgroups per deep bin (each strides over the ranges)
 constexpr uint32_t GS_DEEP_UNITS = GS_DEEP_MAX_BINS * 4u * GS_CHUNKS_MAX;   // (bin, quadrant, chunk) waves of the deep pass
-constexpr uint32_t GS_POOL_SLOTS = 8192;                    // chunk partials (4 KB each) the per-bin kernel may close per draw
+constexpr uint32_t GS_POOL_SLOTS = 16384;                   // chunk partials (4 KB each) the per-bin kernel may close per draw
 constexpr uint32_t GS_ENT_SLOT_MASK = (1u << 28) - 1u;     // deep_ent word = record slot | quadrant mask << 28
 constexpr uint32_t GS_DEEP_NONE = 0xFFFFFFFFu;
 // flag words of a draw (gs_mesh::deep_flags): [0] deep bins of this draw  [1] bins over the threshold (mirrored to the host: the
-// NEXT draw launches the deep pass when this is non-zero)  [2] next pool slot  [3] pool exhausted  | deep_list [DEEP_MAX] |
+// NEXT draw launches the deep pass when this is non-zero)  [2] next pool slot  [3] pool exhausted  [4] units of the deep pass's
+// work list | deep_list [DEEP_MAX] |
 // deep_of [bins]
-constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, GS_FLAG_POOL_OVER = 3, GS_FLAG_LIST = 8,
+constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, GS_FLAG_POOL_OVER = 3, GS_FLAG_UNITS = 4, GS_FLAG_LIST = 8,
                    GS_FLAG_OF = GS_FLAG_LIST + GS_DEEP_MAX_BINS;
 
 #ifndef RADIX_TILE_CFG
@@ -357,6 +370,7 @@ struct gs_mesh {
     DevBuf deep_ent;           // uint32 [GS_DEEP_MAX_BINS][GS_DEEP_LIST_CAP]: slot | quadrant mask << 28 per list entry (deep pass)
     DevBuf deep_cnt;           // uint32 [GS_DEEP_MAX_BINS][GS_DEEP_RANGES][4]: survivors per range and quadrant
     DevBuf deep_partial;       // float4 [GS_DEEP_UNITS][256]: {C, T} of every (deep bin, quadrant, chunk)
+    DevBuf deep_work;          // uint32 [GS_DEEP_UNITS]: the (bin, quadrant, chunk) units that exist, packed (k_deep_plan)
     bool no_deep = false;      // GSPLAT_NO_DEEP: never launch the deep pass (the per-bin kernel draws everything)
     bool deep_pass = false;    // this draw runs the deep pass (decided in gs_launch_binning)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
                                                           uint32_t* __restrict__ blend_order, uint32_t deep,
                                                           uint32_t* __restrict__ deep_flags, uint32_t* __restrict__ blend_stats_w,
-                                                          uint32_t deep_min) {
+                                                          uint32_t deep_min, uint32_t deep_factor) {
     __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
     __shared__ unsigned long long s_wsum[4], s_t16[4];
@@ -306,13 +306,24 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
         // instead of by one workgroup - same pixels either way, so this is scheduling only.  Their count goes to the host (the NEXT
         // draw launches the deep pass when it is non-zero); they are only named when THIS draw runs the pass.  Their statistics
         // are then summed atomically by many waves: zeroed here.
+        // (a bin qualifies when it walked >= deep_min pairs AND >= deep_factor x the mean bin: the pass costs three launches, and
+        // only a tail that is long against the body of the frame pays for them - C3T's costliest bins are 3 x its mean and gain
+        // nothing, C3S's are 18 x; .y = half quadrants evaluated = 2 per pair, total_walked is their sum)
+        // Once the pass runs, more bins in it cost next to nothing, and every bin left behind is a workgroup that walks alone at the
+        // end of the launch: membership starts at 3/4 of the mean (and never below deep_min).
+        const uint32_t mean_halves = total_walked / max(blend_bins, 1u);
+        const uint32_t deep_trigger = max(2u * deep_min, deep_factor * mean_halves), deep_thr = max(2u * deep_min, mean_halves - mean_halves / 4u);
+        __shared__ uint32_t s_trigger;
+        if (threadIdx.x == 0) s_trigger = 0u;
         __shared__ uint32_t s_deep_n;
         if (threadIdx.x == 0) s_deep_n = 0u;
         __threadfence_block();
         __syncthreads();                                   // blend_order complete (and visible to this workgroup)
         for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
             const uint32_t i = __hip_atomic_load(&blend_order[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (i < blend_bins && prev_blend_stats[i].y >= 2u * deep_min) {        // .y = half quadrants evaluated = 2 per pair
+            const uint32_t cost = i < blend_bins ? prev_blend_stats[i].y : 0u;
+            if (cost >= deep_trigger) s_trigger = 1u;
+            if (cost >= deep_thr) {
                 const uint32_t k = atomicAdd(&s_deep_n, 1u);
                 if (deep) {
                     deep_flags[GS_FLAG_LIST + k] = i;
@@ -323,9 +334,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            deep_flags[GS_FLAG_CAND] = s_deep_n;
+            // (a draw whose tail no longer reaches the trigger still runs the pass it was launched with - on the bins of the
+            // membership rule - and tells the next one to stop)
+            deep_flags[GS_FLAG_CAND] = s_trigger ? s_deep_n : 0u;
             if (deep) deep_flags[GS_FLAG_COUNT] = s_deep_n;
-            if (mirror) mirror[4] = s_deep_n;
+            if (mirror) mirror[4] = s_trigger ? s_deep_n : 0u;
         }
         BIN_PROF(1, 1, wall_clock64());
         BIN_PROF(1, 2, wall_clock64());
@@ -494,8 +507,9 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // the previous draw's per-bin blend statistics order this draw's blend workgroups, if it drew the same bins
     // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
     // backfilling, and ordering them in one workgroup would cost more than it gives)
-    // deep pass: a bin qualifies when its previous draw walked >= deep_min (splat, quadrant) pairs (3 chunks' worth by default)
-    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 3u * GS_CHUNK;
+    // deep pass: a bin qualifies when its previous draw walked >= deep_min (splat, quadrant) pairs and >= deep_factor x the mean bin
+    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 2u * GS_CHUNK0;   // 2048 pairs
+    static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 3u;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
@@ -506,13 +520,14 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_TRY(m->deep_ent.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_LIST_CAP * 4));
         GS_TRY(m->deep_cnt.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_RANGES * 4 * 4));
         GS_TRY(m->deep_partial.ensure((size_t)GS_DEEP_UNITS * 256 * sizeof(float4)));
+        GS_TRY(m->deep_work.ensure((size_t)GS_DEEP_UNITS * 4));
     }
     // (+ one workgroup that only orders the blend's bins)
     hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_ok ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
                        order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr,
-                       m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min);
+                       m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
     if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));

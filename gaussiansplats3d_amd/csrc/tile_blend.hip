@@ -131,6 +131,11 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
 // pixel still accumulating (T > 1e-4), [11] half quadrants evaluated: what fraction of the blend's pixel work can hit anything
 constexpr unsigned BLEND_PROF_BINS = 40960, BLEND_PROF_WORDS = 12;
 __device__ unsigned long long g_blend_prof[BLEND_PROF_WORDS * BLEND_PROF_BINS];
+// per deep-pass unit: {start, end, windows scanned, survivors composited}
+__device__ unsigned long long g_deep_prof[4 * GS_DEEP_UNITS];
+extern "C" int gs_debug_deep_prof(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_deep_prof), sizeof(unsigned long long) * 4 * GS_DEEP_UNITS, 0, hipMemcpyDeviceToHost);
+}
 extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
     if (bins > BLEND_PROF_BINS) bins = BLEND_PROF_BINS;
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_blend_prof), (size_t)bins * BLEND_PROF_WORDS * 8, 0, hipMemcpyDeviceToHost);
@@ -146,7 +151,7 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef GS_BLEND_CHECK
 #define GS_BLEND_CHECK 4u             // a wave tests its quadrant for saturation after every 4th splat it composites
 #endif
-static_assert(GS_CHUNK % GS_BLEND_CHECK == 0, "a chunk ends on a saturation test");
+static_assert(GS_CHUNK % GS_BLEND_CHECK == 0 && GS_CHUNK0 % GS_BLEND_CHECK == 0, "a chunk ends on a saturation test");
 
 // the 4 pixels of a lane (x = lane & 15, y = (lane >> 4) + 4g) as two packed pairs: [h].x = strip 2h, [h].y = strip 2h + 1
 struct Px {
@@ -169,7 +174,8 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 // `if (A > 8.0) discard` is a saturated multiply-add instead of a compare + select (which does not pack and stalls on VCC):
 // keep = sat((CUT - pw) * 2^100) is exactly 1 for pw < CUT and 0 for pw >= CUT - fp32 cannot represent a positive difference
 // below 2^-100 here.  The two pairs are independent chains the scheduler interleaves.
-__device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+struct Alpha { v2f a[2]; float r, g, b; };
+__device__ __forceinline__ void alpha_of(const LdsSplat* sp, float fx, const v2f (&fy)[2], const Px& px, Alpha& out, uint32_t& p_kept, uint32_t& p_useful) {
 #pragma clang fp contract(off)
     const float4 q0 = *reinterpret_cast<const float4*>(&sp->ax);     // three wave-uniform ds_read_b128 broadcasts
     const float4 q1 = *reinterpret_cast<const float4*>(&sp->bx);
@@ -189,14 +195,37 @@ __device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, cons
         p_useful += (uint32_t)__popcll(__ballot(keep.x > 0.0f && px.T[h].x > GS_T_EPS)) +
                     (uint32_t)__popcll(__ballot(keep.y > 0.0f && px.T[h].y > GS_T_EPS));
 #endif
-        const v2f alpha = e * (v2f{q1.w, q1.w} * keep);
-        const v2f wgt = px.T[h] * alpha;
-        px.Cr[h] = fma2(wgt, v2f{q2.x, q2.x}, px.Cr[h]);
-        px.Cg[h] = fma2(wgt, v2f{q2.y, q2.y}, px.Cg[h]);
-        px.Cb[h] = fma2(wgt, v2f{q2.z, q2.z}, px.Cb[h]);
-        px.T[h] = fma2(-px.T[h], alpha, px.T[h]);                    // T * (1 - alpha) without waiting for wgt
+        out.a[h] = e * (v2f{q1.w, q1.w} * keep);
     }
-    (void)p_kept; (void)p_useful;
+    out.r = q2.x; out.g = q2.y; out.b = q2.z;
+    (void)px; (void)p_kept; (void)p_useful;
+}
+__device__ __forceinline__ void apply_alpha(Px& px, const Alpha& al) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const v2f wgt = px.T[h] * al.a[h];
+        px.Cr[h] = fma2(wgt, v2f{al.r, al.r}, px.Cr[h]);
+        px.Cg[h] = fma2(wgt, v2f{al.g, al.g}, px.Cg[h]);
+        px.Cb[h] = fma2(wgt, v2f{al.b, al.b}, px.Cb[h]);
+        px.T[h] = fma2(-px.T[h], al.a[h], px.T[h]);                  // T * (1 - alpha) without waiting for wgt
+    }
+}
+__device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+    Alpha al;
+    alpha_of(sp, fx, fy, px, al, p_kept, p_useful);
+    apply_alpha(px, al);
+}
+// Two consecutive splats: both alphas first (they do not depend on the pixel's state), then the two composite steps in order -
+// the same operations on the same operands as two composite_one calls, with the second splat's LDS reads and exponentials in
+// the shadow of the first's.  For waves that walk alone (the deep pass's units): they are bound by the latency of one splat's
+// dependent chain (~400 cycles per splat against 132 of VALU issue), not by issue slots.
+__device__ __forceinline__ void composite_two(const LdsSplat* sp, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+    Alpha a0, a1;
+    alpha_of(sp, fx, fy, px, a0, p_kept, p_useful);
+    alpha_of(sp + 1, fx, fy, px, a1, p_kept, p_useful);
+    apply_alpha(px, a0);
+    apply_alpha(px, a1);
 }
 
 // The second level of the chunked composite: chunk partials {C_c, T_c} merged near -> far.  The fold of a single chunk is exact
@@ -212,6 +241,12 @@ struct Folded {
         C[g][1] = __builtin_fmaf(T[g], p.y, C[g][1]);
         C[g][2] = __builtin_fmaf(T[g], p.z, C[g][2]);
         T[g] = __fmul_rn(T[g], p.w);
+    }
+    __device__ __forceinline__ void merge_cum(int g, const float4 p) {   // p.w = the product INCLUDING this chunk (bin_body's pool)
+        C[g][0] = __builtin_fmaf(T[g], p.x, C[g][0]);
+        C[g][1] = __builtin_fmaf(T[g], p.y, C[g][1]);
+        C[g][2] = __builtin_fmaf(T[g], p.z, C[g][2]);
+        T[g] = p.w;
     }
     __device__ __forceinline__ bool open() const {
         const float tmax = fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3]));
@@ -240,8 +275,9 @@ struct DeepArgs {
     uint32_t* ent;              // [GS_DEEP_MAX_BINS][GS_DEEP_LIST_CAP]
     uint32_t* cnt;              // [GS_DEEP_MAX_BINS][GS_DEEP_RANGES][4]
     float4* partial;            // [GS_DEEP_UNITS][256]
+    uint32_t* work;             // [GS_DEEP_UNITS]: d << 7 | c << 2 | q of the units that exist (k_deep_plan)
     float4* pool;               // [GS_POOL_SLOTS][256]
-    uint32_t unit_wgs;          // workgroups of (bin, quadrant, chunk) units in front of the per-bin workgroups (0: no deep pass)
+    uint32_t unit_wgs;          // workgroups of (bin, quadrant, chunk) units behind the per-bin workgroups (0: no deep pass)
 };
 
 struct FrameArgs {
@@ -313,16 +349,20 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
     // one batch ahead, so a batch waits for ONE gather latency, not for two dependent ones.  Long lists whose pixels do not
     // saturate are bound by exactly that latency (tools/blend_profile.py: ~8 us per batch before, a wave only walks
     // ~10 survivors of a batch).
+    // (The loads are unconditional - a lane past the end of the list reads the list's last entry and its result is masked by
+    // `tid < cnt` below: inside an `if` the loop-carried registers became copies placed right behind the loads, i.e. a wait for the
+    // gather in front of the walk it was supposed to hide behind - r03 ISA.)
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     uint2 rect = make_uint2(0xFFFFu, 0u);              // empty
     uint32_t v_next = 0;
-    if (tid < n) {
-        const uint32_t slot = fa.vals[begin + tid];
+    if (n) {                                           // (uniform)
+        const uint32_t last = begin + n - 1u;
+        const uint32_t slot = fa.vals[min(begin + tid, last)];
         rect = fa.rects[slot];
         lo = fa.recs[2 * (size_t)slot];
         hi = fa.recs[2 * (size_t)slot + 1];
+        v_next = fa.vals[min(begin + BLEND_THREADS + tid, last)];
     }
-    if (BLEND_THREADS + tid < n) v_next = fa.vals[begin + BLEND_THREADS + tid];
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
         const uint32_t cnt = min((uint32_t)BLEND_THREADS, n - base);
 #ifdef GS_BLEND_PROFILE
@@ -335,13 +375,11 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
         s_qmask[tid] = qm;
         if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0);
         if (tid == 0) *s_live = 0u;
-        const uint32_t nxt = base + BLEND_THREADS + tid;   // prefetch while this batch is blended
-        if (nxt < n) {
-            rect = fa.rects[v_next];
-            lo = fa.recs[2 * (size_t)v_next];
-            hi = fa.recs[2 * (size_t)v_next + 1];
-        }
-        if (nxt + BLEND_THREADS < n) v_next = fa.vals[begin + nxt + BLEND_THREADS];
+        // prefetch while this batch is blended
+        rect = fa.rects[v_next];
+        lo = fa.recs[2 * (size_t)v_next];
+        hi = fa.recs[2 * (size_t)v_next + 1];
+        v_next = fa.vals[min(begin + base + 2u * BLEND_THREADS + tid, begin + n - 1u)];
         __syncthreads();
         if (live_wave) {
             for (uint32_t g0 = 0; g0 < cnt && live_wave; g0 += 64) {
@@ -365,19 +403,39 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
                             live_wave = false;
                             break;
                         }
-                        if (in_chunk == GS_CHUNK && can_close && closed < GS_CHUNKS_MAX - 1u) {
+                        if (in_chunk == gs_chunk_size(closed) && can_close && closed < GS_CHUNKS_MAX - 1u) {
                             // the chunk is full: its {C, T} goes to a pool slot (merged at the end), the next one starts from T = 1
                             uint32_t slot = 0;
                             if (lane == 0u) slot = atomicAdd(&da.flags[GS_FLAG_POOL_NEXT], 1u);
                             slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
                             if (slot < GS_POOL_SLOTS) {
-                                float4* part = da.pool + (size_t)slot * 256u + lane;
+                                // (the slot keeps the transmittance of ALL chunks so far in .w - the previous slot's times this
+                                // chunk's, the product the merge forms - so that the wave can retire at a chunk boundary, exactly
+                                // where the merge stops, without carrying the running product in registers)
+                                float tr[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+                                if (closed) {
+                                    __threadfence();                       // this wave's own earlier stores, read back from L2
+                                    const float4* prev = da.pool + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)my_slot, (int)(closed - 1u)) * 256u + lane;
 #pragma unroll
-                                for (int g = 0; g < 4; g++) part[64 * g] = acc.get(g);
+                                    for (int g = 0; g < 4; g++) tr[g] = prev[64 * g].w;
+                                }
+                                float4* part = da.pool + (size_t)slot * 256u + lane;
+                                float tmax = 0.0f;
+#pragma unroll
+                                for (int g = 0; g < 4; g++) {
+                                    float4 p = acc.get(g);
+                                    p.w = __fmul_rn(tr[g], p.w);
+                                    tmax = fmaxf(tmax, p.w);
+                                    part[64 * g] = p;
+                                }
                                 if (lane == closed) my_slot = slot;
                                 closed++;
                                 in_chunk = 0;
                                 acc.reset();
+                                if (__ballot(tmax > GS_T_EPS) == 0ull) {   // everything behind is multiplied by <= 1e-4: the merge stops here
+                                    live_wave = false;
+                                    break;
+                                }
                             } else {
                                 // pool exhausted (a frame with > GS_POOL_SLOTS full chunks outside the deep pass): the quadrant goes on
                                 // as one long chunk - a valid composite, but no longer the one another executor would produce
@@ -446,7 +504,7 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
             const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)my_slot, (int)c);
             const float4* part = da.pool + (size_t)slot * 256u + lane;
 #pragma unroll
-            for (int g = 0; g < 4; g++) f.merge(g, part[64 * g]);
+            for (int g = 0; g < 4; g++) f.merge_cum(g, part[64 * g]);
             open = f.open();
         }
         if (open) {
@@ -522,66 +580,179 @@ __device__ __forceinline__ uint32_t deep_prefix(const DeepArgs& da, uint32_t d, 
     return v;
 }
 
-__device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& da, const uint32_t wg, LdsSplat* s_batch) {
+// The units that exist: chunk c of quadrant q of deep bin d for every c below the quadrant's chunk count (a quadrant outside
+// the strip / viewport, and every quadrant of a list too long for the tables, has none), packed in (d, q, c) order.
+__global__ __launch_bounds__(1024) void k_deep_plan(FrameArgs fa, DeepArgs da) {
+    __shared__ uint32_t s_tmp[16];
+    constexpr uint32_t PER = GS_DEEP_MAX_BINS * 4u / 1024u;                 // (bin, quadrant) pairs per thread, consecutive
+    static_assert(GS_DEEP_MAX_BINS * 4u % 1024u == 0, "pairs per thread");
+    const uint32_t count = da.flags[GS_FLAG_COUNT];
+    uint32_t nch[PER], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t p = threadIdx.x * PER + k, d = p >> 2, q = p & 3u;
+        nch[k] = 0;
+        if (d < count) {
+            const BinGeom bg(fa, da.flags[GS_FLAG_LIST + d]);
+            if (bg.n <= GS_DEEP_LIST_CAP && bg.live(fa, q)) {
+                const uint32_t nr = (bg.n + GS_DEEP_RLEN - 1u) / GS_DEEP_RLEN;
+                uint32_t total = 0;
+                for (uint32_t r = 0; r < nr; r++) total += da.cnt[((size_t)d * GS_DEEP_RANGES + r) * 4u + q];
+                nch[k] = gs_chunk_count(total);
+            }
+        }
+        mine += nch[k];
+    }
+    // exclusive scan over the 1024 threads (16 waves)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63u) s_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine, total_units = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; w++) {
+        const uint32_t v = s_tmp[w];
+        base += w < wave ? v : 0u;
+        total_units += v;
+    }
+#ifdef GS_BLEND_PROFILE
+    for (uint32_t i = threadIdx.x; i < 4u * GS_DEEP_UNITS; i += 1024u) g_deep_prof[i] = 0ull;
+#endif
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint32_t p = threadIdx.x * PER + k;
+        for (uint32_t c = 0; c < nch[k]; c++) da.work[base + c] = ((p >> 2) << 7) | (c << 2) | (p & 3u);
+        base += nch[k];
+    }
+    if (threadIdx.x == 0) da.flags[GS_FLAG_UNITS] = total_units;
+}
+
+__device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& da, const uint32_t wg, LdsSplat* s_batch, uint32_t* s_queue) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t unit = wg * 4u + wave;                                   // a workgroup = the 4 quadrants of one (bin, chunk)
-    const uint32_t d = unit / (4u * GS_CHUNKS_MAX), c = (unit / 4u) % GS_CHUNKS_MAX, q = unit % 4u;
-    if (d >= da.flags[GS_FLAG_COUNT]) return;
+    // Wave u takes unit u of the packed work list (k_deep_plan).  (Fixed (bin, chunk) x 4 quadrants per workgroup left most
+    // workgroups with one or two live waves - a workgroup holds its CU slot until its last wave ends - and, before that, bin-major
+    // order let the chunk index choose the XCD: 620, then 1900 waves busy out of 6144; r03y profiles.)
+    const uint32_t u = wg * 4u + wave;
+    if (u >= da.flags[GS_FLAG_UNITS]) return;
+    const uint32_t word = da.work[u];
+    const uint32_t d = word >> 7, c = (word >> 2) & 31u, q = word & 3u;
+    static_assert(GS_CHUNKS_MAX == 32 && GS_DEEP_MAX_BINS <= (1u << 25), "work word layout");
+    const uint32_t unit = (d * GS_CHUNKS_MAX + c) * 4u + q;
+#ifdef GS_BLEND_PROFILE
+    const unsigned long long t_start = wall_clock64();
+    uint32_t windows = 0;
+#endif
     const uint32_t bin = da.flags[GS_FLAG_LIST + d];
     const BinGeom bg(fa, bin);
-    if (bg.n > GS_DEEP_LIST_CAP || !bg.live(fa, q)) return;
     const uint32_t incl = deep_prefix(da, d, q, bg.n, lane);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t first = c * GS_CHUNK;
-    if (first >= total) return;                                             // the quadrant has no chunk c
+    const uint32_t first = gs_chunk_first(c);
     const uint32_t r0 = (uint32_t)__builtin_ctzll(__ballot(incl > first));  // the range that holds survivor `first`
     const uint32_t before = r0 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(r0 - 1u)) : 0u;
     uint32_t skip = first - before;                                         // survivors of that range in front of the chunk
-    const uint32_t limit = c == GS_CHUNKS_MAX - 1u ? 0xFFFFFFFFu : GS_CHUNK; // the last chunk takes the rest
+    const uint32_t limit = c == GS_CHUNKS_MAX - 1u ? 0xFFFFFFFFu : gs_chunk_size(c);   // the last chunk takes the rest
 
     const float bin_x0 = (float)(bg.bx * GS_BIN), bin_y0 = (float)(bg.by * GS_BIN);
     const float fx = (float)((q & 1u) * GS_TILE + (lane & 15u)) + 0.5f;
     const float fy0 = (float)((q >> 1) * GS_TILE + (lane >> 4)) + 0.5f;
     const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
     LdsSplat* mine = s_batch + 64u * wave;                                  // this wave's quarter of the batch buffer
+    uint32_t* qs = s_queue + 128u * wave;                                   // slots of survivors found but not yet composited
     const uint32_t* ent = da.ent + (size_t)d * GS_DEEP_LIST_CAP;
     Px acc;
     acc.reset();
     uint32_t done = 0, since_check = 0, p_kept = 0, p_useful = 0;
+    uint32_t pend = 0, queued = 0;                                          // in the queue; found so far (<= limit)
     bool open = true;
-    uint32_t pos = r0 * GS_DEEP_RLEN;
-    uint32_t e_next = pos + lane < bg.n ? ent[pos + lane] : 0u;
-    while (pos < bg.n && done < limit && open) {
-        const uint32_t e = e_next;
-        pos += 64u;
-        e_next = pos + lane < bg.n ? ent[pos + lane] : 0u;                 // the next window travels while this one is composited
-        unsigned long long m = __ballot((e >> (28u + q)) & 1u);
-        if (skip) {
-            const uint32_t k = (uint32_t)__popcll(m);
-            if (k <= skip) { skip -= k; continue; }
-            for (; skip; skip--) m &= m - 1ull;
+    // The scan reads GS_SCAN_AHEAD windows of 64 entry words at a time and asks for the next group before it looks at this one: a
+    // sparse quadrant (2 survivors per window) is bound by how many loads are in flight - with one window ahead a 50 k list took
+    // ~0.8 ms to scan.
+    constexpr uint32_t GS_SCAN_AHEAD = 4;
+    uint32_t pos = r0 * GS_DEEP_RLEN;                                       // first entry of the group in `cur`
+    uint32_t cur[GS_SCAN_AHEAD], nxt[GS_SCAN_AHEAD], wnd = 0;               // wnd: next window of `cur` to look at
+#pragma unroll
+    for (uint32_t k = 0; k < GS_SCAN_AHEAD; k++) cur[k] = pos + 64u * k + lane < bg.n ? ent[pos + 64u * k + lane] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < GS_SCAN_AHEAD; k++) nxt[k] = pos + 64u * (GS_SCAN_AHEAD + k) + lane < bg.n ? ent[pos + 64u * (GS_SCAN_AHEAD + k) + lane] : 0u;
+    while (open) {
+        // Fill: scan windows of 64 entries until 64 survivors wait (one gather per window was 2 us of latency per 2 splats of a
+        // sparse quadrant)
+        while (pend < 64u && pos + 64u * wnd < bg.n && queued < limit) {
+            uint32_t e = cur[0];
+#ifdef GS_BLEND_PROFILE
+            windows++;
+#endif
+#pragma unroll
+            for (uint32_t k = 1; k < GS_SCAN_AHEAD; k++) e = wnd == k ? cur[k] : e;   // (wnd is wave-uniform)
+            if (++wnd == GS_SCAN_AHEAD) {
+                wnd = 0;
+                pos += 64u * GS_SCAN_AHEAD;
+#pragma unroll
+                for (uint32_t k = 0; k < GS_SCAN_AHEAD; k++) {
+                    cur[k] = nxt[k];
+                    nxt[k] = pos + 64u * (GS_SCAN_AHEAD + k) + lane < bg.n ? ent[pos + 64u * (GS_SCAN_AHEAD + k) + lane] : 0u;
+                }
+            }
+            unsigned long long m = __ballot((e >> (28u + q)) & 1u);
+            if (skip) {
+                const uint32_t k = (uint32_t)__popcll(m);
+                if (k <= skip) { skip -= k; continue; }
+                for (; skip; skip--) m &= m - 1ull;
+            }
+            if (!m) continue;
+            const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (((m >> lane) & 1ull) && rank < limit - queued) qs[pend + rank] = e & GS_ENT_SLOT_MASK;
+            const uint32_t k = min((uint32_t)__popcll(m), limit - queued);
+            pend += k;
+            queued += k;
         }
-        if (!m) continue;
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const bool take = ((m >> lane) & 1ull) && rank < limit - done;
-        if (take) {
-            const uint32_t slot = e & GS_ENT_SLOT_MASK;
-            stage_entry(&mine[rank], fa.recs[2 * (size_t)slot], fa.recs[2 * (size_t)slot + 1], bin_x0, bin_y0);
-        }
-        const uint32_t k = min((uint32_t)__popcll(m), limit - done);
+        if (pend == 0u) break;
+        const uint32_t k = min(pend, 64u), rem = pend - k;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t jj = 0; jj < k; jj++) {
+        if (lane < k) {
+            const uint32_t slot = qs[lane];
+            stage_entry(&mine[lane], fa.recs[2 * (size_t)slot], fa.recs[2 * (size_t)slot + 1], bin_x0, bin_y0);
+        }
+        const uint32_t carry = lane < rem ? qs[64u + lane] : 0u;           // what is left moves to the front of the queue
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rem) qs[lane] = carry;
+        pend = rem;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t jj = 0;
+        if ((since_check & 1u) && k) {                                      // (pairs never straddle a saturation test)
+            composite_one(&mine[0], fx, fy, acc, p_kept, p_useful);
+            jj = 1; done++;
+            if (++since_check == GS_BLEND_CHECK) { since_check = 0; if (!acc.open()) open = false; }
+        }
+        for (; jj + 1u < k && open; jj += 2u) {
+            composite_two(&mine[jj], fx, fy, acc, p_kept, p_useful);
+            done += 2u;
+            since_check += 2u;
+            if (since_check == GS_BLEND_CHECK) {                            // the per-bin kernel's stop rule
+                since_check = 0;
+                if (!acc.open()) open = false;
+            }
+        }
+        if (jj < k && open) {
             composite_one(&mine[jj], fx, fy, acc, p_kept, p_useful);
             done++;
-            if (++since_check == GS_BLEND_CHECK) {                          // the per-bin kernel's stop rule
-                since_check = 0;
-                if (!acc.open()) { open = false; break; }
-            }
+            if (++since_check == GS_BLEND_CHECK) { since_check = 0; if (!acc.open()) open = false; }
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef GS_BLEND_PROFILE
+    if (lane == 0u) {
+        g_deep_prof[4 * unit] = t_start; g_deep_prof[4 * unit + 1] = wall_clock64();
+        g_deep_prof[4 * unit + 2] = windows; g_deep_prof[4 * unit + 3] = done;
+    }
+#endif
     float4* part = da.partial + (size_t)unit * 256u + lane;                // unit = ((d * CHUNKS_MAX + c) * 4 + q)
 #pragma unroll
     for (int g = 0; g < 4; g++) part[64 * g] = acc.get(g);
@@ -591,14 +762,17 @@ __device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& d
     }
 }
 
-// One launch: the deep pass's units first (the long ones start first), then one workgroup per bin.
-__global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameArgs fa, DeepArgs da) {
+// One launch: one workgroup per bin (heaviest first, k_bin_emit's order), then the deep pass's units, which fill the slots the light
+// bins free (units first: the per-bin workgroups sat behind 16 k mostly empty unit workgroups in the dispatcher's queue and
+// started 0.26 ms late - they, not the units, ended the launch: r03y profile).
+__global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameArgs fa, DeepArgs da, uint32_t bins) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_live;
     __shared__ uint32_t s_walked[4];
-    if (blockIdx.x < da.unit_wgs) deep_unit(fa, da, blockIdx.x, s_batch);
-    else bin_body(fa, da, blockIdx.x - da.unit_wgs, s_batch, s_qmask, &s_live, s_walked);
+    __shared__ uint32_t s_queue[512];                  // (deep units: 128 pending survivor slots per wave)
+    if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
+    else deep_unit(fa, da, blockIdx.x - bins, s_batch, s_queue);
 }
 
 __global__ __launch_bounds__(BLEND_THREADS) void k_deep_fold(FrameArgs fa, DeepArgs da) {
@@ -611,7 +785,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_deep_fold(FrameArgs fa, DeepA
     if (bg.n > GS_DEEP_LIST_CAP || !bg.live(fa, q)) return;
     const uint32_t incl = deep_prefix(da, d, q, bg.n, lane);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t chunks = min((total + GS_CHUNK - 1u) / GS_CHUNK, GS_CHUNKS_MAX);
+    const uint32_t chunks = gs_chunk_count(total);
     Folded f;
     f.reset();
     bool open = true;
@@ -649,9 +823,13 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     da.cnt = m->deep_cnt.as<uint32_t>();
     da.partial = m->deep_partial.as<float4>();
     da.pool = m->chunk_pool.as<float4>();
+    da.work = m->deep_work.as<uint32_t>();
     da.unit_wgs = m->deep_pass ? GS_DEEP_UNITS / 4u : 0u;
-    if (m->deep_pass) hipLaunchKernelGGL(k_deep_scan, dim3(GS_DEEP_MAX_BINS * GS_DEEP_SCAN_WGS), dim3(256), 0, st, fa, da);
-    hipLaunchKernelGGL(k_tile_blend, dim3(da.unit_wgs + bins), dim3(BLEND_THREADS), 0, st, fa, da);
+    if (m->deep_pass) {
+        hipLaunchKernelGGL(k_deep_scan, dim3(GS_DEEP_MAX_BINS * GS_DEEP_SCAN_WGS), dim3(256), 0, st, fa, da);
+        hipLaunchKernelGGL(k_deep_plan, dim3(1), dim3(1024), 0, st, fa, da);
+    }
+    hipLaunchKernelGGL(k_tile_blend, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     if (m->deep_pass) hipLaunchKernelGGL(k_deep_fold, dim3(GS_DEEP_MAX_BINS), dim3(BLEND_THREADS), 0, st, fa, da);
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;

@@ -263,7 +263,7 @@ class SplatMesh:
     def deep_pass_info(self):
         """{bins drawn by the deep pass, bins over its threshold, chunk partials the per-bin kernel closed itself, whether its
         partial pool ran out} of the last draw."""
-        out = np.zeros(4 + 256, dtype=np.uint32)               # 4 words + at most GS_DEEP_MAX_BINS = 256 bins
+        out = np.zeros(4 + 512, dtype=np.uint32)               # 4 words + at most GS_DEEP_MAX_BINS = 512 bins
         L.check(self.lib.gs_mesh_debug_read(self.handle, 5, out.ctypes.data, out.size))
         return {"bins": out[4:4 + int(out[0])].copy(), "candidates": int(out[1]), "chunks_closed_by_bins": int(out[2]),
                 "pool_exhausted": bool(out[3])}

@@ -84,7 +84,9 @@ def test_deep_pass_and_per_bin_kernel_produce_the_same_bits(ctx):
     again, st = rig.draw()
     np.testing.assert_array_equal(again, plain)
     assert len(rig.mesh.deep_pass_info()["bins"]) >= 1
-    assert abs(int(st.splats_walked) - int(st0.splats_walked)) <= 0.02 * st0.splats_walked
+    # (the waves of the pass cannot know that the chunks in front of theirs already saturated the quadrant: they composite what
+    # the merge then ignores - never less than the per-bin kernel walks)
+    assert int(st.splats_walked) >= int(st0.splats_walked)
     rig.close()
 
 

@@ -15,8 +15,15 @@ from gaussiansplats3d_amd import _lib, camera, scenes, util
 
 
 def use_library(path):
+    """(an older build may lack entry points added since: they are dropped from the table for that library only)"""
+    import ctypes
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(path)
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    if not hasattr(use_library, "all_symbols"):
+        use_library.all_symbols = dict(_lib.SYMBOLS)
+    _lib.SYMBOLS.clear()
+    _lib.SYMBOLS.update({k: v for k, v in use_library.all_symbols.items() if hasattr(probe, k)})
     return _lib.load()
 
 

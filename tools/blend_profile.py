@@ -14,10 +14,11 @@ w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from"
 mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half).build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
 mesh.set_camera(cam)
 mesh.use_sorter_result(w, N)
-for _ in range(3):
+for _ in range(5):
     w.sort_on_device(cam.sort_mvp(), N)
-    _, st = mesh.render(to_host=False, want_stats=True)
+    _, st = mesh.render(to_host=True, want_stats=True)       # (to_host: the deep pass's verdict reaches the next draw)
 ctx.synchronize()
+info = mesh.deep_pass_info()
 bins = ((cfg["width"] + 31) // 32) * ((cfg["height"] + 31) // 32)
 bins = min(bins, 40960)
 buf = np.zeros((bins, 12), dtype=np.uint64)     # BLEND_PROF_WORDS per bin (tile_blend.hip)
@@ -46,3 +47,25 @@ for a, b in zip(edges[:-1], edges[1:]):
 late = np.argsort(rel1)[-8:]
 for i in late[::-1]:
     print(f"  bin {i} ({i % ((cfg['width']+31)//32)},{i // ((cfg['width']+31)//32)}) start {rel0[i]:.1f} end {rel1[i]:.1f} dur {dur[i]:.1f} n {n[i]} walked {walked[i].tolist()}")
+
+# the deep pass's units (one wave per bin, quadrant, chunk), if the last draw ran it
+if len(info["bins"]) and hasattr(lib, "gs_debug_deep_prof"):
+    CM, D = 32, 512
+    ub = np.zeros((D * CM * 4, 4), dtype=np.uint64)
+    lib.gs_debug_deep_prof.argtypes = [C.c_void_p]
+    assert lib.gs_debug_deep_prof(ub.ctypes.data) == 0
+    live = ub[:, 1] > 0
+    u0, u1 = (ub[live, 0].astype(np.int64) - start) / 100.0, (ub[live, 1].astype(np.int64) - start) / 100.0
+    ud, uw, un = u1 - u0, ub[live, 2].astype(np.int64), ub[live, 3].astype(np.int64)
+    # (bins the pass drew keep their old words in the per-bin table: drop them from the per-bin numbers)
+    drawn = np.ones(bins, bool); drawn[info["bins"][info["bins"] < bins]] = False
+    print("deep pass: %d bins, %d units that composited something; unit duration us: mean %.1f p50 %.1f p90 %.1f max %.1f; start: first %.1f "
+          "last %.1f; end of the last unit %.1f us | windows scanned per unit mean %.0f max %d | survivors per unit mean %.0f max %d" %
+          (len(info["bins"]), live.sum(), ud.mean(), np.percentile(ud, 50), np.percentile(ud, 90), ud.max(), u0.min(), u0.max(), u1.max(),
+           uw.mean(), uw.max(), un.mean(), un.max()))
+    print("per-bin workgroups of the same launch: first start %.1f, last end %.1f us" % (rel0[drawn].min(), rel1[drawn].max()))
+    slow = np.argsort(ud)[-6:]
+    idx = np.nonzero(live)[0]
+    for k in slow[::-1]:
+        u = idx[k]
+        print("  unit d=%d c=%d q=%d: %.1f us, start %.1f, windows %d, survivors %d" % (u // (4 * CM), (u // 4) % CM, u % 4, ud[k], u0[k], uw[k], un[k]))

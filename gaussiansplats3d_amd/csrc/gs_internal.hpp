@@ -88,23 +88,33 @@ constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
 // CHUNKED COMPOSITE (tile_blend.hip).  The value of a pixel is DEFINED per 16x16 quadrant as a two-level fold: the quadrant's
 // ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks (below), each
 // chunk is composited front to back from T = 1, C = 0, and the chunks are merged near -> far (C = fma(T, C_c, C); T = T * T_c).
-// A quadrant with <= GS_CHUNK0 survivors (every quadrant of the BASELINE configurations) is one chunk and the merge is exact, so
+// A quadrant with <= 1024 survivors (all quadrants of the BASELINE configurations but a few dozen of C3T) is one chunk and the
+// merge is exact, so
 // this IS the plain front-to-back composite there; a quadrant that is thousands of splats deep and does not saturate (a surface
 // seen at a grazing angle) can be composited by many waves at once - the "over" operator is associative - and the frame does not
 // depend on who did it.  The last chunk (index GS_CHUNKS_MAX - 1) is unbounded.
-constexpr uint32_t GS_CHUNK0 = 1024, GS_CHUNK = 1024, GS_CHUNKS_MAX = 32;
-// Chunk 0 holds the first GS_CHUNK0 survivors, every later chunk GS_CHUNK (both 1024 now; the code keeps them apart).  A chunk
-// stops by ITS OWN transmittance (that is what makes it independent of the chunks in front of it), and the merge stops at chunk
-// boundaries - so a quadrant that saturates inside a later chunk is composited up to that chunk's end.  Measured: 512 everywhere
-// made C3T (~450 survivors per quadrant, a few up to ~1500) walk 17 % more splats, 1024 makes it walk 0.15 % more; 2048 for chunk
-// 0 made the first unit of every deep quadrant the long pole of the deep pass; 512 for the later chunks left quadrants deeper than
-// 16 k survivors with an unbounded last chunk of thousands (1 ms on one wave).  32 x 1024 covers 32 k survivors per quadrant.
-__host__ __device__ constexpr uint32_t gs_chunk_first(uint32_t c) { return c ? GS_CHUNK0 + (c - 1u) * GS_CHUNK : 0u; }
-__host__ __device__ constexpr uint32_t gs_chunk_size(uint32_t c) { return c ? GS_CHUNK : GS_CHUNK0; }
-__host__ __device__ constexpr uint32_t gs_chunk_count(uint32_t survivors) {
-    return survivors <= GS_CHUNK0 ? (survivors ? 1u : 0u)
-                                  : (1u + (survivors - GS_CHUNK0 + GS_CHUNK - 1u) / GS_CHUNK < GS_CHUNKS_MAX ? 1u + (survivors - GS_CHUNK0 + GS_CHUNK - 1u) / GS_CHUNK : GS_CHUNKS_MAX);
+constexpr uint32_t GS_CHUNKS_MAX = 32;
+// Chunk sizes: 1024, then 4 x 256, 4 x 512, then 1024 each (boundaries at 1024, 1280, ... 2048, 2560, ... 4096, 5120, ...; the
+// last chunk, index 31, is unbounded: 26.6 k survivors are covered by bounded chunks).  A chunk stops by ITS OWN transmittance
+// (that is what makes it independent of the chunks in front of it), and the merge stops at chunk boundaries - so a quadrant that
+// saturates inside a later chunk is composited up to that chunk's end.  The first chunk is long so that the quadrants of ordinary
+// frames never leave it; the chunks right behind it are short because that is where it costs: C3T's deepest quadrants saturate
+// after ~1100-1500 survivors and their bins END the blend launch - with a second chunk of 1024 they walked to 2048 and the C3T
+// blend went 0.39 -> 0.51 ms; with 512 everywhere C3T walked 17 % more splats; with 2048 first, the first unit of every deep
+// quadrant was the long pole of the deep pass (profiles/r03y_*).  Deep quadrants want long chunks (fewer partials, less overshoot
+// relative to their depth), hence the growth.
+__host__ __device__ constexpr uint32_t gs_chunk_size(uint32_t c) { return c == 0u ? 1024u : c < 5u ? 256u : c < 9u ? 512u : 1024u; }
+__host__ __device__ constexpr uint32_t gs_chunk_first(uint32_t c) {
+    return c == 0u ? 0u : c < 5u ? 1024u + (c - 1u) * 256u : c < 9u ? 2048u + (c - 5u) * 512u : 4096u + (c - 9u) * 1024u;
 }
+__host__ __device__ constexpr uint32_t gs_chunk_count(uint32_t s) {
+    return s == 0u ? 0u : s <= 1024u ? 1u : s <= 2048u ? 1u + (s - 1024u + 255u) / 256u : s <= 4096u ? 5u + (s - 2048u + 511u) / 512u
+         : (9u + (s - 4096u + 1023u) / 1024u < GS_CHUNKS_MAX ? 9u + (s - 4096u + 1023u) / 1024u : GS_CHUNKS_MAX);
+}
+static_assert(gs_chunk_first(5) == 2048u && gs_chunk_first(9) == 4096u && gs_chunk_count(1025) == 2u && gs_chunk_count(2048) == 5u &&
+              gs_chunk_count(2049) == 6u && gs_chunk_count(4096) == 9u && gs_chunk_count(4097) == 10u && gs_chunk_count(1u << 20) == GS_CHUNKS_MAX,
+              "chunk table");
+constexpr uint32_t GS_CHUNK = 1024;                         // the first (and the typical deep) chunk
 // The deep pass: the <= GS_DEEP_MAX_BINS bins that cost most in the previous draw (and more than a threshold) are scanned once
 // (k_deep_scan: exact quadrant masks of every list entry + survivor counts per GS_DEEP_RLEN entries) and composited by one wave per
 // (bin, quadrant, chunk); k_deep_fold merges.  Lists longer than GS_DEEP_LIST_CAP stay with the one-workgroup-per-bin kernel, which

@@ -148,10 +148,13 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #ifndef BLEND_OCC
 #define BLEND_OCC 6
 #endif
+#ifndef GS_BLEND_PAIRS
+#define GS_BLEND_PAIRS 0              // 1: the per-bin kernel composites two survivors per iteration where it can (A/B)
+#endif
 #ifndef GS_BLEND_CHECK
 #define GS_BLEND_CHECK 4u             // a wave tests its quadrant for saturation after every 4th splat it composites
 #endif
-static_assert(GS_CHUNK % GS_BLEND_CHECK == 0 && GS_CHUNK0 % GS_BLEND_CHECK == 0, "a chunk ends on a saturation test");
+static_assert(256u % GS_BLEND_CHECK == 0, "every chunk ends on a saturation test");
 
 // the 4 pixels of a lane (x = lane & 15, y = (lane >> 4) + 4g) as two packed pairs: [h].x = strip 2h, [h].y = strip 2h + 1
 struct Px {
@@ -220,10 +223,10 @@ __device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, cons
 // the same operations on the same operands as two composite_one calls, with the second splat's LDS reads and exponentials in
 // the shadow of the first's.  For waves that walk alone (the deep pass's units): they are bound by the latency of one splat's
 // dependent chain (~400 cycles per splat against 132 of VALU issue), not by issue slots.
-__device__ __forceinline__ void composite_two(const LdsSplat* sp, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+__device__ __forceinline__ void composite_two(const LdsSplat* sp, const LdsSplat* sp1, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
     Alpha a0, a1;
     alpha_of(sp, fx, fy, px, a0, p_kept, p_useful);
-    alpha_of(sp + 1, fx, fy, px, a1, p_kept, p_useful);
+    alpha_of(sp1, fx, fy, px, a1, p_kept, p_useful);
     apply_alpha(px, a0);
     apply_alpha(px, a1);
 }
@@ -389,6 +392,16 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
                     const uint32_t j = g0 + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1ull;
                     walked++;
+#if GS_BLEND_PAIRS
+                    // (two splats in flight when the next survivor of the group does not straddle a saturation test: A/B knob)
+                    if (m && !(since_check & 1u)) {
+                        const uint32_t j1 = g0 + (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        walked++;
+                        since_check++;
+                        composite_two(&s_batch[j], &s_batch[j1], fx, fy, acc, p_kept, p_useful);
+                    } else
+#endif
                     composite_one(&s_batch[j], fx, fy, acc, p_kept, p_useful);
                     // Retire the wave when the open chunk has saturated its whole quadrant (every T <= 1e-4; everything behind is
                     // then multiplied by <= 1e-4).  Tested after every GS_BLEND_CHECK-th splat of the chunk and nowhere else, so a
@@ -732,7 +745,7 @@ __device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& d
             if (++since_check == GS_BLEND_CHECK) { since_check = 0; if (!acc.open()) open = false; }
         }
         for (; jj + 1u < k && open; jj += 2u) {
-            composite_two(&mine[jj], fx, fy, acc, p_kept, p_useful);
+            composite_two(&mine[jj], &mine[jj + 1u], fx, fy, acc, p_kept, p_useful);
             done += 2u;
             since_check += 2u;
             if (since_check == GS_BLEND_CHECK) {                            // the per-bin kernel's stop rule
@@ -771,8 +784,13 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameAr
     __shared__ uint32_t s_live;
     __shared__ uint32_t s_walked[4];
     __shared__ uint32_t s_queue[512];                  // (deep units: 128 pending survivor slots per wave)
+#ifdef GS_AB_NO_DEEP_UNIT            // (A/B: the per-bin kernel alone)
+    if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
+    (void)s_queue;
+#else
     if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
     else deep_unit(fa, da, blockIdx.x - bins, s_batch, s_queue);
+#endif
 }
 
 __global__ __launch_bounds__(BLEND_THREADS) void k_deep_fold(FrameArgs fa, DeepArgs da) {

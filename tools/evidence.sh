@@ -1,6 +1,7 @@
 #!/bin/bash
 # One-box evidence set for a round tag: GPU tests, the bench line (and the lines of the other configs), rocprofv3 kernel
-# stats of the headline frames, the HBM and VALU counter passes (C3 and, HBM only, C4), the blend's lane counters, the
+# stats of the headline frames, the HBM and VALU counter passes (C3 and, HBM only, C4), the blend's lane counters, the deep pass
+# A/B and unit timeline, the
 # vertex stage's floors, the cull-on kernel table, the per-rank cost of strip-sharded frames and a 2-rank
 # dry run.  Everything lands under gpurun_out/<tag>/; copy what should be judged into profiles/.   usage: tools/evidence.sh <tag>
 TAG=${1:-rXX}
@@ -25,6 +26,14 @@ python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_C4 gpurun_out/$TAG/pmc_traffic
 (GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 400 python tools/blend_lanes.py C3 C3T C2 C5 C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_lanes.txt
 (python tools/project_floor.py C3; GSPLAT_NO_BLOCK_CULL=1 python tools/project_floor.py C3) 2>&1 | grep k_project > gpurun_out/$TAG/project_floor.txt
 (GSPLAT_SERIAL=1 bash tools/prof_script.sh ${TAG}_cull 44 /root/repo/tools/cull_prof.py; grep "cull-on" gpurun_out/${TAG}_cull/log.txt) > gpurun_out/$TAG/cull_on_serial_kstats.txt 2>&1
+# the deep pass on / off (same pixels), its unit timeline on the capture-like scene, and this tree against the library of the
+# previous evidence set (gpurun_ab/lib_r03x.so, built by tools/build_variant.sh from that commit) in one process
+(timeout 300 python tools/deep_ab.py "C3S C3T C3" 10 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/deep_ab.txt
+(GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 200 python tools/blend_profile.py C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_profile_C3S.txt
+if [ -f gpurun_ab/lib_r03x.so ]; then
+  cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
+  (timeout 400 python tools/ab_libs.py "C3 C3T C2 C5 C4 C3S" gpurun_ab/lib_r03x.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/ab_r03x_vs_this_tree.txt
+fi
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 (timeout 400 python bench.py --gpus 2 --steps 10 --no-cpu --no-cull 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_2ranks_dry_run.json
 cp gpurun_out/crops_C*.json gpurun_out/$TAG/ 2>/dev/null

@@ -45,7 +45,7 @@ def _uniforms(cam, scene_sh, **kw):
 def make_case(name):
     up, pos, look = camera.DEMO_POSES["garden"]
     cam = camera.demo_camera("garden", 512, 288)
-    n = 240
+    n = 2000
     case = dict(cov_half=False, sh8=False, scene_idx=None, kernel2d=0.3, max_splat_px=1024.0, antialiased=False)
     if name == "sh0":
         sc = helpers.small_scene(n, 0, seed=301)

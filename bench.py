@@ -295,11 +295,13 @@ class Rig:
         return st
 
     def timed(self, steps, out_ptr, tile_rows=None, after=None):
+        """out_ptr: a device pointer, or a callable that names the target of the next frame (alternating strip buffers of an
+        overlapped multi-GPU gather); after: called behind every frame (the gather)."""
         torch = self.torch
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            self.frame(out_ptr, tile_rows)
+            self.frame(out_ptr() if callable(out_ptr) else out_ptr, tile_rows)
             if after:
                 after()
         enq = time.perf_counter() - t0
@@ -316,7 +318,7 @@ class Rig:
         torch.cuda.synchronize()
         for a, b in evs:
             a.record(stream)
-            self.frame(out_ptr, tile_rows)
+            self.frame(out_ptr() if callable(out_ptr) else out_ptr, tile_rows)
             if after:
                 after()
             b.record(stream)
@@ -396,18 +398,51 @@ def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frame
         del probe
         tile_rows = my if world > 1 else None
         gather, gather_kind = None, None
+        target = strip.data_ptr()                             # or, with an overlapped gather, a callable: the next frame's strip
+        overlap = world > 1 and not os.environ.get("GS_BENCH_NO_OVERLAP")
+        m["gather_overlapped"] = bool(overlap)
         if world > 1:
             # every rank keys all splats but sorts / bins / blends only what reaches its strip
             worker.set_visibility_cull(True)
+            # The strips of an 8K frame are 133 MB - 16.6 MB from each of 7 peers over one xGMI link each, about as long as a
+            # rank's whole frame (with 2 ranks: 66 MB over ONE link, longer than the frame).  The transfer of frame k therefore
+            # runs on a stream of its own beside the draw of frame k + 1, out of / into alternating buffers; the draw of frame
+            # k + 2 waits for it.  Every frame is still drawn and gathered inside the timed region.
+            strips_buf = [strip, torch.empty_like(strip)] if overlap else [strip]
+            fulls_buf = ([full, torch.zeros_like(full)] if overlap else [full]) if rank == 0 else [None, None]
+            turn = {"k": 0}
+            nbuf = len(strips_buf)
+            if overlap:
+                target = lambda: strips_buf[turn["k"] % nbuf].data_ptr()                                # noqa: E731
             if env.group is not None:
-                gather_kind = "gs_group_gather_strips (RCCL grouped send/recv behind the C ABI)"
-                full_ptr = full.data_ptr() if rank == 0 else 0
-                gather = lambda: env.group.gather_strips(strip.data_ptr(), full_ptr, W, strips, H)      # noqa: E731
+                env.group.set_overlap(overlap)
+                gather_kind = "gs_group_gather_strips (RCCL grouped send/recv behind the C ABI)" + (", overlapped with the next frame" if overlap else "")
+
+                def gather():
+                    i = turn["k"] % nbuf
+                    env.group.gather_strips(strips_buf[i].data_ptr(), fulls_buf[i].data_ptr() if rank == 0 else 0, W, strips, H)
+                    turn["k"] += 1
             else:
-                gather_kind = f"torch.distributed batch_isend_irecv ({env.backend})"
-                gather = lambda: gdist.gather_strips(strip, strips, full, rank, world, dist)            # noqa: E731
+                gather_kind = f"torch.distributed batch_isend_irecv ({env.backend})" + (", overlapped with the next frame" if overlap else "")
+                side = torch.cuda.Stream(device=device) if overlap else None
+                last_done = [None]
+
+                def gather():
+                    i = turn["k"] % nbuf
+                    if overlap:
+                        side.wait_stream(stream)                  # the transfer starts when this frame's draw has finished
+                        if last_done[0] is not None:
+                            stream.wait_event(last_done[0])       # the next draw waits for the previous transfer
+                        with torch.cuda.stream(side):
+                            gdist.gather_strips(strips_buf[i], strips, fulls_buf[i], rank, world, dist)
+                            done = torch.cuda.Event()
+                            done.record(side)
+                        last_done[0] = done
+                    else:
+                        gdist.gather_strips(strips_buf[i], strips, fulls_buf[i], rank, world, dist)
+                    turn["k"] += 1
         for _ in range(warmup):
-            rig.frame(strip.data_ptr(), tile_rows)
+            rig.frame(target() if callable(target) else target, tile_rows)
             if gather:
                 gather()
         stream.synchronize()
@@ -415,14 +450,16 @@ def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frame
         mesh.kernel_time(0, reset=True)                       # start the per-launch k_project clock
         if world > 1:
             dist.barrier()
-        elapsed, t_enqueued = rig.timed(steps, strip.data_ptr(), tile_rows, gather)
+        elapsed, t_enqueued = rig.timed(steps, target, tile_rows, gather)
         if world > 1:
             dist.barrier()
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if env.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         if dump and rank == 0:                                # tests: the frame the timed steps left on rank 0
-            np.save(dump, full.cpu().numpy())
+            torch.cuda.synchronize()
+            last_full = fulls_buf[(turn["k"] - 1) % nbuf] if world > 1 else full
+            np.save(dump, last_full.cpu().numpy())
         m["proj_ms_sum"], m["proj_launches"] = mesh.kernel_time(0, reset=True)    # HIP events on the kernel's own stream
         st_timed = mesh.last_stats()                          # the list-bin size the timed frames used, and their entries
         m["list_px"], m["D32"] = int(st_timed.list_bin_px), int(st_timed.tile_entries)
@@ -436,7 +473,7 @@ def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frame
         if median_frames > 0:
             if world > 1:
                 dist.barrier()
-            ev_ms = rig.event_frames(median_frames, stream, strip.data_ptr(), tile_rows, gather)
+            ev_ms = rig.event_frames(median_frames, stream, target, tile_rows, gather)
             med = float(np.median(ev_ms))
             if world > 1:
                 t = torch.tensor([med], dtype=torch.float64, device=device if env.backend == "nccl" else "cpu")
@@ -806,7 +843,8 @@ def main():
             "data": "synthetic" if scene.name in (headline, "C3") else f"file:{scene.name}",
             "config": {"workload": f"{headline}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
-                       "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)",
+                       "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)" if not M.get("gather_overlapped") else
+                                  "sort -> draw on one stream per rank; the strip gather of frame k on a second stream beside frame k + 1",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
                        "strips": strips if world > 1 else None, "backend": backend if world > 1 else None,
                        "sort": "full list (R = N)" if world == 1 else "per rank: keys over all N, radix passes over the splats "

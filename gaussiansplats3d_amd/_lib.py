@@ -119,6 +119,8 @@ SYMBOLS = {
     "gs_group_create": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_group_destroy": (None, [_VP]),
     "gs_group_gather_strips": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP, _VP, C.c_uint32]),
+    "gs_group_set_overlap": (C.c_int, [_VP, C.c_int]),
+    "gs_group_wait": (C.c_int, [_VP]),
     "gs_group_render_gather": (C.c_int, [_VP, _VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.c_uint32, _VP]),
     "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),

@@ -66,6 +66,13 @@ struct gs_group {
     comm_t comm = nullptr;
     uint32_t world = 1, rank = 0;
     DevBuf full;                       // the root's gathered frame (gs_group_render_gather)
+    // overlapped gathers (gs_group_set_overlap): the transfers run on `coll`; call k records `ready` on the context's stream
+    // (what it has to wait for) and `done[k & 1]` behind the transfer (what call k + 1 makes the context's stream wait for)
+    bool overlap = false;
+    hipStream_t coll = nullptr;
+    hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+    uint32_t calls = 0;
+    DevBuf full_alt, strip_alt[2];     // gs_group_render_gather's second frame buffer and its two draw targets
 };
 
 #define GS_NCCL(expr)                                                                              \
@@ -125,12 +132,39 @@ int gs_group_create(gs_context* ctx, const uint8_t* id_bytes, uint32_t world_siz
 
 void gs_group_destroy(gs_group* g) {
     if (!g) return;
+    ScopedDevice sd(g->ctx->device);
+    if (g->coll) (void)hipStreamSynchronize(g->coll);
     if (g->comm) {
-        ScopedDevice sd(g->ctx->device);
         (void)hipStreamSynchronize(g->ctx->stream);
         if (Rccl* R = rccl()) (void)R->CommDestroy(g->comm);
     }
+    if (g->ready) (void)hipEventDestroy(g->ready);
+    for (hipEvent_t e : g->done) if (e) (void)hipEventDestroy(e);
+    if (g->coll) (void)hipStreamDestroy(g->coll);
     delete g;
+}
+
+int gs_group_set_overlap(gs_group* g, int enabled) {
+    GS_REQUIRE(g, "group == NULL");
+    ScopedDevice sd(g->ctx->device);
+    if (enabled && !g->coll) {
+        GS_HIP(hipStreamCreateWithFlags(&g->coll, hipStreamNonBlocking));
+        GS_HIP(hipEventCreateWithFlags(&g->ready, hipEventDisableTiming));
+        for (hipEvent_t& e : g->done) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!enabled && g->overlap) {                          // back on the context's stream: nothing may still be in flight
+        GS_HIP(hipStreamSynchronize(g->coll));
+        g->calls = 0;
+    }
+    g->overlap = enabled != 0;
+    return GS_OK;
+}
+
+int gs_group_wait(gs_group* g) {
+    GS_REQUIRE(g, "group == NULL");
+    ScopedDevice sd(g->ctx->device);
+    if (g->coll) GS_HIP(hipStreamSynchronize(g->coll));
+    return GS_OK;
 }
 
 int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, uint32_t width, const uint32_t* row_begin,
@@ -144,6 +178,21 @@ int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, u
     GS_REQUIRE(mine == 0 || strip_dev, "strip_dev == NULL");
     ScopedDevice sd(g->ctx->device);
     hipStream_t st = g->ctx->stream;
+    // records the end of this call's transfer (overlap mode), whichever way the function leaves
+    struct Done {
+        gs_group* g; bool armed;
+        ~Done() { if (armed) { (void)hipEventRecord(g->done[g->calls & 1u], g->coll); g->calls++; } }
+    } done_guard{g, false};
+    if (g->overlap) {
+        // the transfer starts when the context's stream has finished what it holds now (this frame's draw) and runs beside
+        // whatever the caller enqueues next; the context's stream in turn waits for the PREVIOUS call's transfer, so that the
+        // draw after this call may reuse the buffers of the call before that one (the caller alternates two sets)
+        GS_HIP(hipEventRecord(g->ready, st));
+        GS_HIP(hipStreamWaitEvent(g->coll, g->ready, 0));
+        if (g->calls) GS_HIP(hipStreamWaitEvent(st, g->done[(g->calls - 1u) & 1u], 0));
+        st = g->coll;
+        done_guard.armed = true;
+    }
     if (g->rank == root && mine)
         GS_HIP(hipMemcpyAsync(static_cast<char*>(full_dev) + (size_t)row_begin[root] * row_bytes, strip_dev, mine, hipMemcpyDeviceToDevice, st));
     if (g->world == 1) return GS_OK;
@@ -183,24 +232,30 @@ int gs_group_render_gather(gs_group* g, gs_mesh* m, const gs_camera* cam, const 
     // into the gather, and the root would wait for this rank's strip forever, so this rank always takes part: it sends
     // whatever its strip buffer holds (zeros if the draw never ran) and reports its own error afterwards.
     int status = GS_OK;
-    if (g->rank == root) status = g->full.ensure(frame_bytes + 16);
-    int st_fb = m->fb.ensure(strip_bytes + 16);            // the draw's target; also what a failed draw sends
+    // overlap mode: the draw targets and the root's frame alternate between two buffers (the transfer of the previous call may
+    // still be reading / writing the other set)
+    const uint32_t flip = g->overlap ? (g->calls & 1u) : 0u;
+    DevBuf& full = flip ? g->full_alt : g->full;
+    DevBuf& target = g->overlap ? g->strip_alt[flip] : m->fb;      // the draw's target; also what a failed draw sends
+    if (g->rank == root) status = full.ensure(frame_bytes + 16);
+    int st_fb = target.ensure(strip_bytes + 16);
     if (status >= 0 && st_fb < 0) status = st_fb;
-    if (status >= 0 && y1 > y0) {                         // the strip goes to the mesh's own framebuffer
-        const int st_draw = gs_mesh_render(m, &c, sorted_host, sorter, render_count, nullptr, nullptr, nullptr);
-        if (st_draw < 0 && m->fb.p && strip_bytes) (void)hipMemsetAsync(m->fb.p, 0, strip_bytes, g->ctx->stream);
+    if (status >= 0 && y1 > y0) {
+        const int st_draw = gs_mesh_render(m, &c, sorted_host, sorter, render_count, nullptr, g->overlap ? target.p : nullptr, nullptr);
+        if (st_draw < 0 && target.p && strip_bytes) (void)hipMemsetAsync(target.p, 0, strip_bytes, g->ctx->stream);
         status = st_draw;
     }
-    if (st_fb < 0 || (g->rank == root && !g->full.p)) {
+    if (st_fb < 0 || (g->rank == root && !full.p)) {
         // no buffer to send from / receive into: the only case that cannot take part; the peers' watchdog (bench.py) or the
         // caller's own timeout has to end the collective
         return status < 0 ? status : GS_ERR_NOMEM;
     }
-    const int st_gather = gs_group_gather_strips(g, y1 > y0 ? m->fb.p : nullptr, g->full.p, cam->width, row_begin, row_end, root);
+    const int st_gather = gs_group_gather_strips(g, y1 > y0 ? target.p : nullptr, full.p, cam->width, row_begin, row_end, root);
     if (status >= 0 && st_gather < 0) status = st_gather;
     if (status >= 0 && g->rank == root && rgba_out_host) {
-        GS_HIP(hipMemcpyAsync(rgba_out_host, g->full.p, frame_bytes, hipMemcpyDeviceToHost, g->ctx->stream));
-        GS_HIP(hipStreamSynchronize(g->ctx->stream));
+        hipStream_t rs = g->overlap ? g->coll : g->ctx->stream;    // (behind the transfer)
+        GS_HIP(hipMemcpyAsync(rgba_out_host, full.p, frame_bytes, hipMemcpyDeviceToHost, rs));
+        GS_HIP(hipStreamSynchronize(rs));
     }
     return status;
 }

@@ -100,6 +100,15 @@ class StripGroup:
         L.check(self.lib.gs_group_gather_strips(self.handle, C.c_void_p(local_strip_ptr or None), C.c_void_p(full_ptr or None),
                                                 int(width), b.ctypes.data, e.ctypes.data, int(dst)))
 
+    def set_overlap(self, enabled):
+        """Transfers on the group's own stream, beside the next frame (the caller alternates two strip / frame buffers)."""
+        from . import _lib as L
+        L.check(self.lib.gs_group_set_overlap(self.handle, 1 if enabled else 0))
+
+    def wait(self):
+        from . import _lib as L
+        L.check(self.lib.gs_group_wait(self.handle))
+
     def close(self):
         if self.handle:
             self.lib.gs_group_destroy(self.handle)

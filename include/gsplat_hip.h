@@ -390,6 +390,17 @@ void gs_group_destroy(gs_group* g);
  * is row_begin[r]); strip_dev = this rank's rows, full_dev = the whole frame on `root` (ignored elsewhere).  Collective. */
 int gs_group_gather_strips(gs_group* g, const void* strip_dev, void* full_dev, uint32_t width, const uint32_t* row_begin,
                            const uint32_t* row_end, uint32_t root);
+/* Overlapped gathers (off by default).  The strips of an 8K frame are 133 MB: the root receives 16.6 MB from each of 7 peers
+ * (~0.25 ms over one xGMI link each; with 2 ranks 66 MB over ONE link, ~0.9 ms) - as long as a rank's whole frame.  With
+ * overlap on, gs_group_gather_strips / gs_group_render_gather enqueue the transfer on a stream of the group: it starts when
+ * everything enqueued on the context's stream so far (the draw of this frame) has finished, and runs while the context's
+ * stream goes on with the next frame.  Contract: the caller ALTERNATES between two strip buffers and two full-frame buffers
+ * (gs_group_render_gather does that itself; its root's frame alternates between two internal buffers too); call k makes the
+ * context's stream wait for the transfer of call k-1, so the draw that follows may overwrite the buffers of call k-1's
+ * predecessor.  gs_group_wait blocks the host until every transfer issued so far has completed (the root's consumer calls it -
+ * or synchronises the device - before it reads a gathered frame).  Every rank of the group must use the same setting. */
+int gs_group_set_overlap(gs_group* g, int enabled);
+int gs_group_wait(gs_group* g);
 
 /* One rank's whole share of a multi-GPU draw: gs_mesh_render (same sorted_host | sorter choice) of its strip (pixel rows [row_begin[rank], row_end[rank]),
  * whole 16-px tile rows; `cam` describes the full viewport) into the mesh's own device framebuffer, then the gather above.

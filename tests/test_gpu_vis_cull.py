@@ -106,6 +106,46 @@ def test_group_of_one_gathers_its_strip_into_the_frame(ctx):
     group.close()
 
 
+def test_overlapped_gathers_of_a_group_of_one():
+    """gs_group_set_overlap: the transfer runs on the group's own stream beside what the context's stream does next, out of
+    / into alternating buffers; the context's stream waits for the previous transfer before it goes on.  Twenty frames of
+    changing content through two buffer sets, every one checked."""
+    s = torch.cuda.Stream()
+    c = Context(0, stream=s.cuda_stream, single_stream=True)
+    group = gdist.StripGroup(c, 0, 1)
+    group.set_overlap(True)
+    h, w = 2048, 1024                                    # 6 MB strips: a transfer long enough to overlap something
+    strips = [(2, 98)]                                   # tile rows -> pixel rows [32, 1568)
+    rows = 1568 - 32
+    bufs = [torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    fulls = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    seen = []
+    for k in range(20):
+        with torch.cuda.stream(s):
+            bufs[k & 1].fill_(10 + k)                    # "the draw" of frame k, on the context's stream
+        group.gather_strips(bufs[k & 1].data_ptr(), fulls[k & 1].data_ptr(), w, strips, h)
+        if k >= 1:
+            # what call k - 1 gathered: complete once the context's stream has passed the wait that call k put in front of
+            # everything enqueued after it, and not written again before call k + 1's transfer
+            with torch.cuda.stream(s):
+                seen.append((k - 1, fulls[(k - 1) & 1][40, 3, 1].clone(), fulls[(k - 1) & 1][1567, w - 1, 2].clone()))
+    group.wait()
+    torch.cuda.synchronize()
+    for k, a, b in seen:
+        assert int(a) == 10 + k and int(b) == 10 + k, (k, int(a), int(b))
+    assert int(fulls[1][100, 5, 0]) == 29 and int(fulls[0][100, 5, 0]) == 28
+    assert not fulls[1][:32].any() and not fulls[1][1568:].any()
+    group.set_overlap(False)
+    strip = torch.randint(0, 255, (rows, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    group.gather_strips(strip.data_ptr(), fulls[0].data_ptr(), w, strips, h)
+    c.synchronize()
+    assert torch.equal(fulls[0][32:1568], strip)
+    group.close()
+    c.close()
+
+
 def test_visibility_mask_lifecycle(ctx):
     """The mask a projection leaves is consumed (and re-zeroed) by the sort that reads it.  Whatever the order of calls - two
     projections in a row, a sort that covers fewer splats than were projected, a projection for another camera - the next

@@ -542,6 +542,11 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
 //                 buffer and composites them from T = 1 with the per-bin kernel's own arithmetic and stop rule -> {C, T} partial;
 //   k_deep_fold   per quadrant: the partials merged near -> far with the per-bin kernel's own tail fold.
 // Which bins take this route is decided from the previous draw's statistics (k_bin_emit) - scheduling only.
+// The units composite chunks the merge then ignores (C3S: 5.3 M pairs where 3.3 M reach the frame).  Tried: units in chunk-major
+// order, each first multiplying the finished partials in front of it per pixel and leaving when nothing can get through (a
+// per-chunk scalar bound never triggers: different chunks saturate different pixels).  Pairs walked 7.10 -> 6.7 M, but the units
+// of a bin no longer run together (its entry words and records fall out of L2) and each starts with up to 31 dependent reads:
+// unit time 197 -> 242 us, C3S frame 1.31 -> 1.45 ms.  Not kept.
 // (r03l tried the same with DEPTH slabs - chunks cut by the sort bucket instead of by position: deep bins keep their entries
 // within 2-3 of 64 slabs, every list needed slab tags and a wider entry sort, early termination across slabs was lost: C3S
 // 4.6 -> 5.3 ms, C3 0.30 -> 0.40 ms, profiles/r03x_slab_ab.txt.  Removed.)

@@ -142,9 +142,11 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 }
 #endif
 
-// 6 workgroups per CU: the exact quadrant test needs ~80 VGPRs (at 8 per CU = 64 VGPRs it spilled 50 of them to scratch:
-// 132 MB of HBM traffic per launch instead of 34), and with 2040 bins at 1080p a quarter of the workgroups then start late,
-// into whatever CU frees up first
+// 6 workgroups per CU: the kernel wants 80 VGPRs.  In r02 8 per CU (64 VGPRs) spilled 50 registers (132 MB of HBM traffic
+// per launch instead of 34).  Re-measured on the r03 kernel, which spills only 8 / 16 dwords at 7 / 8 per CU and none of them in
+// the inner loop (profiles/r03zz_ab_blend_occupancy.txt, blend ms at 6 / 7 / 8): C3 0.057 / 0.061 / 0.067, C3T 0.396 / 0.465 /
+// 0.626, C2 0.156 / 0.184 / 0.231, C5 0.579 / 0.584 / 0.600 - all 2040 bins of a 1080p frame resident at once does not pay for
+// the scratch traffic of the staging code.  With 6, a quarter of the workgroups start late, into whatever CU frees up first.
 #ifndef BLEND_OCC
 #define BLEND_OCC 6
 #endif

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     // that sees nothing 26.0 -> 20.2 us: the floor is now the dispatch of 22.6 k workgroups, not their memory traffic.  Both
     // ways around that floor were built and measured slower: a fixed grid of workgroups looping over the blocks (the loop needs
     // 76 VGPRs instead of 46: 72.5 / 51.9 / 25.4 us) and four blocks per 1024-thread workgroup (92.7 / 71.9 / 36.1 us: sixteen
-    // waves have to find room at once and wait for each other at the barrier).
+    // waves have to find room at once and wait for each other at the barrier).  The same test again per WAVE (a box per 64 splats,
+    // dead waves of live blocks skip their centre loads and the shader) is slower as well: the test costs every live wave ~60
+    // instructions and a 32-byte read, and Morton blocks are already nearly all-or-nothing (C3 59.5 -> 62.8 us, C2 34.0 -> 37.5,
+    // C4 262 -> 300).
     if (pp.block_cull) {
         __shared__ uint32_t s_dead;
         if (threadIdx.x < 64u) {

@@ -79,6 +79,10 @@ struct ArrayLoader {
     __device__ __forceinline__ Raw fetch(uint32_t j) const { return Raw{(uint32_t)keys[j], vals[j]}; }
     __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const { k = r.key; v = r.val; }
     __device__ __forceinline__ bool valid(uint32_t) const { return true; }
+    // the histogram's view of element j: the memory read, then the arithmetic on it
+    typedef uint32_t HRaw;
+    __device__ __forceinline__ HRaw hist_fetch(uint32_t j) const { return (uint32_t)keys[j]; }
+    __device__ __forceinline__ uint32_t hist_key(HRaw r) const { return r; }
     __device__ __forceinline__ void note_clamp(bool) const {}
     static __device__ __forceinline__ int prof_slot(int shift) { return shift == 8 && sizeof(KeyT) == 2 ? 1 : -1; }   // GS_RADIX_PROFILE
 };
@@ -126,33 +130,75 @@ __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
 constexpr int HIST_THREADS = 1024;
 constexpr int HIST_ITEMS = RADIX_TILE / HIST_THREADS;
 
-// counts the digits of one full 4096-key tile with 16-byte loads (order is irrelevant for a histogram)
+// The histogram of a workgroup's tiles, HIST_GROUP tiles at a time: all their loads are issued before the first LDS atomic,
+// so the workgroup waits for one memory round trip per group instead of one per tile.  Measured r03 (same box, ab_libs): C4 sort
+// 0.240 -> 0.231 ms, entry sort 0.245 -> 0.241; C3 / C5 within noise (their histograms already overlapped).  Order is irrelevant
+// for a histogram.
+constexpr uint32_t HIST_GROUP = 4;
+
+// full tiles of an array of keys: 16-byte loads
 template <class KeyT>
-__device__ __forceinline__ void hist_full_tile(const ArrayLoader<KeyT>& ld, uint32_t base, int shift, uint32_t* hist) {
-    const uint4* src = reinterpret_cast<const uint4*>(ld.keys + base);          // base is a multiple of 4096 keys
+__device__ __forceinline__ void hist_tiles(const ArrayLoader<KeyT>& ld, uint32_t tile, uint32_t tiles, uint32_t n, int shift, uint32_t* hist) {
     constexpr uint32_t LOADS = RADIX_TILE * (uint32_t)sizeof(KeyT) / 16u;        // 16-byte loads per tile
+    constexpr uint32_t PER = (LOADS + HIST_THREADS - 1) / HIST_THREADS;          // per thread and tile (1 for 16- and 32-bit keys)
+    uint4 v[HIST_GROUP][PER];
+    bool full[HIST_GROUP];
 #pragma unroll
-    for (uint32_t l = threadIdx.x; l < LOADS; l += HIST_THREADS) {
-        const uint4 v = src[l];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (uint32_t g = 0; g < HIST_GROUP; g++) {
+        const uint32_t base = (tile + g) * RADIX_TILE;                           // a multiple of 4096 keys
+        full[g] = g < tiles && base + RADIX_TILE <= n;
+        const uint4* src = reinterpret_cast<const uint4*>(ld.keys + base);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (sizeof(KeyT) == 2) {
-                atomicAdd(&hist[((w[c] & 0xFFFFu) >> shift) & 255u], 1u);
-                atomicAdd(&hist[((w[c] >> 16) >> shift) & 255u], 1u);
-            } else {
-                atomicAdd(&hist[(w[c] >> shift) & 255u], 1u);
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t l = k * HIST_THREADS + threadIdx.x;
+            v[g][k] = (full[g] && l < LOADS) ? src[l] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+#pragma unroll
+    for (uint32_t g = 0; g < HIST_GROUP; g++) {
+        if (full[g]) {
+#pragma unroll
+            for (uint32_t k = 0; k < PER; k++) {
+                if (k * HIST_THREADS + threadIdx.x >= LOADS) continue;
+                const uint32_t w[4] = {v[g][k].x, v[g][k].y, v[g][k].z, v[g][k].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (sizeof(KeyT) == 2) {
+                        atomicAdd(&hist[((w[c] & 0xFFFFu) >> shift) & 255u], 1u);
+                        atomicAdd(&hist[((w[c] >> 16) >> shift) & 255u], 1u);
+                    } else {
+                        atomicAdd(&hist[(w[c] >> shift) & 255u], 1u);
+                    }
+                }
+            }
+        } else if (g < tiles) {                                                   // the ragged last tile
+            const uint32_t base = (tile + g) * RADIX_TILE;
+#pragma unroll
+            for (int r = 0; r < HIST_ITEMS; r++) {
+                const uint32_t j = base + r * HIST_THREADS + threadIdx.x;
+                if (j < n) atomicAdd(&hist[((uint32_t)ld.keys[j] >> shift) & 255u], 1u);
             }
         }
     }
 }
+// any other loader (the depth keys: one 4-byte read per element, a keep bit for the culled variants)
 template <class Loader>
-__device__ __forceinline__ void hist_full_tile(const Loader& ld, uint32_t base, int shift, uint32_t* hist) {
+__device__ __forceinline__ void hist_tiles(const Loader& ld, uint32_t tile, uint32_t tiles, uint32_t n, int shift, uint32_t* hist) {
+    typename Loader::HRaw raw[HIST_GROUP][HIST_ITEMS];
+    bool ok[HIST_GROUP][HIST_ITEMS];
 #pragma unroll
-    for (int r = 0; r < HIST_ITEMS; r++) {
-        const uint32_t j = base + r * HIST_THREADS + threadIdx.x;
-        if (ld.valid(j)) atomicAdd(&hist[(ld.key(j) >> shift) & 255u], 1u);
-    }
+    for (uint32_t g = 0; g < HIST_GROUP; g++)
+#pragma unroll
+        for (int r = 0; r < HIST_ITEMS; r++) {
+            const uint32_t j = (tile + g) * RADIX_TILE + r * HIST_THREADS + threadIdx.x;
+            ok[g][r] = g < tiles && j < n && ld.valid(j);
+            raw[g][r] = ok[g][r] ? ld.hist_fetch(j) : typename Loader::HRaw();
+        }
+#pragma unroll
+    for (uint32_t g = 0; g < HIST_GROUP; g++)
+#pragma unroll
+        for (int r = 0; r < HIST_ITEMS; r++)
+            if (ok[g][r]) atomicAdd(&hist[(ld.hist_key(raw[g][r]) >> shift) & 255u], 1u);
 }
 
 template <class Loader>
@@ -164,18 +210,8 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
     const uint32_t tid = threadIdx.x, wave = (tid >> 6) & 3u;
     (&s_hist[0][0])[tid] = 0;
     __syncthreads();
-    for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
-        const uint32_t base = tile * RADIX_TILE;
-        if (base + RADIX_TILE <= ch.n) {
-            hist_full_tile(ld, base, shift, s_hist[wave]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < HIST_ITEMS; r++) {
-                const uint32_t j = base + r * HIST_THREADS + tid;
-                if (j < ch.n && ld.valid(j)) atomicAdd(&s_hist[wave][(ld.key(j) >> shift) & 255u], 1u);
-            }
-        }
-    }
+    for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile += HIST_GROUP)
+        hist_tiles(ld, tile, min(HIST_GROUP, ch.tile_end - tile), ch.n, shift, s_hist[wave]);
     __syncthreads();
     if (tid >= RADIX_BINS) return;
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];

@@ -539,6 +539,10 @@ struct DepthLoaderT {
         k = (range - 1) - bucket_of(r.depth);
         v = r.payload;
     }
+    // the histogram's view of element j
+    typedef int32_t HRaw;
+    __device__ __forceinline__ HRaw hist_fetch(uint32_t j) const { return keys[render_count - 1 - j]; }
+    __device__ __forceinline__ uint32_t hist_key(HRaw depth) const { return (range - 1) - bucket_of(depth); }
     __device__ __forceinline__ bool valid(uint32_t j) const {
         if (!CULL) return true;
         const uint32_t i = render_count - 1 - j;

@@ -281,7 +281,8 @@ struct DeepArgs {
     uint32_t* cnt;              // [GS_DEEP_MAX_BINS][GS_DEEP_RANGES][4]
     float4* partial;            // [GS_DEEP_UNITS][256]
     uint32_t* work;             // [GS_DEEP_UNITS]: d << 7 | c << 2 | q of the units that exist (k_deep_plan)
-    float4* pool;               // [GS_POOL_SLOTS][256]
+    float4* pool;               // [pool_slots][256]
+    uint32_t pool_slots;        // GS_POOL_SLOTS (tests shrink it: $GSPLAT_POOL_SLOTS)
     uint32_t unit_wgs;          // workgroups of (bin, quadrant, chunk) units behind the per-bin workgroups (0: no deep pass)
 };
 
@@ -423,7 +424,7 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
                             uint32_t slot = 0;
                             if (lane == 0u) slot = atomicAdd(&da.flags[GS_FLAG_POOL_NEXT], 1u);
                             slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-                            if (slot < GS_POOL_SLOTS) {
+                            if (slot < da.pool_slots) {
                                 // (the slot keeps the transmittance of ALL chunks so far in .w - the previous slot's times this
                                 // chunk's, the product the merge forms - so that the wave can retire at a chunk boundary, exactly
                                 // where the merge stops, without carrying the running product in registers)
@@ -848,6 +849,8 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     da.cnt = m->deep_cnt.as<uint32_t>();
     da.partial = m->deep_partial.as<float4>();
     da.pool = m->chunk_pool.as<float4>();
+    static const uint32_t pool_slots = getenv("GSPLAT_POOL_SLOTS") ? std::min<uint32_t>((uint32_t)atoi(getenv("GSPLAT_POOL_SLOTS")), GS_POOL_SLOTS) : GS_POOL_SLOTS;
+    da.pool_slots = pool_slots;
     da.work = m->deep_work.as<uint32_t>();
     da.unit_wgs = m->deep_pass ? GS_DEEP_UNITS / 4u : 0u;
     if (m->deep_pass) {

@@ -146,3 +146,39 @@ def test_lists_longer_than_the_deep_tables_stay_with_the_per_bin_kernel(ctx, mon
         f, _ = rig.draw()
         np.testing.assert_array_equal(f, plain)
     rig.close()
+
+
+def test_an_exhausted_partial_pool_is_flagged_and_still_composites(tmp_path):
+    """The per-bin kernel closes chunks into a finite pool.  With the pool shrunk to 2 slots ($GSPLAT_POOL_SLOTS, read once per
+    process: a child process) most quadrants of the pile go on as one long chunk: the draw says so and the frame is the same
+    composite up to fp32 rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import json, sys
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import numpy as np
+import test_gpu_deep as T
+from gaussiansplats3d_amd import Context, camera
+c = Context(0)
+rig = T.Rig(c, T._pile(60000, 41), camera.demo_camera("garden", 480, 270))
+rig.mesh.set_deep_pass(False)
+f, st = rig.draw()
+np.save({str(tmp_path / 'frame.npy')!r}, f)
+print(json.dumps(rig.mesh.deep_pass_info(), default=lambda o: o.tolist() if hasattr(o, 'tolist') else o))
+rig.close(); c.close()
+"""
+    infos = []
+    for slots in ("2", None):
+        env = dict(os.environ)
+        if slots:
+            env["GSPLAT_POOL_SLOTS"] = slots
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        infos.append((json.loads(out.stdout.strip().splitlines()[-1]), np.load(tmp_path / "frame.npy")))
+    (small, f_small), (full, f_full) = infos
+    assert small["pool_exhausted"] and not full["pool_exhausted"] and full["chunks_closed_by_bins"] >= 4
+    d = np.abs(f_small.astype(np.int32) - f_full.astype(np.int32))
+    assert d.max() <= 1, int(d.max())

@@ -236,6 +236,8 @@ class SplatMeshHIP {
   }
   setSplatScale(s = 1) { this.splatScale = s; }
   setPointCloudModeEnabled(e) { this.pointCloudModeEnabled = !!e; }
+  // HIP-engine extra: whether very deep bins may be composited by many waves at once (same pixels either way)
+  setDeepPass(enabled) { addon.meshSetDeepPass(this.handle, enabled ? 1 : 0); }
   _camera() {
     const c = this.cam;
     c.splatScale = this.splatScale;
@@ -278,6 +280,10 @@ class StripGroup {
     this.worldSize = worldSize; this.rank = rank;
     this.handle = addon.groupCreate(getContext(device).handle, worldSize > 1 ? id : null, worldSize, rank);
   }
+  // the strip transfer of frame k runs beside the draw of frame k + 1 (renderStrip alternates its buffers itself); every rank
+  // sets the same; wait() = all transfers issued so far have completed
+  setOverlap(enabled) { addon.groupSetOverlap(this.handle, enabled ? 1 : 0); }
+  wait() { addon.groupWait(this.handle); }
   dispose() { if (this.handle) { addon.groupDestroy(this.handle); this.handle = null; } }
 }
 

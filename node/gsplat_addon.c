@@ -525,6 +525,30 @@ static napi_value GroupDestroy(napi_env env, napi_callback_info info) {
     LOCKED(gs_group_destroy((gs_group*)get_external(env, argv[0])));
     return NULL;
 }
+/* groupSetOverlap(group, enabled): the strip transfer of frame k beside the draw of frame k + 1 (gs_group_set_overlap) */
+static napi_value GroupSetOverlap(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    int st;
+    LOCKED(st = gs_group_set_overlap((gs_group*)get_external(env, argv[0]), (int)get_u32(env, argv[1])));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* groupWait(group): every transfer issued so far has completed */
+static napi_value GroupWait(napi_env env, napi_callback_info info) {
+    ARGS(1)
+    int st;
+    LOCKED(st = gs_group_wait((gs_group*)get_external(env, argv[0])));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+/* meshSetDeepPass(mesh, enabled): scheduling only, the pixels do not change (gs_mesh_set_deep_pass) */
+static napi_value MeshSetDeepPass(napi_env env, napi_callback_info info) {
+    ARGS(2)
+    int st;
+    LOCKED(st = gs_mesh_set_deep_pass((gs_mesh*)get_external(env, argv[0]), (int)get_u32(env, argv[1])));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
 /* groupRenderGather(group, mesh, camera, sortedIndexes Uint32Array|null, sorter|null, renderCount, rowBegin Uint32Array,
  *                   rowEnd Uint32Array, root, out Uint8Array|null) */
 static napi_value GroupRenderGather(napi_env env, napi_callback_info info) {
@@ -744,7 +768,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"treeGather", TreeGather},         {"treeRead", TreeRead},         {"assetLoad", AssetLoad},
         {"meshProject", MeshProject},       {"sorterSetVisibilityCull", SorterSetVisibilityCull},
         {"groupUniqueId", GroupUniqueId},   {"groupCreate", GroupCreate},     {"groupDestroy", GroupDestroy},
-        {"groupRenderGather", GroupRenderGather},
+        {"groupRenderGather", GroupRenderGather}, {"groupSetOverlap", GroupSetOverlap}, {"groupWait", GroupWait},
+        {"meshSetDeepPass", MeshSetDeepPass},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -127,9 +127,9 @@ constexpr uint32_t GS_ENT_SLOT_MASK = (1u << 28) - 1u;     // deep_ent word = re
 constexpr uint32_t GS_DEEP_NONE = 0xFFFFFFFFu;
 // flag words of a draw (gs_mesh::deep_flags): [0] deep bins of this draw  [1] bins over the threshold (mirrored to the host: the
 // NEXT draw launches the deep pass when this is non-zero)  [2] next pool slot  [3] pool exhausted  [4] units of the deep pass's
-// work list | deep_list [DEEP_MAX] |
+// work list  [5] the next unit a wave of the pass takes | deep_list [DEEP_MAX] |
 // deep_of [bins]
-constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, GS_FLAG_POOL_OVER = 3, GS_FLAG_UNITS = 4, GS_FLAG_LIST = 8,
+constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, GS_FLAG_POOL_OVER = 3, GS_FLAG_UNITS = 4, GS_FLAG_UNIT_NEXT = 5, GS_FLAG_LIST = 8,
                    GS_FLAG_OF = GS_FLAG_LIST + GS_DEEP_MAX_BINS;
 
 #ifndef RADIX_TILE_CFG

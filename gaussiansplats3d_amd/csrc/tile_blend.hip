@@ -650,17 +650,31 @@ __global__ __launch_bounds__(1024) void k_deep_plan(FrameArgs fa, DeepArgs da) {
         for (uint32_t c = 0; c < nch[k]; c++) da.work[base + c] = ((p >> 2) << 7) | (c << 2) | (p & 3u);
         base += nch[k];
     }
-    if (threadIdx.x == 0) da.flags[GS_FLAG_UNITS] = total_units;
+    if (threadIdx.x == 0) { da.flags[GS_FLAG_UNITS] = total_units; da.flags[GS_FLAG_UNIT_NEXT] = 0u; }
 }
 
-__device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& da, const uint32_t wg, LdsSplat* s_batch, uint32_t* s_queue) {
+__device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArgs& da, const uint32_t u, LdsSplat* s_batch, uint32_t* s_queue);
+
+// The waves of the pass's workgroups TAKE units from the packed work list (k_deep_plan) until it is empty.  (History, r03y
+// profiles: fixed (bin, chunk) x 4 quadrants per workgroup left most workgroups with one or two live waves, and bin-major order
+// let the chunk index choose the XCD - 620, then 1900 waves busy out of 6144; one unit per wave of a packed list still left a
+// workgroup's other waves idle behind its slowest unit - a workgroup holds its CU slot until its last wave ends.)
+__device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& da, LdsSplat* s_batch, uint32_t* s_queue) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t units = da.flags[GS_FLAG_UNITS];
+    for (;;) {
+        uint32_t u = 0;
+        if (lane == 0u) u = atomicAdd(&da.flags[GS_FLAG_UNIT_NEXT], 1u);
+        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= units) return;
+        deep_unit_one(fa, da, u, s_batch, s_queue);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArgs& da, const uint32_t u, LdsSplat* s_batch, uint32_t* s_queue) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // Wave u takes unit u of the packed work list (k_deep_plan).  (Fixed (bin, chunk) x 4 quadrants per workgroup left most
-    // workgroups with one or two live waves - a workgroup holds its CU slot until its last wave ends - and, before that, bin-major
-    // order let the chunk index choose the XCD: 620, then 1900 waves busy out of 6144; r03y profiles.)
-    const uint32_t u = wg * 4u + wave;
-    if (u >= da.flags[GS_FLAG_UNITS]) return;
     const uint32_t word = da.work[u];
     const uint32_t d = word >> 7, c = (word >> 2) & 31u, q = word & 3u;
     static_assert(GS_CHUNKS_MAX == 32 && GS_DEEP_MAX_BINS <= (1u << 25), "work word layout");
@@ -797,7 +811,7 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameAr
     (void)s_queue;
 #else
     if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
-    else deep_unit(fa, da, blockIdx.x - bins, s_batch, s_queue);
+    else deep_unit(fa, da, s_batch, s_queue);
 #endif
 }
 
@@ -852,7 +866,8 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     static const uint32_t pool_slots = getenv("GSPLAT_POOL_SLOTS") ? std::min<uint32_t>((uint32_t)atoi(getenv("GSPLAT_POOL_SLOTS")), GS_POOL_SLOTS) : GS_POOL_SLOTS;
     da.pool_slots = pool_slots;
     da.work = m->deep_work.as<uint32_t>();
-    da.unit_wgs = m->deep_pass ? GS_DEEP_UNITS / 4u : 0u;
+    // (as many workgroups as the device holds at BLEND_OCC per CU: their waves loop over the unit list)
+    da.unit_wgs = m->deep_pass ? (uint32_t)m->ctx->cu_count * BLEND_OCC : 0u;
     if (m->deep_pass) {
         hipLaunchKernelGGL(k_deep_scan, dim3(GS_DEEP_MAX_BINS * GS_DEEP_SCAN_WGS), dim3(256), 0, st, fa, da);
         hipLaunchKernelGGL(k_deep_plan, dim3(1), dim3(1024), 0, st, fa, da);

@@ -550,6 +550,10 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
 // per-chunk scalar bound never triggers: different chunks saturate different pixels).  Pairs walked 7.10 -> 6.7 M, but the units
 // of a bin no longer run together (its entry words and records fall out of L2) and each starts with up to 31 dependent reads:
 // unit time 197 -> 242 us, C3S frame 1.31 -> 1.45 ms.  Not kept.
+// Also tried: half masks per entry from k_deep_scan and units that composite only the half of the quadrant a splat reaches
+// (C3S keeps 12 % of its evaluated lanes): the extra code paths pushed the shared kernel to 23 spilled dwords, some of them
+// in front of the per-bin path - C3S blend 0.92 -> 1.31 ms, C3T 0.398 -> 0.408, C2 0.156 -> 0.163.  Not kept; it would need
+// the units in a kernel (and a register budget) of their own, i.e. on a second stream to still run beside the per-bin bins.
 // (r03l tried the same with DEPTH slabs - chunks cut by the sort bucket instead of by position: deep bins keep their entries
 // within 2-3 of 64 slabs, every list needed slab tags and a wider entry sort, early termination across slabs was lost: C3S
 // 4.6 -> 5.3 ms, C3 0.30 -> 0.40 ms, profiles/r03x_slab_ab.txt.  Removed.)

@@ -508,7 +508,9 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // (only while the bins outnumber the resident workgroups by a small factor: an 8K frame's 32 k bins balance themselves by
     // backfilling, and ordering them in one workgroup would cost more than it gives)
     // deep pass: a bin qualifies when its previous draw walked >= deep_min (splat, quadrant) pairs and >= deep_factor x the mean bin
-    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 2u * GS_CHUNK;   // 2048 pairs
+    // (4096 pairs.  C3S frame ms at 2048 / 3072 / 4096 / 6144 / 8192: 1.336 / 1.338 / 1.309 / 1.296 / 1.500 - k_deep_scan costs
+    // 0.17 ms for 512 bins and is bound by its gathers, so: fewer, deeper bins; profiles/r03zz_kstats_C3S.txt)
+    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 4u * GS_CHUNK;
     static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 3u;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");

@@ -51,175 +51,116 @@ class HipSplatScene {
 }
 
 export class SplatMesh {
-  constructor(splatRenderMode = SplatRenderMode.ThreeD, dynamicMode = false, enableOptionalEffects = false,
-              halfPrecisionCovariancesOnGPU = false, devicePixelRatio = 1, enableDistancesComputationOnGPU = true,
-              integerBasedDistancesComputation = false, antialiased = false, maxScreenSpaceSplatSize = 1024, logLevel = 0,
-              sphericalHarmonicsDegree = 0, sceneFadeInRateMultiplier = 1.0, kernel2DSize = 0.3) {
-    if (splatRenderMode !== SplatRenderMode.ThreeD) throw new Error('SplatMesh (HIP): only SplatRenderMode.ThreeD is implemented');
-    this.renderer = undefined;
-    this.splatRenderMode = splatRenderMode;
-    this.dynamicMode = dynamicMode;
-    this.enableOptionalEffects = enableOptionalEffects;
-    this.halfPrecisionCovariancesOnGPU = halfPrecisionCovariancesOnGPU;
-    this.devicePixelRatio = devicePixelRatio;
+  // Same positional arguments as the reference's constructor (src/splatmesh/SplatMesh.js:34-40); the Viewer's text reads the
+  // public fields by these names.
+  constructor(...args) {
+    const names = ['splatRenderMode', 'dynamicMode', 'enableOptionalEffects', 'halfPrecisionCovariancesOnGPU', 'devicePixelRatio',
+                   'enableDistancesComputationOnGPU', 'integerBasedDistancesComputation', 'antialiased', 'maxScreenSpaceSplatSize',
+                   'logLevel', 'sphericalHarmonicsDegree', 'sceneFadeInRateMultiplier', 'kernel2DSize'];
+    const defaults = [SplatRenderMode.ThreeD, false, false, false, 1, true, false, false, 1024, 0, 0, 1.0, 0.3];
+    names.forEach((name, k) => { this[name] = args[k] === undefined ? defaults[k] : args[k]; });
+    if (this.splatRenderMode !== SplatRenderMode.ThreeD) throw new Error('SplatMesh (HIP): only SplatRenderMode.ThreeD is implemented');
     this.enableDistancesComputationOnGPU = false;           // the device sort keys the splats itself (see the header)
-    this.integerBasedDistancesComputation = integerBasedDistancesComputation;
-    this.antialiased = antialiased;
-    this.kernel2DSize = kernel2DSize;
-    this.maxScreenSpaceSplatSize = maxScreenSpaceSplatSize;
-    this.logLevel = logLevel;
-    this.sphericalHarmonicsDegree = sphericalHarmonicsDegree;
-    this.minSphericalHarmonicsDegree = 0;
-    this.sceneFadeInRateMultiplier = sceneFadeInRateMultiplier;
-    this.scenes = [];
-    this.sceneOptions = undefined;
-    this.splatTree = null;
-    this.baseSplatTree = null;
-    this.splatDataTextures = {};
-    this.globalSplatIndexToLocalSplatIndexMap = [];
-    this.globalSplatIndexToSceneIndexMap = [];
-    this.lastBuildSplatCount = 0;
-    this.lastBuildScenes = [];
-    this.lastBuildMaxSplatCount = 0;
-    this.lastBuildSceneCount = 0;
-    this.firstRenderTime = -1;
-    this.finalBuild = false;
-    this.splatScale = 1.0;
-    this.pointCloudModeEnabled = false;
-    this.disposed = false;
-    this.visible = false;
-    this.frustumCulled = false;
-    this.matrixWorld = new THREE.Matrix4();                 // Object3D.matrixWorld (src/Viewer.js:1891 multiplies by it)
-    this.core = null;                                       // the device-side mesh (gs_mesh_*)
-    this.frame = null;
-    this.onSplatTreeReadyCallback = null;
-    this.shCompressionLevel = 1;
+    Object.assign(this, {
+      renderer: undefined, scenes: [], sceneOptions: undefined, minSphericalHarmonicsDegree: 0,
+      splatTree: null, baseSplatTree: null, onSplatTreeReadyCallback: null, splatDataTextures: {},
+      globalSplatIndexToLocalSplatIndexMap: [], globalSplatIndexToSceneIndexMap: [],
+      lastBuildScenes: [], lastBuildSplatCount: 0, lastBuildMaxSplatCount: 0, lastBuildSceneCount: 0,
+      firstRenderTime: -1, finalBuild: false, splatScale: 1.0, pointCloudModeEnabled: false,
+      disposed: false, visible: false, frustumCulled: false,
+      matrixWorld: new THREE.Matrix4(),                     // Object3D.matrixWorld (src/Viewer.js:1891 multiplies by it)
+      core: null,                                           // the device-side mesh (gs_mesh_*)
+      frame: null, shCompressionLevel: 1 });
   }
 
   // ---- statics, as the reference (:173-228, :1311-1341) --------------------------------------------------------------
   static buildScenes(parentObject, splatBuffers, sceneOptions) {
-    const scenes = [];
-    scenes.length = splatBuffers.length;
-    for (let i = 0; i < splatBuffers.length; i++) {
-      const options = sceneOptions[i] || {};
-      const position = new THREE.Vector3().fromArray(options['position'] || [0, 0, 0]);
-      const rotation = new THREE.Quaternion().fromArray(options['rotation'] || [0, 0, 0, 1]);
-      const scale = new THREE.Vector3().fromArray(options['scale'] || [1, 1, 1]);
-      scenes[i] = SplatMesh.createScene(splatBuffers[i], position, rotation, scale, options.splatAlphaRemovalThreshold || 1,
-                                        options.opacity, options.visible);
-    }
-    return scenes;
+    const vec = (v, fallback) => new THREE.Vector3().fromArray(v || fallback);
+    return splatBuffers.map((buffer, k) => {
+      const o = sceneOptions[k] || {};
+      return SplatMesh.createScene(buffer, vec(o.position, [0, 0, 0]), new THREE.Quaternion().fromArray(o.rotation || [0, 0, 0, 1]),
+                                   vec(o.scale, [1, 1, 1]), o.splatAlphaRemovalThreshold || 1, o.opacity, o.visible);
+    });
   }
   static createScene(splatBuffer, position, rotation, scale, minimumAlpha, opacity = 1.0, visible = true) {
     return new HipSplatScene(splatBuffer, position, rotation, scale, minimumAlpha, opacity, visible);
   }
+  // global splat index -> (index inside its buffer, scene): every buffer owns getMaxSplatCount() consecutive global indexes
   static buildSplatIndexMaps(splatBuffers) {
     const localSplatIndexMap = [], sceneIndexMap = [];
-    let total = 0;
-    for (let s = 0; s < splatBuffers.length; s++) {
-      const maxSplatCount = splatBuffers[s].getMaxSplatCount();
-      for (let i = 0; i < maxSplatCount; i++) { localSplatIndexMap[total] = i; sceneIndexMap[total] = s; total++; }
-    }
+    splatBuffers.forEach((buffer, sceneIndex) => {
+      for (let local = 0, n = buffer.getMaxSplatCount(); local < n; local++) { localSplatIndexMap.push(local); sceneIndexMap.push(sceneIndex); }
+    });
     return { localSplatIndexMap, sceneIndexMap };
   }
-  static getTotalSplatCountForScenes(scenes) {
-    let n = 0;
-    for (const scene of scenes) if (scene && scene.splatBuffer) n += scene.splatBuffer.getSplatCount();
-    return n;
-  }
-  static getTotalSplatCountForSplatBuffers(splatBuffers) { let n = 0; for (const b of splatBuffers) n += b.getSplatCount(); return n; }
-  static getTotalMaxSplatCountForScenes(scenes) {
-    let n = 0;
-    for (const scene of scenes) if (scene && scene.splatBuffer) n += scene.splatBuffer.getMaxSplatCount();
-    return n;
-  }
-  static getTotalMaxSplatCountForSplatBuffers(splatBuffers) { let n = 0; for (const b of splatBuffers) n += b.getMaxSplatCount(); return n; }
+  static _sum(items, pick) { return items.reduce((n, item) => n + pick(item), 0); }
+  static getTotalSplatCountForScenes(scenes) { return SplatMesh._sum(scenes, (sc) => (sc && sc.splatBuffer ? sc.splatBuffer.getSplatCount() : 0)); }
+  static getTotalSplatCountForSplatBuffers(splatBuffers) { return SplatMesh._sum(splatBuffers, (b) => b.getSplatCount()); }
+  static getTotalMaxSplatCountForScenes(scenes) { return SplatMesh._sum(scenes, (sc) => (sc && sc.splatBuffer ? sc.splatBuffer.getMaxSplatCount() : 0)); }
+  static getTotalMaxSplatCountForSplatBuffers(splatBuffers) { return SplatMesh._sum(splatBuffers, (b) => b.getMaxSplatCount()); }
 
   // ---- build (:306-405) ----------------------------------------------------------------------------------------------
   build(splatBuffers, sceneOptions, keepSceneTransforms = true, finalBuild = false, onSplatTreeIndexesUpload, onSplatTreeConstruction,
         preserveVisibleRegion = true) {
-    this.sceneOptions = sceneOptions;
-    this.finalBuild = finalBuild;
-    const maxSplatCount = SplatMesh.getTotalMaxSplatCountForSplatBuffers(splatBuffers);
-    const newScenes = SplatMesh.buildScenes(this, splatBuffers, sceneOptions);
+    Object.assign(this, { sceneOptions, finalBuild });
+    const incoming = SplatMesh.buildScenes(this, splatBuffers, sceneOptions);
     if (keepSceneTransforms) {
-      for (let i = 0; i < this.scenes.length && i < newScenes.length; i++) newScenes[i].copyTransformData(this.getScene(i));
+      const shared = Math.min(this.scenes.length, incoming.length);
+      for (let k = 0; k < shared; k++) incoming[k].copyTransformData(this.getScene(k));
     }
-    this.scenes = newScenes;
-    let minDegree = 3;
-    for (const splatBuffer of splatBuffers) minDegree = Math.min(minDegree, splatBuffer.getMinSphericalHarmonicsDegree());
-    this.minSphericalHarmonicsDegree = Math.min(minDegree, this.sphericalHarmonicsDegree);
-
-    let splatBuffersChanged = splatBuffers.length !== this.lastBuildScenes.length;
-    for (let i = 0; !splatBuffersChanged && i < splatBuffers.length; i++) {
-      if (splatBuffers[i] !== this.lastBuildScenes[i].splatBuffer) splatBuffersChanged = true;
-    }
-    let isUpdateBuild = true;
-    if (this.scenes.length !== 1 || this.lastBuildSceneCount !== this.scenes.length || this.lastBuildMaxSplatCount !== maxSplatCount ||
-        splatBuffersChanged) isUpdateBuild = false;
-    if (!isUpdateBuild) {
-      this.lastBuildScenes = [];
-      this.lastBuildSplatCount = 0;
-      this.lastBuildMaxSplatCount = 0;
+    this.scenes = incoming;
+    this.minSphericalHarmonicsDegree = splatBuffers.reduce((d, buffer) => Math.min(d, buffer.getMinSphericalHarmonicsDegree()),
+                                                           Math.min(3, this.sphericalHarmonicsDegree));
+    // An "update build" appends splats to the one buffer the previous build already uploaded (progressive loading); anything
+    // else starts the device mesh afresh (the reference's isUpdateBuild rule, :336-352).
+    const capacity = SplatMesh.getTotalMaxSplatCountForSplatBuffers(splatBuffers);
+    const sameBuffers = splatBuffers.length === this.lastBuildScenes.length &&
+                        splatBuffers.every((buffer, k) => buffer === this.lastBuildScenes[k].splatBuffer);
+    const appendOnly = sameBuffers && this.scenes.length === 1 && this.lastBuildSceneCount === 1 && this.lastBuildMaxSplatCount === capacity;
+    if (!appendOnly) {
+      Object.assign(this, { lastBuildScenes: [], lastBuildSplatCount: 0, lastBuildMaxSplatCount: 0 });
       this.disposeMeshData();
-      const indexMaps = SplatMesh.buildSplatIndexMaps(splatBuffers);
-      this.globalSplatIndexToLocalSplatIndexMap = indexMaps.localSplatIndexMap;
-      this.globalSplatIndexToSceneIndexMap = indexMaps.sceneIndexMap;
+      const maps = SplatMesh.buildSplatIndexMaps(splatBuffers);
+      this.globalSplatIndexToLocalSplatIndexMap = maps.localSplatIndexMap;
+      this.globalSplatIndexToSceneIndexMap = maps.sceneIndexMap;
     }
     this.updateTransforms();                                // the scenes' matrices exist before the first data fill
-    const splatBufferSplatCount = this.getSplatCount(true);
-    const dataUpdateResults = this.refreshGPUDataFromSplatBuffers(isUpdateBuild);
-    for (let i = 0; i < this.scenes.length; i++) this.lastBuildScenes[i] = this.scenes[i];
-    this.lastBuildSplatCount = splatBufferSplatCount;
-    this.lastBuildMaxSplatCount = this.getMaxSplatCount();
-    this.lastBuildSceneCount = this.scenes.length;
-    if (finalBuild && this.scenes.length > 0) {
-      this.buildSplatTree(sceneOptions.map((options) => options.splatAlphaRemovalThreshold || 1), onSplatTreeIndexesUpload,
-                          onSplatTreeConstruction).then(() => {
-        if (this.onSplatTreeReadyCallback) this.onSplatTreeReadyCallback(this.splatTree);
+    const uploadedUpTo = this.getSplatCount(true);
+    const update = this.refreshGPUDataFromSplatBuffers(appendOnly);
+    Object.assign(this, { lastBuildScenes: this.scenes.slice(), lastBuildSplatCount: uploadedUpTo,
+                          lastBuildMaxSplatCount: this.getMaxSplatCount(), lastBuildSceneCount: this.scenes.length });
+    if (finalBuild && this.scenes.length) {
+      const minAlphas = sceneOptions.map((o) => o.splatAlphaRemovalThreshold || 1);
+      this.buildSplatTree(minAlphas, onSplatTreeIndexesUpload, onSplatTreeConstruction).then(() => {
+        const callback = this.onSplatTreeReadyCallback;
         this.onSplatTreeReadyCallback = null;
+        if (callback) callback(this.splatTree);
       });
     }
-    this.visible = (this.scenes.length > 0);
-    return dataUpdateResults;
+    this.visible = this.scenes.length > 0;
+    return update;
   }
 
   // setupDataTextures' decisions (:637-690, 1060-1090) without the textures: covariance as fp16 when asked for, SH as fp16
   // (compression level <= 1) or uint8 (level 2: kept 8-bit end to end, like the reference's sphericalHarmonics8BitMode)
-  getMaximumSplatBufferCompressionLevel() {
-    let level;
-    for (let i = 0; i < this.scenes.length; i++) {
-      const l = this.getScene(i).splatBuffer.compressionLevel;
-      if (i === 0 || l > level) level = l;
-    }
-    return level;
-  }
-  getMinimumSplatBufferCompressionLevel() {
-    let level;
-    for (let i = 0; i < this.scenes.length; i++) {
-      const l = this.getScene(i).splatBuffer.compressionLevel;
-      if (i === 0 || l < level) level = l;
-    }
-    return level;
-  }
+  _compressionLevels() { return this.scenes.map((sc) => sc.splatBuffer.compressionLevel); }
+  getMaximumSplatBufferCompressionLevel() { const l = this._compressionLevels(); return l.length ? Math.max(...l) : undefined; }
+  getMinimumSplatBufferCompressionLevel() { const l = this._compressionLevels(); return l.length ? Math.min(...l) : undefined; }
   getTargetCovarianceCompressionLevel() { return this.halfPrecisionCovariancesOnGPU ? 1 : 0; }
   getTargetSphericalHarmonicsCompressionLevel() { return Math.max(1, this.getMaximumSplatBufferCompressionLevel()); }
 
-  refreshGPUDataFromSplatBuffers(sinceLastBuildOnly) {      // :588-609
-    const splatCount = this.getSplatCount(true);
+  // what the sort worker needs about the freshly uploaded range (the reply shape of :588-609)
+  refreshGPUDataFromSplatBuffers(sinceLastBuildOnly) {
+    const last = this.getSplatCount(true) - 1, first = sinceLastBuildOnly ? this.lastBuildSplatCount : 0;
     this.refreshDataTexturesFromSplatBuffers(sinceLastBuildOnly);
-    const updateStart = sinceLastBuildOnly ? this.lastBuildSplatCount : 0;
-    const { centers, sceneIndexes } = this.getDataForDistancesComputation(updateStart, splatCount - 1);
-    return { 'from': updateStart, 'to': splatCount - 1, 'count': splatCount - updateStart, 'centers': centers, 'sceneIndexes': sceneIndexes };
+    return Object.assign({ from: first, to: last, count: last - first + 1 }, this.getDataForDistancesComputation(first, last));
   }
 
   // :621-635 + :900-1058: the splat buffers' own fill methods produce the arrays; they go to device planes instead of
   // padded data textures
   refreshDataTexturesFromSplatBuffers(sinceLastBuildOnly) {
-    const splatCount = this.getSplatCount(true);
     const maxSplatCount = this.getMaxSplatCount();
-    const fromSplat = sinceLastBuildOnly ? this.lastBuildSplatCount : 0;
-    const toSplat = splatCount - 1;
+    const fromSplat = sinceLastBuildOnly ? this.lastBuildSplatCount : 0, toSplat = this.getSplatCount(true) - 1;
     if (!sinceLastBuildOnly || !this.core) {
       if (this.core) this.core.dispose();
       this.shCompressionLevel = this.getTargetSphericalHarmonicsCompressionLevel();
@@ -266,62 +207,55 @@ export class SplatMesh {
   // :1853-1902, argument for argument
   fillSplatDataArrays(covariances, scales, rotations, centers, colors, sphericalHarmonics, applySceneTransform, covarianceCompressionLevel = 0,
                       scaleRotationCompressionLevel = 0, sphericalHarmonicsCompressionLevel = 1, srcStart, srcEnd, destStart = 0, sceneIndex) {
-    const scaleOverride = new THREE.Vector3();
-    scaleOverride.x = undefined; scaleOverride.y = undefined; scaleOverride.z = undefined;
-    const tempTransform = new THREE.Matrix4();
-    let startSceneIndex = 0, endSceneIndex = this.scenes.length - 1;
-    if (sceneIndex !== undefined && sceneIndex !== null && sceneIndex >= 0 && sceneIndex <= this.scenes.length) {
-      startSceneIndex = sceneIndex; endSceneIndex = sceneIndex;
-    }
-    for (let i = startSceneIndex; i <= endSceneIndex; i++) {
-      if (applySceneTransform === undefined || applySceneTransform === null) applySceneTransform = this.dynamicMode ? false : true;
-      const scene = this.getScene(i);
-      const splatBuffer = scene.splatBuffer;
-      let sceneTransform;
-      if (applySceneTransform) { this.getSceneTransform(i, tempTransform); sceneTransform = tempTransform; }
-      if (covariances) splatBuffer.fillSplatCovarianceArray(covariances, sceneTransform, srcStart, srcEnd, destStart, covarianceCompressionLevel);
-      if (scales || rotations) {
-        if (!scales || !rotations) throw new Error('SplatMesh::fillSplatDataArrays() -> "scales" and "rotations" must both be valid.');
-        splatBuffer.fillSplatScaleRotationArray(scales, rotations, sceneTransform, srcStart, srcEnd, destStart, scaleRotationCompressionLevel, scaleOverride);
-      }
-      if (centers) splatBuffer.fillSplatCenterArray(centers, sceneTransform, srcStart, srcEnd, destStart);
-      if (colors) splatBuffer.fillSplatColorArray(colors, scene.minimumAlpha, srcStart, srcEnd, destStart);
+    const noScaleOverride = new THREE.Vector3();
+    noScaleOverride.x = noScaleOverride.y = noScaleOverride.z = undefined;       // "no override" for fillSplatScaleRotationArray
+    const matrix = new THREE.Matrix4();
+    const oneScene = Number.isInteger(sceneIndex) && sceneIndex >= 0 && sceneIndex <= this.scenes.length;
+    const firstScene = oneScene ? sceneIndex : 0, lastScene = oneScene ? sceneIndex : this.scenes.length - 1;
+    if (applySceneTransform === undefined || applySceneTransform === null) applySceneTransform = !this.dynamicMode;
+    if ((scales || rotations) && !(scales && rotations)) throw new Error('SplatMesh::fillSplatDataArrays() -> "scales" and "rotations" must both be valid.');
+    let dest = destStart;
+    for (let k = firstScene; k <= lastScene; k++) {
+      const scene = this.getScene(k), buffer = scene.splatBuffer;
+      let transform;                                                         // undefined = none (what the fill methods expect)
+      if (applySceneTransform) { this.getSceneTransform(k, matrix); transform = matrix; }
+      if (covariances) buffer.fillSplatCovarianceArray(covariances, transform, srcStart, srcEnd, dest, covarianceCompressionLevel);
+      if (scales) buffer.fillSplatScaleRotationArray(scales, rotations, transform, srcStart, srcEnd, dest, scaleRotationCompressionLevel, noScaleOverride);
+      if (centers) buffer.fillSplatCenterArray(centers, transform, srcStart, srcEnd, dest);
+      if (colors) buffer.fillSplatColorArray(colors, scene.minimumAlpha, srcStart, srcEnd, dest);
       if (sphericalHarmonics) {
-        splatBuffer.fillSphericalHarmonicsArray(sphericalHarmonics, this.minSphericalHarmonicsDegree, sceneTransform, srcStart, srcEnd, destStart,
-                                                sphericalHarmonicsCompressionLevel);
+        buffer.fillSphericalHarmonicsArray(sphericalHarmonics, this.minSphericalHarmonicsDegree, transform, srcStart, srcEnd, dest,
+                                           sphericalHarmonicsCompressionLevel);
       }
-      destStart += splatBuffer.getSplatCount();
+      dest += buffer.getSplatCount();
     }
   }
 
-  getIntegerCenters(start, end, padFour = false) {          // :1912-1926
-    const splatCount = end - start + 1;
-    const floatCenters = new Float32Array(splatCount * 3);
-    this.fillSplatDataArrays(null, null, null, floatCenters, null, null, undefined, undefined, undefined, undefined, start);
-    const componentCount = padFour ? 4 : 3;
-    const intCenters = new Int32Array(splatCount * componentCount);
-    for (let i = 0; i < splatCount; i++) {
-      for (let t = 0; t < 3; t++) intCenters[i * componentCount + t] = Math.round(floatCenters[i * 3 + t] * 1000.0);
-      if (padFour) intCenters[i * componentCount + 3] = 1000;
-    }
-    return intCenters;
+  // centres of splats [start, end] as the sort worker wants them (:1912-1948): x1000 rounded to int32, or float; 3 or 4 per splat
+  _centers(start, end) {
+    const xyz = new Float32Array((end - start + 1) * 3);
+    this.fillSplatDataArrays(null, null, null, xyz, null, null, undefined, undefined, undefined, undefined, start);
+    return xyz;
   }
-  getFloatCenters(start, end, padFour = false) {            // :1935-1948
-    const splatCount = end - start + 1;
-    const floatCenters = new Float32Array(splatCount * 3);
-    this.fillSplatDataArrays(null, null, null, floatCenters, null, null, undefined, undefined, undefined, undefined, start);
-    if (!padFour) return floatCenters;
-    const padded = new Float32Array(splatCount * 4);
-    for (let i = 0; i < splatCount; i++) {
-      for (let t = 0; t < 3; t++) padded[i * 4 + t] = floatCenters[i * 3 + t];
-      padded[i * 4 + 3] = 1.0;
+  getIntegerCenters(start, end, padFour = false) {
+    const xyz = this._centers(start, end), stride = padFour ? 4 : 3, out = new Int32Array((xyz.length / 3) * stride);
+    for (let k = 0, o = 0; k < xyz.length; k += 3, o += stride) {
+      out[o] = Math.round(xyz[k] * 1000.0); out[o + 1] = Math.round(xyz[k + 1] * 1000.0); out[o + 2] = Math.round(xyz[k + 2] * 1000.0);
+      if (padFour) out[o + 3] = 1000;
     }
-    return padded;
+    return out;
   }
-  getSceneIndexes(start, end) {                             // :1667-1677
-    const sceneIndexes = new Uint32Array(end - start + 1);
-    for (let i = start; i <= end; i++) sceneIndexes[i] = this.globalSplatIndexToSceneIndexMap[i];
-    return sceneIndexes;
+  getFloatCenters(start, end, padFour = false) {
+    const xyz = this._centers(start, end);
+    if (!padFour) return xyz;
+    const out = new Float32Array((xyz.length / 3) * 4);
+    for (let k = 0, o = 0; k < xyz.length; k += 3, o += 4) { out[o] = xyz[k]; out[o + 1] = xyz[k + 1]; out[o + 2] = xyz[k + 2]; out[o + 3] = 1.0; }
+    return out;
+  }
+  getSceneIndexes(start, end) {                             // (:1667-1677; written at [start, end] of the array, as there)
+    const out = new Uint32Array(end - start + 1);
+    for (let g = start; g <= end; g++) out[g] = this.globalSplatIndexToSceneIndexMap[g];
+    return out;
   }
 
   // ---- counts, scenes, transforms ------------------------------------------------------------------------------------
@@ -330,27 +264,24 @@ export class SplatMesh {
   }
   getMaxSplatCount() { return SplatMesh.getTotalMaxSplatCountForScenes(this.scenes); }
   getScene(sceneIndex) {
-    if (sceneIndex < 0 || sceneIndex >= this.scenes.length) throw new Error('SplatMesh::getScene() -> Invalid scene index.');
-    return this.scenes[sceneIndex];
+    const scene = this.scenes[sceneIndex];
+    if (!(sceneIndex >= 0 && sceneIndex < this.scenes.length)) throw new Error('SplatMesh::getScene() -> Invalid scene index.');
+    return scene;
   }
   getSceneCount() { return this.scenes.length; }
   getSceneTransform(sceneIndex, outTransform) {             // :2019-2028
-    const scene = this.getScene(sceneIndex);
-    scene.updateTransform(this.dynamicMode);
-    outTransform.copy(scene.transform);
+    const sc = this.getScene(sceneIndex);
+    sc.updateTransform(this.dynamicMode);
+    outTransform.copy(sc.transform);
   }
   getSplatBufferForSplat(globalIndex) { return this.getScene(this.globalSplatIndexToSceneIndexMap[globalIndex]).splatBuffer; }
   getSceneIndexForSplat(globalIndex) { return this.globalSplatIndexToSceneIndexMap[globalIndex]; }
   getSplatLocalIndex(globalIndex) { return this.globalSplatIndexToLocalSplatIndexMap[globalIndex]; }
-  updateTransforms() { for (let i = 0; i < this.scenes.length; i++) this.getScene(i).updateTransform(this.dynamicMode); this._scenesDirty = true; }
-  fillTransformsArray(array) {                              // :1683-1699
-    const temp = [];
-    temp.length = array.length;
-    for (let i = 0; i < this.scenes.length; i++) {
-      const e = this.getScene(i).transform.elements;
-      for (let j = 0; j < 16; j++) temp[i * 16 + j] = e[j];
-    }
-    array.set(temp);
+  updateTransforms() { this.scenes.forEach((sc) => sc.updateTransform(this.dynamicMode)); this._scenesDirty = true; }
+  fillTransformsArray(array) {                              // :1683-1699: 16 floats per scene; the slots of absent scenes become NaN, as there
+    const flat = new Array(array.length);
+    this.scenes.forEach((sc, k) => sc.transform.elements.forEach((value, j) => { flat[16 * k + j] = value; }));
+    array.set(flat);
   }
   getSplatDataTextures() { return this.splatDataTextures; }
   setRenderer(renderer) { this.renderer = renderer; }
@@ -411,16 +342,16 @@ export class SplatMesh {
 
   // ---- splat tree (:231-280): built by the engine (on the device), exposed in the reference's shape ---------------------
   buildSplatTree(minAlphas = [], onSplatTreeIndexesUpload, onSplatTreeConstruction) {
+    this.disposeSplatTree();
     return new Promise((resolve) => {
-      this.disposeSplatTree();
-      const splatCount = this.getSplatCount(true);
-      const centers = new Float32Array(splatCount * 3), colors = new Uint8Array(splatCount * 4);
+      const total = this.getSplatCount(true), splatCount = total;
+      const centers = new Float32Array(total * 3), colors = new Uint8Array(total * 4);
       // getSplatCenter / getSplatColor of every splat (:239-244): scene transforms applied as for a static mesh, alpha filter
       this.fillSplatDataArrays(null, null, null, centers, null, null, this.dynamicMode ? false : true);
       const keep = new Uint8Array(splatCount);
       let dest = 0;
-      for (let s = 0; s < this.scenes.length; s++) {
-        const buffer = this.getScene(s).splatBuffer, n = buffer.getSplatCount();
+      for (const sc of this.scenes) {
+        const s = this.scenes.indexOf(sc), buffer = sc.splatBuffer, n = buffer.getSplatCount();
         buffer.fillSplatColorArray(colors, 0, undefined, undefined, dest);
         const minAlpha = minAlphas[s] || 1;
         for (let i = 0; i < n; i++) keep[dest + i] = colors[4 * (dest + i) + 3] >= minAlpha ? 1 : 0;
@@ -430,8 +361,7 @@ export class SplatMesh {
       const handle = addon.treeCreate(this.core.ctx.handle, centers, keep, splatCount, 0, 8, 1000);      // maxDepth 8, 1000 per node (:236)
       if (onSplatTreeIndexesUpload) onSplatTreeIndexesUpload(true);
       if (onSplatTreeConstruction) onSplatTreeConstruction(false);
-      this.baseSplatTree = new HipSplatTree(handle, this);
-      this.splatTree = this.baseSplatTree;
+      this.splatTree = this.baseSplatTree = new HipSplatTree(handle, this);
       if (onSplatTreeConstruction) onSplatTreeConstruction(true);
       resolve();
     });
@@ -440,8 +370,7 @@ export class SplatMesh {
   onSplatTreeReady(callback) { this.onSplatTreeReadyCallback = callback; }
   disposeSplatTree() {
     if (this.baseSplatTree) this.baseSplatTree.dispose();
-    this.splatTree = null;
-    this.baseSplatTree = null;
+    this.splatTree = this.baseSplatTree = null;
   }
   disposeMeshData() { if (this.core) { this.core.dispose(); this.core = null; } }
   dispose() { this.disposeSplatTree(); this.disposeMeshData(); this.disposed = true; return Promise.resolve(); }

@@ -139,7 +139,7 @@ constexpr int RADIX_TILE = RADIX_TILE_CFG;                // keys per workgroup 
 // Grid cap of a radix pass.  Every scatter workgroup starts by summing rows of the two-level offset table, so fewer,
 // longer workgroups win: same-box A/B on C3 (r01e) 2048: 0.498 ms/frame, 1024: 0.477, 512: 0.471, 384: 0.489, 256: 0.483.
 #ifndef RADIX_MAX_BLOCKS_CFG
-#define RADIX_MAX_BLOCKS_CFG 512
+#define RADIX_MAX_BLOCKS_CFG 1024
 #endif
 constexpr int RADIX_MAX_BLOCKS = RADIX_MAX_BLOCKS_CFG;
 constexpr int RADIX_BINS = 256;

@@ -39,6 +39,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
+// The same scan on the DPP network (no LDS round trips): Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8: a lane
+// whose source falls outside its row adds 0), then lane 15 of row r into row r + 1 (rows 1 and 3), then lane 31 into rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // exclusive scan of one value per thread over a WAVES*64-thread block; returns exclusive prefix, *total = block sum
 template <int WAVES>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp /*>=WAVES*/, uint32_t* total) {
@@ -61,6 +73,19 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* s_
     return block_excl_scan<4>(v, s_tmp, total);
 }
 
+// Element `index` of an array that is < 4 GiB long (every array a radix pass touches: gs_sorter_create / the mesh bound their
+// element counts): the byte offset is formed in 32 bits, so the access is `global_load v, v_offset, s[base:base+1]` - ONE address
+// VGPR per access instead of a 64-bit pair (the scatter kernel holds 16 loads in flight per lane; with 64-bit addresses it
+// spilled 44 dwords per lane at 64 VGPRs).
+template <class T>
+__device__ __forceinline__ T ld32(const T* base, uint32_t index) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + index * (uint32_t)sizeof(T));
+}
+template <class T>
+__device__ __forceinline__ void st32(T* base, uint32_t index, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + index * (uint32_t)sizeof(T)) = v;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // loaders: logical element j in [0, count()) -> (key, payload)
 // ---------------------------------------------------------------------------------------------------
@@ -74,9 +99,10 @@ struct ArrayLoader {
     __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (uint32_t)keys[j]; }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return vals[j]; }
-    // fetch = the memory reads of element j, decode = the arithmetic on them (none here)
+    // pre + fetch = the memory reads of element j (two dependent stages), decode = the arithmetic on them (none here)
     struct Raw { uint32_t key, val; };
-    __device__ __forceinline__ Raw fetch(uint32_t j) const { return Raw{(uint32_t)keys[j], vals[j]}; }
+    __device__ __forceinline__ uint32_t pre(uint32_t) const { return 0u; }       // (a loader with an index list reads it here)
+    __device__ __forceinline__ Raw fetch(uint32_t j, uint32_t) const { return Raw{(uint32_t)ld32(keys, j), ld32(vals, j)}; }
     __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const { k = r.key; v = r.val; }
     __device__ __forceinline__ bool valid(uint32_t) const { return true; }
     // the histogram's view of element j: the memory read, then the arithmetic on it
@@ -113,12 +139,28 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t grid) {
 struct RadixChunk {
     uint32_t n, tile_begin, tile_end, id;
 };
+// Chunk = a contiguous run of tiles; chunk c's row of the offset table is row c.  RADIX_XCD_CONTIG: the workgroups of one XCD
+// (b % 8, the observed dispatch rule: speed only) take CONTIGUOUS chunks, so for every digit the slots an XCD writes are one
+// contiguous range and the partial lines at the ends of neighbouring tiles' digit runs meet in ONE L2 instead of leaving two
+// L2s as two masked writes (the r03 counters had pass 0 at 1.82x its algorithmic write bytes).
+#ifndef RADIX_XCD_CONTIG
+#define RADIX_XCD_CONTIG 1
+#endif
+__device__ __forceinline__ uint32_t radix_chunk_id(uint32_t b, uint32_t grid) {
+#if RADIX_XCD_CONTIG
+    const uint32_t x = b % 8u, k = b / 8u, q = grid / 8u, rem = grid % 8u;
+    return x * q + min(x, rem) + k;                              // XCD x owns q (+1 for x < rem) chunks from there
+#else
+    (void)grid;
+    return b;
+#endif
+}
 __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
     const uint32_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
     RadixChunk c;
     c.n = n;
-    c.id = blockIdx.x;
+    c.id = radix_chunk_id(blockIdx.x, gridDim.x);
     c.tile_begin = min(c.id * per, tiles);
     c.tile_end = min(c.tile_begin + per, tiles);
     return c;
@@ -127,14 +169,20 @@ __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
 // The histogram kernel runs 1024-thread workgroups: its grid is the scatter's (one table row per workgroup, <= 512 of
 // them), and a gather-type loader (the depth keys) needs more waves in flight than 4 per workgroup to hide its latency
 // (r01e: 20.5 us with 256 threads).
-constexpr int HIST_THREADS = 1024;
+#ifndef HIST_THREADS_CFG
+#define HIST_THREADS_CFG 1024
+#endif
+constexpr int HIST_THREADS = HIST_THREADS_CFG;
 constexpr int HIST_ITEMS = RADIX_TILE / HIST_THREADS;
 
 // The histogram of a workgroup's tiles, HIST_GROUP tiles at a time: all their loads are issued before the first LDS atomic,
 // so the workgroup waits for one memory round trip per group instead of one per tile.  Measured r03 (same box, ab_libs): C4 sort
 // 0.240 -> 0.231 ms, entry sort 0.245 -> 0.241; C3 / C5 within noise (their histograms already overlapped).  Order is irrelevant
 // for a histogram.
-constexpr uint32_t HIST_GROUP = 4;
+#ifndef HIST_GROUP_CFG
+#define HIST_GROUP_CFG 4
+#endif
+constexpr uint32_t HIST_GROUP = HIST_GROUP_CFG;
 
 // full tiles of an array of keys: 16-byte loads
 template <class KeyT>
@@ -186,19 +234,22 @@ template <class Loader>
 __device__ __forceinline__ void hist_tiles(const Loader& ld, uint32_t tile, uint32_t tiles, uint32_t n, int shift, uint32_t* hist) {
     typename Loader::HRaw raw[HIST_GROUP][HIST_ITEMS];
     bool ok[HIST_GROUP][HIST_ITEMS];
+    // (unconditional loads of clamped positions: one batch, no exec-masked branch per load; n > 0 when a workgroup has tiles)
 #pragma unroll
     for (uint32_t g = 0; g < HIST_GROUP; g++)
 #pragma unroll
         for (int r = 0; r < HIST_ITEMS; r++) {
             const uint32_t j = (tile + g) * RADIX_TILE + r * HIST_THREADS + threadIdx.x;
-            ok[g][r] = g < tiles && j < n && ld.valid(j);
-            raw[g][r] = ok[g][r] ? ld.hist_fetch(j) : typename Loader::HRaw();
+            const uint32_t jc = j < n ? j : n - 1u;
+            ok[g][r] = g < tiles && j < n && ld.valid(jc);
+            raw[g][r] = ld.hist_fetch(jc);
         }
 #pragma unroll
     for (uint32_t g = 0; g < HIST_GROUP; g++)
 #pragma unroll
-        for (int r = 0; r < HIST_ITEMS; r++)
-            if (ok[g][r]) atomicAdd(&hist[(ld.hist_key(raw[g][r]) >> shift) & 255u], 1u);
+        for (int r = 0; r < HIST_ITEMS; r++) {
+            if (ok[g][r]) atomicAdd(&hist[(ld.hist_key(raw[g][r]) >> shift) & 255u], 1u);     // (hist_key may count a clamp: valid elements only)
+        }
 }
 
 template <class Loader>
@@ -208,7 +259,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
     const uint32_t tid = threadIdx.x, wave = (tid >> 6) & 3u;
-    (&s_hist[0][0])[tid] = 0;
+    for (uint32_t k = tid; k < 4u * RADIX_BINS; k += HIST_THREADS) (&s_hist[0][0])[k] = 0;
     __syncthreads();
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile += HIST_GROUP)
         hist_tiles(ld, tile, min(HIST_GROUP, ch.tile_end - tile), ch.n, shift, s_hist[wave]);
@@ -222,50 +273,63 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
 }
 
 
-// WRITE_KEYS: also emit the keys (needed by every pass but the last).
-// RANGES: this is the last pass of a multi-pass tile sort - publish each key's [begin,end) in the sorted output.  Inside a
-// workgroup tile equal keys are contiguous (the earlier passes ordered the lower digits, this pass is stable), so a
-// run boundary costs one atomicMin/atomicMax pair; `ranges` must be pre-set to (0xFFFFFFFF, 0).
+// One scatter pass.  Template switches:
+//   WRITE_KEYS  also emit the keys (every pass but the last of a key + value sort).
+//   RANGES      the last pass of a multi-pass tile sort: publish each key's [begin,end) in the sorted output.  Inside a
+//               workgroup tile equal keys are contiguous (the earlier passes ordered the lower digits, this pass is stable),
+//               so a run boundary costs one atomicMin/atomicMax pair; `ranges` must be pre-set to (0xFFFFFFFF, 0).
+//   PACK_OUT    key and value leave as ONE 32-bit word, (key >> (shift + 8)) << val_bits | value: what is left of the key
+//               after this pass's digit, above a value of val_bits bits (the depth sort: 16-bit buckets over < 2^24 splat
+//               positions -> 4 bytes per element instead of 2 + 4, and digit runs of whole words).  The digit cannot be
+//               recovered from that word, so the staging area holds it as a byte (KeyOutT = uint8_t).
 //
-// Geometry: 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and ~35 KB LDS (16-bit keys
-// are staged as 16 bits).  The kernel is a chain of load -> rank -> barrier -> reorder -> barrier -> store phases per
-// tile; with the grid capped at 512 a CU holds two workgroups (16 waves) whose phases overlap each other.
-// 1024-thread workgroups sort faster in isolation (0.173 vs 0.186 ms for C3) but pipeline worse against the draw of the
-// previous frame (0.483 vs 0.468 ms per frame, same-box A/B r01e): 512 it is.
+// Geometry (round 4): 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and <= 40 KB LDS, so that
+// FOUR workgroups (32 waves) share a CU, on a grid of up to RADIX_MAX_BLOCKS = 1024 workgroups: a tile is a chain of
+// load -> rank -> scan -> reorder -> store phases with a memory round trip at either end, and what hides those is the other
+// workgroups of the CU.  (Rounds 1-3 ran <= 512 workgroups of 82-91 VGPRs: fewer than two per CU.  The r03 kernel table had
+// pass 0 of the C3 depth sort at 42.9 us for 81 MB.)  Per tile there are four barriers: ranks are taken on a per-wave
+// histogram that only its own wave zeroes and increments (no barrier between the two), the digit offsets of all waves are
+// folded into that same table (one LDS look-up per key in the reorder), and the running global base of every digit lives in a
+// register of the thread that owns the digit.  The first tile's loads are issued BEFORE the offset prologue's, so both round
+// trips overlap.
 #ifndef SCATTER_THREADS_CFG
-#define SCATTER_THREADS_CFG 512
+#define SCATTER_THREADS_CFG 1024
+#endif
+#ifndef SCATTER_OCC_CFG
+#define SCATTER_OCC_CFG 8              // waves per SIMD the register allocation must allow (8 <=> 64 VGPRs <=> 4 workgroups of 512)
 #endif
 constexpr int SCATTER_THREADS = SCATTER_THREADS_CFG;
 constexpr int SCATTER_WAVES = SCATTER_THREADS / 64;
 constexpr int SCATTER_ITEMS = RADIX_TILE / SCATTER_THREADS;
 constexpr int SCATTER_PARTS = SCATTER_THREADS / RADIX_BINS;     // threads per digit in the offset prologue
 static_assert(SCATTER_THREADS % RADIX_BINS == 0 && 2 * SCATTER_PARTS <= SCATTER_WAVES, "offset prologue layout");
+static_assert(SCATTER_ITEMS * SCATTER_THREADS == RADIX_TILE && SCATTER_ITEMS <= 32, "tile layout");
 
 #ifdef GS_RADIX_PROFILE
 // tools/radix_profile.py: per scatter workgroup (slot = shift / 8 of the depth sort: 0 / 1) the 100 MHz clock at kernel start,
 // after the offset prologue, and for its FIRST tile: data decoded, ranked, offsets scanned, reordered in LDS, stored; then the
 // end of the kernel and the number of tiles
-static __device__ unsigned long long g_radix_prof[2 * 512 * 10];      // one copy per translation unit; sorter.hip's is read
-#define RADIX_PROF(slot, v) do { const int ps_ = Loader::prof_slot(shift); if (threadIdx.x == 0 && blockIdx.x < 512u && ps_ >= 0) g_radix_prof[(ps_ * 512 + blockIdx.x) * 10 + (slot)] = (v); } while (0)
+static __device__ unsigned long long g_radix_prof[2 * 1024 * 10];      // one copy per translation unit; sorter.hip's is read
+#define RADIX_PROF(slot, v) do { const int ps_ = Loader::prof_slot(shift); if (threadIdx.x == 0 && blockIdx.x < 1024u && ps_ >= 0) g_radix_prof[(ps_ * 1024 + blockIdx.x) * 10 + (slot)] = (v); } while (0)
 #define RADIX_PROF_WAIT() __builtin_amdgcn_s_waitcnt(0)
 #else
 #define RADIX_PROF(slot, v) do { } while (0)
 #define RADIX_PROF_WAIT() do { } while (0)
 #endif
 
-template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK>
-__global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld, int shift,
+template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool ATOMIC_RANK, bool PACK_OUT>
+__global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scatter(Loader ld, int shift,
                                                                       const uint32_t* __restrict__ block_hist,
                                                                       const uint32_t* __restrict__ group_hist,
                                                                       KeyOutT* __restrict__ keys_out,
                                                                       uint32_t* __restrict__ vals_out, uint2* ranges,
-                                                                      uint32_t direct_ranges) {
-    __shared__ KeyOutT s_keys[RADIX_TILE];                  // staged in the output key width (u16 or u32)
-    __shared__ uint32_t s_vals[RADIX_TILE];
-    __shared__ uint32_t s_wave[SCATTER_WAVES][RADIX_BINS];  // per-wave digit counts, then per-wave exclusive offsets
-    __shared__ uint32_t s_base[RADIX_BINS];                 // running global offset of each digit for this workgroup
-    __shared__ uint32_t s_local[RADIX_BINS];                // first staging slot of each digit in the current tile
-    __shared__ uint32_t s_total[RADIX_BINS];
+                                                                      uint32_t direct_ranges, uint32_t val_bits) {
+    static_assert(!PACK_OUT || (sizeof(KeyOutT) == 1 && !WRITE_KEYS && !RANGES), "a packing pass stages the digit as a byte");
+    __shared__ KeyOutT s_keys[RADIX_TILE];                  // staged in the output key width (PACK_OUT: the digit)
+    __shared__ uint32_t s_vals[RADIX_TILE];                 // the value (PACK_OUT: the packed word)
+    __shared__ __attribute__((aligned(16))) uint32_t s_wave[SCATTER_WAVES][RADIX_BINS];  // per-wave digit counts, then: first staging slot of (wave, digit)
+    __shared__ __attribute__((aligned(16))) uint32_t s_gbase[RADIX_BINS];   // global slot of a digit's first staged key minus its staging slot
+    __shared__ __attribute__((aligned(16))) uint32_t s_base[RADIX_BINS];    // next global slot of each digit for this workgroup
     __shared__ uint32_t s_tmp[SCATTER_WAVES];
 
     RADIX_PROF(0, wall_clock64());
@@ -274,35 +338,66 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];
+    const int dshift = PACK_OUT ? 0 : shift;                // the staged key of a packing pass IS the digit
+
+    uint32_t okm = 0;                                       // bit r: element r of this lane exists (and survives the loader)
+    typename Loader::Raw raw[SCATTER_ITEMS];
+    // wave-striped load: the stable order inside a tile is (wave, r, lane).  All memory reads first, then the arithmetic.
+    // Branch-free: an element beyond the list re-reads the last one (its okm bit stays clear), so the eight loads of a lane are
+    // one batch behind one wait instead of eight exec-masked branches.
+    auto fetch_tile = [&](uint32_t tile) {
+        const uint32_t wbase = tile * RADIX_TILE + wave * (64 * SCATTER_ITEMS) + lane;
+        uint32_t o[SCATTER_ITEMS];
+        okm = 0;
+#pragma unroll
+        for (int r = 0; r < SCATTER_ITEMS; r++) {
+            const uint32_t j = wbase + r * 64;
+            const bool in = j < ch.n;
+            const uint32_t jc = in ? j : ch.n - 1u;
+            const bool ok = in && ld.valid(jc);              // a loader that drops elements turns the pass into a stable compaction
+            o[r] = ld.pre(jc);
+            okm |= ok ? (1u << r) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < SCATTER_ITEMS; r++) {
+            const uint32_t j = wbase + r * 64;
+            raw[r] = ld.fetch(j < ch.n ? j : ch.n - 1u, o[r]);
+        }
+    };
 
     {   // this workgroup's first output slot per digit = keys with a smaller digit + keys of this digit in earlier
-        // workgroups; two threads per digit split the rows, every load is independent of the others
+        // workgroups; SCATTER_PARTS threads per digit split the rows, every load is independent of the others
         const uint32_t d = tid & 255u, half = tid >> 8;      // `half` = which of the SCATTER_PARTS row subsets
         const uint32_t g = ch.id / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
-        // fixed trip counts, fully unrolled and predicated: every load of the prologue is in flight at once (one memory
-        // round trip instead of a chain of batches: isolated C3 sort 0.182 -> 0.176 ms)
+        // fixed trip counts, fully unrolled and predicated: every load of the prologue is in flight at once
         constexpr uint32_t GROUP_LOADS = (RADIX_MAX_GROUPS + SCATTER_PARTS - 1) / SCATTER_PARTS;
         constexpr uint32_t ROW_LOADS = (RADIX_GROUP + SCATTER_PARTS - 1) / SCATTER_PARTS;
-        uint32_t gv[GROUP_LOADS], rv[ROW_LOADS];
-#pragma unroll
-        for (uint32_t k = 0; k < GROUP_LOADS; k++) {
-            const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
-            gv[k] = r < groups ? group_hist[r * RADIX_BINS + d] : 0u;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < ROW_LOADS; k++) {
-            const uint32_t r = g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS;
-            rv[k] = r < ch.id ? block_hist[r * RADIX_BINS + d] : 0u;
-        }
         uint32_t before = 0, all = 0;
+        {
+            // (unconditional loads of clamped rows + a select: one batch of loads, no exec-masked branch per load)
+            uint32_t gv[GROUP_LOADS];
 #pragma unroll
-        for (uint32_t k = 0; k < GROUP_LOADS; k++) {
-            all += gv[k];
-            before += (half + k * (uint32_t)SCATTER_PARTS) < g ? gv[k] : 0u;
+            for (uint32_t k = 0; k < GROUP_LOADS; k++) {
+                const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
+                gv[k] = ld32(group_hist, min(r, groups - 1u) * RADIX_BINS + d);
+            }
+            uint32_t rv[ROW_LOADS];
+#pragma unroll
+            for (uint32_t k = 0; k < ROW_LOADS; k++) {
+                const uint32_t r = g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS;
+                rv[k] = ld32(block_hist, min(r, ch.id) * RADIX_BINS + d);
+            }
+            if (ch.tile_begin < ch.tile_end) fetch_tile(ch.tile_begin);      // the first tile travels with the table rows
+#pragma unroll
+            for (uint32_t k = 0; k < GROUP_LOADS; k++) {
+                const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
+                all += r < groups ? gv[k] : 0u;
+                before += r < g ? gv[k] : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < ROW_LOADS; k++) before += (g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS) < ch.id ? rv[k] : 0u;
         }
-#pragma unroll
-        for (uint32_t k = 0; k < ROW_LOADS; k++) before += rv[k];
-        uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop zeroes it
+        uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop uses it
         uint32_t* s_all = &s_wave[SCATTER_PARTS][0];
         s_before[tid] = before;
         s_all[tid] = all;
@@ -315,119 +410,153 @@ __global__ __launch_bounds__(SCATTER_THREADS, 4) void k_radix_scatter(Loader ld,
                 mine += s_before[q * RADIX_BINS + tid];
             }
         }
-        const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);
-        if (tid < RADIX_BINS) s_base[tid] = smaller + mine;
+        const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);     // (two barriers: s_wave is free after it)
+        if (tid < RADIX_BINS) s_base[tid] = smaller + mine;  // (read after barrier (1) of the first tile)
         // A single-pass sort's digit IS the key, so key d ends up in [smaller, smaller + tot): workgroup 0 publishes the
         // ranges of the first `direct_ranges` keys with plain stores.  (The RANGES path's atomicMin / atomicMax pairs all
         // land on ~9 cache lines when there are only 135 keys: 100 us for the 1080p entry sort instead of 30.)
         if (direct_ranges && blockIdx.x == 0 && tid < direct_ranges)
             ranges[tid] = tot ? make_uint2(smaller, smaller + tot) : make_uint2(0xFFFFFFFFu, 0u);
-        __syncthreads();                                     // s_wave is rewritten below
     }
+    // every wave zeroes, increments and (after the scan) reads only ITS OWN row of s_wave
+    *reinterpret_cast<uint4*>(&s_wave[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
 
     RADIX_PROF(1, wall_clock64());
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
         const bool prof_tile = tile == ch.tile_begin;
         (void)prof_tile;
-        uint32_t key[SCATTER_ITEMS], val[SCATTER_ITEMS], rank[SCATTER_ITEMS];
-        bool ok[SCATTER_ITEMS];
-        typename Loader::Raw raw[SCATTER_ITEMS];
-        // wave-striped load: the stable order inside a tile is (wave, r, lane).  All memory reads first, then the arithmetic
-        // on them.  (Issuing the next tile's reads before ranking this one changed nothing: 0.100 vs 0.100 ms per C3 sort.)
-        const uint32_t wbase = tile * RADIX_TILE + wave * (64 * SCATTER_ITEMS) + lane;
+        // per element: `a` = what is staged as the value (PACK_OUT: the packed word), `b` = the staged key (PACK_OUT: the digit),
+        // `rk` = its rank among the equal digits its wave has seen in this tile
+        uint32_t a[SCATTER_ITEMS], b[SCATTER_ITEMS], rk[SCATTER_ITEMS];
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
-            const uint32_t j = wbase + r * 64;
-            ok[r] = j < ch.n && ld.valid(j);      // a loader that drops elements turns the pass into a stable compaction
-            if (ok[r]) raw[r] = ld.fetch(j);
-        }
-#pragma unroll
-        for (int r = 0; r < SCATTER_ITEMS; r++) {
-            key[r] = 0xFFFFFFFFu;
-            val[r] = 0u;
-            if (ok[r]) ld.decode(raw[r], key[r], val[r]);
+            uint32_t k = 0xFFFFFFFFu, v = 0u;
+            ld.decode(raw[r], k, v);
+            if (PACK_OUT) {
+                a[r] = ((k >> (shift + 8)) << val_bits) | v;
+                b[r] = (k >> shift) & 255u;
+            } else {
+                a[r] = v;
+                b[r] = k;
+            }
         }
         RADIX_PROF_WAIT();
         if (prof_tile) RADIX_PROF(2, wall_clock64());
-#pragma unroll
-        for (int k = 0; k < SCATTER_WAVES * RADIX_BINS / SCATTER_THREADS; k++) (&s_wave[0][0])[k * SCATTER_THREADS + tid] = 0;
-        __syncthreads();
 
         if (ATOMIC_RANK) {
 #pragma unroll
             for (int r = 0; r < SCATTER_ITEMS; r++) {
-                const uint32_t digit = (key[r] >> shift) & 255u;
+                const uint32_t digit = (b[r] >> dshift) & 255u;
                 // lanes of this instruction that share `digit` are served in ascending lane order (see header)
-                if (ok[r]) rank[r] = atomicAdd(&s_wave[wave][digit], 1u);
+                rk[r] = 0u;
+                if ((okm >> r) & 1u) rk[r] = atomicAdd(&s_wave[wave][digit], 1u);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < SCATTER_ITEMS; r++) {
-                const uint32_t digit = (key[r] >> shift) & 255u;
-                uint64_t same = __ballot(ok[r]);
+                const uint32_t digit = (b[r] >> dshift) & 255u;
+                const bool ok = (okm >> r) & 1u;
+                uint64_t same = __ballot(ok);
 #pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const uint64_t vote = __ballot(ok[r] && ((digit >> b) & 1u));
-                    same &= ((digit >> b) & 1u) ? vote : ~vote;
+                for (int bit = 0; bit < 8; bit++) {
+                    const uint64_t vote = __ballot(ok && ((digit >> bit) & 1u));
+                    same &= ((digit >> bit) & 1u) ? vote : ~vote;
                 }
-                if (ok[r]) {
+                rk[r] = 0u;
+                if (ok) {
                     const uint32_t prior = my_hist[digit];
-                    rank[r] = prior + __popcll(same & lt_mask);
+                    rk[r] = prior + __popcll(same & lt_mask);
                     if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);   // highest lane of the group
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                                     // (1) every wave's digit counts are final
         if (prof_tile) RADIX_PROF(3, wall_clock64());
 
-        uint32_t tile_count = 0;                    // keys staged by this tile (= its length unless the loader drops some)
-        {   // thread t < 256 owns digit t: wave-exclusive offsets and the tile-local digit base
-            uint32_t tot = 0;
-            if (tid < RADIX_BINS) {
+        // ONE wave turns the counts into offsets, four digits per lane (16-byte LDS accesses, the scan on the DPP network): no
+        // second barrier, no cross-wave exchange.  s_wave[w][d] becomes the first staging slot of (wave w, digit d); s_gbase[d] =
+        // global slot of digit d's first staged key minus its staging slot; s_base[d] = the workgroup's next global slot of d.
+        if (wave == 0) {
+            uint4 tot = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                for (int w = 0; w < SCATTER_WAVES; w++) {
-                    const uint32_t c = s_wave[w][tid];
-                    s_wave[w][tid] = tot;
-                    tot += c;
-                }
-                s_total[tid] = tot;
+            for (int w = 0; w < SCATTER_WAVES; w++) {
+                const uint4 c = *reinterpret_cast<const uint4*>(&s_wave[w][4 * lane]);
+                tot.x += c.x; tot.y += c.y; tot.z += c.z; tot.w += c.w;
             }
-            const uint32_t excl = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, &tile_count);   // contains the barriers
-            if (tid < RADIX_BINS) s_local[tid] = excl;
+            const uint32_t t4 = tot.x + tot.y + tot.z + tot.w;
+            const uint32_t incl = wave_incl_scan_dpp(t4);
+            uint4 first;                                     // first staging slot of each of the four digits
+            first.x = incl - t4;
+            first.y = first.x + tot.x;
+            first.z = first.y + tot.y;
+            first.w = first.z + tot.z;
+            uint4 base = *reinterpret_cast<const uint4*>(&s_base[4 * lane]);
+            *reinterpret_cast<uint4*>(&s_gbase[4 * lane]) = make_uint4(base.x - first.x, base.y - first.y, base.z - first.z, base.w - first.w);
+            base.x += tot.x; base.y += tot.y; base.z += tot.z; base.w += tot.w;
+            *reinterpret_cast<uint4*>(&s_base[4 * lane]) = base;
+#pragma unroll
+            for (int w = 0; w < SCATTER_WAVES; w++) {
+                uint4* row = reinterpret_cast<uint4*>(&s_wave[w][4 * lane]);
+                const uint4 c = *row;
+                *row = first;
+                first.x += c.x; first.y += c.y; first.z += c.z; first.w += c.w;
+            }
+            if (lane == 63) s_tmp[0] = incl;                 // keys staged by this tile (= its length unless the loader drops some)
         }
-        __syncthreads();
+        __syncthreads();                                     // (2)
+        const uint32_t tile_count = s_tmp[0];
         if (prof_tile) RADIX_PROF(4, wall_clock64());
 #pragma unroll
         for (int r = 0; r < SCATTER_ITEMS; r++) {
-            if (ok[r]) {
-                const uint32_t digit = (key[r] >> shift) & 255u;
-                const uint32_t pos = s_local[digit] + s_wave[wave][digit] + rank[r];
-                s_keys[pos] = (KeyOutT)key[r];
-                s_vals[pos] = val[r];
+            if ((okm >> r) & 1u) {
+                const uint32_t digit = (b[r] >> dshift) & 255u;
+                const uint32_t pos = s_wave[wave][digit] + rk[r];
+                s_keys[pos] = (KeyOutT)b[r];
+                s_vals[pos] = a[r];
             }
         }
-        __syncthreads();
+        // the registers are free: the next tile's reads travel while this one is stored
+        okm = 0;
+        if (tile + 1 < ch.tile_end) fetch_tile(tile + 1);
+        __syncthreads();                                     // (3)
         if (prof_tile) RADIX_PROF(5, wall_clock64());
+        *reinterpret_cast<uint4*>(&s_wave[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);   // own row, read for the last time above
+        if (!RANGES && tile_count == (uint32_t)RADIX_TILE) {
+            // a full tile: every LDS read first, then the stores, no predicate
+            uint32_t kk[SCATTER_ITEMS], vv[SCATTER_ITEMS], gg[SCATTER_ITEMS];
 #pragma unroll
-        for (int k = 0; k < SCATTER_ITEMS; k++) {
-            const uint32_t e = k * SCATTER_THREADS + tid;
-            if (e < tile_count) {
-                const uint32_t kk = s_keys[e];
-                const uint32_t digit = (kk >> shift) & 255u;
-                const uint32_t g = s_base[digit] + (e - s_local[digit]);
-                if (WRITE_KEYS) keys_out[g] = (KeyOutT)kk;
-                vals_out[g] = s_vals[e];
-                if (RANGES) {
-                    if (e == 0 || (uint32_t)s_keys[e - 1] != kk) atomicMin(&ranges[kk].x, g);
-                    if (e + 1 == tile_count || (uint32_t)s_keys[e + 1] != kk) atomicMax(&ranges[kk].y, g + 1u);
+            for (int k = 0; k < SCATTER_ITEMS; k++) {
+                kk[k] = s_keys[k * SCATTER_THREADS + tid];
+                vv[k] = s_vals[k * SCATTER_THREADS + tid];
+            }
+#pragma unroll
+            for (int k = 0; k < SCATTER_ITEMS; k++) gg[k] = s_gbase[(kk[k] >> dshift) & 255u] + (k * SCATTER_THREADS + tid);
+#pragma unroll
+            for (int k = 0; k < SCATTER_ITEMS; k++) {
+                if (WRITE_KEYS) st32(keys_out, gg[k], (KeyOutT)kk[k]);
+                st32(vals_out, gg[k], vv[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCATTER_ITEMS; k++) {
+                const uint32_t e = k * SCATTER_THREADS + tid;
+                if (e < tile_count) {
+                    const uint32_t kk = s_keys[e];
+                    const uint32_t digit = (kk >> dshift) & 255u;
+                    const uint32_t g = s_gbase[digit] + e;
+                    if (WRITE_KEYS) st32(keys_out, g, (KeyOutT)kk);
+                    st32(vals_out, g, s_vals[e]);
+                    if (RANGES) {
+                        if (e == 0 || (uint32_t)s_keys[e - 1] != kk) atomicMin(&ranges[kk].x, g);
+                        if (e + 1 == tile_count || (uint32_t)s_keys[e + 1] != kk) atomicMax(&ranges[kk].y, g + 1u);
+                    }
                 }
             }
         }
         RADIX_PROF_WAIT();
-        __syncthreads();
         if (prof_tile) RADIX_PROF(6, wall_clock64());
-        if (tid < RADIX_BINS) s_base[tid] += s_total[tid];
-        // the next iteration's first barrier orders this update before its use
+        // no barrier here: the staging area is next written after barrier (2) of the next tile, s_gbase and s_tmp after its
+        // barrier (1), and a wave passes those only when every wave has left this loop
     }
     RADIX_PROF(7, wall_clock64());
     RADIX_PROF(8, (unsigned long long)(ch.tile_end - ch.tile_begin));
@@ -446,19 +575,26 @@ inline uint32_t radix_grid_for(uint32_t n_upper) {
 
 // n_upper: host-side upper bound of the element count (sizes the grid); pass_slot picks the zeroed
 // digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
-template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES = false>
-int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
-               KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr, uint32_t direct_ranges = 0) {
+template <class HistLoader, class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool PACK_OUT>
+int radix_pass_ex(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift, const Loader& ld, uint32_t n_upper, int shift,
+                  int pass_slot, KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges, uint32_t direct_ranges, uint32_t val_bits) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
     uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
-    hipLaunchKernelGGL((k_radix_hist<Loader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, shift, bh, dt);
+    hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
     if (ex.atomic_rank)
-        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges);
+        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true, PACK_OUT>), dim3(grid), dim3(SCATTER_THREADS), 0,
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits);
     else
-        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges);
+        hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false, PACK_OUT>), dim3(grid), dim3(SCATTER_THREADS), 0,
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits);
     GS_HIP(hipGetLastError());
     return GS_OK;
+}
+
+template <class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES = false>
+int radix_pass(const RadixExec& ex, const Loader& ld_hist, const Loader& ld, uint32_t n_upper, int shift, int pass_slot,
+               KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges = nullptr, uint32_t direct_ranges = 0) {
+    return radix_pass_ex<Loader, Loader, KeyOutT, WRITE_KEYS, RANGES, false>(ex, ld_hist, shift, ld, n_upper, shift, pass_slot, keys_out,
+                                                                             vals_out, ranges, direct_ranges, 0u);
 }

@@ -19,6 +19,9 @@ __host__ __device__ static inline int32_t trunc_f64_i32(double v) {
 }
 
 constexpr uint32_t MODE_INT = 1, MODE_DYNAMIC = 2, MODE_PRECOMPUTED = 4;
+#ifndef GS_KEY_GRID_MULT
+#define GS_KEY_GRID_MULT 2             // workgroups of k_depth_key<VEC4> per CU
+#endif
 
 struct SceneRows {                 // per-scene clip-z row (mvp * transform)[2], as int x1000 and as float
     int32_t im[GS_MAX_SCENES][4];
@@ -499,58 +502,80 @@ struct DepthLoaderT {
         }
         // sorter.cpp:142-143: (float)(range-1) / ((float)max - (float)min), fp32, correctly rounded
         range_map = __fdiv_rn((float)(range - 1), __fsub_rn((float)hi, (float)lo));
+        // wave-uniform by construction: keep both in scalar registers
+        lo = __builtin_amdgcn_readfirstlane(lo);
+        range_map = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(range_map)));
     }
     __device__ __forceinline__ uint32_t count() const { return render_count - sort_start; }
-    __device__ __forceinline__ uint32_t bucket(uint32_t i) const { return bucket_of(keys[i]); }
+    __device__ __forceinline__ uint32_t bucket(uint32_t i) const { return bucket_of<false>(keys[i]); }
+    // sorter.cpp:146: (int)((float)(mapped - min) * rangeMap): int32 wrap, one fp32 multiply, truncation.  Branch-free (selects):
+    // the scatter decodes eight of these per lane between two waits.  COUNT: the histogram launch counts the clamped ones.
+    template <bool COUNT>
     __device__ __forceinline__ uint32_t bucket_of(int32_t depth) const {
-        // sorter.cpp:146: (int)((float)(mapped - min) * rangeMap): int32 wrap, one fp32 multiply, truncation
         const int32_t diff = (int32_t)((uint32_t)depth - (uint32_t)lo);
         const float f = __fmul_rn((float)diff, range_map);
-        if (!(f >= -2147483648.0f && f < 2147483648.0f)) return 0u;   // NaN (hi==lo) / overflow: WASM -> bucket 0
-        const int32_t b = (int32_t)f;
-        if (b < 0) {
-            if (count_clamps) atomicAdd(&frame->clamped, 1u);
-            return 0u;
-        }
-        if ((uint32_t)b >= range) {
-            if (count_clamps) atomicAdd(&frame->clamped, 1u);
-            return range - 1;
-        }
-        return (uint32_t)b;
+        const bool fits = f >= -2147483648.0f && f < 2147483648.0f;   // else NaN (hi==lo) / overflow: WASM -> bucket 0
+        const int32_t b = fits ? (int32_t)f : 0;
+        const bool under = b < 0, over = !under && (uint32_t)b >= range;
+        if (COUNT && count_clamps && (under || over)) atomicAdd(&frame->clamped, 1u);
+        return under ? 0u : (over ? range - 1u : (uint32_t)b);
     }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (range - 1) - bucket(render_count - 1 - j); }
     __device__ __forceinline__ uint32_t payload(uint32_t i) const {
-        const uint32_t o = idx ? min(idx[i], last_splat) : i;
-        return map ? map[o] : o;
+        const uint32_t o = idx ? min(ld32(idx, i), last_splat) : i;
+        return map ? ld32(map, o) : o;
     }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return payload(render_count - 1 - j); }
-    // fetch = the memory reads of element j, decode = the arithmetic on them: the scatter issues the fetches of its next
-    // tile before it ranks the current one (radix.hpp)
+    // pre + fetch = the memory reads of element j (the index list first, then everything that depends on it, so that a tile's
+    // loads leave as two batches), decode = the arithmetic on them
     struct Raw { int32_t depth; uint32_t payload; };
     static __device__ __forceinline__ int prof_slot(int) { return 0; }       // GS_RADIX_PROFILE
-    __device__ __forceinline__ Raw fetch(uint32_t j) const {
+    __device__ __forceinline__ uint32_t pre(uint32_t j) const {
         const uint32_t i = render_count - 1 - j;
+        return idx ? min(ld32(idx, i), last_splat) : i;
+    }
+    __device__ __forceinline__ Raw fetch(uint32_t j, uint32_t o) const {
         Raw r;
-        r.depth = keys[i];
-        r.payload = payload(i);
+        r.depth = ld32(keys, render_count - 1 - j);
+        r.payload = map ? ld32(map, o) : o;
         return r;
     }
     __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const {
-        k = (range - 1) - bucket_of(r.depth);
+        k = (range - 1) - bucket_of<false>(r.depth);
         v = r.payload;
     }
     // the histogram's view of element j
     typedef int32_t HRaw;
-    __device__ __forceinline__ HRaw hist_fetch(uint32_t j) const { return keys[render_count - 1 - j]; }
-    __device__ __forceinline__ uint32_t hist_key(HRaw depth) const { return (range - 1) - bucket_of(depth); }
+    __device__ __forceinline__ HRaw hist_fetch(uint32_t j) const { return ld32(keys, render_count - 1 - j); }
+    __device__ __forceinline__ uint32_t hist_key(HRaw depth) const { return (range - 1) - bucket_of<true>(depth); }
     __device__ __forceinline__ bool valid(uint32_t j) const {
         if (!CULL) return true;
         const uint32_t i = render_count - 1 - j;
-        return (keep[i >> 6] >> (i & 63u)) & 1ull;
+        return (ld32(keep, i >> 6) >> (i & 63u)) & 1ull;
     }
 };
 typedef DepthLoaderT<false> DepthLoader;
 typedef DepthLoaderT<true> DepthLoaderCull;
+
+// A pass that follows a PACKING pass (radix.hpp, PACK_OUT) reads ONE word per element: what is left of the key above a value of
+// `val_bits` bits; its digit is the low byte of that remainder (shift 0), its histogram is ArrayLoader<uint32_t>'s over the same
+// words with shift = val_bits.
+struct PackedLoader {
+    const uint32_t* __restrict__ words;
+    const uint32_t* __restrict__ n_dev;   // device-resident count (nullable)
+    uint32_t n_host, val_bits;
+    __device__ __forceinline__ void prepare() {}
+    __device__ __forceinline__ uint32_t count() const { return n_dev ? *n_dev : n_host; }
+    struct Raw { uint32_t w; };
+    __device__ __forceinline__ uint32_t pre(uint32_t) const { return 0u; }
+    __device__ __forceinline__ Raw fetch(uint32_t j, uint32_t) const { return Raw{ld32(words, j)}; }
+    __device__ __forceinline__ void decode(const Raw& r, uint32_t& k, uint32_t& v) const {
+        k = r.w >> val_bits;
+        v = r.w & ((1u << val_bits) - 1u);
+    }
+    __device__ __forceinline__ bool valid(uint32_t) const { return true; }
+    static __device__ __forceinline__ int prof_slot(int) { return 1; }       // GS_RADIX_PROFILE
+};
 
 __global__ void k_copy_head(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ map, uint32_t* __restrict__ out,
                             uint32_t n, uint32_t last_splat) {
@@ -582,7 +607,7 @@ static inline uint32_t grid_for(uint32_t n, uint32_t per_block, uint32_t cap) {
 
 #ifdef GS_RADIX_PROFILE
 extern "C" int gs_debug_radix_prof(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_radix_prof), sizeof(unsigned long long) * 2 * 512 * 10, 0, hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_radix_prof), sizeof(g_radix_prof), 0, hipMemcpyDeviceToHost);
 }
 #endif
 
@@ -827,7 +852,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         else if (cull)
             hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
         else if (vec4)
-            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+            hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * GS_KEY_GRID_MULT)), dim3(256), 0, st, kp);
         else
             hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         GS_HIP(hipGetLastError());
@@ -843,12 +868,22 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         dl.n_dev = vis_cull ? &kp.frame->kept : list_count_dev;
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
-        const bool wide = s->precision > 16;
         void* kbuf[2] = {s->keyA.p, s->keyB.p};
         uint32_t* vbuf[2] = {s->valA.as<uint32_t>(), s->valB.as<uint32_t>()};
+        // What travels between the passes: after pass p the key still holds precision - 8 (p + 1) bits.  When those fit above the
+        // payload in one 32-bit word (payloads are splat positions < uploaded: 23 bits at 5.8 M splats, 24 at 16 M, so the default
+        // 16-bit buckets always do below 2^24 splats) the pass writes that word instead of a key array and a value array
+        // (radix.hpp PACK_OUT); otherwise 16- or 32-bit keys + values as before, and a later pass packs as soon as it can.
+        uint32_t val_bits = 1;
+        while (val_bits < 32u && (kp.last_splat >> val_bits)) val_bits++;
+        static const bool no_pack = getenv("GSPLAT_NO_SORT_PACK") != nullptr;       // A/B and tests: the unpacked path
+        const bool wide = s->precision > 16;
+        bool in_packed = false;                                                       // the previous pass packed
         for (uint32_t p = 0; p < passes; p++) {
             const bool last = (p + 1 == passes);
-            const int shift = 8 * (int)p;
+            const int left = (int)s->precision - 8 * (int)(p + 1);                    // key bits after this pass
+            const bool pack = !last && !no_pack && (uint32_t)left + val_bits <= 32u;
+            const int shift = in_packed ? 0 : 8 * (int)p;
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
             const uint32_t* n_dev = (cull || vis_cull || list_count_dev) ? &kp.frame->kept : nullptr;
@@ -859,22 +894,31 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 dc.n_dev = dl.n_dev;
                 DepthLoaderCull h = dc;
                 h.count_clamps = 1;
-                if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
+                if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
+                else if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
                 else GS_TRY((radix_pass<DepthLoaderCull, uint16_t, true>(ex, h, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
             } else if (p == 0) {
                 DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
                 h.count_clamps = 1;
-                if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
+                if (pack) GS_TRY((radix_pass_ex<DepthLoader, DepthLoader, uint8_t, false, false, true>(ex, h, shift, dl, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
+                else if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
                 else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ex, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+            } else if (in_packed) {
+                PackedLoader pl = {vbuf[(p - 1) & 1], n_dev, Rs, val_bits};
+                ArrayLoader<uint32_t> ph = {vbuf[(p - 1) & 1], nullptr, n_dev, Rs};
+                if (last) GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, PackedLoader, uint8_t, false, false, false>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, 0u)));
+                else GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, PackedLoader, uint8_t, false, false, true>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
             } else if (wide) {
                 ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], n_dev, Rs};
                 if (last) GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, false>(ex, al, al, Rs, shift, (int)p, (uint32_t*)nullptr, vo)));
+                else if (pack) GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, ArrayLoader<uint32_t>, uint8_t, false, false, true>(ex, al, shift, al, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
                 else GS_TRY((radix_pass<ArrayLoader<uint32_t>, uint32_t, true>(ex, al, al, Rs, shift, (int)p, (uint32_t*)kbuf[p & 1], vo)));
             } else {
                 ArrayLoader<uint16_t> al = {(const uint16_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], n_dev, Rs};
                 if (last) GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, false>(ex, al, al, Rs, shift, (int)p, (uint16_t*)nullptr, vo)));
                 else GS_TRY((radix_pass<ArrayLoader<uint16_t>, uint16_t, true>(ex, al, al, Rs, shift, (int)p, (uint16_t*)kbuf[p & 1], vo)));
             }
+            in_packed = in_packed || pack;
         }
     }
     if (sort_start > 0) {

@@ -24,7 +24,7 @@ for _ in range(40 if frames else 4):
     if frames:
         mesh.render(to_host=False, want_stats=False)
 ctx.synchronize()
-buf = np.zeros((2, 512, 10), dtype=np.uint64)
+buf = np.zeros((2, 1024, 10), dtype=np.uint64)
 lib = _lib.load()
 lib.gs_debug_radix_prof.argtypes = [C.c_void_p]
 assert lib.gs_debug_radix_prof(buf.ctypes.data) == 0

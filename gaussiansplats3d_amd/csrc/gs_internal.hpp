@@ -136,12 +136,20 @@ constexpr uint32_t GS_FLAG_COUNT = 0, GS_FLAG_CAND = 1, GS_FLAG_POOL_NEXT = 2, G
 #define RADIX_TILE_CFG 4096
 #endif
 constexpr int RADIX_TILE = RADIX_TILE_CFG;                // keys per workgroup iteration
-// Grid cap of a radix pass.  Every scatter workgroup starts by summing rows of the two-level offset table, so fewer,
-// longer workgroups win: same-box A/B on C3 (r01e) 2048: 0.498 ms/frame, 1024: 0.477, 512: 0.471, 384: 0.489, 256: 0.483.
+// Rows of a radix pass's offset table = the most workgroups (chunks) a pass may have.  The chunk-staged passes of the depth
+// sort (radix.hpp) want <= 3 tiles per workgroup: 2048 rows cover 25 M keys.
 #ifndef RADIX_MAX_BLOCKS_CFG
-#define RADIX_MAX_BLOCKS_CFG 1024
+#define RADIX_MAX_BLOCKS_CFG 2048
 #endif
 constexpr int RADIX_MAX_BLOCKS = RADIX_MAX_BLOCKS_CFG;
+// Grid cap of the tile-at-a-time scatter kernel.  Every workgroup starts by summing rows of the two-level offset table, so fewer,
+// longer workgroups win: same-box A/B of the isolated C3 depth sort (r04a/b) 256: 0.0806 ms, 384: 0.0798, 512: 0.0733,
+// 1024: 0.0822, 2048: 0.093 (r01e, whole frames: 2048: 0.498, 1024: 0.477, 512: 0.471, 384: 0.489, 256: 0.483).
+#ifndef RADIX_TILE_GRID_CFG
+#define RADIX_TILE_GRID_CFG 512
+#endif
+constexpr int RADIX_TILE_GRID = RADIX_TILE_GRID_CFG;
+static_assert(RADIX_TILE_GRID <= RADIX_MAX_BLOCKS, "the tile kernel's grid needs a table row per workgroup");
 constexpr int RADIX_BINS = 256;
 constexpr int RADIX_MAX_PASSES = 4;
 constexpr int RADIX_GROUP = 32;                           // workgroups per group row of the two-level offset table (radix.hpp)

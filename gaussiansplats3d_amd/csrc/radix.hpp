@@ -6,14 +6,15 @@
 //   * the tile-entry sort of the rasteriser (key = tile id, payload = splat index), which must be STABLE so
 //     that each tile's list keeps the depth order established by the first sort.
 //
-// One pass = k_radix_hist -> k_radix_scatter.  The histogram kernel leaves a two-level table: one 1 KiB row of digit
-// counts per workgroup plus one row per GROUP of 32 workgroups (atomics, 32 adders per word); every scatter workgroup
-// sums the <= 16 group rows and the <= 31 rows of its own group that precede it (coalesced 1 KiB rows) and scans the
-// 256 digit totals itself, so no separate scan kernel (10.7 us and two kernel boundaries per pass on MI355X) sits
+// One pass = k_radix_hist -> k_radix_scatter (tile at a time) or k_radix_scatter_chunk (the depth sort's packed passes: a
+// workgroup's whole chunk staged in LDS, one store sweep).  The histogram kernel leaves a two-level table: one 1 KiB row of
+// digit counts per workgroup plus one row per GROUP of 32 workgroups (atomics, 32 adders per word); every scatter workgroup
+// sums the group rows and the <= 31 rows of its own group that precede it (coalesced 1 KiB rows, batches of 8 loads) and scans
+// the 256 digit totals itself, so no separate scan kernel (10.7 us and two kernel boundaries per pass on MI355X) sits
 // between the two.  Deterministic: integer sums only, no inter-workgroup spinning, no dependence on dispatch order
-// (cdna_hip_programming.md §6 G16).  A fixed grid of <= RADIX_MAX_BLOCKS = 512 workgroups walks contiguous runs of
-// 4096-key tiles (C3's depth sort: 472 workgroups x 3 tiles), so the table stays <= 0.5 MB whatever N is, and N may
-// live in device memory (the tile-entry count and the length of a frustum-culled list only exist on the device).
+// (cdna_hip_programming.md §6 G16).  A workgroup walks a contiguous run of 4096-key tiles (C3's depth sort: 472 workgroups x 3
+// tiles), the table has <= RADIX_MAX_BLOCKS rows whatever N is, and N may live in device memory (the tile-entry count and
+// the length of a frustum-culled list only exist on the device).
 //
 // Ranking inside a tile is wave64-native.  Fast path (ATOMIC_RANK): one `ds_add_rtn_u32` on a per-wave LDS
 // histogram per key.  gfx950's LDS serves the lanes of ONE wave instruction that hit the same address in ascending
@@ -283,20 +284,23 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
 //               positions -> 4 bytes per element instead of 2 + 4, and digit runs of whole words).  The digit cannot be
 //               recovered from that word, so the staging area holds it as a byte (KeyOutT = uint8_t).
 //
-// Geometry (round 4): 512 threads = 8 waves x 8 keys per lane over a 4096-key tile, <= 64 VGPRs and <= 40 KB LDS, so that
-// FOUR workgroups (32 waves) share a CU, on a grid of up to RADIX_MAX_BLOCKS = 1024 workgroups: a tile is a chain of
-// load -> rank -> scan -> reorder -> store phases with a memory round trip at either end, and what hides those is the other
-// workgroups of the CU.  (Rounds 1-3 ran <= 512 workgroups of 82-91 VGPRs: fewer than two per CU.  The r03 kernel table had
-// pass 0 of the C3 depth sort at 42.9 us for 81 MB.)  Per tile there are four barriers: ranks are taken on a per-wave
-// histogram that only its own wave zeroes and increments (no barrier between the two), the digit offsets of all waves are
-// folded into that same table (one LDS look-up per key in the reorder), and the running global base of every digit lives in a
-// register of the thread that owns the digit.  The first tile's loads are issued BEFORE the offset prologue's, so both round
-// trips overlap.
+// Geometry: 512 threads = 8 waves x 8 keys per lane over a 4096-key tile on a grid of <= RADIX_TILE_GRID = 512 workgroups
+// (fewer, longer workgroups win: gs_internal.hpp).  A tile is a chain of load -> rank -> offsets -> reorder -> store phases;
+// round 4 cut it to three barriers: ranks are taken on a per-wave histogram that only its own wave zeroes and increments (no
+// barrier between the two), ONE wave turns all counts into offsets (four digits per lane, 16-byte LDS accesses, the scan over
+// the 256 digits on the DPP network), the offsets are folded into the per-wave table (one LDS look-up per key in the reorder),
+// a full tile is stored without predicates (all LDS reads, then all stores), and the next tile's loads are issued before the
+// stores of this one (the first tile's before the offset prologue's), as branch-free batches with 32-bit offsets.
+// Measured (isolated C3 depth sort, same box, profiles/r04*): r03 0.0865 ms -> 0.0717 ms with this kernel for both passes ->
+// 0.0667 ms with the chunk-staged kernel below for the packed passes (which the depth sort uses whenever it can; this kernel
+// remains for key + value sorts - the tile-entry sort, the octree and Morton sorts - and for lists of more than 25 M keys).
+// 64 VGPRs (4 workgroups per CU) was tried and is slower (spills; and more than two workgroups per CU do not help: r04a
+// 1024-workgroup grids 0.0795-0.0822 ms against 0.0727-0.0748 at 512).
 #ifndef SCATTER_THREADS_CFG
-#define SCATTER_THREADS_CFG 1024
+#define SCATTER_THREADS_CFG 512
 #endif
 #ifndef SCATTER_OCC_CFG
-#define SCATTER_OCC_CFG 8              // waves per SIMD the register allocation must allow (8 <=> 64 VGPRs <=> 4 workgroups of 512)
+#define SCATTER_OCC_CFG 5              // waves per SIMD the register allocation must allow (5 <=> 96 VGPRs <=> 2 workgroups of 512 per CU)
 #endif
 constexpr int SCATTER_THREADS = SCATTER_THREADS_CFG;
 constexpr int SCATTER_WAVES = SCATTER_THREADS / 64;
@@ -369,33 +373,26 @@ __global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scat
         // workgroups; SCATTER_PARTS threads per digit split the rows, every load is independent of the others
         const uint32_t d = tid & 255u, half = tid >> 8;      // `half` = which of the SCATTER_PARTS row subsets
         const uint32_t g = ch.id / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
-        // fixed trip counts, fully unrolled and predicated: every load of the prologue is in flight at once
-        constexpr uint32_t GROUP_LOADS = (RADIX_MAX_GROUPS + SCATTER_PARTS - 1) / SCATTER_PARTS;
-        constexpr uint32_t ROW_LOADS = (RADIX_GROUP + SCATTER_PARTS - 1) / SCATTER_PARTS;
         uint32_t before = 0, all = 0;
-        {
-            // (unconditional loads of clamped rows + a select: one batch of loads, no exec-masked branch per load)
-            uint32_t gv[GROUP_LOADS];
+        if (ch.tile_begin < ch.tile_end) fetch_tile(ch.tile_begin);      // the first tile travels with the table rows
+        // batches of 8 independent loads (clamped rows + selects: no exec-masked branch per load); two to four round trips to L2
+        for (uint32_t r0 = half; r0 < groups; r0 += 8u * SCATTER_PARTS) {
+            uint32_t v[8];
 #pragma unroll
-            for (uint32_t k = 0; k < GROUP_LOADS; k++) {
-                const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
-                gv[k] = ld32(group_hist, min(r, groups - 1u) * RADIX_BINS + d);
+            for (uint32_t k = 0; k < 8u; k++) v[k] = ld32(group_hist, min(r0 + k * SCATTER_PARTS, groups - 1u) * RADIX_BINS + d);
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t r = r0 + k * SCATTER_PARTS;
+                all += r < groups ? v[k] : 0u;
+                before += r < g ? v[k] : 0u;
             }
-            uint32_t rv[ROW_LOADS];
+        }
+        for (uint32_t r0 = g * RADIX_GROUP + half; r0 < ch.id; r0 += 8u * SCATTER_PARTS) {
+            uint32_t v[8];
 #pragma unroll
-            for (uint32_t k = 0; k < ROW_LOADS; k++) {
-                const uint32_t r = g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS;
-                rv[k] = ld32(block_hist, min(r, ch.id) * RADIX_BINS + d);
-            }
-            if (ch.tile_begin < ch.tile_end) fetch_tile(ch.tile_begin);      // the first tile travels with the table rows
+            for (uint32_t k = 0; k < 8u; k++) v[k] = ld32(block_hist, min(r0 + k * SCATTER_PARTS, ch.id) * RADIX_BINS + d);
 #pragma unroll
-            for (uint32_t k = 0; k < GROUP_LOADS; k++) {
-                const uint32_t r = half + k * (uint32_t)SCATTER_PARTS;
-                all += r < groups ? gv[k] : 0u;
-                before += r < g ? gv[k] : 0u;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < ROW_LOADS; k++) before += (g * RADIX_GROUP + half + k * (uint32_t)SCATTER_PARTS) < ch.id ? rv[k] : 0u;
+            for (uint32_t k = 0; k < 8u; k++) before += (r0 + k * SCATTER_PARTS) < ch.id ? v[k] : 0u;
         }
         uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop uses it
         uint32_t* s_all = &s_wave[SCATTER_PARTS][0];
@@ -563,13 +560,232 @@ __global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scat
 }
 
 // ---------------------------------------------------------------------------------------------------
+// chunk-staged scatter (round 4): the depth sort's passes
+// ---------------------------------------------------------------------------------------------------
+// The tile kernel above stores every 4096-key tile on its own: 256 digit runs of ~16 keys = 64 bytes each, at arbitrary
+// alignment, and gfx950's L2 forwards a store to the fabric as it arrives (MI355X_MICROARCH.md: "all bytes leave L2 every pass"),
+// so a 64-byte run costs two 64-byte write requests - the counters had pass 0 at 1.95x its algorithmic write bytes
+// (profiles/r04c).  Here a workgroup keeps its WHOLE chunk (<= CHUNK_TILES tiles) in LDS: the histogram kernel's row of this
+// chunk already holds its digit counts, so every key's final staging slot is known while the tiles are still being ranked, and
+// ONE sweep at the end stores digit runs that are CHUNK_TILES times longer (3 tiles: 48 keys = 192 bytes, 1.33 requests per
+// useful one).  A tile is rank -> barrier -> per-wave offsets -> barrier -> reorder (two barriers, no store phase, no digit scan);
+// the scan over the 256 digits happens once per chunk.  Elements travel as ONE word:
+//   PACK_OUT   out word = (key >> (shift + 8)) << val_bits | value (what the next pass reads), digit staged as a byte beside it;
+//   otherwise  the last pass after a packing one: staged digit << 24 | value (value < 2^24 whenever a pass packs 8 key bits), out = value.
+// Geometry: 512 threads, 8 keys per lane and tile; LDS = 5 (4) bytes per key of the chunk + 8 KB: two workgroups per CU.
+#ifndef CHUNK_TILES_CFG
+#define CHUNK_TILES_CFG 3
+#endif
+#ifndef CHUNK_THREADS_CFG
+#define CHUNK_THREADS_CFG 512
+#endif
+#ifndef CHUNK_OCC_CFG
+#define CHUNK_OCC_CFG 4
+#endif
+constexpr int CHUNK_TILES = CHUNK_TILES_CFG;
+constexpr int CHUNK_THREADS = CHUNK_THREADS_CFG;
+constexpr int CHUNK_WAVES = CHUNK_THREADS / 64;
+constexpr int CHUNK_ITEMS = RADIX_TILE / CHUNK_THREADS;
+constexpr int CHUNK_PARTS = CHUNK_THREADS / RADIX_BINS;
+constexpr int CHUNK_KEYS = CHUNK_TILES * RADIX_TILE;
+#ifndef CHUNK_TARGET_BLOCKS_CFG
+#define CHUNK_TARGET_BLOCKS_CFG 512
+#endif
+constexpr int CHUNK_TARGET_BLOCKS = CHUNK_TARGET_BLOCKS_CFG;                   // two workgroups per CU: the chunk length aims at this many of them
+static_assert(CHUNK_THREADS % RADIX_BINS == 0 && 2 * CHUNK_PARTS <= CHUNK_WAVES, "offset prologue layout");
+
+inline uint32_t radix_chunk_grid_for(uint32_t n_upper) {    // 0: too long for chunk-sized workgroups (the tile kernel takes it)
+    uint32_t tiles = (n_upper + RADIX_TILE - 1) / RADIX_TILE;
+    if (tiles < 1) tiles = 1;
+    uint32_t per = (tiles + CHUNK_TARGET_BLOCKS - 1) / CHUNK_TARGET_BLOCKS;
+    if (per > (uint32_t)CHUNK_TILES) per = CHUNK_TILES;
+    const uint32_t grid = (tiles + per - 1) / per;
+    return grid <= (uint32_t)RADIX_MAX_BLOCKS ? grid : 0u;
+}
+
+template <class Loader, bool PACK_OUT, bool ATOMIC_RANK>
+__global__ __launch_bounds__(CHUNK_THREADS, CHUNK_OCC_CFG) void k_radix_scatter_chunk(Loader ld, int shift,
+                                                                                     const uint32_t* __restrict__ block_hist,
+                                                                                     const uint32_t* __restrict__ group_hist,
+                                                                                     uint32_t* __restrict__ out, uint32_t val_bits) {
+    __shared__ uint32_t s_stage[CHUNK_KEYS];
+    __shared__ uint8_t s_digit[PACK_OUT ? CHUNK_KEYS : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_wave[CHUNK_WAVES][RADIX_BINS];   // per-wave digit counts, then first slot of (wave, digit)
+    __shared__ uint32_t s_run[RADIX_BINS];                  // next staging slot of each digit
+    __shared__ uint32_t s_gbase[RADIX_BINS];                // global slot of a digit's run minus its staging slot
+    __shared__ uint32_t s_tmp[CHUNK_WAVES];
+
+    ld.prepare();
+    const RadixChunk ch = radix_chunk(ld.count());
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    volatile uint32_t* my_hist = s_wave[wave];
+
+    uint32_t okm = 0;
+    typename Loader::Raw raw[CHUNK_ITEMS];
+    auto fetch_tile = [&](uint32_t tile) {
+        const uint32_t wbase = tile * RADIX_TILE + wave * (64 * CHUNK_ITEMS) + lane;
+        uint32_t o[CHUNK_ITEMS];
+        okm = 0;
+#pragma unroll
+        for (int r = 0; r < CHUNK_ITEMS; r++) {
+            const uint32_t j = wbase + r * 64;
+            const bool in = j < ch.n;
+            const uint32_t jc = in ? j : ch.n - 1u;
+            const bool ok = in && ld.valid(jc);
+            o[r] = ld.pre(jc);
+            okm |= ok ? (1u << r) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < CHUNK_ITEMS; r++) {
+            const uint32_t j = wbase + r * 64;
+            raw[r] = ld.fetch(j < ch.n ? j : ch.n - 1u, o[r]);
+        }
+    };
+    if (ch.tile_begin < ch.tile_end) fetch_tile(ch.tile_begin);         // travels with the table rows below
+
+    uint32_t chunk_count = 0;
+    {   // global slot of this chunk's first key of every digit = keys with a smaller digit + keys of the digit in earlier chunks
+        const uint32_t d = tid & 255u, part = tid >> 8;
+        const uint32_t g = ch.id / RADIX_GROUP, groups = (gridDim.x + RADIX_GROUP - 1) / RADIX_GROUP;
+        uint32_t before = 0, all = 0;
+        // batches of 8 independent loads (clamped rows + selects: no exec-masked branch per load); two to four round trips to L2
+        for (uint32_t r0 = part; r0 < groups; r0 += 8u * CHUNK_PARTS) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) v[k] = ld32(group_hist, min(r0 + k * CHUNK_PARTS, groups - 1u) * RADIX_BINS + d);
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) {
+                const uint32_t r = r0 + k * CHUNK_PARTS;
+                all += r < groups ? v[k] : 0u;
+                before += r < g ? v[k] : 0u;
+            }
+        }
+        for (uint32_t r0 = g * RADIX_GROUP + part; r0 < ch.id; r0 += 8u * CHUNK_PARTS) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) v[k] = ld32(block_hist, min(r0 + k * CHUNK_PARTS, ch.id) * RADIX_BINS + d);
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) before += (r0 + k * CHUNK_PARTS) < ch.id ? v[k] : 0u;
+        }
+        const uint32_t own = tid < RADIX_BINS ? ld32(block_hist, ch.id * RADIX_BINS + d) : 0u;    // this chunk's keys of digit d
+        uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop uses it
+        uint32_t* s_all = &s_wave[CHUNK_PARTS][0];
+        s_before[tid] = before;
+        s_all[tid] = all;
+        __syncthreads();
+        uint32_t tot = 0, mine = 0;
+        if (tid < RADIX_BINS) {
+#pragma unroll
+            for (int q = 0; q < CHUNK_PARTS; q++) {
+                tot += s_all[q * RADIX_BINS + tid];
+                mine += s_before[q * RADIX_BINS + tid];
+            }
+        }
+        const uint32_t smaller = block_excl_scan<CHUNK_WAVES>(tot, s_tmp, nullptr);
+        const uint32_t first = block_excl_scan<CHUNK_WAVES>(own, s_tmp, &chunk_count);   // first staging slot of digit d
+        if (tid < RADIX_BINS) {
+            s_run[tid] = first;
+            s_gbase[tid] = smaller + mine - first;
+        }
+    }
+    *reinterpret_cast<uint4*>(&s_wave[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);    // every wave zeroes and increments only its own row
+
+    for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile++) {
+        uint32_t a[CHUNK_ITEMS], dg[CHUNK_ITEMS], rk[CHUNK_ITEMS];
+#pragma unroll
+        for (int r = 0; r < CHUNK_ITEMS; r++) {
+            uint32_t k = 0xFFFFFFFFu, v = 0u;
+            ld.decode(raw[r], k, v);
+            dg[r] = (k >> shift) & 255u;
+            a[r] = PACK_OUT ? (((k >> (shift + 8)) << val_bits) | v) : ((dg[r] << 24) | v);
+        }
+        if (ATOMIC_RANK) {
+#pragma unroll
+            for (int r = 0; r < CHUNK_ITEMS; r++) {
+                rk[r] = 0u;
+                if ((okm >> r) & 1u) rk[r] = atomicAdd(&s_wave[wave][dg[r]], 1u);   // same-digit lanes are served in lane order (header)
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < CHUNK_ITEMS; r++) {
+                const uint32_t digit = dg[r];
+                const bool ok = (okm >> r) & 1u;
+                uint64_t same = __ballot(ok);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const uint64_t vote = __ballot(ok && ((digit >> bit) & 1u));
+                    same &= ((digit >> bit) & 1u) ? vote : ~vote;
+                }
+                rk[r] = 0u;
+                if (ok) {
+                    const uint32_t prior = my_hist[digit];
+                    rk[r] = prior + __popcll(same & lt_mask);
+                    if ((same >> lane) == 1ull) my_hist[digit] = prior + __popcll(same);
+                }
+            }
+        }
+        __syncthreads();                                     // (1) every wave's counts of this tile are final
+        if (tid < RADIX_BINS) {                              // thread d: counts -> first slot of (wave, d), the digit's next slot moves on
+            uint32_t run = s_run[tid];
+#pragma unroll
+            for (int w = 0; w < CHUNK_WAVES; w++) {
+                const uint32_t c = s_wave[w][tid];
+                s_wave[w][tid] = run;
+                run += c;
+            }
+            s_run[tid] = run;
+        }
+        __syncthreads();                                     // (2)
+#pragma unroll
+        for (int r = 0; r < CHUNK_ITEMS; r++) {
+            if ((okm >> r) & 1u) {
+                const uint32_t pos = s_wave[wave][dg[r]] + rk[r];
+                s_stage[pos] = a[r];
+                if (PACK_OUT) s_digit[pos] = (uint8_t)dg[r];
+            }
+        }
+        okm = 0;
+        if (tile + 1 < ch.tile_end) fetch_tile(tile + 1);   // the registers are free: the next tile's reads travel meanwhile
+        *reinterpret_cast<uint4*>(&s_wave[wave][4 * lane]) = make_uint4(0u, 0u, 0u, 0u);   // own row, read for the last time above
+    }
+    __syncthreads();                                         // the chunk is staged
+    const uint32_t vmask = 0x00FFFFFFu;
+    for (uint32_t e0 = 0; e0 < chunk_count; e0 += 8u * CHUNK_THREADS) {
+        if (e0 + 8u * CHUNK_THREADS <= chunk_count) {        // all LDS reads first, then the stores, no predicate
+            uint32_t w[8], g[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t e = e0 + k * CHUNK_THREADS + tid;
+                w[k] = s_stage[e];
+                g[k] = PACK_OUT ? (uint32_t)s_digit[e] : (w[k] >> 24);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) g[k] = s_gbase[g[k]] + (e0 + k * CHUNK_THREADS + tid);
+#pragma unroll
+            for (int k = 0; k < 8; k++) st32(out, g[k], PACK_OUT ? w[k] : (w[k] & vmask));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t e = e0 + k * CHUNK_THREADS + tid;
+                if (e < chunk_count) {
+                    const uint32_t w = s_stage[e];
+                    const uint32_t d = PACK_OUT ? (uint32_t)s_digit[e] : (w >> 24);
+                    st32(out, s_gbase[d] + e, PACK_OUT ? w : (w & vmask));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host launcher for one pass
 // ---------------------------------------------------------------------------------------------------
 inline uint32_t radix_grid_for(uint32_t n_upper) {
     uint32_t tiles = (n_upper + RADIX_TILE - 1) / RADIX_TILE;
     if (tiles < 1) tiles = 1;
-    if (tiles <= (uint32_t)RADIX_MAX_BLOCKS) return tiles;
-    const uint32_t per = (tiles + RADIX_MAX_BLOCKS - 1) / RADIX_MAX_BLOCKS;
+    if (tiles <= (uint32_t)RADIX_TILE_GRID) return tiles;
+    const uint32_t per = (tiles + RADIX_TILE_GRID - 1) / RADIX_TILE_GRID;
     return (tiles + per - 1) / per;
 }
 
@@ -588,6 +804,22 @@ int radix_pass_ex(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift
     else
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false, PACK_OUT>), dim3(grid), dim3(SCATTER_THREADS), 0,
                            ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+// A pass of the depth sort between / after packing passes (see k_radix_scatter_chunk); the caller checked radix_chunk_grid_for.
+template <class HistLoader, class Loader, bool PACK_OUT>
+int radix_pass_chunk(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift, const Loader& ld, uint32_t n_upper, int shift,
+                     int pass_slot, uint32_t* out, uint32_t val_bits) {
+    const uint32_t grid = radix_chunk_grid_for(n_upper);
+    uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
+    uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
+    hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
+    if (ex.atomic_rank)
+        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, true>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits);
+    else
+        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, false>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

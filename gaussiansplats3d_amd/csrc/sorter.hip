@@ -877,6 +877,10 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         uint32_t val_bits = 1;
         while (val_bits < 32u && (kp.last_splat >> val_bits)) val_bits++;
         static const bool no_pack = getenv("GSPLAT_NO_SORT_PACK") != nullptr;       // A/B and tests: the unpacked path
+        static const bool no_chunk = getenv("GSPLAT_NO_SORT_CHUNK") != nullptr;     // ... the tile-at-a-time scatter for packed passes
+        // packed passes stage a whole chunk in LDS (radix.hpp) when the list is short enough for <= CHUNK_TILES tiles per
+        // workgroup and the payload leaves 8 bits for the digit beside it in the last pass's staging word
+        const bool chunked = !no_chunk && val_bits <= 24u && radix_chunk_grid_for(Rs) != 0u;
         const bool wide = s->precision > 16;
         bool in_packed = false;                                                       // the previous pass packed
         for (uint32_t p = 0; p < passes; p++) {
@@ -894,19 +898,23 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 dc.n_dev = dl.n_dev;
                 DepthLoaderCull h = dc;
                 h.count_clamps = 1;
-                if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
+                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoaderCull, DepthLoaderCull, true>(ex, h, shift, dc, Rs, shift, (int)p, vo, val_bits)));
+                else if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
                 else if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
                 else GS_TRY((radix_pass<DepthLoaderCull, uint16_t, true>(ex, h, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
             } else if (p == 0) {
                 DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
                 h.count_clamps = 1;
-                if (pack) GS_TRY((radix_pass_ex<DepthLoader, DepthLoader, uint8_t, false, false, true>(ex, h, shift, dl, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
+                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoader, DepthLoader, true>(ex, h, shift, dl, Rs, shift, (int)p, vo, val_bits)));
+                else if (pack) GS_TRY((radix_pass_ex<DepthLoader, DepthLoader, uint8_t, false, false, true>(ex, h, shift, dl, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
                 else if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
                 else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ex, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
             } else if (in_packed) {
                 PackedLoader pl = {vbuf[(p - 1) & 1], n_dev, Rs, val_bits};
                 ArrayLoader<uint32_t> ph = {vbuf[(p - 1) & 1], nullptr, n_dev, Rs};
-                if (last) GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, PackedLoader, uint8_t, false, false, false>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, 0u)));
+                if (chunked && last) GS_TRY((radix_pass_chunk<ArrayLoader<uint32_t>, PackedLoader, false>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, vo, 0u)));
+                else if (chunked) GS_TRY((radix_pass_chunk<ArrayLoader<uint32_t>, PackedLoader, true>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, vo, val_bits)));
+                else if (last) GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, PackedLoader, uint8_t, false, false, false>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, 0u)));
                 else GS_TRY((radix_pass_ex<ArrayLoader<uint32_t>, PackedLoader, uint8_t, false, false, true>(ex, ph, (int)val_bits, pl, Rs, 0, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
             } else if (wide) {
                 ArrayLoader<uint32_t> al = {(const uint32_t*)kbuf[(p - 1) & 1], vbuf[(p - 1) & 1], n_dev, Rs};

@@ -93,6 +93,28 @@ def pmc_frame_traffic(config="C3"):
     return int(d["frame_hbm_bytes"]), src
 
 
+SORT_KERNELS = ("k_depth_key", "k_minmax_count", "k_mask_compact", "k_radix_hist<DepthLoader", "k_radix_hist<ArrayLoader<unsigned int>",
+                "k_radix_hist<ArrayLoader<unsigned short>", "k_radix_scatter_chunk", "k_radix_scatter<DepthLoader", "k_radix_scatter<PackedLoader")
+
+
+def sort_profile(config="C3"):
+    """The depth sort's kernels in the newest committed profiles of THIS config: per-kernel microseconds per frame from the
+    rocprofv3 kernel table (profiles/*_kstats.json, tools/kstats.py) and counter bytes per frame (profiles/*pmc_traffic.json).
+    The tile-entry sort's 16-bit-key kernels are the draw's, not the sort's; the 32-bit-key instances run at upload only."""
+    out = {"per_kernel_us": None, "kernel_us_sum": None, "kernels_source": None, "counter_bytes": None, "counter_source": None}
+    d, src = _newest_profile("*_kstats.json", config)
+    if d is not None:
+        ks = {n: v["us_per_frame"] for n, v in d["kernels"].items()
+              if n.startswith(SORT_KERNELS) and "unsigned short" not in n and not (n.startswith("k_radix_scatter<ArrayLoader"))}
+        out["per_kernel_us"], out["kernel_us_sum"], out["kernels_source"] = ks, round(sum(ks.values()), 2), src
+    d, src = _newest_profile("*pmc_traffic.json", config)
+    if d is not None and "frame_kernels_bytes_per_frame" in d:
+        b = sum(v for n, v in d["frame_kernels_bytes_per_frame"].items()
+                if n.startswith(SORT_KERNELS) and "unsigned short" not in n)
+        out["counter_bytes"], out["counter_source"] = int(b), src
+    return out
+
+
 def pmc_valu(kernel, config="C3"):
     """VALU-busy fraction of `kernel` from the newest committed SQ counter pass (profiles/*pmc_valu.json)."""
     d, src = _newest_profile("*pmc_valu.json", config)
@@ -863,6 +885,24 @@ def main():
                          # the vertex stage is co-limited: its SIMDs issue vector instructions most of the launch as well
                          "valu_busy_frac": proj_valu.get("valu_busy_frac") if proj_valu else None,
                          "visible_splats": visible, "note": roof_note},
+            # the depth sort (the north star's first half): all of its kernels together.  `achieved` / `frac` price SURVEY 8d's
+            # FORMULA (56 bytes per sorted splat for two radix passes) against the sort's device time in the frames (the library's
+            # HIP events around the sort, median of the synchronised frames below); `traffic` is what the COUNTERS saw the sort's
+            # kernels move per frame ((2 x FETCH_SIZE + WRITE_SIZE) of a separate rocprofv3 --pmc pass), `engine_bytes` what the
+            # passes have to move by construction (keys 12 r + 4 w, two histograms 4 r each, pass 0: 4 r key + 4 r payload map + 4 w
+            # packed word, pass 1: 4 r + 4 w)
+            "roofline_sort": (lambda sp, sms: {
+                "bound": "hbm", "kernels": "k_depth_key + 2 x (k_radix_hist + k_radix_scatter_chunk)",
+                "sort_ms": round(sms, 4) if sms else None, "sort_ms_source": "gs_sort_stats.device_ms, median of the synchronised frames",
+                "algorithmic_bytes": 56 * Rs, "algorithmic_bytes_source": "SURVEY 8d formula: 56 B per sorted splat",
+                "achieved": round(56 * Rs / (sms * 1e-3) / 1e9, 1) if sms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(56 * Rs / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sms else None,
+                "engine_bytes": 48 * Rs,
+                "traffic": sp["counter_bytes"], "traffic_source": sp["counter_source"],
+                "traffic_frac": round(sp["counter_bytes"] / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (sp["counter_bytes"] and sms) else None,
+                "per_kernel_us": sp["per_kernel_us"], "kernel_us_sum": sp["kernel_us_sum"], "kernels_source": sp["kernels_source"],
+                "verdict": "frac is the formula's; traffic_frac the counters' - the sort moves fewer bytes than the formula charges"
+            })(sort_profile(headline), stage_ms.get("sort")) if world == 1 else None,
             # the largest kernel of the frame
             "blend": {"kernel": "k_tile_blend", "bound": "valu", "ms": round(blend_ms, 4) if blend_ms else None,
                       "splats_walked": walked, "halves_evaluated": halves, "entries_scanned": scanned, "list_entries": M["D32"],

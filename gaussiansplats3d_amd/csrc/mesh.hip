@@ -422,8 +422,16 @@ static int mesh_upload_segment(gs_mesh* m, uint32_t from, uint32_t count, const 
     if (ncoef)
         hipLaunchKernelGGL(k_split_sh, g, b, 0, st, (const uint16_t*)(stg + off_sh), count, from, perm, ncoef, m->sh0.as<uint4>(),
                            m->sh1.p, m->sh2.as<uint4>());
-    {   // the boxes of the storage blocks this segment touches (its splats own the slots [from, from + count))
-        const uint32_t b0 = from / 256u, b1 = (from + count + 255u) / 256u;
+    {   // The boxes of the storage blocks this segment touches.  A fresh segment owns the slots [from, from + count); splats
+        // uploaded before keep THEIR slots, scattered over the Morton run(s) of the earlier upload(s) - anywhere inside the merged
+        // slotted range that contains the segment (segments are cut at the borders of those ranges): all of its blocks are redone.
+        // (only [from, from + count) was redone, so a block kept the box of the data it held before the edit and
+        // k_project's block cull could drop splats that had moved into view.)
+        uint32_t lo = from, hi = from + count;
+        if (!fresh && m->reorder)
+            for (const auto& r : m->slotted)
+                if (r.first <= from && from + count <= r.second) { lo = r.first; hi = r.second; }
+        const uint32_t b0 = lo / 256u, b1 = (hi + 255u) / 256u;
         hipLaunchKernelGGL(k_block_boxes, dim3(b1 - b0), dim3(256), 0, st, m->px.as<float>(), m->py.as<float>(), m->pz.as<float>(),
                            m->cov_bound.as<float>(), m->max_count, b0, m->block_box.as<float>());
     }

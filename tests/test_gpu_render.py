@@ -507,6 +507,43 @@ def test_out_of_range_indexes_are_harmless(ctx):
         m.dispose()
 
 
+def test_block_boxes_follow_a_re_upload_of_moved_splats(ctx, monkeypatch):
+    """Splats uploaded before keep their storage slots (scattered over the Morton run of the first upload), so replacing the
+    data of a sub-range must redo the block boxes of every block of that run, not of [from, from + count) - else a block keeps
+    the box of what it held before and k_project's whole-block test drops splats that moved into view.
+    The scene sits behind the camera, a sub-range is moved in front of it: the frame must equal the one drawn with the block test
+    off, and it must not be empty."""
+    n = 6000
+    scene = scenes.scene_like(n, 1, 777)
+    W, H = 320, 192
+    cam = camera.PerspectiveCamera(W, H, (0.0, 0.0, 0.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0))
+    moved = scenes.scene_like(n, 1, 777)
+    behind = scene.centers.copy()
+    behind[:, 2] = np.abs(behind[:, 2]) + 12.0                          # every splat behind the camera (it looks down -z)
+    scene.centers[:] = behind
+    moved.centers[:] = behind
+    lo, hi = 1000, 2500
+    moved.centers[lo:hi, 2] = -(np.abs(moved.centers[lo:hi, 2]) - 12.0) - 3.0      # ... this range in front of it
+    frames = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("GSPLAT_NO_BLOCK_CULL", "1")
+        m = build_mesh(ctx, scene)
+        if off:
+            monkeypatch.delenv("GSPLAT_NO_BLOCK_CULL")
+        m.set_camera(cam)
+        m.update_render_indexes(sorted_order(scene, cam), n)
+        assert int(m.render()[1].visible_splats) == 0
+        m.build(moved.centers[lo:hi], moved.cov[lo:hi], moved.rgba[lo:hi], moved.sh[lo:hi], start=lo)
+        m.update_render_indexes(sorted_order(moved, cam), n)
+        f, st = m.render()
+        frames.append((f, int(st.visible_splats)))
+        m.dispose()
+    assert frames[1][1] > 100
+    assert frames[0][1] == frames[1][1]
+    np.testing.assert_array_equal(frames[0][0], frames[1][0])
+
+
 def test_block_level_cull_changes_nothing(ctx, monkeypatch):
     """k_project drops whole 256-splat storage blocks whose box fails the frustum (or cannot reach the rank's strip) before it
     reads their centres.  Same frames, same visible counts and the same per-splat visibility masks as with the block test off

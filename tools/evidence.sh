@@ -13,10 +13,11 @@ python tools/pmc_traffic.py gpurun_out/pmc_$TAG gpurun_out/$TAG/pmc_traffic.json
 python tools/pmc_valu.py gpurun_out/pmc_$TAG gpurun_out/$TAG/pmc_valu.json > gpurun_out/$TAG/pmc_valu.txt 2>&1
 # the bench reads the counter summaries from profiles/: stage this run's so that the line it prints quotes them
 cp gpurun_out/$TAG/pmc_traffic.json profiles/${TAG}_pmc_traffic.json; cp gpurun_out/$TAG/pmc_valu.json profiles/${TAG}_pmc_valu.json
-(timeout 700 python bench.py 2>gpurun_out/$TAG/bench.err | tail -1) > gpurun_out/$TAG/bench.json
 bash tools/prof.sh ${TAG}_kstats > gpurun_out/$TAG/kstats.txt 2>&1
 cp gpurun_out/${TAG}_kstats/kernel_stats.csv gpurun_out/$TAG/kernel_stats.csv
 cp gpurun_out/${TAG}_kstats/bench_under_rocprof.json gpurun_out/$TAG/bench_under_rocprof.json
+cp gpurun_out/${TAG}_kstats/kstats.json gpurun_out/$TAG/kstats.json; cp gpurun_out/$TAG/kstats.json profiles/${TAG}_kstats.json   # (the line's per-kernel sort times)
+(timeout 700 python bench.py 2>gpurun_out/$TAG/bench.err | tail -1) > gpurun_out/$TAG/bench.json
 for C in C2 C4 C5; do (timeout 300 python bench.py --config $C --no-cpu --no-cull --steps 30 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_$C.json; done
 (timeout 200 python bench.py --config C1 --steps 30 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_C1.json
 # C4: the configuration where the binner and the entry sort weigh most

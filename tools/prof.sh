@@ -12,4 +12,5 @@ cd /root/repo
 STATS=$(ls $OUT/prof/*/*_kernel_stats.csv | head -1)
 cp $STATS $OUT/kernel_stats.csv
 FRAMES=$(python -c "import json;print(json.load(open('$OUT/bench_under_rocprof.json'))['frames_drawn_before_timing_ended'])")
-python tools/kstats.py $OUT/kernel_stats.csv $FRAMES
+CFG=$(python -c "import json;print(json.load(open('$OUT/bench_under_rocprof.json'))['config']['workload'].split(':')[0])")
+python tools/kstats.py $OUT/kernel_stats.csv $FRAMES $OUT/kstats.json $CFG

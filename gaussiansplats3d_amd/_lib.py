@@ -56,7 +56,7 @@ class RenderStats(C.Structure):
     _fields_ = [("device_ms", C.c_float), ("project_ms", C.c_float), ("bin_ms", C.c_float),
                 ("tile_sort_ms", C.c_float), ("blend_ms", C.c_float), ("visible_splats", C.c_uint32),
                 ("tile_entries", C.c_uint64), ("entry_capacity", C.c_uint32), ("overflowed", C.c_uint32),
-                ("tiles16", C.c_uint64), ("list_bin_px", C.c_uint32), ("pad", C.c_uint32),
+                ("tiles16", C.c_uint64), ("list_bin_px", C.c_uint32), ("flags", C.c_uint32),
                 ("entries_scanned", C.c_uint64), ("splats_walked", C.c_uint64), ("halves_evaluated", C.c_uint64)]
 
 

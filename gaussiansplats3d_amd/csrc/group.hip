@@ -148,9 +148,25 @@ int gs_group_set_overlap(gs_group* g, int enabled) {
     GS_REQUIRE(g, "group == NULL");
     ScopedDevice sd(g->ctx->device);
     if (enabled && !g->coll) {
-        GS_HIP(hipStreamCreateWithFlags(&g->coll, hipStreamNonBlocking));
-        GS_HIP(hipEventCreateWithFlags(&g->ready, hipEventDisableTiming));
-        for (hipEvent_t& e : g->done) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        // created into locals and committed together: a failure half-way must not leave a stream without its events behind
+        // (a later call would skip creation and record / wait on null events)
+        hipStream_t coll = nullptr;
+        hipEvent_t ready = nullptr;
+        constexpr size_t ND = sizeof(g->done) / sizeof(g->done[0]);
+        hipEvent_t done[ND] = {};
+        bool ok = hipStreamCreateWithFlags(&coll, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ready, hipEventDisableTiming) == hipSuccess;
+        for (size_t k = 0; ok && k < ND; k++) ok = hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+            if (ready) (void)hipEventDestroy(ready);
+            if (coll) (void)hipStreamDestroy(coll);
+            gs_set_error("gs_group_set_overlap: creating the gather stream / events failed");
+            return GS_ERR_HIP;
+        }
+        g->coll = coll;
+        g->ready = ready;
+        for (size_t k = 0; k < ND; k++) g->done[k] = done[k];
     }
     if (!enabled && g->overlap) {                          // back on the context's stream: nothing may still be in flight
         GS_HIP(hipStreamSynchronize(g->coll));

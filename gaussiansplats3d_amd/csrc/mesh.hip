@@ -572,6 +572,13 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;
     m->last.list_bin_px = GS_TILE << m->drawn_list_shift;
+    m->last.flags = 0;
+    if (m->deep_flags.p) {                                 // the chunked composite's per-draw words (tile_blend.hip)
+        uint32_t w[8];
+        GS_HIP(hipMemcpyAsync(w, m->deep_flags.p, sizeof(w), hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (w[GS_FLAG_POOL_OVER]) m->last.flags |= GS_DRAW_POOL_EXHAUSTED;
+    }
     m->last.entries_scanned = 0;
     m->last.splats_walked = 0;
     m->last.halves_evaluated = 0;

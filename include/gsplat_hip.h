@@ -307,6 +307,7 @@ typedef struct gs_camera {
 #define GS_CAM_SCENE_EFFECTS 16u /* enableOptionalEffects: per-scene opacity / visibility, SplatMaterial.js:129 */
 #define GS_CAM_DYNAMIC 32u       /* dynamicMode: per-scene transforms, SplatMaterial.js:140-144,179-183         */
 #define GS_TILE 16u
+#define GS_DRAW_POOL_EXHAUSTED 1u   /* gs_render_stats.flags */
 
 typedef struct gs_render_stats {
     float device_ms;          /* whole draw; the five times are 0 after a draw made without `stats` and
@@ -319,12 +320,16 @@ typedef struct gs_render_stats {
     uint64_t tiles16;         /* D of SURVEY.md 8d = sum over splats of 16x16-px tiles touched               */
     uint32_t list_bin_px;     /* edge of a list bin of this draw (32 or 128): the unit of the entry lists and of
                                  gs_mesh_debug_read(what = 2); chosen per mesh from the previous measured draw    */
-    uint32_t pad;
+    uint32_t flags;           /* GS_DRAW_*: bit 0 = the per-bin blend ran out of chunk-partial slots (a list thousands of
+                                 splats deep outside the deep pass): the affected quadrants were composited as one long chunk -
+                                 still a valid front-to-back composite, but no longer bit-identical to what a strip of another
+                                 cut or the deep pass would produce (was `pad`, always 0, before round 4)                    */
     uint64_t entries_scanned; /* list entries the blend read before its pixels saturated (<= tile_entries per 32-px
                                  bin of a list)                                                                  */
     uint64_t splats_walked;   /* (splat, 16x16-px tile) pairs the blend evaluated                                */
-    uint64_t halves_evaluated; /* (splat, 16x8-px half tile) pairs among them whose 128 pixels were really evaluated: a
-                                 half the splat's ellipse cannot reach is skipped (ABI 3)                          */
+    uint64_t halves_evaluated; /* = 2 x splats_walked: both 16x8-px halves of a walked (splat, tile) pair are evaluated (the
+                                 per-half skip of ABI 3's first draft was measured slower and removed; the field stays
+                                 for layout compatibility)                                                         */
 } gs_render_stats;
 
 /* Entry-buffer overflow: a draw that returns statistics or pixels to the host checks and re-runs itself after growing the

@@ -408,6 +408,7 @@ static napi_value MeshRender(napi_env env, napi_callback_info info) {
     set(env, r, "tiles16", (double)stats.tiles16);
     set(env, r, "listBinPx", stats.list_bin_px);
     set(env, r, "overflowed", stats.overflowed);
+    set(env, r, "flags", (double)stats.flags);                 /* GS_DRAW_POOL_EXHAUSTED = 1 */
     set(env, r, "entriesScanned", (double)stats.entries_scanned);
     set(env, r, "splatsWalked", (double)stats.splats_walked);
     set(env, r, "halvesEvaluated", (double)stats.halves_evaluated);

@@ -123,6 +123,11 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
                                   "engine_vs_rop8_max": round(float(ours.max()), 3),
                                   "engine_vs_rop8_mean": round(float(ours.mean()), 4)})
         print(msg, "| rop8 gap max %.2f mean %.3f (1/255 units)" % (gap.max(), gap.mean()))
+        # The reference's real target is RGBA8 and rounds after every splat (SplatMaterial3D.js:65-75); the engine composites in
+        # fp32 and rounds once.  The distance between the two is not an engine error, but it is GATED so that it cannot grow
+        # unnoticed: worst 3-4 and mean 0.3-0.9 of 1/255 on every window of rounds 2-3 (profiles/r03z_crops_*.json).
+        assert ours.max() <= 4.0 and ours.mean() <= 1.0, \
+            f"{tag} {name}: engine vs the RGBA8-ROP-emulating oracle: max {ours.max():.2f} mean {ours.mean():.3f} (limits 4 / 1.0 of 1/255)"
     report["ambiguous_pixels_total"] = amb_pixels
     report["entries_scanned"] = int(stats.entries_scanned)
     report["splats_walked"] = int(stats.splats_walked)

@@ -167,7 +167,9 @@ rig = T.Rig(c, T._pile(60000, 41), camera.demo_camera("garden", 480, 270))
 rig.mesh.set_deep_pass(False)
 f, st = rig.draw()
 np.save({str(tmp_path / 'frame.npy')!r}, f)
-print(json.dumps(rig.mesh.deep_pass_info(), default=lambda o: o.tolist() if hasattr(o, 'tolist') else o))
+info = rig.mesh.deep_pass_info()
+info["stats_flags"] = int(st.flags)                  # gs_render_stats.flags: the draw itself says so (GS_DRAW_POOL_EXHAUSTED)
+print(json.dumps(info, default=lambda o: o.tolist() if hasattr(o, 'tolist') else o))
 rig.close(); c.close()
 """
     infos = []
@@ -180,5 +182,6 @@ rig.close(); c.close()
         infos.append((json.loads(out.stdout.strip().splitlines()[-1]), np.load(tmp_path / "frame.npy")))
     (small, f_small), (full, f_full) = infos
     assert small["pool_exhausted"] and not full["pool_exhausted"] and full["chunks_closed_by_bins"] >= 4
+    assert (small["stats_flags"] & 1) == 1 and (full["stats_flags"] & 1) == 0
     d = np.abs(f_small.astype(np.int32) - f_full.astype(np.int32))
     assert d.max() <= 1, int(d.max())

@@ -34,6 +34,7 @@ __global__ void k_stream(const uint4* __restrict__ p, size_t n16, uint32_t* out)
 
 template <class T, int PER>
 static void run(const char* what, const uint32_t* d_idx, const void* d_table, uint32_t n, size_t table_bytes, bool warm, void* d_trash, size_t trash_bytes, uint32_t* d_out, int grid) {
+    printf("start %s\n", what);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9f, sum = 0;
     for (int it = 0; it < 6; it++) {
@@ -46,10 +47,11 @@ static void run(const char* what, const uint32_t* d_idx, const void* d_table, ui
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (it > 0) { best = ms < best ? ms : best; sum += ms; }
     }
-    printf("%-44s n=%u table=%4zu MB %s grid=%4d per=%d: best %.3f ms  mean %.3f ms  = %.1f G gathers/s\n", what, n, table_bytes >> 20, warm ? "warm" : "cold", grid, PER, best, sum / 5, n / best / 1e6);
+    fflush(stdout); printf("%-44s n=%u table=%4zu MB %s grid=%4d per=%d: best %.3f ms  mean %.3f ms  = %.1f G gathers/s\n", what, n, table_bytes >> 20, warm ? "warm" : "cold", grid, PER, best, sum / 5, n / best / 1e6);
 }
 
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const uint32_t n = 16000000;
     std::vector<uint32_t> idx(n);
     for (uint32_t i = 0; i < n; i++) idx[i] = i;

@@ -719,7 +719,7 @@ def main():
                         "ms_per_frame": round(cull_ms, 4), "max_abs_diff_vs_cull_off_frame_u8": cull_diff,
                         "Msplats_per_s_scene": round(N / (cull_ms * 1e-3) / 1e6, 1),
                         "Msplats_per_s_rendered": round(Rc / (cull_ms * 1e-3) / 1e6, 1), "tree_build_s": round(t_tree, 2),
-                        "note": "asynchronous gather (one grid-synchronised plan kernel + a coalesced copy, no memset, no host round trip) + sort with the per-splat frustum cull on top "
+                        "note": "asynchronous gather (four small plan kernels; the copy of the kept leaves' lists is fused with the sort's key kernel and streams leaf-ordered centres; no host round trip) + sort with the per-splat frustum cull on top "
                                 "+ draw, EVERY frame; render_count = R kept by the reference's leaf test, scene = all N splats per frame.  "
                                 "The reference gathers and sorts only when the camera has turned or moved enough (Viewer.runSplatSort, "
                                 "src/Viewer.js:1858-1961) and keeps drawing with the last order in between"}

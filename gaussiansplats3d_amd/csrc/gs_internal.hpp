@@ -233,6 +233,18 @@ struct SortFrame {            // device-resident per-sort scalars
     uint32_t kept;            // frustum-cull variant: list positions that survive = length of the sorted result
 };
 
+// A planned octree gather as the sorter's fused copy + key kernel sees it (tree.hip -> sorter.hip): per LEAF the first slot of
+// its index list in indexesToSort (0xFFFFFFFF = culled), its length and where its indexes start in the leaf-major list.
+struct gs_tree;
+struct TreeGatherView {
+    uint64_t tree_uid;            // identifies the tree (and so the leaf-major order) for the sorter's per-tree caches
+    uint32_t leaves, tree_splats;
+    const uint32_t *leaf_offset, *leaf_count, *leaf_begin, *leaf_indexes, *totals;   // totals: {splats gathered, leaves kept}
+};
+void gs_tree_view(gs_tree* t, TreeGatherView* v);
+int gs_tree_copy_plain(gs_tree* t, uint32_t* out_dev, hipStream_t st);   // the kept leaves' index lists -> indexesToSort
+void gs_tree_forget_sorter(gs_tree* t, gs_sorter* s);                    // the sorter consumed (or dropped) the pending gather
+
 struct gs_sorter {
     gs_context* ctx = nullptr;
     uint32_t max_count = 0, flags = 0, precision = 16, uploaded = 0;
@@ -263,7 +275,17 @@ struct gs_sorter {
                                        // gathered_on_device: the asynchronous gather leaves the real count in gathered_dev)
     bool has_gathered = false;
     bool gathered_on_device = false;
-    DevBuf gathered_dev;               // uint32: splatRenderCount of that list, written by k_tree_plan
+    DevBuf gathered_dev;               // uint32: splatRenderCount of that list, written by the gather's plan
+    gs_tree* pending_tree = nullptr;   // gs_tree_gather planned a gather whose lists this sorter has still to copy (deferred so
+                                       // that a full sort of a static scene can fuse the copy with its key kernel)
+    bool pending_keep_zeroed = false;  // ... and zeroed this sorter's keep mask for a fused per-splat cull
+    uint32_t centers_version = 0;      // bumped by gs_sorter_upload_centers (invalidates the leaf-major caches below)
+    DevBuf pay_in;                     // uint32 [max]: the gathered list's payloads (positions in the bound mesh, or the indexes)
+    DevBuf leaf_centers, leaf_pos;     // the centres / payloads of the tree's splats in ITS leaf-major order: the fused copy
+                                       // streams them instead of gathering 16 bytes per list entry at random
+    uint64_t leaf_cache_tree = 0;      // what the two caches were built for
+    uint32_t leaf_cache_centers = 0, leaf_cache_layout = 0, leaf_cache_uploaded = 0;
+    const void* leaf_cache_mesh = nullptr;
     uint32_t last_render = 0, last_sort = 0, last_passes = 0;
     bool last_identity = true;
     bool has_result = false;
@@ -354,6 +376,7 @@ struct gs_mesh {
     DevBuf inv_perm;           // uint32 [n]: internal position -> original splat index
     std::vector<std::pair<uint32_t, uint32_t>> slotted;   // [begin, end) ranges of splats that own storage slots (disjoint, sorted)
     bool reorder = true;
+    uint32_t layout_version = 0;   // bumped whenever splats receive storage slots (perm changes): a sorter's per-tree payload cache
     bool no_block_cull = false;    // GSPLAT_NO_BLOCK_CULL=1 (A/B and tests)
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)

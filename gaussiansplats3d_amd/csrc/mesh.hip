@@ -381,6 +381,7 @@ static int mesh_upload_segment(gs_mesh* m, uint32_t from, uint32_t count, const 
     if (ncoef) GS_HIP(hipMemcpyAsync(stg + off_sh, sh_f16, b_sh, hipMemcpyHostToDevice, st));
     const dim3 g(up_grid(count)), b(256);
     const uint32_t* perm = m->reorder ? m->perm.as<uint32_t>() : nullptr;
+    if (fresh) m->layout_version++;
     if (m->reorder && fresh) {
         // Morton order of this segment: bounds on the host (the centres are host memory anyway), 30-bit codes, 4 stable
         // radix passes with the entry ping-pong buffers as scratch, then perm[original] = internal

@@ -353,6 +353,136 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Octree-gathered lists (gs_tree_gather -> gs_sorter_sort_gathered): the copy and phase A in one kernel.
+// gs_tree_gather only PLANS (per kept leaf: where its index list goes); a full sort of a static scene then runs this kernel
+// instead of k_tree_copy + k_depth_key(_cull): one wave per leaf streams the leaf's indexes, its centres and its payloads from
+// arrays kept in the TREE'S leaf-major order (leaf_centers / leaf_pos: built once per (tree, centres, bound mesh) by
+// k_tree_leaf_cache), and writes the list, its payloads, its keys, min / max and - with the per-splat frustum cull - the keep
+// bits.  Rounds 2-3 keyed the gathered list through 16-byte centre gathers at random (86 us for 4.4 M entries: MI355X retires
+// ~55 G random accesses per second whatever their size, tools/probes/gather_rate.hip) and translated the payloads through
+// another random gather in pass 0 of the radix sort.
+struct TreeCopyParams {
+    TreeGatherView v;
+    const uint4* leaf_centers;
+    const uint32_t* leaf_pos;
+    uint32_t* idx_out;
+    uint32_t* pay_out;
+};
+
+__global__ __launch_bounds__(256) void k_tree_leaf_cache(const uint32_t* __restrict__ leaf_indexes, uint32_t n, const uint4* __restrict__ caos,
+                                                         const uint32_t* __restrict__ map, uint32_t last_splat,
+                                                         uint4* __restrict__ leaf_centers, uint32_t* __restrict__ leaf_pos) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t o = min(leaf_indexes[j], last_splat);
+        leaf_centers[j] = caos[o];
+        leaf_pos[j] = map ? map[o] : o;
+    }
+}
+
+template <bool CULL>
+__global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyParams p) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    __shared__ uint32_t s_kept[4];
+    const uint32_t stride = gridDim.x * blockDim.x, gt = blockIdx.x * blockDim.x + threadIdx.x;
+    // the housekeeping of a sort's first kernel (see k_depth_key)
+    for (uint32_t w = gt; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (gt < SORT_SHARDS) {
+        p.next_frame->key_min[gt] = 2147483640;
+        p.next_frame->key_max[gt] = -2147483640;
+    }
+    if (gt == 0) {
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+        if (!CULL) p.frame->kept = c.v.totals[0];            // the list's length, where the consumers of a culled sort look for it
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int32_t lo = 2147483640, hi = -2147483640;
+    uint32_t kept = 0;
+    // (the next leaf's three words are fetched while this one is copied: one dependent round trip per leaf less)
+    uint32_t leaf = blockIdx.x * 4u + wave;
+    uint32_t m_off = 0xFFFFFFFFu, m_n = 0, m_src = 0;
+    if (leaf < c.v.leaves) { m_off = c.v.leaf_offset[leaf]; m_n = c.v.leaf_count[leaf]; m_src = c.v.leaf_begin[leaf]; }
+    for (; leaf < c.v.leaves; leaf += gridDim.x * 4u) {
+        const uint32_t off = m_off, n = m_n, src = m_src;
+        const uint32_t nxt = leaf + gridDim.x * 4u;
+        if (nxt < c.v.leaves) { m_off = c.v.leaf_offset[nxt]; m_n = c.v.leaf_count[nxt]; m_src = c.v.leaf_begin[nxt]; }
+        if (off == 0xFFFFFFFFu) continue;                    // culled leaf
+        // four 64-splat slices of the leaf per round: their twelve loads leave together (a leaf holds ~200 splats, so a wave's
+        // work is two or three dependent memory round trips whatever its length - what hides them is the loads in flight)
+        for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
+            uint32_t idx[4], pos[4];
+            uint4 ce[4];
+            bool in[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t t = t0 + 64u * k + lane;
+                in[k] = t < n;
+                const uint32_t j = src + (in[k] ? t : 0u);
+                idx[k] = c.v.leaf_indexes[j];
+                pos[k] = c.leaf_pos[j];
+                ce[k] = c.leaf_centers[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t t = t0 + 64u * k + lane;
+                int32_t key;
+                float x, y, z;
+                if (p.mode & MODE_INT) {
+                    key = (int32_t)(ce[k].x * (uint32_t)p.im0 + ce[k].y * (uint32_t)p.im1 + ce[k].z * (uint32_t)p.im2);
+                    x = __fmul_rn((float)(int32_t)ce[k].x, 0.001f); y = __fmul_rn((float)(int32_t)ce[k].y, 0.001f);
+                    z = __fmul_rn((float)(int32_t)ce[k].z, 0.001f);
+                } else {
+                    x = __uint_as_float(ce[k].x); y = __uint_as_float(ce[k].y); z = __uint_as_float(ce[k].z);
+                    float s = __fmul_rn(p.fm0, x);
+                    s = __fadd_rn(s, __fmul_rn(p.fm1, y));
+                    s = __fadd_rn(s, __fmul_rn(p.fm2, z));
+                    key = trunc_f64_i32((double)s * 4096.0);
+                }
+                if (in[k]) {
+                    c.idx_out[off + t] = idx[k];
+                    c.pay_out[off + t] = pos[k];
+                    p.keys_out[off + t] = key;
+                    lo = min(lo, key);
+                    hi = max(hi, key);
+                }
+                if (CULL) {
+                    const unsigned long long bits = __ballot(in[k] && frustum_keep_one(p.mvp, x, y, z));
+                    if (lane == 0u && bits) {                // list positions first .. first + 63: two words of the (zeroed) mask
+                        const uint32_t first = off + t0 + 64u * k, sh = first & 63u;
+                        atomicOr(&p.keep[first >> 6], bits << sh);
+                        if (sh) atomicOr(&p.keep[(first >> 6) + 1u], bits >> (64u - sh));
+                    }
+                    kept += (uint32_t)__popcll(bits);        // (the same value in every lane)
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+        s_kept[wave] = kept;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+        if (lo <= hi) {
+            atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
+            atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
+        }
+        if (CULL) {
+            const uint32_t k = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+            if (k) atomicAdd(&p.frame->kept, k);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Visibility-culled sort (gs_sorter_set_visibility_cull): compact, then sort the survivors.
 // The bound mesh's vertex stage left one bit per ORIGINAL splat index (gs_mesh::vis_orig) for this camera and strip.  The
 // reference's buckets depend on min / max over every sorted position, so every splat is still keyed once - but nothing is
@@ -673,6 +803,7 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
 
 void gs_sorter_destroy(gs_sorter* s) {
     if (!s) return;
+    if (s->pending_tree) gs_tree_forget_sorter(s->pending_tree, s);
     ScopedDevice sd(s->ctx->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipStreamSynchronize(s->ctx->stream);        // a draw may still be reading `sorted`
@@ -701,6 +832,7 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
         GS_HIP(hipMemcpyAsync(s->scene_idx.as<uint32_t>() + from, scene_indexes, (size_t)count * 4, hipMemcpyHostToDevice, st));
     GS_HIP(hipStreamSynchronize(st));   // staging and the caller's buffers are reusable on return
     if (from + count > s->uploaded) s->uploaded = from + count;   // uploadedSplatCount, SortWorker.js:97
+    s->centers_version++;
     return GS_OK;
 }
 
@@ -767,8 +899,17 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     }
 
     const uint32_t* idx_dev = nullptr;
+    bool fused_tree = false;                               // the gathered list is still to be copied, and this sort does it itself
     if (device_list) {
-        idx_dev = s->idx_in.as<uint32_t>();                // written by gs_tree_gather on this stream
+        idx_dev = s->idx_in.as<uint32_t>();                // written by gs_tree_gather on this stream ...
+        if (s->pending_tree) {                             // ... or only planned by it (tree.hip): the copy is ours
+            static const bool no_fuse = getenv("GSPLAT_TREE_NO_FUSE") != nullptr;
+            fused_tree = !no_fuse && Rs == R && Rs > 0 && !dynamic && !precomputed && !vis_cull && (!cull || s->pending_keep_zeroed);
+            if (!fused_tree) {
+                GS_TRY(gs_tree_copy_plain(s->pending_tree, s->idx_in.as<uint32_t>(), st));
+                gs_tree_forget_sorter(s->pending_tree, s);
+            }
+        }
     } else if (indexes_to_sort) {
         GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
         if (R) GS_HIP(hipMemcpyAsync(s->idx_in.p, indexes_to_sort, (size_t)R * 4, hipMemcpyHostToDevice, st));
@@ -828,7 +969,36 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
-        if (vis_cull) {
+        if (fused_tree) {
+            // copy + keys (+ keep bits) of the planned gather in one kernel over leaf-major copies of the centres and payloads
+            TreeCopyParams cp;
+            gs_tree_view(s->pending_tree, &cp.v);
+            const void* mesh_key = map ? (const void*)s->bound_mesh : nullptr;
+            const uint32_t layout = map ? s->bound_mesh->layout_version : 0u;
+            GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
+            if (s->leaf_cache_tree != cp.v.tree_uid || s->leaf_cache_centers != s->centers_version || s->leaf_cache_mesh != mesh_key ||
+                s->leaf_cache_layout != layout || s->leaf_cache_uploaded != s->uploaded || !s->leaf_centers.p) {
+                GS_TRY(s->leaf_centers.ensure((size_t)cp.v.tree_splats * 16 + 16));
+                GS_TRY(s->leaf_pos.ensure((size_t)cp.v.tree_splats * 4 + 16));
+                if (cp.v.tree_splats)
+                    hipLaunchKernelGGL(k_tree_leaf_cache, dim3(grid_for(cp.v.tree_splats, 1024, 4096)), dim3(256), 0, st, cp.v.leaf_indexes,
+                                       cp.v.tree_splats, s->caos.as<uint4>(), map, kp.last_splat, s->leaf_centers.as<uint4>(),
+                                       s->leaf_pos.as<uint32_t>());
+                s->leaf_cache_tree = cp.v.tree_uid; s->leaf_cache_centers = s->centers_version; s->leaf_cache_mesh = mesh_key;
+                s->leaf_cache_layout = layout; s->leaf_cache_uploaded = s->uploaded;
+            }
+            cp.leaf_centers = s->leaf_centers.as<uint4>();
+            cp.leaf_pos = s->leaf_pos.as<uint32_t>();
+            cp.idx_out = s->idx_in.as<uint32_t>();
+            cp.pay_out = s->pay_in.as<uint32_t>();
+            // (a workgroup ends with one atomic on the sort's kept counter, and same-address atomics retire at ~12 ns each:
+            // 6.5 k workgroups queue ~80 us of them behind 30 us of memory traffic - eight workgroups per CU walk the leaves)
+            uint32_t cgrid = (cp.v.leaves + 3u) / 4u;
+            cgrid = cgrid < 1u ? 1u : (cgrid > (uint32_t)ctx->cu_count * 8u ? (uint32_t)ctx->cu_count * 8u : cgrid);
+            if (cull) hipLaunchKernelGGL(k_tree_copy_keys<true>, dim3(cgrid), dim3(256), 0, st, cp, kp);
+            else hipLaunchKernelGGL(k_tree_copy_keys<false>, dim3(cgrid), dim3(256), 0, st, cp, kp);
+            gs_tree_forget_sorter(s->pending_tree, s);
+        } else if (vis_cull) {
             // compact, then sort the survivors (see k_minmax_count): the list is what the bound mesh's vertex stage kept
             const uint32_t spans = (R + VC_SPAN - 1u) / VC_SPAN;
             const uint32_t grid = spans < (uint32_t)ctx->cu_count * 2u ? spans : (uint32_t)ctx->cu_count * 2u;
@@ -858,8 +1028,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         GS_HIP(hipGetLastError());
         DepthLoader dl = {};
         dl.keys = s->keys.as<int32_t>();
-        dl.idx = idx_dev;
-        dl.map = map;
+        dl.idx = fused_tree ? s->pay_in.as<uint32_t>() : idx_dev;     // (the fused copy wrote the payloads themselves)
+        dl.map = fused_tree ? nullptr : map;
         dl.frame = kp.frame;
         dl.sort_start = sort_start;
         dl.render_count = R;

@@ -35,14 +35,17 @@ struct gs_tree {
     uint32_t max_depth = 8, max_centers = 1000;
     uint32_t all_leaves = 0, nodes = 0;
     bool built_on_device = false;
-    uint32_t barrier_epoch = 0;     // launches of k_tree_plan so far (its grid barriers count arrivals on one monotonic word)
+    uint64_t uid = 0;               // unique per tree of this process (a sorter's leaf-major caches are keyed on it)
+    double prev_scale = 1.0;        // bucket scale of the previous gather (its member counters are reset by the next one)
+    uint32_t gather_serial = 0;     // gathers planned so far
+    gs_sorter* pending_sorter = nullptr;   // a sorter that has not yet copied the last planned gather's lists (deferred, fused copy)
     double scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
     std::vector<TreeLeaf> leaves;          // nodesWithIndexes order
     std::vector<uint32_t> indexes;
     // device mirror
     DevBuf d_center, d_size, d_begin, d_count, d_indexes;
-    DevBuf d_bucket;            // uint32 [hist 65536 | fill 65536 | start 65537]; hist / fill are zero between gathers
-    DevBuf d_key, d_rank, d_sorted_cnt, d_sorted_leaf, d_offset, d_total, d_out;   // d_total: {splats gathered, leaves kept}
+    DevBuf d_bucket;            // uint64 hist [TREE_BUCKETS] | uint64 start [TREE_BUCKETS] | uint32 fill [TREE_BUCKETS] | uint64 chunk sums
+    DevBuf d_key, d_rank, d_offset, d_total, d_out;   // d_total: {splats gathered, leaves kept}
 };
 
 namespace {
@@ -413,13 +416,6 @@ struct GatherParams {
     uint32_t gather_all, leaves;
 };
 
-// bucket of a distance key: top 20 bits of (float)key (8 exponent + 11 mantissa bits: 0.05 % wide), monotonic in key; any bit
-// pattern stays below TREE_BUCKETS.  (r03g: with 16-bit buckets - 0.8 % wide - the leaves 10 units from the camera share a
-// bucket by the hundred and the slowest thread's exact ranking, a chain of dependent loads, set the plan's length: 113 us.)
-constexpr uint32_t TREE_BUCKET_BITS = 20;
-constexpr uint32_t TREE_BUCKETS = 1u << TREE_BUCKET_BITS;
-__device__ __forceinline__ uint32_t tree_bucket(double key) { return __float_as_uint((float)key) >> (32u - TREE_BUCKET_BITS); }
-
 // Viewer.js:2010-2035 for one leaf: the sort key (distance, or +inf when the leaf is culled)
 __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x, double y, double z, double size) {
     const double* e = p.mv;
@@ -444,193 +440,194 @@ __device__ __forceinline__ double tree_leaf_key(const GatherParams& p, double x,
     return skip ? __longlong_as_double(0x7FF0000000000000ll) : dist;         // +inf: the leaf takes no part in the ranking
 }
 
-// Rank of a leaf in ascending (distance, leaf number) order.  An all-pairs count is O(leaves^2); instead the leaves are
-// bucketed by the top 20 bits of (float)distance (monotonic in the distance: 8 exponent + 11 mantissa bits, i.e. 0.05 % wide
-// buckets), the buckets are scanned, and a leaf is ranked exactly - on the full fp64 key and its number - only against the
-// members of its own bucket.  The result is the same total order; only the work is smaller.
-//
-// ONE launch plans the whole gather: PLAN_GRID workgroups (one per CU, all resident) pass through six phases separated by
-// grid-wide barriers (a monotonic arrival counter in global memory; no workgroup waits for anything but "everybody has
-// arrived", and every workgroup is resident, so there is no circular wait).  The phases are a handful of microseconds of
-// latency-bound work each; as separate launches they cost 8-60 us apiece (r03f profile: test 12, a one-workgroup scan of
-// the 65536 counters 44, fill 13, rank 31, a one-workgroup offset scan 62 = 181 us per gather with the copy), and as ONE
-// workgroup of 1024 threads the ranking alone was 1.3 ms (26 k leaves x ~55 bucket members = a serial chain of dependent L2
-// loads per thread).
-//   1 test     every leaf: distance key (or +inf when culled), one atomic on its bucket's counter
-//   2 scan     workgroup g owns a chunk of 4096 buckets: exclusive scan inside the chunk -> start_local, chunk total;
-//              the histogram is handed back zeroed
-//   3 fill     chunk bases = scan of the 256 chunk totals (every workgroup, in LDS); members[base + start_local + fill++]
-//   4 rank     exact rank inside the bucket (its members read eight at a time) -> leaf and count at their rank
-//   5 sums     workgroup g owns a contiguous run of ranks: its count total
-//   6 offsets  offset[r] = total - inclusive_prefix(counts by rank)[r]: the nearest leaf, r = 0, ends the buffer
-//              (Viewer.js:2046-2055 copies from the END backwards); totals = {splats gathered, leaves kept}; count_out =
-//              the sorter's own copy of splatRenderCount (nullable); the fill counters are handed back zeroed
+// THE PLAN (round 4).  What the copy needs per kept leaf is only WHERE its index list goes: the reference lays the kept leaves
+// out far -> near (Viewer.js:2046-2055 copies from the END backwards), so leaf i starts at
+//     offset(i) = total - before(i) - count(i),   before(i) = sum of count(j) over the kept leaves j with (key_j, j) < (key_i, i)
+// - a count-WEIGHTED rank.  No leaf-by-rank arrays, no second prefix over the ranks: rounds 2-3 built those in one launch of 256
+// resident workgroups with five hand-rolled grid barriers (13 us each on MI355X: 67 us per gather, and a spin barrier that
+// needs every workgroup resident - ADVICE r03); now four small launches do it (a kernel boundary is ~2 us):
+//   k_tree_test     every leaf: its key (fp64 distance, +inf when culled) and ONE 64-bit atomic on its bucket's counter
+//                   (members << 40 | splats).  Buckets are LINEAR in the distance: floor(key * scale) with scale from the largest
+//                   distance any leaf centre can have (the farthest corner of the scene box, computed on the host for this
+//                   modelView); monotonic in the key whatever scale is, so the order below is exact - scale only spreads the
+//                   leaves (2^18 buckets over ~26 k leaves: mostly one per bucket; the float-bit buckets of round 3 put the
+//                   leaves 10 units away six to a bucket)
+//   k_tree_scan     256 workgroups x 1024 buckets: exclusive scan inside the chunk (both fields at once), chunk totals
+//   k_tree_fill     chunk bases (every workgroup scans the 256 totals in LDS), then members[base + local + fill++] = leaf
+//   k_tree_offsets  before(i) = the scan's splat field + the splats of the members of its own bucket that precede it on the
+//                   full fp64 key and the leaf number -> offset(i); totals; the fused cull's keep words go back to zero
+// (the counters are handed back zeroed: hist by k_tree_fill, fill by the NEXT gather's k_tree_test)
+// Deterministic (integer sums; the order of a bucket's members is arbitrary but only their set matters).
+constexpr uint32_t TREE_BUCKET_BITS = 18;
+constexpr uint32_t TREE_BUCKETS = 1u << TREE_BUCKET_BITS;
 constexpr uint32_t PLAN_GRID = 256, PLAN_THREADS = 256;
-constexpr uint32_t PLAN_BARRIERS = 5;      // grid barriers per launch: the arrival counter advances by exactly PLAN_BARRIERS * PLAN_GRID
-constexpr uint32_t PLAN_CHUNK = TREE_BUCKETS / PLAN_GRID;          // buckets per workgroup of the plan
-constexpr uint32_t PLAN_PER_THREAD = PLAN_CHUNK / PLAN_THREADS;    // ... and per thread: 16 consecutive ones
-static_assert(PLAN_PER_THREAD * PLAN_THREADS * PLAN_GRID == TREE_BUCKETS && PLAN_PER_THREAD % 4 == 0, "plan geometry");
+constexpr uint32_t PLAN_CHUNK = TREE_BUCKETS / PLAN_GRID;          // buckets per workgroup of the scan
+constexpr uint32_t PLAN_PER_THREAD = PLAN_CHUNK / PLAN_THREADS;    // ... and per thread: consecutive ones
+static_assert(PLAN_PER_THREAD * PLAN_THREADS * PLAN_GRID == TREE_BUCKETS && PLAN_PER_THREAD % 2 == 0, "plan geometry");
+constexpr unsigned long long TREE_INF = 0x7FF0000000000000ull;
+constexpr unsigned long long TREE_W_MASK = (1ull << 40) - 1ull;    // low 40 bits: splats; above: members
+constexpr uint32_t TREE_CULLED = 0xFFFFFFFFu;
 
-// arrivals count on `counter`; the last one to arrive publishes the target in `flag` (another cache line), which is what the
-// others poll - 255 pollers on the counter's own line would queue in front of the remaining arrivals' atomics
-__device__ __forceinline__ void plan_grid_barrier(uint32_t* counter, uint32_t* flag, uint32_t target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                    // this workgroup's writes are visible before it arrives
-        const uint32_t prev = atomicAdd(counter, 1u);
-        if (prev + 1u == target) {
-            __hip_atomic_store(flag, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(8);
-        }
-        __threadfence();                                    // ... and the others' writes before anybody here reads them
-    }
-    __syncthreads();
+__device__ __forceinline__ uint32_t tree_bucket(double key, double scale) {
+    const double b = key * scale;                                   // key >= 0 and finite here
+    return b < (double)(TREE_BUCKETS - 1u) ? (uint32_t)b : TREE_BUCKETS - 1u;
 }
 
 struct PlanBuffers {
     const double* center; const double* size; const uint32_t* count;      // per leaf
-    unsigned long long* key;                                              // per leaf: sortable bits of the distance
-    uint32_t* hist; uint32_t* fill; uint32_t* start_local;                // per bucket
-    uint32_t* chunk_sum;                                                  // [2][PLAN_GRID]: bucket chunks | rank chunks
-    uint32_t* members; uint32_t* sorted_cnt; uint32_t* sorted_leaf; uint32_t* offset;   // per kept leaf / rank
-    uint32_t* totals; uint32_t* count_out; uint32_t* barrier;
+    unsigned long long* key;                                              // per leaf: the bits of the distance (sortable: >= 0)
+    unsigned long long* hist;                                             // per bucket: members << 40 | splats; zero between gathers
+    unsigned long long* start;                                            // per bucket: the same two fields, exclusive inside its chunk
+    uint32_t* fill;                                                       // per bucket: members placed so far; zero between gathers
+    unsigned long long* chunk_sum;                                        // [PLAN_GRID]
+    uint32_t* members;                                                    // kept leaves grouped by bucket
+    uint32_t* offset;                                                     // per leaf: first slot of its list, TREE_CULLED when culled
+    uint32_t* totals; uint32_t* count_out;                                // {splats gathered, leaves kept}; the sorter's copy of the first
+    unsigned long long* keep_zero; uint32_t keep_words;                   // the sorter's keep mask of a fused per-splat cull (nullable)
 };
 
-__global__ __launch_bounds__(PLAN_THREADS) void k_tree_plan(GatherParams p, PlanBuffers B, uint32_t barrier_base) {
-    __shared__ uint32_t s_tmp[4];
-    __shared__ uint32_t s_base[PLAN_GRID];
-    const uint32_t tid = threadIdx.x, wg = blockIdx.x, L = p.leaves;
-    const uint32_t gid = wg * PLAN_THREADS + tid, stride = PLAN_GRID * PLAN_THREADS;
-    const unsigned long long INF = 0x7FF0000000000000ull;
-    uint32_t phase = 0;
-    auto barrier = [&]() { plan_grid_barrier(B.barrier, B.barrier + 32, barrier_base + (++phase) * PLAN_GRID); };
-    // 1. test
-    for (uint32_t i = gid; i < L; i += stride) {
-        const double k = tree_leaf_key(p, B.center[3 * (size_t)i], B.center[3 * (size_t)i + 1], B.center[3 * (size_t)i + 2], B.size[i]);
-        const unsigned long long kb = (unsigned long long)__double_as_longlong(k);   // non-negative doubles order like their bits
-        B.key[i] = kb;
-        if (kb != INF) atomicAdd(&B.hist[tree_bucket(k)], 1u);                      // culled leaves take no part in the ranking
-    }
-    barrier();
-    // 2. scan inside this workgroup's chunk of buckets (thread t owns PLAN_PER_THREAD consecutive ones, 16-byte accesses)
-    {
-        uint4* hp = reinterpret_cast<uint4*>(B.hist + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
-        uint4* sp = reinterpret_cast<uint4*>(B.start_local + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
-        uint32_t v[PLAN_PER_THREAD], sum = 0;
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_test(GatherParams p, PlanBuffers B, double scale, double prev_scale) {
+    const uint32_t i = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    if (i >= p.leaves) return;
+    // the member counters of the PREVIOUS gather go back to zero first (its keys are still here; +inf before the first gather)
+    const unsigned long long old = B.key[i];
+    if (old != TREE_INF) B.fill[tree_bucket(__longlong_as_double((long long)old), prev_scale)] = 0u;
+    const double k = tree_leaf_key(p, B.center[3 * (size_t)i], B.center[3 * (size_t)i + 1], B.center[3 * (size_t)i + 2], B.size[i]);
+    const unsigned long long kb = (unsigned long long)__double_as_longlong(k);       // non-negative doubles order like their bits
+    B.key[i] = kb;
+    if (kb != TREE_INF) atomicAdd(&B.hist[tree_bucket(k, scale)], (1ull << 40) | (unsigned long long)B.count[i]);
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_scan(PlanBuffers B) {
+    __shared__ unsigned long long s_w[4];
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63u, wave = tid >> 6;
+    ulonglong2* hp = reinterpret_cast<ulonglong2*>(B.hist + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
+    ulonglong2* sp = reinterpret_cast<ulonglong2*>(B.start + (size_t)wg * PLAN_CHUNK + tid * PLAN_PER_THREAD);
+    unsigned long long v[PLAN_PER_THREAD], sum = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < PLAN_PER_THREAD / 4; k++) {
-            const uint4 q = hp[k];
-            v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-            sum += q.x + q.y + q.z + q.w;
-            if (q.x | q.y | q.z | q.w) hp[k] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        uint32_t total;
-        uint32_t run = block_excl_scan_256(sum, s_tmp, &total);
+    for (uint32_t k = 0; k < PLAN_PER_THREAD / 2; k++) {
+        const ulonglong2 q = hp[k];
+        v[2 * k] = q.x; v[2 * k + 1] = q.y;
+        sum += q.x + q.y;
+    }
+    unsigned long long incl = sum;
 #pragma unroll
-        for (uint32_t k = 0; k < PLAN_PER_THREAD / 4; k++) {
-            uint4 o;
-            o.x = run; run += v[4 * k];
-            o.y = run; run += v[4 * k + 1];
-            o.z = run; run += v[4 * k + 2];
-            o.w = run; run += v[4 * k + 3];
-            sp[k] = o;
-        }
-        if (tid == 0) B.chunk_sum[wg] = total;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
     }
-    barrier();
-    // 3. chunk bases (every workgroup scans the 256 chunk totals), then the members of every bucket
-    uint32_t K;
-    {
-        const uint32_t c = B.chunk_sum[tid];
-        const uint32_t excl = block_excl_scan_256(c, s_tmp, &K);       // K = kept leaves
-        s_base[tid] = excl;
-        __syncthreads();
-    }
-    for (uint32_t i = gid; i < L; i += stride) {
-        const unsigned long long kb = B.key[i];
-        if (kb == INF) continue;
-        const uint32_t b = tree_bucket(__longlong_as_double((long long)kb));
-        B.members[s_base[b / PLAN_CHUNK] + B.start_local[b] + atomicAdd(&B.fill[b], 1u)] = i;   // order inside a bucket is arbitrary
-    }
-    barrier();
-    // 4. exact rank inside the bucket -> the leaf and its count at their rank
-    for (uint32_t i = gid; i < L; i += stride) {
-        const unsigned long long mine = B.key[i];
-        if (mine == INF) continue;                             // culled: has no rank
-        const uint32_t b = tree_bucket(__longlong_as_double((long long)mine));
-        const uint32_t lo = s_base[b / PLAN_CHUNK] + B.start_local[b], hi = lo + B.fill[b];
-        uint32_t r = lo;
-        for (uint32_t q = lo; q < hi; q += 8u) {
-            uint32_t m[8];
-            unsigned long long k[8];
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    unsigned long long run = incl - sum, total = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; j++) m[j] = q + j < hi ? B.members[q + j] : i;   // padding = the leaf itself: counts 0
+    for (uint32_t w = 0; w < 4; w++) {
+        const unsigned long long c = s_w[w];
+        run += w < wave ? c : 0ull;
+        total += c;
+    }
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; j++) k[j] = B.key[m[j]];
+    for (uint32_t k = 0; k < PLAN_PER_THREAD / 2; k++) {
+        ulonglong2 o;
+        o.x = run; run += v[2 * k];
+        o.y = run; run += v[2 * k + 1];
+        sp[k] = o;
+    }
+    if (tid == 0) B.chunk_sum[wg] = total;
+}
+
+// exclusive prefix of the PLAN_GRID chunk totals into LDS (thread t owns chunk t); returns the grand total
+__device__ __forceinline__ unsigned long long plan_chunk_bases(const unsigned long long* chunk_sum, unsigned long long* s_base, unsigned long long* s_w) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long c = chunk_sum[tid];
+    unsigned long long incl = c;
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; j++) r += (k[j] < mine || (k[j] == mine && m[j] < i)) ? 1u : 0u;
-        }
-        B.sorted_cnt[r] = B.count[i];
-        B.sorted_leaf[r] = i;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += t;
     }
-    barrier();
-    // 5. this workgroup's run of ranks [r0, r1): its total
-    const uint32_t per = (K + PLAN_GRID - 1u) / PLAN_GRID;
-    const uint32_t r0 = min(wg * per, K), r1 = min(r0 + per, K);
-    {
-        uint32_t sum = 0;
-        for (uint32_t r = r0 + tid; r < r1; r += PLAN_THREADS) sum += B.sorted_cnt[r];
-        uint32_t total;
-        (void)block_excl_scan_256(sum, s_tmp, &total);
-        if (tid == 0) B.chunk_sum[PLAN_GRID + wg] = total;
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    unsigned long long base = incl - c, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const unsigned long long t = s_w[w];
+        base += w < wave ? t : 0ull;
+        total += t;
     }
-    barrier();
-    // (phase == PLAN_BARRIERS here)
-    // 6. offsets of this workgroup's ranks; the fill counters go back to zero (nobody reads them any more)
-    {
-        const uint32_t c = B.chunk_sum[PLAN_GRID + tid];
-        uint32_t total;
-        const uint32_t excl = block_excl_scan_256(c, s_tmp, &total);
-        __syncthreads();
-        s_base[tid] = excl;
-        __syncthreads();
-        uint32_t run = s_base[wg];
-        if (gid == 0) {
-            B.totals[0] = total;
-            B.totals[1] = K;
-            if (B.count_out) *B.count_out = total;
-        }
-        for (uint32_t rb = r0; rb < r1; rb += PLAN_THREADS) {
-            const uint32_t r = rb + tid;
-            const uint32_t v = r < r1 ? B.sorted_cnt[r] : 0u;
-            uint32_t round_total;
-            const uint32_t ex = block_excl_scan_256(v, s_tmp, &round_total);
-            if (r < r1) B.offset[r] = total - (run + ex + v);
-            run += round_total;
-        }
-        for (uint32_t i = gid; i < L; i += stride) {
-            const unsigned long long kb = B.key[i];
-            if (kb != INF) B.fill[tree_bucket(__longlong_as_double((long long)kb))] = 0u;    // same value from every member
-        }
+    s_base[tid] = base;
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_fill(GatherParams p, PlanBuffers B, double scale) {
+    __shared__ unsigned long long s_base[PLAN_GRID], s_w[4];
+    (void)plan_chunk_bases(B.chunk_sum, s_base, s_w);
+    const uint32_t i = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    if (i >= p.leaves) return;
+    const unsigned long long kb = B.key[i];
+    if (kb == TREE_INF) return;
+    const uint32_t b = tree_bucket(__longlong_as_double((long long)kb), scale);
+    const uint32_t first = (uint32_t)((s_base[b / PLAN_CHUNK] + B.start[b]) >> 40);
+    B.members[first + atomicAdd(&B.fill[b], 1u)] = i;                 // the order inside a bucket is arbitrary
+    B.hist[b] = 0ull;                                                  // consumed by the scan: zero for the next gather
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void k_tree_offsets(GatherParams p, PlanBuffers B, double scale) {
+    __shared__ unsigned long long s_base[PLAN_GRID], s_w[4];
+    const unsigned long long all = plan_chunk_bases(B.chunk_sum, s_base, s_w);
+    const uint32_t total = (uint32_t)(all & TREE_W_MASK);
+    const uint32_t gid = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    if (gid == 0) {
+        B.totals[0] = total;
+        B.totals[1] = (uint32_t)(all >> 40);
+        if (B.count_out) *B.count_out = total;
     }
+    // the keep mask of a fused per-splat cull is filled with atomicOr by the copy: zero it here
+    for (uint32_t w = gid; w < B.keep_words; w += gridDim.x * PLAN_THREADS) B.keep_zero[w] = 0ull;
+    if (gid >= p.leaves) return;
+    const uint32_t i = gid;
+    const unsigned long long mine = B.key[i];
+    if (mine == TREE_INF) {
+        B.offset[i] = TREE_CULLED;
+        return;
+    }
+    const uint32_t b = tree_bucket(__longlong_as_double((long long)mine), scale);
+    const unsigned long long at = s_base[b / PLAN_CHUNK] + B.start[b];
+    const uint32_t lo = (uint32_t)(at >> 40), n = B.fill[b];         // (complete: k_tree_fill has finished)
+    uint32_t before = (uint32_t)(at & TREE_W_MASK);
+    for (uint32_t q = 0; q < n; q += 8u) {
+        uint32_t m[8], c[8];
+        unsigned long long k[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) m[j] = q + j < n ? B.members[lo + q + j] : i;      // padding = the leaf itself: adds 0
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) { k[j] = B.key[m[j]]; c[j] = B.count[m[j]]; }
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) before += (k[j] < mine || (k[j] == mine && m[j] < i)) ? c[j] : 0u;
+    }
+    B.offset[i] = total - before - B.count[i];
 }
 
 // Coalesced copy of the kept leaves' index lists (<= ~1000 indexes each) to their places in indexesToSort: one wave per
-// rank, four ranks per workgroup; ranks >= the kept count (read on the device) have nothing to copy.
+// leaf, four leaves per workgroup.  (A sorter that sorts the whole list of a static scene does this copy itself, fused with
+// its key kernel: sorter.hip, k_tree_copy_keys.)
 constexpr uint32_t COPY_WAVES = 4;
-__global__ __launch_bounds__(64 * COPY_WAVES) void k_tree_copy(const uint32_t* __restrict__ totals, const uint32_t* __restrict__ sorted_leaf,
-                                                                const uint32_t* __restrict__ sorted_cnt, const uint32_t* __restrict__ offset,
+__global__ __launch_bounds__(64 * COPY_WAVES) void k_tree_copy(uint32_t leaves, const uint32_t* __restrict__ leaf_offset,
+                                                                const uint32_t* __restrict__ leaf_count,
                                                                 const uint32_t* __restrict__ leaf_begin,
                                                                 const uint32_t* __restrict__ leaf_indexes, uint32_t* __restrict__ out) {
-    const uint32_t K = totals[1], lane = threadIdx.x & 63u;
-    for (uint32_t r = blockIdx.x * COPY_WAVES + (threadIdx.x >> 6); r < K; r += gridDim.x * COPY_WAVES) {
-        const uint32_t n = sorted_cnt[r];
-        const uint32_t* src = leaf_indexes + leaf_begin[sorted_leaf[r]];
-        uint32_t* dst = out + offset[r];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = blockIdx.x * COPY_WAVES + (threadIdx.x >> 6); i < leaves; i += gridDim.x * COPY_WAVES) {
+        const uint32_t off = leaf_offset[i];
+        if (off == TREE_CULLED) continue;
+        const uint32_t n = leaf_count[i];
+        const uint32_t* src = leaf_indexes + leaf_begin[i];
+        uint32_t* dst = out + off;
         for (uint32_t t = lane; t < n; t += 64u) dst[t] = src[t];
     }
 }
+
+static uint64_t g_tree_uid = 0;
 
 extern "C" {
 
@@ -642,6 +639,7 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
     gs_tree* t = new (std::nothrow) gs_tree();
     if (!t) return GS_ERR_NOMEM;
     t->ctx = ctx;
+    t->uid = ++g_tree_uid;
     t->max_depth = max_depth;
     t->max_centers = max_centers_per_node;
     try {
@@ -704,9 +702,9 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         auto A = [&](DevBuf& buf, size_t bytes) { if (st == GS_OK) st = buf.alloc(bytes); };
         A(t->d_center, 24 * L + 24); A(t->d_size, 8 * L + 8); A(t->d_begin, 4 * L + 4); A(t->d_count, 4 * L + 4);
         if (!t->built_on_device) A(t->d_indexes, 4 * t->indexes.size() + 4);      // the device build left them there
-        A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_bucket, 4 * (2 * (size_t)TREE_BUCKETS + TREE_BUCKETS + 4)); A(t->d_sorted_cnt, 4 * L + 4);
-        A(t->d_sorted_leaf, 4 * L + 4); A(t->d_offset, 4 * L + 4);
-        A(t->d_total, 16 + 8 * PLAN_GRID + 512);  // {splats, kept leaves, pad} + the plan's two chunk-total tables + its barrier words
+        A(t->d_key, 8 * L + 8); A(t->d_rank, 4 * L + 4); A(t->d_offset, 4 * L + 4);
+        A(t->d_bucket, (size_t)TREE_BUCKETS * (8 + 8 + 4) + 8 * PLAN_GRID);
+        A(t->d_total, 64);                        // {splats gathered, kept leaves}
         if (st != GS_OK) {
             delete t;
             return st;
@@ -719,8 +717,10 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
         UP(t->d_center, center.data(), 24 * L); UP(t->d_size, size.data(), 8 * L); UP(t->d_begin, begin.data(), 4 * L);
         UP(t->d_count, cnt.data(), 4 * L);
         if (!t->built_on_device) UP(t->d_indexes, t->indexes.data(), 4 * t->indexes.size());
-        if (e == hipSuccess) e = hipMemsetAsync(t->d_total.p, 0, 16 + 8 * PLAN_GRID + 512, s);
-        if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, sizeof(uint32_t) * 2 * TREE_BUCKETS, s);   // the gather kernels keep them zero
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_total.p, 0, 64, s);
+        if (e == hipSuccess) e = hipMemsetAsync(t->d_bucket.p, 0, (size_t)TREE_BUCKETS * (8 + 8 + 4) + 8 * PLAN_GRID, s);   // the gather kernels keep hist / fill zero
+        std::vector<unsigned long long> inf(L + 1, TREE_INF);          // "no previous gather": nothing for k_tree_test to reset
+        UP(t->d_key, inf.data(), 8 * L);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
             gs_set_error("uploading the splat tree failed: %s", hipGetErrorString(e));
@@ -734,6 +734,11 @@ int gs_tree_create(gs_context* ctx, const float* centers, const uint8_t* keep, u
 
 void gs_tree_destroy(gs_tree* t) {
     if (!t) return;
+    if (t->pending_sorter) {                               // a sorter still waits to copy this tree's last gather: it has no list
+        t->pending_sorter->pending_tree = nullptr;
+        t->pending_sorter->has_gathered = false;
+        t->pending_sorter = nullptr;
+    }
     if (t->ctx) {
         ScopedDevice sd(t->ctx->device);
         (void)hipDeviceSynchronize();
@@ -783,6 +788,15 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     ScopedDevice sd(ctx->device);
     hipStream_t st = dst ? dst->stream : ctx->stream;      // the list is produced where the sort will consume it
     const uint32_t L = (uint32_t)t->leaves.size();
+    // another sorter has not yet copied the previous gather, whose offsets are about to be overwritten: it copies now
+    if (t->pending_sorter && t->pending_sorter != dst) {
+        gs_sorter* o = t->pending_sorter;
+        GS_TRY(o->idx_in.ensure((size_t)o->max_count * 4));
+        GS_TRY(gs_tree_copy_plain(t, o->idx_in.as<uint32_t>(), o->stream));
+        GS_HIP(hipStreamSynchronize(o->stream));
+        gs_tree_forget_sorter(t, o);
+    }
+    if (dst && dst->pending_tree && dst->pending_tree != t) gs_tree_forget_sorter(dst->pending_tree, dst);   // superseded
     uint32_t* out_dev = nullptr;
     if (dst) {
         GS_TRY(dst->idx_in.ensure((size_t)dst->max_count * 4));
@@ -806,32 +820,62 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
     p.thr_y = cos(fov_y2) - .6;
     p.gather_all = gp->gather_all ? 1u : 0u;
     p.leaves = L;
-    uint32_t* bhist = t->d_bucket.as<uint32_t>();
-    uint32_t* bfill = bhist + TREE_BUCKETS;
-    uint32_t* bstart = bfill + TREE_BUCKETS;
+    // bucket scale: the farthest a leaf centre can be from the eye = the farthest corner of the scene box under this modelView
+    // (the distance is convex in the point); the order never depends on it (tree_bucket clamps), only how the leaves spread
+    double far = 0.0;
+    for (int c = 0; c < 8; c++) {
+        const double x = (c & 1) ? t->scene_max[0] : t->scene_min[0], y = (c & 2) ? t->scene_max[1] : t->scene_min[1],
+                     z = (c & 4) ? t->scene_max[2] : t->scene_min[2];
+        const double* e = p.mv;
+        double w = e[3] * x + e[7] * y + e[11] * z + e[15];
+        w = w != 0.0 ? 1.0 / w : 1.0;
+        const double vx = (e[0] * x + e[4] * y + e[8] * z + e[12]) * w, vy = (e[1] * x + e[5] * y + e[9] * z + e[13]) * w,
+                     vz = (e[2] * x + e[6] * y + e[10] * z + e[14]) * w;
+        const double d = sqrt(vx * vx + vy * vy + vz * vz);
+        if (d > far) far = d;
+    }
+    const double scale = (far > 0.0 && far < 1e300) ? (double)TREE_BUCKETS / (far * 1.0001) : 1.0;
     // the sorter gets the list's length on the device as well
     uint32_t* count_dev = nullptr;
     if (dst) {
         GS_TRY(dst->gathered_dev.ensure(16));
         count_dev = dst->gathered_dev.as<uint32_t>();
     }
+    // The copy is DEFERRED to the sorter when nothing but the sorter will read the list: a full sort of a static scene then
+    // copies the lists, keys them (and tests them against the frustum) in one kernel that streams the centres in leaf order
+    // (sorter.hip, k_tree_copy_keys); any other sort copies first (gs_tree_copy_plain) and goes on as before.
+    const bool deferred = dst && !indexes_out_host && !(dst->flags & GS_SORT_DYNAMIC) && !getenv("GSPLAT_TREE_NO_DEFER");
     PlanBuffers pb;
     pb.center = t->d_center.as<double>(); pb.size = t->d_size.as<double>(); pb.count = t->d_count.as<uint32_t>();
     pb.key = t->d_key.as<unsigned long long>();
-    pb.hist = bhist; pb.fill = bfill; pb.start_local = bstart;
-    pb.chunk_sum = t->d_total.as<uint32_t>() + 4;
-    pb.members = t->d_rank.as<uint32_t>(); pb.sorted_cnt = t->d_sorted_cnt.as<uint32_t>();
-    pb.sorted_leaf = t->d_sorted_leaf.as<uint32_t>(); pb.offset = t->d_offset.as<uint32_t>();
+    pb.hist = t->d_bucket.as<unsigned long long>();
+    pb.start = pb.hist + TREE_BUCKETS;
+    pb.chunk_sum = pb.start + TREE_BUCKETS;
+    pb.fill = reinterpret_cast<uint32_t*>(pb.chunk_sum + PLAN_GRID);
+    pb.members = t->d_rank.as<uint32_t>(); pb.offset = t->d_offset.as<uint32_t>();
     pb.totals = t->d_total.as<uint32_t>(); pb.count_out = count_dev;
-    pb.barrier = t->d_total.as<uint32_t>() + 4 + 2 * PLAN_GRID + 32;      // arrival counter; its release flag 128 bytes further
-    // PLAN_BARRIERS grid barriers per launch on one monotonic counter (wrap-safe: compared by difference)
-    hipLaunchKernelGGL(k_tree_plan, dim3(PLAN_GRID), dim3(PLAN_THREADS), 0, st, p, pb, t->barrier_epoch * PLAN_BARRIERS * PLAN_GRID);
-    t->barrier_epoch++;
-    const uint32_t copy_grid = (L + COPY_WAVES - 1u) / COPY_WAVES;
-    hipLaunchKernelGGL(k_tree_copy, dim3(copy_grid < 8192u ? copy_grid : 8192u), dim3(64 * COPY_WAVES), 0, st, t->d_total.as<uint32_t>(),
-                       t->d_sorted_leaf.as<uint32_t>(), t->d_sorted_cnt.as<uint32_t>(), t->d_offset.as<uint32_t>(),
-                       t->d_begin.as<uint32_t>(), t->d_indexes.as<uint32_t>(), out_dev);
+    pb.keep_zero = nullptr; pb.keep_words = 0;
+    if (deferred && dst->frustum_cull) {                   // the fused copy ORs its keep bits into a zeroed mask
+        GS_TRY(dst->keep_mask.ensure((((size_t)dst->max_count + 63) / 64 + 8) * 8));
+        pb.keep_zero = dst->keep_mask.as<unsigned long long>();
+        pb.keep_words = (uint32_t)(((size_t)t->indexes.size() + 63) / 64 + 2);
+    }
+    const uint32_t lgrid = (L + PLAN_THREADS - 1u) / PLAN_THREADS;
+    hipLaunchKernelGGL(k_tree_test, dim3(lgrid), dim3(PLAN_THREADS), 0, st, p, pb, scale, t->prev_scale);
+    hipLaunchKernelGGL(k_tree_scan, dim3(PLAN_GRID), dim3(PLAN_THREADS), 0, st, pb);
+    hipLaunchKernelGGL(k_tree_fill, dim3(lgrid), dim3(PLAN_THREADS), 0, st, p, pb, scale);
+    hipLaunchKernelGGL(k_tree_offsets, dim3(lgrid), dim3(PLAN_THREADS), 0, st, p, pb, scale);
     GS_HIP(hipGetLastError());
+    t->prev_scale = scale;
+    t->gather_serial++;
+    if (deferred) {
+        dst->pending_tree = t;
+        dst->pending_keep_zeroed = pb.keep_zero != nullptr;
+        t->pending_sorter = dst;
+    } else {
+        GS_TRY(gs_tree_copy_plain(t, out_dev, st));
+        if (dst && dst->pending_tree == t) gs_tree_forget_sorter(t, dst);
+    }
     if (!render_count) {
         // asynchronous: nothing returns to the host, splatRenderCount stays on the device next to the list; the sorter takes
         // both from there (gs_sorter_sort_gathered), the draw takes the sorted list's length from the sorter
@@ -857,3 +901,29 @@ int gs_tree_gather(gs_tree* t, const gs_gather_params* gp, gs_sorter* dst, uint3
 }
 
 }  // extern "C"
+
+void gs_tree_view(gs_tree* t, TreeGatherView* v) {
+    v->tree_uid = t->uid;
+    v->leaves = (uint32_t)t->leaves.size();
+    v->tree_splats = (uint32_t)t->indexes.size();
+    v->leaf_offset = t->d_offset.as<uint32_t>();
+    v->leaf_count = t->d_count.as<uint32_t>();
+    v->leaf_begin = t->d_begin.as<uint32_t>();
+    v->leaf_indexes = t->d_indexes.as<uint32_t>();
+    v->totals = t->d_total.as<uint32_t>();
+}
+
+int gs_tree_copy_plain(gs_tree* t, uint32_t* out_dev, hipStream_t st) {
+    const uint32_t L = (uint32_t)t->leaves.size();
+    if (L == 0) return GS_OK;
+    const uint32_t copy_grid = (L + COPY_WAVES - 1u) / COPY_WAVES;
+    hipLaunchKernelGGL(k_tree_copy, dim3(copy_grid < 8192u ? copy_grid : 8192u), dim3(64 * COPY_WAVES), 0, st, L, t->d_offset.as<uint32_t>(),
+                       t->d_count.as<uint32_t>(), t->d_begin.as<uint32_t>(), t->d_indexes.as<uint32_t>(), out_dev);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
+void gs_tree_forget_sorter(gs_tree* t, gs_sorter* s) {
+    if (t && t->pending_sorter == s) t->pending_sorter = nullptr;
+    if (s && s->pending_tree == t) s->pending_tree = nullptr;
+}

@@ -188,7 +188,9 @@ typedef struct gs_gather_params {
     uint32_t pad;
 } gs_gather_params;
 /* Tests every leaf, orders the kept ones by distance and lays their index lists out far -> near (the nearest leaf
- * ends the buffer), on the device (two launches: the plan - one grid-synchronised kernel - and the copy).
+ * ends the buffer), on the device: four small launches plan where every kept leaf's list goes (a count-weighted rank by
+ * distance), then the lists are copied - at once, or, when a static sorter is the only reader, by that sorter's next full sort,
+ * fused with its key kernel (the list is then in place when gs_sorter_sort_gathered returns).
  *   dst               sorter whose device-side indexesToSort buffer receives the list (then call
  *                     gs_sorter_sort_gathered), or NULL
  *   render_count      out: splatRenderCount (this waits for the device); or NULL = asynchronous: nothing returns to the host,

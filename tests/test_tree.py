@@ -314,6 +314,59 @@ def test_asynchronous_gather_sorts_and_draws_without_a_host_round_trip(ctx, frus
 
 
 @pytest.mark.gpu
+def test_deferred_gather_copy_float_sorter_and_lifecycle(ctx, monkeypatch):
+    """gs_tree_gather only plans when a static sorter is its only reader; the sorter copies the lists itself, fused with its key
+    kernel (sorter.hip, k_tree_copy_keys).  The float sorter goes through the same kernel; the list must equal the one of the
+    immediate copy (GSPLAT_TREE_NO_DEFER=1) and the reference sorter on the oracle's gathered list.  Lifecycle: a second gather
+    before the sort supersedes the first; a tree destroyed before the sort leaves the sorter without a list (an error, not a
+    dangling pointer); a second sorter gathering from the same tree makes the first one copy at once."""
+    import oracle
+    from oracle import tree_oracle
+    from gaussiansplats3d_amd import create_sort_worker
+    case = tree_cases.make_case("clusters40k")
+    c = case["centers"]
+    n = c.shape[0]
+    cf = np.concatenate([c.astype(np.float32), np.ones((n, 1), np.float32)], axis=1)
+    cams = [camera.demo_camera("garden", 1280, 720), camera.orbit_cameras("garden", 1280, 720, 6)[2]]
+    tree = SplatTree(ctx, 8, 300).process_splat_mesh(c)
+    leaves, _ = tree_oracle.build_tree(c, None, 8, 300)
+    w = create_sort_worker(ctx, n, integer_based_sort=False)
+    w.post_message({"centers": cf, "range": {"from": 0, "to": n - 1, "count": n}})
+    lists = {}
+    for defer in (True, False):
+        if not defer:
+            monkeypatch.setenv("GSPLAT_TREE_NO_DEFER", "1")
+        for k, cam in enumerate(cams):
+            idx = tree_oracle.gather(leaves, cam.view, 50.0, 1280, 720)
+            if defer and k == 1:                              # an unconsumed gather for another camera first: superseded
+                tree.gather_scene_nodes_for_sort(cams[0], sort_worker=w, to_host=False)
+            r = tree.gather_scene_nodes_for_sort(cam, sort_worker=w, to_host=False)
+            assert r["splatRenderCount"] == len(idx)
+            reply = w.sort_gathered(cam.sort_mvp())
+            expect = oracle.sort_indexes(idx, cf, cam.sort_mvp(), use_int=False)
+            np.testing.assert_array_equal(reply["sortedIndexes"], expect)
+            lists[(defer, k)] = reply["sortedIndexes"]
+        if not defer:
+            monkeypatch.delenv("GSPLAT_TREE_NO_DEFER")
+    for k in range(len(cams)):
+        np.testing.assert_array_equal(lists[(True, k)], lists[(False, k)])
+    # two sorters, one tree: the second gather makes the first sorter copy its (still planned) list at once
+    w2 = create_sort_worker(ctx, n, integer_based_sort=False)
+    w2.post_message({"centers": cf, "range": {"from": 0, "to": n - 1, "count": n}})
+    tree.gather_scene_nodes_for_sort(cams[0], sort_worker=w, to_host=False)
+    tree.gather_scene_nodes_for_sort(cams[1], sort_worker=w2, to_host=False)
+    np.testing.assert_array_equal(w.sort_gathered(cams[0].sort_mvp())["sortedIndexes"], lists[(True, 0)])
+    np.testing.assert_array_equal(w2.sort_gathered(cams[1].sort_mvp())["sortedIndexes"], lists[(True, 1)])
+    # the tree goes away under a planned gather: the sort is refused
+    tree.gather_scene_nodes_for_sort(cams[0], sort_worker=w, to_host=False)
+    tree.dispose()
+    with pytest.raises(Exception):
+        w.sort_gathered(cams[0].sort_mvp())
+    w.terminate()
+    w2.terminate()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", tree_cases.CASES)
 def test_device_builder_matches_the_reference_tree(ctx, name):
     """gs_tree_create with a context builds the octree ON THE DEVICE (level-synchronous memberships, first-visitor claim,

@@ -413,7 +413,29 @@ def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frame
         probe = torch.empty((H, W, 4), dtype=torch.uint8, device=device)
         m["st_probe"] = rig.probe(probe.data_ptr())
         row_cost = mesh.tile_row_costs()
-        strips = gdist.balanced_row_strips(row_cost, world) if world > 1 else [(0, rows_total)]
+        strips = [(0, rows_total)]
+        m["strip_balance"] = None
+        if world > 1:
+            # Strips balanced for drawing AND for the transfer to the root (gdist.transfer_balanced_row_strips): with 2 or 4 ranks
+            # a peer's strip takes longer to cross its xGMI link than to draw, so the root takes more rows.  The draw model comes
+            # from rank 0's probe frame (the blend's time per unit of row cost, the other stages as a fixed part) and is
+            # broadcast: every rank must cut the frame alike.  $GS_LINK_GBPS = the per-link, per-direction rate assumed
+            # (default 77); $GS_STRIP_BALANCE=cost restores the cost-only cut.
+            st0 = m["st_probe"]
+            total_cost = float(np.sum(row_cost)) + len(row_cost)
+            model = [float(st0.blend_ms) / max(total_cost, 1.0), max(float(st0.device_ms) - float(st0.blend_ms), 0.0) + 0.07]
+            obj = [model]
+            dist.broadcast_object_list(obj, src=0)
+            model = obj[0]
+            link = float(os.environ.get("GS_LINK_GBPS", "77"))
+            if os.environ.get("GS_STRIP_BALANCE", "transfer") == "cost" or model[0] <= 0.0:
+                strips = gdist.balanced_row_strips(row_cost, world)
+                m["strip_balance"] = {"kind": "cost"}
+            else:
+                strips = gdist.transfer_balanced_row_strips(row_cost, world, W, model[0], model[1], link_GBps=link)
+                d_ms, x_ms = gdist.strip_frame_model(strips, row_cost, W, model[0], model[1], link_GBps=link)
+                m["strip_balance"] = {"kind": "transfer-aware", "link_GBps_assumed": link, "model_draw_ms": round(d_ms, 4),
+                                      "model_transfer_ms": round(x_ms, 4), "ms_per_cost": model[0], "fixed_ms": round(model[1], 4)}
         my = strips[rank]
         y0, y1 = gdist.strip_pixel_rows(my, H)
         strip = full if (world == 1) else torch.empty((max(y1 - y0, 0), W, 4), dtype=torch.uint8, device=device)
@@ -530,7 +552,7 @@ def brief(m, N):
     return {"workload": m["cfg"], "width": m["W"], "height": m["H"], "n_gpus": m["world"],
             "ms_per_step": round(m["ms_per_step"], 4), "value": round(N / (m["ms_per_step"] * 1e-3) / 1e6, 2), "unit": "Msplats/s",
             "median_ms_per_step": round(m["median_ms"], 4) if m["median_ms"] else None, "median_frames": m["median_frames"],
-            "strips": m["strips"] if m["world"] > 1 else None,
+            "strips": m["strips"] if m["world"] > 1 else None, "strip_balance": m.get("strip_balance"),
             "visible_splats": int(m["st_probe"].visible_splats), "tiles16_D": int(m["st_probe"].tiles16),
             "list_entries": m["D32"], "list_bin_px": m["list_px"],
             "stage_ms_isolated_frame": {k: round(v, 4) for k, v in m["stage_ms"].items()} or None}
@@ -870,7 +892,8 @@ def main():
                        "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)" if not M.get("gather_overlapped") else
                                   "sort -> draw on one stream per rank; the strip gather of frame k on a second stream beside frame k + 1",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",
-                       "strips": strips if world > 1 else None, "backend": backend if world > 1 else None,
+                       "strips": strips if world > 1 else None, "strip_balance": M.get("strip_balance"),
+                       "backend": backend if world > 1 else None,
                        "sort": "full list (R = N)" if world == 1 else "per rank: keys over all N, radix passes over the splats "
                                "its strip draws (gs_sorter_set_visibility_cull)",
                        "gather": M["gather_kind"],

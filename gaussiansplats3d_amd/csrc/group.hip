@@ -84,6 +84,59 @@ struct gs_group {
         }                                                                                          \
     } while (0)
 
+extern "C" void gs_group_destroy(gs_group* g);
+
+// rank r sends SELFTEST_BASE + 4096 * r bytes, byte i = (uint8_t)(i * 131 + r * 29 + 7); the root receives the strips
+// back to back and compares them on the host
+static int group_selftest(gs_group* g) {
+    Rccl* R = rccl();
+    GS_REQUIRE(R != nullptr, "RCCL is gone");
+    constexpr size_t SELFTEST_BASE = 64 * 1024;
+    ScopedDevice sd(g->ctx->device);
+    hipStream_t st = g->ctx->stream;
+    auto len = [&](uint32_t r) { return SELFTEST_BASE + 4096 * (size_t)r; };
+    auto val = [](uint32_t r, size_t i) { return (uint8_t)(i * 131u + r * 29u + 7u); };
+    size_t total = 0;
+    for (uint32_t r = 0; r < g->world; r++) total += len(r);
+    DevBuf mine, all;
+    GS_TRY(mine.alloc(len(g->rank)));
+    std::vector<uint8_t> host(len(g->rank));
+    for (size_t i = 0; i < host.size(); i++) host[i] = val(g->rank, i);
+    GS_HIP(hipMemcpyAsync(mine.p, host.data(), host.size(), hipMemcpyHostToDevice, st));
+    if (g->rank == 0) {
+        GS_TRY(all.alloc(total));
+        GS_HIP(hipMemsetAsync(all.p, 0, total, st));
+        GS_HIP(hipMemcpyAsync(all.p, mine.p, len(0), hipMemcpyDeviceToDevice, st));
+    }
+    GS_NCCL(R->GroupStart());
+    if (g->rank == 0) {
+        size_t off = len(0);
+        for (uint32_t r = 1; r < g->world; r++) {
+            GS_NCCL(R->Recv(all.as<char>() + off, len(r), kUint8, (int)r, g->comm, st));
+            off += len(r);
+        }
+    } else {
+        GS_NCCL(R->Send(mine.p, len(g->rank), kUint8, 0, g->comm, st));
+    }
+    GS_NCCL(R->GroupEnd());
+    GS_HIP(hipStreamSynchronize(st));
+    if (g->rank == 0) {
+        std::vector<uint8_t> got(total);
+        GS_HIP(hipMemcpy(got.data(), all.p, total, hipMemcpyDeviceToHost));
+        size_t off = 0;
+        for (uint32_t r = 0; r < g->world; r++) {
+            for (size_t i = 0; i < len(r); i++)
+                if (got[off + i] != val(r, i)) {
+                    gs_set_error("gs_group_create self-test: byte %zu of rank %u's %zu-byte pattern arrived as %u, expected %u - the RCCL "
+                                 "gather does not deliver what the ranks send", i, r, len(r), (unsigned)got[off + i], (unsigned)val(r, i));
+                    return GS_ERR_HIP;
+                }
+            off += len(r);
+        }
+    }
+    return GS_OK;
+}
+
 extern "C" {
 
 int gs_group_unique_id(uint8_t* id_out) {
@@ -124,6 +177,20 @@ int gs_group_create(gs_context* ctx, const uint8_t* id_bytes, uint32_t world_siz
             gs_set_error("ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
             delete g;
             return GS_ERR_HIP;
+        }
+    }
+    // First use of the RCCL branch: prove it.  Every rank sends a known pattern to rank 0 through the very calls the strip
+    // gather makes (one grouped ncclSend / ncclRecv on the context's stream, ragged lengths), the root checks every byte.
+    // This builder never had two GPUs: the first run on a real node either proves the path or fails HERE, loudly, instead of
+    // handing back a plausible-looking frame.  GS_GROUP_SELFTEST=0 skips it.
+    if (world_size > 1) {
+        const char* e = getenv("GS_GROUP_SELFTEST");
+        if (!e || strcmp(e, "0") != 0) {
+            const int st = group_selftest(g);
+            if (st != GS_OK) {
+                gs_group_destroy(g);
+                return st;
+            }
         }
     }
     *out = g;

@@ -32,6 +32,63 @@ def balanced_row_strips(row_cost, world_size, align=1):
     return [(cuts[i], cuts[i + 1]) for i in range(world_size)]
 
 
+def transfer_balanced_row_strips(row_cost, world_size, width, ms_per_cost, fixed_ms=0.0, link_GBps=77.0, root=0, align=2,
+                                 overlapped=True):
+    """Strips balanced for DRAWING AND TRANSFER.  The root draws its own strip and receives every other strip over that peer's
+    own point-to-point xGMI link (`link_GBps` per direction, per link; transfers from different peers run in parallel), so with
+    few ranks the strips are long and a peer's transfer, not its draw, sets the frame rate: at 8K, 2 ranks, the peer's 66 MB take
+    0.87 ms at 77 GB/s against a 0.55 ms draw.  The root therefore takes more rows than an equal-cost cut gives
+    it.  Model per rank r with tile rows [b, e):
+        draw_r = fixed_ms + ms_per_cost * sum(row_cost[b:e])          xfer_r = (e - b) * 16 * width * 4 bytes / link rate  (r != root)
+    overlapped (the gather of frame k runs beside the draw of frame k + 1): minimise max_r max(draw_r, xfer_r);
+    serial: minimise max_r draw_r + max_r xfer_r (here: by the same cut, which bounds it).
+    Contiguous strips in rank order, cut at multiples of `align` tile rows; a binary search on the frame time with a greedy
+    front-to-back feasibility test (maximal strips are optimal for a monotone cost).  Returns [(begin, end)] * world_size."""
+    rows = len(row_cost)
+    if world_size <= 1:
+        return [(0, rows)]
+    cost = np.asarray(row_cost, dtype=np.float64) + 1.0
+    groups = list(range(0, rows, align)) + [rows]                       # cut positions
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    row_ms = GS_TILE * width * 4 / (link_GBps * 1e9) * 1e3               # transfer of one tile row
+
+    def draw(b, e):
+        return fixed_ms + ms_per_cost * (csum[e] - csum[b]) if e > b else 0.0
+
+    def fits(T):
+        cuts, g = [0], 0
+        for r in range(world_size):
+            k = g
+            while k + 1 < len(groups):
+                e = groups[k + 1]
+                if draw(groups[g], e) > T or (r != root and (e - groups[g]) * row_ms > T):
+                    break
+                k += 1
+            g = k
+            cuts.append(groups[g])
+        return cuts if cuts[-1] == rows else None
+
+    lo, hi = 0.0, fixed_ms + ms_per_cost * csum[-1] + rows * row_ms + 1e-9
+    best = fits(hi)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        c = fits(mid)
+        if c is None:
+            lo = mid
+        else:
+            hi, best = mid, c
+    return [(best[i], best[i + 1]) for i in range(world_size)]
+
+
+def strip_frame_model(strips, row_cost, width, ms_per_cost, fixed_ms=0.0, link_GBps=77.0, root=0):
+    """(max draw ms, max transfer ms) of a strip assignment under transfer_balanced_row_strips' model."""
+    cost = np.asarray(row_cost, dtype=np.float64) + 1.0
+    row_ms = GS_TILE * width * 4 / (link_GBps * 1e9) * 1e3
+    draws = [fixed_ms + ms_per_cost * cost[b:e].sum() if e > b else 0.0 for b, e in strips]
+    xfers = [(e - b) * row_ms if r != root else 0.0 for r, (b, e) in enumerate(strips)]
+    return max(draws), max(xfers)
+
+
 def equal_row_strips(rows, world_size):
     return balanced_row_strips(np.zeros(rows), world_size)
 
@@ -63,6 +120,68 @@ def gather_strips(local_strip, strips, full, rank, world_size, dist, dst=0):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return full if rank == dst else None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# SORT-MIDDLE split: the design that removes the per-rank work which does not shrink with the strip.
+# With tile-row strips alone every rank still runs the vertex stage and the key / min-max pass over ALL N splats.  Here rank r
+# OWNS the splats with original indexes [r N / W, (r + 1) N / W): it projects and keys only those, the ranks all-reduce the
+# key range (8 bytes: the reference's buckets need the global min / max, sorter.cpp:142-143), and every survivor travels - as
+# {original index, depth key, 32-byte record, 8-byte tile rect} = 48 bytes - to each rank whose strip its tile rect touches
+# (an all-to-all-v: one grouped ncclSend / ncclRecv per peer pair, ~V_strip * 48 bytes received per rank).  A source lists its
+# survivors in ASCENDING original index; the destination concatenates what it receives in source-rank order, which - sources
+# owning ascending index ranges - is again ascending original index: exactly the list the per-rank visibility-culled sort
+# compacts today, so the same two stable radix passes over it reproduce the reference's order (descending bucket, ties in
+# reverse input order) bit for bit, and binning / blending of the strip go on unchanged.
+# What follows is the exchange's index logic on the host (numpy + torch.distributed point-to-point, the primitive RCCL runs
+# too); tests/test_dist_gloo.py drives it with world 2 and 3.  The device path is not built: tools/strip_scaling.py costs the
+# design from measured parts.
+def owner_range(rank, world_size, n):
+    """Original-index range [begin, end) rank `rank` projects and keys in the sort-middle split."""
+    per = (n + world_size - 1) // world_size
+    return min(rank * per, n), min((rank + 1) * per, n)
+
+
+def sort_middle_destinations(tile_rows, strips):
+    """tile_rows: int [m, 2] inclusive tile-row span (ty0, ty1) of m visible splats.  -> bool [m, world]: splat x strip touched."""
+    t = np.asarray(tile_rows).reshape(-1, 2)
+    out = np.zeros((t.shape[0], len(strips)), dtype=bool)
+    for d, (b, e) in enumerate(strips):
+        out[:, d] = (t[:, 0] < e) & (t[:, 1] >= b) & (e > b)
+    return out
+
+
+def sort_middle_exchange(ids, payload, tile_rows, strips, rank, world_size, dist):
+    """One frame's all-to-all-v.  ids: int64 [m] ascending original indexes of this rank's visible splats; payload: uint8 [m, B]
+    their records; tile_rows as above.  Returns (ids_for_my_strip ascending, payload rows in the same order)."""
+    import torch
+    ids = np.asarray(ids, dtype=np.int64)
+    payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(ids.shape[0], -1)
+    B = payload.shape[1]
+    touch = sort_middle_destinations(tile_rows, strips)
+    send_sel = [np.nonzero(touch[:, d])[0] for d in range(world_size)]
+    counts = torch.tensor([len(sel) for sel in send_sel], dtype=torch.int64)
+    table = [torch.zeros(world_size, dtype=torch.int64) for _ in range(world_size)]
+    dist.all_gather(table, counts)                                   # table[s][d] = survivors source s sends to strip d
+    recv_counts = [int(table[s][rank]) for s in range(world_size)]
+    recv_ids = [torch.empty(c, dtype=torch.int64) for c in recv_counts]
+    recv_pay = [torch.empty((c, B), dtype=torch.uint8) for c in recv_counts]
+    ops = []
+    for peer in range(world_size):
+        if peer == rank:
+            recv_ids[rank].copy_(torch.from_numpy(ids[send_sel[rank]]))
+            recv_pay[rank].copy_(torch.from_numpy(payload[send_sel[rank]]))
+            continue
+        if len(send_sel[peer]):
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(ids[send_sel[peer]])), peer))
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(payload[send_sel[peer]])), peer))
+        if recv_counts[peer]:
+            ops.append(dist.P2POp(dist.irecv, recv_ids[peer], peer))
+            ops.append(dist.P2POp(dist.irecv, recv_pay[peer], peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return torch.cat(recv_ids).numpy(), torch.cat(recv_pay).numpy()    # source-rank order = ascending original index
 
 
 class StripGroup:

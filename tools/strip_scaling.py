@@ -1,7 +1,9 @@
 """Per-rank cost of the strip-sharded frame for N = 1, 2, 4, 8, measured on ONE GPU: every rank's frame (vertex stage with
 its strip -> visibility-culled sort -> bin -> blend of the strip) is run in turn on a single-stream context and the slowest
 rank is reported, i.e. what bench.py --gpus N would take without the framebuffer gather.
-usage: python tools/strip_scaling.py [C3|C5|...] [steps] [N:r]     (N:r = only rank r of N, e.g. under rocprofv3)"""
+usage: python tools/strip_scaling.py [C3|C5|...] [steps] [N:r]     (N:r = only rank r of N, e.g. under rocprofv3)
+       python tools/strip_scaling.py [C3|C5|...] [steps] sm       the SORT-MIDDLE split of DESIGN.md 7 costed from measured parts
+                                                                    (8 ranks; the device path of that split is not built)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -44,6 +46,86 @@ def timed(strip, culled):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def sort_middle_parts(n_ranks=8, link_GBps=float(os.environ.get("GS_LINK_GBPS", "77"))):
+    """Per-rank frame of the sort-middle split at `n_ranks`, from parts measured on this one GPU:
+       source      rank r projects and keys only the N / n splats it owns (original-index range): a mesh + sorter holding exactly
+                   those splats: vertex stage over the full frame + min / max + survivor compaction (measured as project +
+                   visibility-culled sort of that sub-scene: an UPPER bound, the source needs no radix passes);
+       exchange    8-byte all-reduce of the key range (~15 us assumed) + all-to-all-v: rank d receives V_d x 48 bytes, 1 / n of it
+                   over each of its links (bytes per link / link rate + 20 us of latency assumed);
+       destination two stable radix passes over the V_d survivors of its strip (measured: a sorter holding exactly those splats,
+                   full sort) + bin + entry sort + blend of the strip (measured stage times of the strip's draw)."""
+    strips = gdist.balanced_row_strips(row_cost, n_ranks, align=int(os.environ.get("GS_STRIP_ALIGN", "2")))
+    per = (N + n_ranks - 1) // n_ranks
+    rows = []
+    ctx.set_stage_timing(True)
+    for r in range(n_ranks):
+        b, e = r * per, min((r + 1) * per, N)
+        # --- source side: the owned sub-scene
+        sub = slice(b, e)
+        w8 = create_sort_worker(ctx, e - b)
+        w8.post_message({"centers": util.integer_centers(scene.centers[sub]), "range": {"from": 0, "to": e - b - 1, "count": e - b}})
+        m8 = SplatMesh(ctx, e - b, scene.sh_degree, scene.cov_half).build(scene.centers[sub], scene.cov[sub], scene.rgba[sub],
+                                                                         scene.sh[sub] if scene.sh_degree else None)
+        m8.set_camera(cam)
+        m8.use_sorter_result(w8, e - b)
+        w8.set_visibility_cull(True)
+        def src():
+            m8.project(None)
+            w8.sort_on_device(mvp, e - b)
+        for _ in range(3):
+            src()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            src()
+        ctx.synchronize()
+        t_src = (time.perf_counter() - t0) / steps * 1e3
+        w8.terminate(); m8.dispose()
+        # --- destination side: the strip's survivors (from the full mesh's own vertex stage for that strip)
+        strip = strips[r]
+        w.set_visibility_cull(True)
+        mesh.project(strip)
+        w.sort_on_device(mvp, N)
+        _, st = mesh.render(tile_rows=strip, to_host=False, want_stats=True)
+        ss, _ = w.last_stats()
+        V = int(ss.result_count)
+        draw_ms = float(st.bin_ms + st.tile_sort_ms + st.blend_ms)
+        ids = np.sort(w.debug_read(2, V).astype(np.int64)) if V else np.zeros(0, np.int64)
+        wd = create_sort_worker(ctx, max(V, 1))
+        if V:
+            wd.post_message({"centers": util.integer_centers(scene.centers[ids]), "range": {"from": 0, "to": V - 1, "count": V}})
+            for _ in range(3):
+                wd.sort_on_device(mvp, V)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                wd.sort_on_device(mvp, V)
+            ctx.synchronize()
+            t_sort = (time.perf_counter() - t0) / steps * 1e3
+        else:
+            t_sort = 0.0
+        wd.terminate()
+        w.set_visibility_cull(False)
+        a2a = V * 48.0 / n_ranks / (link_GBps * 1e9) * 1e3 + 0.020
+        total = t_src + 0.015 + a2a + t_sort + draw_ms
+        rows.append((r, strip, V, t_src, a2a, t_sort, draw_ms, total))
+        print(f"{name} sort-middle rank {r}/{n_ranks}: strip {strip} V={V}: source {t_src:.4f} + all-reduce 0.015 + all-to-all {a2a:.4f} "
+              f"+ radix(V) {t_sort:.4f} + bin/entry sort/blend {draw_ms:.4f} = {total:.4f} ms", flush=True)
+    ctx.set_stage_timing(False)
+    return rows
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "sm":
+    base = timed(None, False)
+    rows = sort_middle_parts(8)
+    slow = max(r[-1] for r in rows)
+    strips8 = gdist.balanced_row_strips(row_cost, 8, align=int(os.environ.get("GS_STRIP_ALIGN", "2")))
+    strip_ms = max(timed(s, True) for s in strips8)
+    print(f"{name} 1 GPU full-sort frame {base:.4f} ms | 8 ranks, strips only (measured, slowest rank): {strip_ms:.4f} ms = {base / strip_ms:.2f}x | "
+          f"8 ranks, sort-middle (from parts, slowest rank): {slow:.4f} ms = {base / slow:.2f}x   (framebuffer gather excluded in both; "
+          f"link {os.environ.get('GS_LINK_GBPS', '77')} GB/s assumed)")
+    sys.exit(0)
 if len(sys.argv) > 3:
     n, r = (int(v) for v in sys.argv[3].split(":"))
     strip = gdist.balanced_row_strips(row_cost, n, align=int(os.environ.get("GS_STRIP_ALIGN", "2")))[r] if n > 1 else None

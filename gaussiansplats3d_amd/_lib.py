@@ -124,6 +124,7 @@ SYMBOLS = {
     "gs_group_render_gather": (C.c_int, [_VP, _VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.c_uint32, _VP]),
     "gs_mesh_render": (C.c_int, [_VP, C.POINTER(Camera), _VP, _VP, C.c_uint32, _VP, _VP, C.POINTER(RenderStats)]),
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
+    "gs_mesh_debug_rop8": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
     "gs_mesh_set_deep_pass": (C.c_int, [_VP, C.c_int]),
     "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),
     "gs_mesh_kernel_time": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -359,6 +359,7 @@ struct gs_mesh {
     gs_context* ctx = nullptr;
     uint32_t list_shift = GS_LIST_SHIFT_LARGE;     // list-bin size of the next draw (mesh_collect_stats re-evaluates it)
     uint32_t drawn_list_shift = GS_LIST_SHIFT_LARGE;   // ... of the last draw (what tile_ranges / the statistics refer to)
+    ProjectParams last_pp = {};                    // the last draw's geometry (gs_mesh_debug_rop8 walks its lists)
     int forced_list_shift = -1;                    // GSPLAT_LIST_SHIFT (A/B and tests)
     uint32_t max_count = 0, sh_degree = 0, flags = 0, uploaded = 0;
     // SoA planes
@@ -455,3 +456,4 @@ const uint32_t* gs_mesh_payload_unmap(gs_mesh* m);
 int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask);
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count);
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);
+int gs_launch_rop8_window(gs_mesh* m, const ProjectParams& pp, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t* out_dev);

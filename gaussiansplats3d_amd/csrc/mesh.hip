@@ -775,6 +775,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     m->projection_pending = false;
     const uint32_t y0 = pp.y0, y1 = pp.y1;
     m->drawn_list_shift = pp.list_shift;
+    m->last_pp = pp;
     const size_t out_bytes = (size_t)(y1 > y0 ? y1 - y0 : 0) * cam->width * 4;
 
     const uint32_t* order_dev = nullptr;
@@ -915,6 +916,22 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
         GS_HIP(hipMemcpyAsync(dst, m->deep_flags.as<uint32_t>(), 16, hipMemcpyDeviceToHost, st));
         if (count > 4) GS_HIP(hipMemcpyAsync(static_cast<uint32_t*>(dst) + 4, m->deep_flags.as<uint32_t>() + GS_FLAG_LIST, (size_t)(count - 4) * 4, hipMemcpyDeviceToHost, st));
     } else GS_REQUIRE(false, "unknown debug selector");
+    GS_HIP(hipStreamSynchronize(st));
+    return GS_OK;
+}
+
+int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height, uint8_t* rgba_out_host) {
+    GS_REQUIRE(m && rgba_out_host, "mesh / out == NULL");
+    GS_REQUIRE(m->has_draw, "no draw yet");
+    GS_REQUIRE(width > 0 && height > 0 && (uint64_t)width * height <= 65536u, "the window holds 1 .. 65536 pixels");
+    const ProjectParams& pp = m->last_pp;
+    GS_REQUIRE(x0 + width <= (uint32_t)pp.width && y0 >= pp.y0 && y0 + height <= pp.y1, "the window leaves the rows the last draw covered");
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    const size_t bytes = (size_t)width * height * 4;
+    GS_TRY(m->staging.ensure(bytes + 64));
+    GS_TRY(gs_launch_rop8_window(m, pp, x0, y0, width, height, m->staging.as<uint32_t>()));
+    GS_HIP(hipMemcpyAsync(rgba_out_host, m->staging.p, bytes, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;
 }

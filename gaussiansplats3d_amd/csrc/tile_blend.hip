@@ -842,6 +842,72 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_deep_fold(FrameArgs fa, DeepA
     write_pixels(fa.out, fa.width, fa.y0, fa.y1, bg.bx * GS_BIN + (q & 1u) * GS_TILE + (lane & 15u), bg.by * GS_BIN + (q >> 1) * GS_TILE + (lane >> 4), f);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// verification: the reference's real render target
+// ---------------------------------------------------------------------------------------------------------------------------
+// The reference blends every splat into an RGBA8 target (SplatMaterial3D.js:65-75: NormalBlending, back to front; clear
+// (0,0,0,0), src/Viewer.js:358-359): after EVERY splat each channel is rounded to 8 bits.  The engine composites front to back in
+// fp32 and rounds once; the distance between the two is gated in tests/test_gpu_crops.py.  This kernel reproduces the reference's
+// own semantics from the last draw's lists and records, for a small window: one thread per pixel walks its list bin's entries
+// from the END (farthest) to the beginning, evaluates the fragment rule with the blend's own arithmetic and applies
+//     rgb = a * src + (1 - a) * rgb ;  alpha = a + (1 - a) * alpha ;  every channel -> floor(clamp01(v) * 255 + 0.5) / 255
+// after every splat - oracle/raster_oracle.c's rop8 mode.  A verification path (gs_mesh_debug_rop8), not a draw mode: a thread
+// walks its whole list.
+__global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0, uint32_t wy0, uint32_t ww, uint32_t wh, uint32_t height,
+                                                      uint32_t* __restrict__ out) {
+#pragma clang fp contract(off)
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ww * wh) return;
+    const uint32_t px = wx0 + t % ww, py = wy0 + t / ww;
+    float r = 0.0f, g = 0.0f, b = 0.0f, al = 0.0f;
+    if (px < fa.width && py < height && py >= fa.y0 && py < fa.y1) {
+        const uint32_t tx = px / GS_TILE, ty = py / GS_TILE;
+        const uint32_t lx = tx >> fa.list_shift, ly = (ty >> fa.list_shift) - fa.list_row_begin;
+        const uint2 range = fa.ranges[ly * fa.lists_x + lx];
+        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+        if (range.y > range.x) {
+            for (uint32_t k = range.y; k-- > range.x;) {
+                const uint32_t slot = fa.vals[k];
+                const uint2 rc = fa.rects[slot];
+                const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
+                if (tx < x0 || tx > x1 || ty < y0 || ty > y1) continue;
+                const uint4 lo = fa.recs[2 * (size_t)slot], hi = fa.recs[2 * (size_t)slot + 1];
+                const float dx = fx - __uint_as_float(lo.x), dy = fy - __uint_as_float(lo.y);
+                const float u = __builtin_fmaf(__uint_as_float(lo.z), dx, __uint_as_float(lo.w) * dy);
+                const float w = __builtin_fmaf(__uint_as_float(hi.x), dx, __uint_as_float(hi.y) * dy);
+                const float pw = __builtin_fmaf(u, u, w * w);
+                if (!(pw < GS_POWER_CUT)) continue;                      // `if (A > 8.0) discard`
+                const float a = __builtin_amdgcn_exp2f(-pw) * ((float)(hi.w >> 16) * (1.0f / 65535.0f));
+                const float sr = (float)(hi.z & 0xFFFFu) * (1.0f / 65535.0f), sg = (float)(hi.z >> 16) * (1.0f / 65535.0f),
+                            sb = (float)(hi.w & 0xFFFFu) * (1.0f / 65535.0f);
+                const float om = 1.0f - a;
+                auto q8 = [](float v) { return floorf(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f) * (1.0f / 255.0f); };
+                r = q8(a * sr + om * r);
+                g = q8(a * sg + om * g);
+                b = q8(a * sb + om * b);
+                al = q8(a + om * al);
+            }
+        }
+    }
+    auto u8 = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+    out[t] = u8(r) | (u8(g) << 8) | (u8(b) << 16) | (u8(al) << 24);
+}
+
+int gs_launch_rop8_window(gs_mesh* m, const ProjectParams& pp, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t* out_dev) {
+    FrameArgs fa = {};
+    fa.ranges = m->tile_ranges.as<uint2>();
+    fa.vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
+    fa.recs = m->recs.as<uint4>();
+    fa.rects = m->rects.as<uint2>();
+    fa.width = (uint32_t)pp.width; fa.y0 = pp.y0; fa.y1 = pp.y1;
+    fa.bins_x = pp.bins_x; fa.bin_row_begin = pp.bin_row_begin;
+    fa.lists_x = pp.lists_x; fa.list_row_begin = pp.list_row_begin; fa.list_shift = pp.list_shift - 0u;
+    // (list_shift here counts 16-px tiles per list bin edge, as in the binner: a list bin is (16 << list_shift) px)
+    hipLaunchKernelGGL(k_rop8_window, dim3((w * h + 255u) / 256u), dim3(256), 0, m->ctx->stream, fa, x0, y0, w, h, (uint32_t)pp.height, out_dev);
+    GS_HIP(hipGetLastError());
+    return GS_OK;
+}
+
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     const uint32_t bins = pp.bins_x * (pp.bin_row_end - pp.bin_row_begin);
     if (bins == 0) return GS_OK;

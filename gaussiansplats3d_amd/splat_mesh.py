@@ -284,6 +284,14 @@ class SplatMesh:
             blend = np.pad(blend, (0, rows_total - blend.shape[0]))
         return blend + 0.25 * entries
 
+    def rop8_window(self, x0, y0, width, height):
+        """Verification: the window [x0, x0+width) x [y0, y0+height) of the LAST draw composited the reference's way - back to
+        front into an RGBA8 target, every channel rounded to 8 bits after every splat (gs_mesh_debug_rop8;
+        SplatMaterial3D.js:65-75).  uint8 [height, width, 4], row 0 = y0 (GL orientation)."""
+        out = np.empty((int(height), int(width), 4), dtype=np.uint8)
+        L.check(self.lib.gs_mesh_debug_rop8(self.handle, int(x0), int(y0), int(width), int(height), out.ctypes.data))
+        return out
+
     def dispose(self):
         if self.handle:
             self.lib.gs_mesh_destroy(self.handle)

@@ -371,6 +371,14 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
  * The frame does not depend on that choice, on list batching or on how a multi-GPU draw cuts its strips. */
 int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
 
+/* VERIFICATION of the blend state (SplatMaterial3D.js:65-75): the reference composites back to front into an RGBA8 target,
+ * rounding every channel to 8 bits after EVERY splat; gs_mesh_render composites front to back in fp32 and rounds once.  This
+ * entry point reproduces the reference's own semantics for a window of <= 65536 pixels of the LAST draw (its lists, records
+ * and camera): rgb = a*src + (1-a)*rgb, alpha = a + (1-a)*alpha, then floor(clamp01(v)*255 + 0.5) per channel, splat by
+ * splat, farthest first.  (x0, y0) in GL window coordinates (row 0 = bottom), inside the rows the last draw covered;
+ * rgba_out_host: uint8[4*width*height], row-major from y0 upwards.  A thread per pixel walks its whole list: not a draw mode. */
+int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height, uint8_t* rgba_out_host);
+
 /* Scheduling switch, 1 by default (0 also via $GSPLAT_NO_DEEP at gs_mesh_create): whether the draws that follow may composite
  * very deep bins through the deep pass.  The frame is the same either way (see the composite above). */
 int gs_mesh_set_deep_pass(gs_mesh* m, int enabled);

@@ -829,6 +829,28 @@ def main():
                         _, st_s = rg.mesh.render(out_device_ptr=out_ptr, to_host=False, want_stats=True)
                         obj["deep_pass"]["off"] = {"ms_per_frame": round(s_el / k_steps * 1e3, 4), "blend_ms": round(float(st_s.blend_ms), 4)}
                         rg.mesh.set_deep_pass(True)
+                        # Under MOTION: the deep pass picks its bins from the PREVIOUS frame's statistics, so a fixed pose flatters
+                        # it.  Two laps of the 60-pose orbit, ONE frame per pose (the selection always comes from the neighbouring
+                        # pose); the first lap only grows the buffers, the second is timed (synchronised frames: latencies).
+                        o_ms, o_bins = [], []
+                        for lap in range(2):
+                            for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
+                                rg.set_view(oc)
+                                torch.cuda.synchronize()
+                                t1 = time.perf_counter()
+                                rg.frame(out_ptr)
+                                torch.cuda.synchronize()
+                                if lap:
+                                    o_ms.append((time.perf_counter() - t1) * 1e3)
+                                    o_bins.append(int(len(rg.mesh.deep_pass_info()["bins"])))
+                        rg.set_view(cam)
+                        obj["orbit"] = {"poses": 60, "frame_latency_ms_median": round(float(np.median(o_ms)), 4),
+                                        "frame_latency_ms_min": round(float(np.min(o_ms)), 4),
+                                        "frame_latency_ms_max": round(float(np.max(o_ms)), 4),
+                                        "frame_latency_ms_p90": round(float(np.percentile(o_ms, 90)), 4),
+                                        "deep_bins_median": int(np.median(o_bins)), "deep_bins_max": int(np.max(o_bins)),
+                                        "note": "one synchronised frame per pose, the deep pass's bins chosen from the previous POSE's "
+                                                "statistics; compare with the fixed pose's frame latency, not with ms_per_frame"}
                     if key == "C3T":
                         obj["note"] = ("opacity ~ sigmoid(N(-2,1)): pixels do not saturate early, the blend scans and walks "
                                        "its entry lists (compare entries_scanned / splats_walked with the `blend` object)")

@@ -31,10 +31,21 @@ python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_C4 gpurun_out/$TAG/pmc_traffic
 # previous evidence set (gpurun_ab/lib_r03x.so, built by tools/build_variant.sh from that commit) in one process
 (timeout 300 python tools/deep_ab.py "C3S C3T C3" 10 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/deep_ab.txt
 (GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 200 python tools/blend_profile.py C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_profile_C3S.txt
-if [ -f gpurun_ab/lib_r03x.so ]; then
+# this tree against the library of the previous round (gpurun_ab/lib_r03.so: tools/build_variant.sh with GS_VARIANT_SRC = a checkout
+# of round 3's last commit) in one process: whole frames, and the depth sort alone (bit-identical lists, checked against the oracle)
+if [ -f gpurun_ab/lib_r03.so ]; then
   cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
-  (timeout 400 python tools/ab_libs.py "C3 C3T C2 C5 C4 C3S" gpurun_ab/lib_r03x.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/ab_r03x_vs_this_tree.txt
+  (timeout 500 python tools/ab_libs.py "C3 C3T C2 C5 C4 C3S" gpurun_ab/lib_r03.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/ab_r03_vs_this_tree.txt
+  (timeout 500 python tools/sort_ab.py "C3 C4 C2" gpurun_ab/lib_r03.so gpurun_ab/lib_this_tree.so --check --sorts 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/sort_ab_r03_vs_this_tree.txt
 fi
+# the depth sort alone: kernel table and counters (FETCH_SIZE / WRITE_SIZE / SQ / LDS, one set per pass)
+cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
+bash tools/sort_prof.sh ${TAG}_sort_k C3 gpurun_ab/lib_this_tree.so 30 > gpurun_out/$TAG/sort_kstats_C3.txt 2>&1
+bash tools/sort_prof.sh ${TAG}_sort_k4 C4 gpurun_ab/lib_this_tree.so 15 > gpurun_out/$TAG/sort_kstats_C4.txt 2>&1
+bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_out/$TAG/sort_pmc_C3.txt 2>&1
+(tools/probes/gather_rate.bin 2>&1 | grep -v "^start") > gpurun_out/$TAG/gather_rate.txt
+(python tools/cull_prof.py 2>&1 | grep cull-on) > gpurun_out/$TAG/cull_on_frame.txt
+(timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 (timeout 400 python bench.py --gpus 2 --steps 10 --no-cpu --no-cull 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_2ranks_dry_run.json
 cp gpurun_out/crops_C*.json gpurun_out/$TAG/ 2>/dev/null

@@ -327,7 +327,8 @@ __global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scat
                                                                       const uint32_t* __restrict__ group_hist,
                                                                       KeyOutT* __restrict__ keys_out,
                                                                       uint32_t* __restrict__ vals_out, uint2* ranges,
-                                                                      uint32_t direct_ranges, uint32_t val_bits) {
+                                                                      uint32_t direct_ranges, uint32_t val_bits,
+                                                                      uint32_t* __restrict__ count_out) {
     static_assert(!PACK_OUT || (sizeof(KeyOutT) == 1 && !WRITE_KEYS && !RANGES), "a packing pass stages the digit as a byte");
     __shared__ KeyOutT s_keys[RADIX_TILE];                  // staged in the output key width (PACK_OUT: the digit)
     __shared__ uint32_t s_vals[RADIX_TILE];                 // the value (PACK_OUT: the packed word)
@@ -407,8 +408,12 @@ __global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scat
                 mine += s_before[q * RADIX_BINS + tid];
             }
         }
-        const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, nullptr);     // (two barriers: s_wave is free after it)
+        uint32_t n_valid;
+        const uint32_t smaller = block_excl_scan<SCATTER_WAVES>(tot, s_tmp, &n_valid);    // (two barriers: s_wave is free after it)
         if (tid < RADIX_BINS) s_base[tid] = smaller + mine;  // (read after barrier (1) of the first tile)
+        // a compacting pass (a loader that drops elements) publishes how many it keeps: the sum of its digit totals - one plain
+        // store, where one atomicAdd per workgroup of the key kernel on a single word cost ~12 ns each (25 us for 2048 of them)
+        if (count_out && blockIdx.x == 0 && tid == 0) *count_out = n_valid;
         // A single-pass sort's digit IS the key, so key d ends up in [smaller, smaller + tot): workgroup 0 publishes the
         // ranges of the first `direct_ranges` keys with plain stores.  (The RANGES path's atomicMin / atomicMax pairs all
         // land on ~9 cache lines when there are only 135 keys: 100 us for the 1080p entry sort instead of 30.)
@@ -607,7 +612,8 @@ template <class Loader, bool PACK_OUT, bool ATOMIC_RANK>
 __global__ __launch_bounds__(CHUNK_THREADS, CHUNK_OCC_CFG) void k_radix_scatter_chunk(Loader ld, int shift,
                                                                                      const uint32_t* __restrict__ block_hist,
                                                                                      const uint32_t* __restrict__ group_hist,
-                                                                                     uint32_t* __restrict__ out, uint32_t val_bits) {
+                                                                                     uint32_t* __restrict__ out, uint32_t val_bits,
+                                                                                     uint32_t* __restrict__ count_out) {
     __shared__ uint32_t s_stage[CHUNK_KEYS];
     __shared__ uint8_t s_digit[PACK_OUT ? CHUNK_KEYS : 4];
     __shared__ __attribute__((aligned(16))) uint32_t s_wave[CHUNK_WAVES][RADIX_BINS];   // per-wave digit counts, then first slot of (wave, digit)
@@ -682,7 +688,9 @@ __global__ __launch_bounds__(CHUNK_THREADS, CHUNK_OCC_CFG) void k_radix_scatter_
                 mine += s_before[q * RADIX_BINS + tid];
             }
         }
-        const uint32_t smaller = block_excl_scan<CHUNK_WAVES>(tot, s_tmp, nullptr);
+        uint32_t n_valid;
+        const uint32_t smaller = block_excl_scan<CHUNK_WAVES>(tot, s_tmp, &n_valid);
+        if (count_out && blockIdx.x == 0 && tid == 0) *count_out = n_valid;              // (see k_radix_scatter)
         const uint32_t first = block_excl_scan<CHUNK_WAVES>(own, s_tmp, &chunk_count);   // first staging slot of digit d
         if (tid < RADIX_BINS) {
             s_run[tid] = first;
@@ -793,17 +801,18 @@ inline uint32_t radix_grid_for(uint32_t n_upper) {
 // digit_total row (the caller zeroes RadixScratch::digit_total once per frame).
 template <class HistLoader, class Loader, class KeyOutT, bool WRITE_KEYS, bool RANGES, bool PACK_OUT>
 int radix_pass_ex(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift, const Loader& ld, uint32_t n_upper, int shift,
-                  int pass_slot, KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges, uint32_t direct_ranges, uint32_t val_bits) {
+                  int pass_slot, KeyOutT* keys_out, uint32_t* vals_out, uint2* ranges, uint32_t direct_ranges, uint32_t val_bits,
+                  uint32_t* count_out = nullptr) {
     const uint32_t grid = radix_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
     uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
     hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
     if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, true, PACK_OUT>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits);
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits, count_out);
     else
         hipLaunchKernelGGL((k_radix_scatter<Loader, KeyOutT, WRITE_KEYS, RANGES, false, PACK_OUT>), dim3(grid), dim3(SCATTER_THREADS), 0,
-                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits);
+                           ex.stream, ld, shift, bh, dt, keys_out, vals_out, ranges, direct_ranges, val_bits, count_out);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }
@@ -811,15 +820,15 @@ int radix_pass_ex(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift
 // A pass of the depth sort between / after packing passes (see k_radix_scatter_chunk); the caller checked radix_chunk_grid_for.
 template <class HistLoader, class Loader, bool PACK_OUT>
 int radix_pass_chunk(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift, const Loader& ld, uint32_t n_upper, int shift,
-                     int pass_slot, uint32_t* out, uint32_t val_bits) {
+                     int pass_slot, uint32_t* out, uint32_t val_bits, uint32_t* count_out = nullptr) {
     const uint32_t grid = radix_chunk_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
     uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
     hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
     if (ex.atomic_rank)
-        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, true>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits);
+        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, true>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits, count_out);
     else
-        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, false>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits);
+        hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, false>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits, count_out);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

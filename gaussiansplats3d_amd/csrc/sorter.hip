@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void k_depth_key_cull(KeyParams p) {
         hi = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
         atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
         atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
-        atomicAdd(&p.frame->kept, s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3]);
+        // (the number of kept positions is published by pass 0 of the radix sort - the sum of its digit totals - instead of by
+        // one atomicAdd per workgroup on a single word here: radix.hpp, count_out)
     }
 }
 
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyPar
         if (off == 0xFFFFFFFFu) continue;                    // culled leaf
         // four 64-splat slices of the leaf per round: their twelve loads leave together (a leaf holds ~200 splats, so a wave's
         // work is two or three dependent memory round trips whatever its length - what hides them is the loads in flight)
+        unsigned long long carry = 0ull;                     // (lane 0) keep bits of this leaf that belong to the next round's first word
         for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
             uint32_t idx[4], pos[4];
             uint4 ce[4];
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyPar
                 pos[k] = c.leaf_pos[j];
                 ce[k] = c.leaf_centers[j];
             }
+            unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t t = t0 + 64u * k + lane;
@@ -446,14 +449,28 @@ __global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyPar
                     hi = max(hi, key);
                 }
                 if (CULL) {
-                    const unsigned long long bits = __ballot(in[k] && frustum_keep_one(p.mvp, x, y, z));
-                    if (lane == 0u && bits) {                // list positions first .. first + 63: two words of the (zeroed) mask
-                        const uint32_t first = off + t0 + 64u * k, sh = first & 63u;
-                        atomicOr(&p.keep[first >> 6], bits << sh);
-                        if (sh) atomicOr(&p.keep[(first >> 6) + 1u], bits >> (64u - sh));
-                    }
-                    kept += (uint32_t)__popcll(bits);        // (the same value in every lane)
+                    bits[k] = __ballot(in[k] && frustum_keep_one(p.mvp, x, y, z));
+                    kept += (uint32_t)__popcll(bits[k]);     // (the same value in every lane)
                 }
+            }
+            if (CULL && lane == 0u) {
+                // The round's 256 list positions start at `first`: four words of the (zeroed) keep mask and a carry into the
+                // fifth, which the next round of this leaf completes.  A word that lies wholly inside this leaf's range is ours
+                // alone - a plain store; the words the leaf shares with its neighbours in the list take an atomicOr (two per
+                // slice, 136 k atomics per gather, were ~15 us of this kernel).
+                const uint32_t first = off + t0, sh = first & 63u, w0 = first >> 6;
+                unsigned long long W[4];
+                W[0] = carry | (bits[0] << sh);
+#pragma unroll
+                for (int j = 1; j < 4; j++) W[j] = (bits[j] << sh) | (sh ? bits[j - 1] >> (64u - sh) : 0ull);
+                carry = sh ? bits[3] >> (64u - sh) : 0ull;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t wbeg = (w0 + (uint32_t)j) * 64u;            // first list position of the word
+                    if (wbeg >= off && wbeg + 64u <= off + n) p.keep[w0 + j] = W[j];
+                    else if (W[j]) atomicOr(&p.keep[w0 + j], W[j]);
+                }
+                if (t0 + 256u >= n && carry) atomicOr(&p.keep[w0 + 4u], carry);   // the leaf's last round: its tail word
             }
         }
     }
@@ -475,10 +492,7 @@ __global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyPar
             atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
             atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
         }
-        if (CULL) {
-            const uint32_t k = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
-            if (k) atomicAdd(&p.frame->kept, k);
-        }
+        // (CULL: the kept count is published by pass 0 of the radix sort, radix.hpp count_out)
     }
 }
 
@@ -1068,10 +1082,11 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 dc.n_dev = dl.n_dev;
                 DepthLoaderCull h = dc;
                 h.count_clamps = 1;
-                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoaderCull, DepthLoaderCull, true>(ex, h, shift, dc, Rs, shift, (int)p, vo, val_bits)));
-                else if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
-                else if (wide) GS_TRY((radix_pass<DepthLoaderCull, uint32_t, true>(ex, h, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
-                else GS_TRY((radix_pass<DepthLoaderCull, uint16_t, true>(ex, h, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+                uint32_t* kept_out = &kp.frame->kept;                  // pass 0 compacts: it publishes the result's length
+                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoaderCull, DepthLoaderCull, true>(ex, h, shift, dc, Rs, shift, (int)p, vo, val_bits, kept_out)));
+                else if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits, kept_out)));
+                else if (wide) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint32_t, true, false, false>(ex, h, shift, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo, nullptr, 0u, 0u, kept_out)));
+                else GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint16_t, true, false, false>(ex, h, shift, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo, nullptr, 0u, 0u, kept_out)));
             } else if (p == 0) {
                 DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
                 h.count_clamps = 1;

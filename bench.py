@@ -679,6 +679,23 @@ def main():
                                      "of frame k's draw (same camera); throughput of whole frames, not the §8d metric"}
                 rig2.close()
                 ctx2.close()
+                # ... and the same streams with SERIAL frames (GS_CTX_FORK_JOIN): the sort and the vertex stage of a frame run side
+                # by side and join at the binner, but no sort starts before the previous frame has finished - the 8d frame
+                # (t_sort + t_raster of one frame at a time), shortened to max(t_sort, t_vertex) + t_bin + t_blend
+                ctx3 = Context(local_rank, stream.cuda_stream, single_stream=False, fork_join=True)
+                rig3 = Rig(ctx3, scene, cam, device, torch)
+                rig3.probe(strip.data_ptr())
+                for _ in range(args.warmup):
+                    rig3.frame(strip.data_ptr())
+                f_el, _ = rig3.timed(args.steps, strip.data_ptr())
+                fj_ev = rig3.event_frames(max(min(args.median_frames, 50), 1), stream, strip.data_ptr())
+                pipelined["fork_join"] = {"ms_per_step": round(f_el / args.steps * 1e3, 4),
+                                          "median_ms_per_step": round(float(np.median(fj_ev)), 4),
+                                          "Msplats_per_s": round(N / (f_el / args.steps) / 1e6, 1),
+                                          "note": "GS_CTX_FORK_JOIN: sort || vertex stage inside ONE frame, frames strictly serial "
+                                                  "(every frame bracketed by events on the caller's stream for the median)"}
+                rig3.close()
+                ctx3.close()
 
             if extras:
                 # a 60-pose orbit about the look-at point, one synchronised frame per pose, for medians (the

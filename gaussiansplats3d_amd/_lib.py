@@ -19,7 +19,7 @@ GS_ERR_INVALID, GS_ERR_HIP, GS_ERR_NOMEM, GS_ERR_CAPACITY, GS_ERR_UNSUPPORTED = 
 GS_SORT_INTEGER, GS_SORT_DYNAMIC = 1, 2
 GS_MESH_COV_HALF, GS_MESH_SH_U8, GS_MESH_KEEP_ORDER = 1, 2, 4
 GS_CAM_ANTIALIASED, GS_CAM_POINT_CLOUD, GS_CAM_ORTHOGRAPHIC, GS_CAM_FADE_IN, GS_CAM_SCENE_EFFECTS, GS_CAM_DYNAMIC = 1, 2, 4, 8, 16, 32
-GS_CTX_SINGLE_STREAM, GS_CTX_STAGE_TIMING = 1, 2
+GS_CTX_SINGLE_STREAM, GS_CTX_STAGE_TIMING, GS_CTX_FORK_JOIN = 1, 2, 4
 GS_TILE = 16
 GS_BIN = 32          # blend workgroups are per 32-px bin (2x2 tiles); entry lists per list bin (RenderStats.list_bin_px)
 GS_MAX_SCENES = 32
@@ -183,7 +183,7 @@ atexit.register(_close_live_contexts)
 class Context:
     """One per GPU (gs_context).  `stream`: a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
 
-    def __init__(self, device=0, stream=None, single_stream=None, stage_timing=False):
+    def __init__(self, device=0, stream=None, single_stream=None, stage_timing=False, fork_join=False):
         """single_stream: True = sorts and draws share one stream (a frame is strictly sort -> draw), False = the sorter
         and the vertex stage get streams of their own (the reference's worker-thread shape), None = $GSPLAT_SERIAL.
         stage_timing: time the stages of every sort / draw, not only of those that return statistics (GS_CTX_STAGE_TIMING)."""
@@ -193,8 +193,8 @@ class Context:
         if single_stream is None:
             check(self.lib.gs_context_create(int(device), st, C.byref(self.handle)))
         else:
-            check(self.lib.gs_context_create_ex(int(device), st, GS_CTX_SINGLE_STREAM if single_stream else 0,
-                                                C.byref(self.handle)))
+            check(self.lib.gs_context_create_ex(int(device), st, (GS_CTX_SINGLE_STREAM if single_stream else 0) |
+                                                (GS_CTX_FORK_JOIN if fork_join else 0), C.byref(self.handle)))
         if stage_timing:
             self.set_stage_timing(True)
         self.device = int(device)

@@ -36,7 +36,8 @@ int gs_context_create(int device, void* hip_stream, gs_context** out) {
 
 int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out) {
     GS_REQUIRE(out != nullptr, "out == NULL");
-    GS_REQUIRE((flags & ~(GS_CTX_SINGLE_STREAM | GS_CTX_STAGE_TIMING)) == 0, "unknown context flags");
+    GS_REQUIRE((flags & ~(GS_CTX_SINGLE_STREAM | GS_CTX_STAGE_TIMING | GS_CTX_FORK_JOIN)) == 0, "unknown context flags");
+    GS_REQUIRE(!((flags & GS_CTX_SINGLE_STREAM) && (flags & GS_CTX_FORK_JOIN)), "GS_CTX_FORK_JOIN needs the streams GS_CTX_SINGLE_STREAM removes");
     *out = nullptr;
     int n = gs_device_count();
     if (n < 0) return n;
@@ -84,6 +85,12 @@ int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_contex
     } else {
         ctx->aux = ctx->stream;
     }
+    ctx->fork_join = (flags & GS_CTX_FORK_JOIN) != 0;
+    if (ctx->fork_join && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) {
+        gs_set_error("hipEventCreate(fork) failed");
+        gs_context_destroy(ctx);
+        return GS_ERR_HIP;
+    }
     int st = ctx->radix.init();
     if (st >= 0) {
         bool ok = false;
@@ -106,6 +113,7 @@ void gs_context_destroy(gs_context* ctx) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
     }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->radix.block_hist.release();
     ctx->radix.digit_total.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

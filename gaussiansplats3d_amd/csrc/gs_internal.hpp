@@ -85,6 +85,12 @@ constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
 constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
 constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
+// ... and 512-px list bins when splats are larger still (a visible splat covers >= 32 tiles: an 8K frame of the garden stand-in
+// covers 101).  Entries shrink again (C5: 5.96 M -> 2.19 M), the 8K frame's 2040 lists become 135 and its two-pass entry sort one
+// pass (0.082 -> 0.022 ms), the binner 0.091 -> 0.056 ms; the blend scans 24 % more entries (0.654 -> 0.686 ms): frame 0.903 ->
+// 0.844 ms, 256-px lists in between (0.879) - r04 same-box runs of bench.py --config C5 under GSPLAT_LIST_SHIFT=3 / 4 / 5.
+constexpr uint32_t GS_LIST_SHIFT_HUGE = 5;                 // 512-px list bins
+constexpr float GS_LIST_TILES_PER_SPLAT_HUGE = 32.0f;
 // CHUNKED COMPOSITE (tile_blend.hip).  The value of a pixel is DEFINED per 16x16 quadrant as a two-level fold: the quadrant's
 // ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks (below), each
 // chunk is composited front to back from T = 1, C = 0, and the chunks are merged near -> far (C = fma(T, C_c, C); T = T * T_c).
@@ -188,6 +194,8 @@ struct gs_context {
     uint32_t kernel_sample = 8;           // GSPLAT_KERNEL_SAMPLE: on a single-stream context k_project is bracketed with events
                                           // every n-th draw (0 = never) for gs_mesh_kernel_time; every draw costs 1.5 % (r02m)
     bool serial = false;                  // GSPLAT_SERIAL=1: everything on `stream` (debugging / per-stage timing)
+    bool fork_join = false;               // GS_CTX_FORK_JOIN: sorts wait for what `stream` holds when they are called (serial frames)
+    hipEvent_t ev_fork = nullptr;         // ... recorded on `stream` by every sort of such a context
     int cu_count = 256;
     bool lds_atomic_lane_order = false;   // self-test result: ds_add_rtn serves same-address lanes in lane order
     RadixScratch radix;                   // scratch of the create-time self-test

@@ -596,8 +596,9 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     }
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them
     if (m->last.visible_splats > 0)
-        m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats ? GS_LIST_SHIFT_LARGE
-                                                                                                            : GS_LIST_SHIFT_SMALL;
+        m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT_HUGE * (float)m->last.visible_splats ? GS_LIST_SHIFT_HUGE
+                      : (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats    ? GS_LIST_SHIFT_LARGE
+                                                                                                             : GS_LIST_SHIFT_SMALL;
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;
 }

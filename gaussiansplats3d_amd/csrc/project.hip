@@ -46,6 +46,9 @@ constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zer
 #ifndef GS_SH_EARLY
 #define GS_SH_EARLY 0
 #endif
+#ifndef GS_COV_EARLY
+#define GS_COV_EARLY 1
+#endif
 struct ShPre {                  // fp16 SH planes fetched together with the covariance (GS_SH_EARLY): one dependent round trip less
     uint4 a, b, c;
     bool have;
@@ -204,6 +207,25 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         const float* MV = pp.view;
         const float* P = pp.proj;
         const float c0 = mp.px[i], c1 = mp.py[i], c2 = mp.pz[i];
+        // A full-frame draw fetches the covariance and the colour WITH the centre: Morton blocks are all-or-nothing (C3: 1.44 M
+        // visible splats in 5.6 k live blocks of 256), so in a block that survived the block test nearly every lane needs them,
+        // and the visible path loses one of its three dependent memory round trips.  A rank's strip of a multi-GPU draw keeps the
+        // lazy fetch: there the per-splat pre-test exists precisely to leave the covariance of the other strips' splats unread.
+        const bool early = GS_COV_EARLY && !(pp.row_begin > 0u || pp.row_end < pp.tiles_y);
+        uint32_t e_rgba = 0;
+        uint4 e_a = make_uint4(0u, 0u, 0u, 0u);
+        uint2 e_b = make_uint2(0u, 0u);
+        if (early) {
+            e_rgba = mp.rgba[i];
+            if (pp.cov_half) {
+                const uint2 a = reinterpret_cast<const uint2*>(mp.covA)[i];
+                e_a.x = a.x; e_a.y = a.y;
+                e_b.x = reinterpret_cast<const uint32_t*>(mp.covB)[i];
+            } else {
+                e_a = reinterpret_cast<const uint4*>(mp.covA)[i];
+                e_b = reinterpret_cast<const uint2*>(mp.covB)[i];
+            }
+        }
         uint32_t scene = 0;
         float opacity_from_scene = 1.0f;
         bool scene_ok = true;
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         }
 
         if (ok) {
-            const uint32_t packed = mp.rgba[i];
+            const uint32_t packed = early ? e_rgba : mp.rgba[i];
             ShPre pre;
             pre.have = false;
             if (GS_SH_EARLY && !EXT && pp.sh_stored >= 2 && pp.sh_degree >= 1) {     // static fp16 SH-2 scene (the benchmark path)
@@ -287,13 +309,22 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
             // SplatMaterial3D.js:87-109 covariance fetch
             float V00, V01, V02, V11, V12, V22;
             if (pp.cov_half) {
-                const uint2 a = reinterpret_cast<const uint2*>(mp.covA)[i];
-                const uint32_t b = reinterpret_cast<const uint32_t*>(mp.covB)[i];
+                uint2 a = make_uint2(e_a.x, e_a.y);
+                uint32_t b = e_b.x;
+                if (!early) {
+                    a = reinterpret_cast<const uint2*>(mp.covA)[i];
+                    b = reinterpret_cast<const uint32_t*>(mp.covB)[i];
+                }
                 V00 = h2f(a.x); V01 = h2f(a.x >> 16); V02 = h2f(a.y); V11 = h2f(a.y >> 16); V12 = h2f(b); V22 = h2f(b >> 16);
             } else {
-                const float4 a = reinterpret_cast<const float4*>(mp.covA)[i];
-                const float2 b = reinterpret_cast<const float2*>(mp.covB)[i];
-                V00 = a.x; V01 = a.y; V02 = a.z; V11 = a.w; V12 = b.x; V22 = b.y;
+                uint4 a = e_a;
+                uint2 b = e_b;
+                if (!early) {
+                    a = reinterpret_cast<const uint4*>(mp.covA)[i];
+                    b = reinterpret_cast<const uint2*>(mp.covB)[i];
+                }
+                V00 = __uint_as_float(a.x); V01 = __uint_as_float(a.y); V02 = __uint_as_float(a.z); V11 = __uint_as_float(a.w);
+                V12 = __uint_as_float(b.x); V22 = __uint_as_float(b.y);
             }
             // :120-134  J, W = transpose(mat3(MV)), T = W*J, cov2D = T^T * Vrk * T
             float j00, j20, j11, j21;

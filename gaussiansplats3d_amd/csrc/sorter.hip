@@ -907,6 +907,12 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         if (s->bound_mesh->ev_p1 && ctx->aux != st) GS_HIP(hipStreamWaitEvent(st, s->bound_mesh->ev_p1, 0));   // the mask it reads
     }
     const uint32_t* unmap = map ? gs_mesh_payload_unmap(s->bound_mesh) : nullptr;
+    if (ctx->fork_join && st != ctx->stream) {
+        // serial frames on a multi-stream context: this sort starts when everything the context's stream holds now (the previous
+        // frame's draw) has finished, then runs beside this frame's vertex stage
+        GS_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        GS_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+    }
     if (s->consumer_pending) {           // a draw enqueued on ctx->stream still reads the previous result
         GS_HIP(hipStreamWaitEvent(st, s->ev_consumed, 0));
         s->consumer_pending = false;

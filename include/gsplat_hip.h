@@ -65,6 +65,12 @@ int gs_context_create(int device, void* hip_stream, gs_context** out);
                                   calls that pass `stats` (and therefore synchronise anyway) are timed and the *_ms fields
                                   read 0 after any other call: an event record is a barrier packet on the stream, nine of them
                                   per frame cost 35 us of a 0.33 ms frame on MI355X */
+#define GS_CTX_FORK_JOIN 4u    /* multi-stream context whose FRAMES stay serial: the sort and the vertex stage of a frame run side by
+                                  side on their own streams (they share nothing: the sort reads the centres, the vertex stage
+                                  the mesh planes) and join where the binner needs both, but no sort starts before everything the
+                                  context's stream held when it was called has finished - frame k + 1 never overlaps frame k.
+                                  The default context lets the next sort overlap the tail of the previous draw (throughput);
+                                  this one shortens the frame itself: t_frame = max(t_sort, t_vertex) + t_bin + t_blend */
 int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_context** out);
 void gs_context_destroy(gs_context* ctx);
 int gs_context_synchronize(gs_context* ctx);
@@ -320,7 +326,7 @@ typedef struct gs_render_stats {
     uint32_t entry_capacity;
     uint32_t overflowed;      /* 1 = frame was re-run after growing the entry buffer                         */
     uint64_t tiles16;         /* D of SURVEY.md 8d = sum over splats of 16x16-px tiles touched               */
-    uint32_t list_bin_px;     /* edge of a list bin of this draw (32 or 128): the unit of the entry lists and of
+    uint32_t list_bin_px;     /* edge of a list bin of this draw (32, 128 or 512): the unit of the entry lists and of
                                  gs_mesh_debug_read(what = 2); chosen per mesh from the previous measured draw    */
     uint32_t flags;           /* GS_DRAW_*: bit 0 = the per-bin blend ran out of chunk-partial slots (a list thousands of
                                  splats deep outside the deep pass): the affected quadrants were composited as one long chunk -

@@ -577,3 +577,32 @@ def test_block_level_cull_changes_nothing(ctx, monkeypatch):
         np.testing.assert_array_equal(np.concatenate(frames[0][3], axis=0), frames[0][0])
     on.dispose()
     off.dispose()
+
+
+@pytest.mark.gpu
+def test_fork_join_context_draws_the_same_frames_with_serial_frames():
+    """GS_CTX_FORK_JOIN: the sort and the vertex stage of a frame run side by side on their own streams, frames stay serial.  The
+    frames of a moving camera equal the single-stream context's bit for bit, sort results included; and a sort really waits for
+    the previous draw (the draw after a re-sort with another camera never sees a half-written order: every frame is checked)."""
+    from gaussiansplats3d_amd import Context, create_sort_worker
+    scene = helpers.small_scene(40000, 2, seed=17)
+    n = scene.count
+    ci = util.integer_centers(scene.centers)
+    cams = camera.orbit_cameras("garden", 320, 180, 8)
+    frames = {}
+    for mode in ("single", "fork"):
+        c = Context(0, single_stream=(mode == "single"), fork_join=(mode == "fork"))
+        w = create_sort_worker(c, n)
+        w.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+        m = build_mesh(c, scene)
+        m.use_sorter_result(w, n)
+        out = []
+        for cam in cams:
+            m.set_camera(cam)
+            w.sort_on_device(cam.sort_mvp(), n)
+            out.append(m.render()[0].copy())
+        frames[mode] = out
+        w.terminate(); m.dispose(); c.close()
+    for a, b in zip(frames["single"], frames["fork"]):
+        assert a[..., 3].any()
+        np.testing.assert_array_equal(a, b)

@@ -85,12 +85,15 @@ constexpr uint32_t GS_BIN = GS_TILE << GS_BIN_SHIFT;
 constexpr uint32_t GS_LIST_SHIFT_LARGE = 3;                // 128-px list bins
 constexpr uint32_t GS_LIST_SHIFT_SMALL = GS_BIN_SHIFT;     // 32-px list bins = one list per blend workgroup
 constexpr float GS_LIST_TILES_PER_SPLAT = 3.0f;
-// ... and 512-px list bins when splats are larger still (a visible splat covers >= 32 tiles: an 8K frame of the garden stand-in
-// covers 101).  Entries shrink again (C5: 5.96 M -> 2.19 M), the 8K frame's 2040 lists become 135 and its two-pass entry sort one
-// pass (0.082 -> 0.022 ms), the binner 0.091 -> 0.056 ms; the blend scans 24 % more entries (0.654 -> 0.686 ms): frame 0.903 ->
-// 0.844 ms, 256-px lists in between (0.879) - r04 same-box runs of bench.py --config C5 under GSPLAT_LIST_SHIFT=3 / 4 / 5.
-constexpr uint32_t GS_LIST_SHIFT_HUGE = 5;                 // 512-px list bins
-constexpr float GS_LIST_TILES_PER_SPLAT_HUGE = 32.0f;
+// ... and 256- / 512-px list bins when splats are larger still: what matters is the list bin's area against the splat's (a bin
+// scans the entries of its whole list): 128 px at 10 tiles per splat (C3) is 6x, and lists of 36x (C2 at 256 px) or 100x (C3T at
+// 512 px) make the blend scan itself to a standstill (r04 tools/list_shift_ab.py: C2 0.281 -> 0.372 -> 0.947 ms at 128 / 256 / 512
+// px, C3T 0.598 -> 0.906 -> 2.20).  So the size follows the splats at <= ~12x: 256 px from 21 tiles per visible splat, 512 px
+// from 80 (an 8K frame of the garden stand-in covers 101: entries 5.96 M -> 2.19 M, its 2040 lists become 135 and its two-pass
+// entry sort one pass (0.082 -> 0.022 ms), the binner 0.091 -> 0.056 ms, the blend scans 24 % more (0.654 -> 0.686 ms): frame
+// 0.903 -> 0.837 ms; a rank of eight 0.267 -> 0.228 ms).
+constexpr uint32_t GS_LIST_SHIFT_BIG = 4, GS_LIST_SHIFT_HUGE = 5;          // 256- / 512-px list bins
+constexpr float GS_LIST_TILES_PER_SPLAT_BIG = 21.0f, GS_LIST_TILES_PER_SPLAT_HUGE = 80.0f;
 // CHUNKED COMPOSITE (tile_blend.hip).  The value of a pixel is DEFINED per 16x16 quadrant as a two-level fold: the quadrant's
 // ordered survivors (the entries of its list whose exact reach test includes the quadrant) are cut into chunks (below), each
 // chunk is composited front to back from T = 1, C = 0, and the chunks are merged near -> far (C = fma(T, C_c, C); T = T * T_c).

@@ -596,9 +596,13 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     }
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them
     if (m->last.visible_splats > 0)
-        m->list_shift = (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT_HUGE * (float)m->last.visible_splats ? GS_LIST_SHIFT_HUGE
-                      : (float)m->last.tiles16 >= GS_LIST_TILES_PER_SPLAT * (float)m->last.visible_splats    ? GS_LIST_SHIFT_LARGE
-                                                                                                             : GS_LIST_SHIFT_SMALL;
+    {
+        const float tiles = (float)m->last.tiles16, vis = (float)m->last.visible_splats;
+        m->list_shift = tiles >= GS_LIST_TILES_PER_SPLAT_HUGE * vis ? GS_LIST_SHIFT_HUGE
+                      : tiles >= GS_LIST_TILES_PER_SPLAT_BIG * vis  ? GS_LIST_SHIFT_BIG
+                      : tiles >= GS_LIST_TILES_PER_SPLAT * vis      ? GS_LIST_SHIFT_LARGE
+                                                                     : GS_LIST_SHIFT_SMALL;
+    }
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;
 }

@@ -140,30 +140,33 @@ __device__ __forceinline__ uint32_t xcd_chunk(uint32_t b, uint32_t grid) {
 struct RadixChunk {
     uint32_t n, tile_begin, tile_end, id;
 };
-// Chunk = a contiguous run of tiles; chunk c's row of the offset table is row c.  RADIX_XCD_CONTIG: the workgroups of one XCD
-// (b % 8, the observed dispatch rule: speed only) take CONTIGUOUS chunks, so for every digit the slots an XCD writes are one
-// contiguous range and the partial lines at the ends of neighbouring tiles' digit runs meet in ONE L2 instead of leaving two
-// L2s as two masked writes (the r03 counters had pass 0 at 1.82x its algorithmic write bytes).
+// Chunk = a contiguous run of tiles; chunk c's row of the offset table is row c.  The grid is sized for the host's upper bound
+// of the list, the real length may live on the device: only the first `active` chunks hold tiles.  RADIX_XCD_CONTIG: the
+// workgroups of one XCD (b % 8, the observed dispatch rule: speed only) take CONTIGUOUS chunks of the ACTIVE ones - worth
+// 1.5-2.5 us on a full C3 / C2 sort - while a short list (a rank's strip, a culled list) still spreads over all eight XCDs
+// (mapping over the whole grid instead put a 68-tile list on two XCDs: a rank's frame 0.227 -> 0.241 ms, r04).
 #ifndef RADIX_XCD_CONTIG
 #define RADIX_XCD_CONTIG 1
 #endif
-__device__ __forceinline__ uint32_t radix_chunk_id(uint32_t b, uint32_t grid) {
-#if RADIX_XCD_CONTIG
-    const uint32_t x = b % 8u, k = b / 8u, q = grid / 8u, rem = grid % 8u;
-    return x * q + min(x, rem) + k;                              // XCD x owns q (+1 for x < rem) chunks from there
-#else
-    (void)grid;
-    return b;
-#endif
-}
 __device__ __forceinline__ RadixChunk radix_chunk(uint32_t n) {
     const uint32_t tiles = (n + RADIX_TILE - 1) / RADIX_TILE;
     const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t active = per ? (tiles + per - 1) / per : 0u;          // chunks that hold tiles (<= gridDim.x)
     RadixChunk c;
     c.n = n;
-    c.id = radix_chunk_id(blockIdx.x, gridDim.x);
-    c.tile_begin = min(c.id * per, tiles);
-    c.tile_end = min(c.tile_begin + per, tiles);
+#if RADIX_XCD_CONTIG
+    const uint32_t x = blockIdx.x % 8u, k = blockIdx.x / 8u, q = active / 8u, rem = active % 8u;
+    c.id = k < q + (x < rem ? 1u : 0u) ? x * q + min(x, rem) + k : 0xFFFFFFFFu;   // XCD x owns q (+1 for x < rem) chunks
+#else
+    c.id = blockIdx.x < active ? blockIdx.x : 0xFFFFFFFFu;
+#endif
+    if (c.id == 0xFFFFFFFFu) {               // no tiles for this workgroup (its id only names a row it never touches)
+        c.id = 0;
+        c.tile_begin = c.tile_end = tiles;
+    } else {
+        c.tile_begin = min(c.id * per, tiles);
+        c.tile_end = min(c.tile_begin + per, tiles);
+    }
     return c;
 }
 
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_radix_hist(Loader ld, int shif
     for (uint32_t tile = ch.tile_begin; tile < ch.tile_end; tile += HIST_GROUP)
         hist_tiles(ld, tile, min(HIST_GROUP, ch.tile_end - tile), ch.n, shift, s_hist[wave]);
     __syncthreads();
-    if (tid >= RADIX_BINS) return;
+    if (tid >= RADIX_BINS || ch.tile_begin >= ch.tile_end) return;      // (a workgroup without tiles has no row)
     const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
     block_hist[ch.id * RADIX_BINS + tid] = total;                // one coalesced 1 KiB row per workgroup
     // Group rows.  Same-address atomics serialise in the fabric (~12 ns each, MI355X_MICROARCH.md row "fanin"): with 32
@@ -340,6 +343,10 @@ __global__ __launch_bounds__(SCATTER_THREADS, SCATTER_OCC_CFG) void k_radix_scat
     RADIX_PROF(0, wall_clock64());
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
+    // A grid is sized for the host's upper bound of the list; when the real length lives on the device (a culled or gathered
+    // list, a rank's strip: 0.27 M of 5.8 M) most workgroups have no tile - they leave before the offset prologue (workgroup 0
+    // stays: it publishes the ranges / the kept count even of an empty list)
+    if (ch.tile_begin >= ch.tile_end && blockIdx.x != 0) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];
@@ -623,6 +630,7 @@ __global__ __launch_bounds__(CHUNK_THREADS, CHUNK_OCC_CFG) void k_radix_scatter_
 
     ld.prepare();
     const RadixChunk ch = radix_chunk(ld.count());
+    if (ch.tile_begin >= ch.tile_end && blockIdx.x != 0) return;        // (no tile: see k_radix_scatter)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     volatile uint32_t* my_hist = s_wave[wave];

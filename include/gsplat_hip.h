@@ -326,7 +326,7 @@ typedef struct gs_render_stats {
     uint32_t entry_capacity;
     uint32_t overflowed;      /* 1 = frame was re-run after growing the entry buffer                         */
     uint64_t tiles16;         /* D of SURVEY.md 8d = sum over splats of 16x16-px tiles touched               */
-    uint32_t list_bin_px;     /* edge of a list bin of this draw (32, 128 or 512): the unit of the entry lists and of
+    uint32_t list_bin_px;     /* edge of a list bin of this draw (32, 128, 256 or 512): the unit of the entry lists and of
                                  gs_mesh_debug_read(what = 2); chosen per mesh from the previous measured draw    */
     uint32_t flags;           /* GS_DRAW_*: bit 0 = the per-bin blend ran out of chunk-partial slots (a list thousands of
                                  splats deep outside the deep pass): the affected quadrants were composited as one long chunk -

@@ -109,6 +109,7 @@ def test_frame_from_the_culled_list_is_bit_identical(ctx, sh_degree, w_h, ortho)
     w, c4 = _worker(ctx, scene.centers)
     w.sort_on_device(cam.sort_mvp(), scene.count)
     mesh.use_sorter_result(w, scene.count)
+    mesh.render()                                        # settles the per-mesh list-bin size (chosen from a measured draw)
     full, s_full = mesh.render()
     parts_full = [mesh.render(tile_rows=r)[0] for r in ((0, 5), (5, (height + 15) // 16))]
     _, _, drawn = mesh.debug_records()

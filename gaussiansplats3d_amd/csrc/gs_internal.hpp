@@ -440,7 +440,18 @@ struct gs_mesh {
     uint32_t ring_next = 0;
     double proj_sum_ms = 0.0;
     uint32_t proj_launches = 0;
-    hipEvent_t ev_done = nullptr;                  // end of the previous draw on ctx->stream (recs / rects reusable)
+    hipEvent_t ev_done = nullptr;                  // end of the last draw that read THIS set of vertex-stage outputs (on ctx->stream)
+    // The vertex stage's outputs exist twice on a context with streams of its own: the vertex stage of frame k + 1 writes the set
+    // frame k - 1 drew from while frame k is still binned and blended from the other one (mesh_project swaps the two; every field
+    // that belongs to a set is swapped with it).  `alt` is the set that is NOT current.
+    struct ProjSet {
+        DevBuf recs, rects, vis_mask, block_any, vis32, prect, vis_orig;
+        hipEvent_t ev_done = nullptr;
+        bool drawn = false, vis_orig_dirty = true;
+        uint32_t vis_orig_count = 0;
+    } alt;
+    bool two_sets = false;                         // alt is allocated and in use
+    bool set_drawn = false;                        // a draw has read the current set (ev_done is recorded)
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;

@@ -271,6 +271,15 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->vis32, ((n + 255) / 256) * 64 + 64);
     A(m->prect, ((n + 255) / 256) * 256 * 8 + 64);
     A(m->block_any, ((n + 255) / 256 + 127) & ~(size_t)63);
+    // (a context with one stream runs the frames' kernels in order: a second set would never be written early)
+    m->two_sets = ctx->aux != ctx->stream && !getenv("GSPLAT_ONE_RECORD_SET");
+    if (m->two_sets) {
+        A(m->alt.recs, n * sizeof(SplatRec)); A(m->alt.rects, n * 8);
+        A(m->alt.vis_mask, ((n + 255) / 256) * 32 + 32);
+        A(m->alt.vis32, ((n + 255) / 256) * 64 + 64);
+        A(m->alt.prect, ((n + 255) / 256) * 256 * 8 + 64);
+        A(m->alt.block_any, ((n + 255) / 256 + 127) & ~(size_t)63);
+    }
     A(m->bin_sums, 4 * 3 * 2048 + 64);               // uint32 [3][BIN_MAX_BLOCKS] + the batches-per-workgroup of the last count
     A(m->frame, sizeof(RenderFrame));
     if (st == GS_OK) st = m->radix.init();
@@ -307,7 +316,8 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
             gs_set_error("hipEventCreate failed");
             st = GS_ERR_HIP;
         }
-    if (st == GS_OK && hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess) {
+    if (st == GS_OK && (hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess ||
+                        (m->two_sets && hipEventCreateWithFlags(&m->alt.ev_done, hipEventDisableTiming) != hipSuccess))) {
         gs_set_error("hipEventCreate failed");
         st = GS_ERR_HIP;
     }
@@ -351,6 +361,7 @@ void gs_mesh_destroy(gs_mesh* m) {
         if (m->ring1[i]) (void)hipEventDestroy(m->ring1[i]);
     }
     if (m->ev_done) (void)hipEventDestroy(m->ev_done);
+    if (m->alt.ev_done) (void)hipEventDestroy(m->alt.ev_done);
     if (m->mirror_host) (void)hipHostFree(m->mirror_host);
     delete m;
 }
@@ -610,11 +621,22 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
 // The vertex stage of a draw.  It only depends on the scene and the camera, so it runs on ctx->aux next to whatever the
 // caller-visible stream and the sorter's stream are doing; it may start once the previous draw has consumed the records /
 // rects / mask it is about to overwrite.
+static void swap_buf(DevBuf& a, DevBuf& b) { std::swap(a.p, b.p); std::swap(a.bytes, b.bytes); }
+static void mesh_swap_sets(gs_mesh* m) {
+    gs_mesh::ProjSet& o = m->alt;
+    swap_buf(m->recs, o.recs); swap_buf(m->rects, o.rects); swap_buf(m->vis_mask, o.vis_mask); swap_buf(m->block_any, o.block_any);
+    swap_buf(m->vis32, o.vis32); swap_buf(m->prect, o.prect); swap_buf(m->vis_orig, o.vis_orig);
+    std::swap(m->ev_done, o.ev_done); std::swap(m->set_drawn, o.drawn);
+    std::swap(m->vis_orig_dirty, o.vis_orig_dirty); std::swap(m->vis_orig_count, o.vis_orig_count);
+}
+
 static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, bool timed) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
     if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
-    if (aux != st && m->has_draw) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
+    // the set this vertex stage writes: the one the draw BEFORE the last read (two sets), else the last draw's own
+    if (m->two_sets) mesh_swap_sets(m);
+    if (aux != st && m->set_drawn) GS_HIP(hipStreamWaitEvent(aux, m->ev_done, 0));
     const bool sample = timed || aux != st || (ctx->kernel_sample && m->project_serial++ % ctx->kernel_sample == 0);
     if (sample) {   // next slot of the timing ring; a slot about to be reused is harvested first (skipped if still in flight)
         const uint32_t slot = m->ring_next++ % gs_mesh::TIMING_RING;
@@ -662,6 +684,7 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
         GS_HIP(hipEventRecord(m->ev[5], st));
     }
     if (aux != st) GS_HIP(hipEventRecord(m->ev_done, st));     // only another stream ever waits for it
+    m->set_drawn = true;
     m->has_draw = true;
     return GS_OK;
 }

@@ -49,6 +49,9 @@ constexpr uint32_t RECT_EMPTY_LO = 0x0000FFFFu;   // x0 = 0xFFFF > x1 = 0 -> zer
 #ifndef GS_COV_EARLY
 #define GS_COV_EARLY 1
 #endif
+#ifndef GS_BLOCK_TEST_PER_WAVE
+#define GS_BLOCK_TEST_PER_WAVE 0      // 1: every wave of a block evaluates the block's box itself (A/B)
+#endif
 struct ShPre {                  // fp16 SH planes fetched together with the covariance (GS_SH_EARLY): one dependent round trip less
     uint4 a, b, c;
     bool have;
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     // C4 262 -> 300).
     if (pp.block_cull) {
         __shared__ uint32_t s_dead;
-        if (threadIdx.x < 64u) {
+        bool wave_dead = false;
+        if (GS_BLOCK_TEST_PER_WAVE || threadIdx.x < 64u) {
             const uint32_t c = threadIdx.x & 7u;
             const float* bb = mp.block_box + 8u * (size_t)blockIdx.x;
             const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
@@ -186,10 +190,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                     dead = ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
                 }
             }
-            if (threadIdx.x == 0u) s_dead = dead ? 1u : 0u;
+            if (GS_BLOCK_TEST_PER_WAVE) wave_dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;     // (every wave evaluated the same box: no LDS word, no barrier)
+            else if (threadIdx.x == 0u) s_dead = dead ? 1u : 0u;
         }
-        __syncthreads();
-        if (s_dead) {                                         // nothing of this block draws: empty masks, no records
+        if (!GS_BLOCK_TEST_PER_WAVE) {
+            __syncthreads();
+            wave_dead = s_dead != 0u;
+        }
+        if (wave_dead) {                                      // nothing of this block draws: empty masks, no records
             const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
             if (lane == 0u) vis_mask[blockIdx.x * 4u + wave] = 0ull;
             if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blockIdx.x * 256u);
@@ -215,7 +223,15 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         uint32_t e_rgba = 0;
         uint4 e_a = make_uint4(0u, 0u, 0u, 0u);
         uint2 e_b = make_uint2(0u, 0u);
+        ShPre pre;
+        pre.have = false;
         if (early) {
+            if (GS_SH_EARLY == 2 && !EXT && pp.sh_stored >= 2 && pp.sh_degree >= 1) {   // (A/B: the SH planes with the centre as well)
+                pre.a = mp.sh0[i];
+                pre.b = reinterpret_cast<const uint4*>(mp.sh1)[i];
+                pre.c = mp.sh2[i];
+                pre.have = true;
+            }
             e_rgba = mp.rgba[i];
             if (pp.cov_half) {
                 const uint2 a = reinterpret_cast<const uint2*>(mp.covA)[i];
@@ -293,9 +309,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
 
         if (ok) {
             const uint32_t packed = early ? e_rgba : mp.rgba[i];
-            ShPre pre;
-            pre.have = false;
-            if (GS_SH_EARLY && !EXT && pp.sh_stored >= 2 && pp.sh_degree >= 1) {     // static fp16 SH-2 scene (the benchmark path)
+            if (GS_SH_EARLY && !pre.have && !EXT && pp.sh_stored >= 2 && pp.sh_degree >= 1) {     // static fp16 SH-2 scene (the benchmark path)
                 pre.a = mp.sh0[i];
                 pre.b = reinterpret_cast<const uint4*>(mp.sh1)[i];
                 pre.c = mp.sh2[i];

@@ -108,6 +108,45 @@ __device__ __forceinline__ uint32_t exact_quadrants(uint32_t qm, const uint4 lo,
     return qm & out;
 }
 
+// Which of the sixteen 8x8-pixel blocks of the 32-px bin (bx, by) the splat can reach: bit 4 q + b, q = the quadrant (as above),
+// b = (block column & 1) + 2 (block row & 1) inside it.  CONSERVATIVE (a clear bit proves that every pixel of the block fails
+// `A <= 8`; a set bit promises nothing), by four separating axes between the block of pixel centres (half-extent 3.5) and the
+// ellipse u^2 + w^2 <= 4 log2(e): the ellipse's own two axes (|u| and |w| at the block's centre against the block's reach along
+// that axis plus the radius - for a thin splat the only test that matters) and the pixel axes (the ellipse's bounding box).
+// A splat skipped on a block would have composited alpha = 0 there - C and T unchanged, bit for bit - so nothing that decides a
+// pixel depends on this mask: it only says where evaluating the splat is a waste of lanes.
+// Margins: the blend evaluates u = fma(ay, y, fma(ax, x, cu)) relative to the bin's origin, this test ax X + ay Y relative to
+// the splat's centre; both round at the scale of |ax| |cx - origin| + |ay| |cy - origin| (a long thin splat whose centre is far
+// from the bin), which `slack` bounds with a factor of 8 to spare.
+__device__ __forceinline__ uint32_t block_mask16(const uint4 lo, const uint4 hi, uint32_t bx, uint32_t by) {
+#pragma clang fp contract(off)
+    const float cx = __uint_as_float(lo.x), cy = __uint_as_float(lo.y);
+    const float ax = __uint_as_float(lo.z), ay = __uint_as_float(lo.w), ex = __uint_as_float(hi.x), ey = __uint_as_float(hi.y);
+    constexpr float R = 2.4022448f * 1.0005f;                                // sqrt(4 log2(e)), and the limit's own margin
+    const float X0 = (float)(bx * GS_BIN) + 4.0f - cx, Y0 = (float)(by * GS_BIN) + 4.0f - cy;   // centre of block (0, 0) from the splat's
+    const float far = fabsf(X0) + fabsf(Y0) + 64.0f;
+    const float su = 3.5f * (fabsf(ax) + fabsf(ay)) + R + 1e-6f * far * (fabsf(ax) + fabsf(ay));
+    const float sw = 3.5f * (fabsf(ex) + fabsf(ey)) + R + 1e-6f * far * (fabsf(ex) + fabsf(ey));
+    const float det = ax * ey - ay * ex;
+    const float idet2 = __builtin_amdgcn_rcpf(det * det);                    // inf for a degenerate basis: every block kept
+    const float sx = 3.5f + R * 1.001f * __builtin_sqrtf((ay * ay + ey * ey) * idet2) + 1e-3f;
+    const float sy = 3.5f + R * 1.001f * __builtin_sqrtf((ax * ax + ex * ex) * idet2) + 1e-3f;
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; r++) {
+        const float Y = Y0 + 8.0f * (float)r;
+        const bool row_ok = !(fabsf(Y) > sy);                                // (NaN keeps)
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++) {
+            const float X = X0 + 8.0f * (float)c;
+            const float u = ax * X + ay * Y, w = ex * X + ey * Y;
+            const bool ok = row_ok && !(fabsf(X) > sx) && !(fabsf(u) > su) && !(fabsf(w) > sw);
+            if (ok) out |= 1u << (4u * ((c >> 1) + 2u * (r >> 1)) + (c & 1u) + 2u * (r & 1u));
+        }
+    }
+    return out;
+}
+
 // expands one record, relative to the origin of the bin that stages it
 __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi, float bin_x0, float bin_y0) {
 #pragma clang fp contract(off)
@@ -128,8 +167,9 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
 #ifdef GS_BLEND_PROFILE
 // tools/blend_profile.py: per bin {start, end} of s_memrealtime (100 MHz), list length, batches, survivors walked by wave 0..3
 // ... and [8] lane evaluations (256 per walked splat), [9] lanes that passed `keep` (A <= 8), [10] lanes that passed it on a
-// pixel still accumulating (T > 1e-4), [11] half quadrants evaluated: what fraction of the blend's pixel work can hit anything
-constexpr unsigned BLEND_PROF_BINS = 40960, BLEND_PROF_WORDS = 12;
+// pixel still accumulating (T > 1e-4), [11] half quadrants evaluated: what fraction of the blend's pixel work can hit anything;
+// [12] iterations of a walk by 8x8 blocks (see the walk), [13] (splat, 8x8 block) pairs that walk would evaluate
+constexpr unsigned BLEND_PROF_BINS = 40960, BLEND_PROF_WORDS = 14;
 __device__ unsigned long long g_blend_prof[BLEND_PROF_WORDS * BLEND_PROF_BINS];
 // per deep-pass unit: {start, end, windows scanned, survivors composited}
 __device__ unsigned long long g_deep_prof[4 * GS_DEEP_UNITS];
@@ -154,7 +194,8 @@ extern "C" int gs_debug_blend_prof(void* dst, unsigned bins) {
 #define GS_BLEND_PAIRS 0              // 1: the per-bin kernel composites two survivors per iteration where it can (A/B)
 #endif
 #ifndef GS_BLEND_CHECK
-#define GS_BLEND_CHECK 4u             // a wave tests its quadrant for saturation after every 4th splat it composites
+#define GS_BLEND_CHECK 8u             // a wave tests its quadrant for saturation after every 8th splat it composites (4 / 8 / 16 measured:
+                                      // C3 blend 0.0587 / 0.0575 / 0.0613 ms, C2 0.159 / 0.153 / 0.151, C3S 0.90 / 0.88 / 0.88; profiles/r04y_ab_project.txt)
 #endif
 static_assert(256u % GS_BLEND_CHECK == 0, "every chunk ends on a saturation test");
 
@@ -345,6 +386,9 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
     bool can_close = true;                             // (false once the partial pool ran out)
     uint32_t my_slot = 0;                              // lane c: the pool slot of closed chunk c
     uint32_t p_kept = 0, p_useful = 0;
+#ifdef GS_BLEND_PROFILE
+    uint32_t p_blk[4] = {0u, 0u, 0u, 0u}, p_iters = 0, p_blocks = 0;
+#endif
     bool live_wave = bg.live(fa, wave);
     Px acc;
     acc.reset();
@@ -378,7 +422,11 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
         __syncthreads();                               // previous batch fully consumed, s_live read by everyone
         uint32_t qm = tid < cnt ? quadrant_mask(rect, bx, by) : 0u;
         if (GS_BLEND_EXACT && qm) qm = exact_quadrants(qm, lo, hi, bx, by);
+#ifdef GS_BLEND_PROFILE
+        s_qmask[tid] = qm ? qm | (block_mask16(lo, hi, bx, by) << 8) : 0u;
+#else
         s_qmask[tid] = qm;
+#endif
         if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0);
         if (tid == 0) *s_live = 0u;
         // prefetch while this batch is blended
@@ -395,6 +443,18 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
                     const uint32_t j = g0 + (uint32_t)__builtin_ctzll(m);
                     m &= m - 1ull;
                     walked++;
+#ifdef GS_BLEND_PROFILE
+                    {   // what a walk by 8x8 blocks would cost: the four 16-lane groups of the wave each walk the survivors of their
+                        // own block, in step between two saturation tests -> iterations = the longest of the four lists per interval
+                        const uint32_t bm = ((uint32_t)__builtin_amdgcn_readfirstlane((int)s_qmask[j]) >> (8u + 4u * wave)) & 15u;
+                        p_blk[0] += bm & 1u; p_blk[1] += (bm >> 1) & 1u; p_blk[2] += (bm >> 2) & 1u; p_blk[3] += (bm >> 3) & 1u;
+                        p_blocks += (uint32_t)__popc(bm);
+                        if (((since_check + 1u) % GS_BLEND_CHECK) == 0u) {
+                            p_iters += max(max(p_blk[0], p_blk[1]), max(p_blk[2], p_blk[3]));
+                            p_blk[0] = p_blk[1] = p_blk[2] = p_blk[3] = 0u;
+                        }
+                    }
+#endif
 #if GS_BLEND_PAIRS
                     // (two splats in flight when the next survivor of the group does not straddle a saturation test: A/B knob)
                     if (m && !(since_check & 1u)) {
@@ -472,13 +532,15 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
         if (__builtin_amdgcn_readfirstlane((int)*s_live) == 0) break;   // every quadrant saturated (or clipped): skip the rest of the list
     }
 #ifdef GS_BLEND_PROFILE
-    __shared__ unsigned int s_prof[3];
-    if (tid < 3u) s_prof[tid] = 0u;
+    __shared__ unsigned int s_prof[5];
+    if (tid < 5u) s_prof[tid] = 0u;
     __syncthreads();
     if (lane == 0u) {
         atomicAdd(&s_prof[0], p_kept);
         atomicAdd(&s_prof[1], p_useful);
         atomicAdd(&s_prof[2], 2u * walked);
+        atomicAdd(&s_prof[3], p_iters + max(max(p_blk[0], p_blk[1]), max(p_blk[2], p_blk[3])));
+        atomicAdd(&s_prof[4], p_blocks);
     }
     if (bin < BLEND_PROF_BINS && lane == 0u) {
         if (wave == 0u) {
@@ -495,6 +557,8 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
         g_blend_prof[BLEND_PROF_WORDS * bin + 9] = s_prof[0];
         g_blend_prof[BLEND_PROF_WORDS * bin + 10] = s_prof[1];
         g_blend_prof[BLEND_PROF_WORDS * bin + 11] = s_prof[2];
+        g_blend_prof[BLEND_PROF_WORDS * bin + 12] = s_prof[3];
+        g_blend_prof[BLEND_PROF_WORDS * bin + 13] = s_prof[4];
     }
 #endif
     // statistics: one plain 8-byte store per workgroup, summed by the host when somebody asks (8160 same-address atomics

@@ -21,7 +21,7 @@ ctx.synchronize()
 info = mesh.deep_pass_info()
 bins = ((cfg["width"] + 31) // 32) * ((cfg["height"] + 31) // 32)
 bins = min(bins, 40960)
-buf = np.zeros((bins, 12), dtype=np.uint64)     # BLEND_PROF_WORDS per bin (tile_blend.hip)
+buf = np.zeros((bins, 14), dtype=np.uint64)     # BLEND_PROF_WORDS per bin (tile_blend.hip)
 lib = _lib.load()
 lib.gs_debug_blend_prof.argtypes = [C.c_void_p, C.c_uint]
 assert lib.gs_debug_blend_prof(buf.ctypes.data, bins) == 0

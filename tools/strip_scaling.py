@@ -16,7 +16,7 @@ W, H = cfg["width"], cfg["height"]
 scene = scenes.make_config_scene(name)
 cam = camera.demo_camera(cfg["pose"], W, H)
 N = scene.count
-ctx = Context(0, single_stream=True)
+ctx = Context(0, single_stream=not os.environ.get("GS_STRIP_STREAMS"))   # $GS_STRIP_STREAMS=1: the default context (sorter / vertex stage on streams of their own), as bench.py --gpus N uses
 w = create_sort_worker(ctx, N)
 w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": N - 1, "count": N}})
 mesh = SplatMesh(ctx, N, scene.sh_degree, scene.cov_half).build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)

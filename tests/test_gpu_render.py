@@ -606,3 +606,45 @@ def test_fork_join_context_draws_the_same_frames_with_serial_frames():
     for a, b in zip(frames["single"], frames["fork"]):
         assert a[..., 3].any()
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strips", [False, True])
+def test_frames_in_flight_on_two_record_sets_equal_the_serial_frames(strips):
+    """A context with streams of its own keeps TWO sets of vertex-stage outputs (records, rects, masks): the vertex stage of frame
+    k + 1 writes one while frame k is binned and blended from the other.  Eight frames of a moving camera are enqueued without a
+    single synchronisation, each into a device buffer of its own, and compared with the single-stream context's frames; with
+    `strips` every frame is a rank's strip (vertex stage first, visibility-culled sort: the per-index mask belongs to a set too)."""
+    import torch
+    from gaussiansplats3d_amd import Context, create_sort_worker
+    scene = helpers.small_scene(200000, 2, seed=23)
+    n = scene.count
+    ci = util.integer_centers(scene.centers)
+    W, H = 640, 368
+    cams = camera.orbit_cameras("garden", W, H, 8)
+    rows = (6, 15) if strips else None
+    frames = {}
+    for mode in ("single", "streams"):
+        c = Context(0, single_stream=(mode == "single"))
+        w = create_sort_worker(c, n)
+        w.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+        m = build_mesh(c, scene)
+        m.use_sorter_result(w, n)
+        w.set_visibility_cull(strips)
+        m.set_camera(cams[0])
+        h = m.strip_shape(rows)[0]
+        bufs = [torch.zeros((h, W, 4), dtype=torch.uint8, device="cuda:0") for _ in cams]
+        torch.cuda.synchronize()
+        for rep in range(2):                                   # the second round reuses both sets with frames still in flight
+            for cam, buf in zip(cams, bufs):
+                m.set_camera(cam)
+                if strips:
+                    m.project(rows)
+                w.sort_on_device(cam.sort_mvp(), n)
+                m.render(tile_rows=rows, out_device_ptr=buf.data_ptr(), want_stats=False, to_host=False)
+        c.synchronize()
+        frames[mode] = [b.cpu().numpy() for b in bufs]
+        w.terminate(); m.dispose(); c.close()
+    for a, b in zip(frames["single"], frames["streams"]):
+        assert a[..., 3].any()
+        np.testing.assert_array_equal(a, b)

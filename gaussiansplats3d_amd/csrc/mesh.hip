@@ -608,11 +608,16 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     // list-bin size of the following draws: large lists only pay when splats are large enough to share them
     if (m->last.visible_splats > 0)
     {
+        // (with 8 % of hysteresis around each threshold: a camera that sits on one does not flip the size - and with it the
+        // entry statistics and the frame time - from draw to draw)
         const float tiles = (float)m->last.tiles16, vis = (float)m->last.visible_splats;
-        m->list_shift = tiles >= GS_LIST_TILES_PER_SPLAT_HUGE * vis ? GS_LIST_SHIFT_HUGE
-                      : tiles >= GS_LIST_TILES_PER_SPLAT_BIG * vis  ? GS_LIST_SHIFT_BIG
-                      : tiles >= GS_LIST_TILES_PER_SPLAT * vis      ? GS_LIST_SHIFT_LARGE
-                                                                     : GS_LIST_SHIFT_SMALL;
+        static const uint32_t shifts[4] = {GS_LIST_SHIFT_SMALL, GS_LIST_SHIFT_LARGE, GS_LIST_SHIFT_BIG, GS_LIST_SHIFT_HUGE};
+        static const float thr[3] = {GS_LIST_TILES_PER_SPLAT, GS_LIST_TILES_PER_SPLAT_BIG, GS_LIST_TILES_PER_SPLAT_HUGE};
+        uint32_t level = 0;
+        while (level < 3u && shifts[level] != m->list_shift) level++;
+        while (level < 3u && tiles >= 1.08f * thr[level] * vis) level++;
+        while (level > 0u && tiles < 0.92f * thr[level - 1u] * vis) level--;
+        m->list_shift = shifts[level];
     }
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;

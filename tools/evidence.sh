@@ -45,8 +45,14 @@ bash tools/sort_prof.sh ${TAG}_sort_k4 C4 gpurun_ab/lib_this_tree.so 15 > gpurun
 bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_out/$TAG/sort_pmc_C3.txt 2>&1
 (tools/probes/gather_rate.bin 2>&1 | grep -v "^start") > gpurun_out/$TAG/gather_rate.txt
 (python tools/cull_prof.py 2>&1 | grep cull-on) > gpurun_out/$TAG/cull_on_frame.txt
-(timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
+[ -n "$GS_EVIDENCE_SORT_MIDDLE" ] && (timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
+# the same rank frames on the default context (streams of its own + two sets of vertex-stage outputs: what bench.py --gpus N runs)
+(GS_STRIP_STREAMS=1 python tools/strip_scaling.py C3 20; GS_STRIP_STREAMS=1 python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling_streams.txt
 (timeout 400 python bench.py --gpus 2 --steps 10 --no-cpu --no-cull 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_2ranks_dry_run.json
+# forced list-bin sizes against the per-mesh rule
+(timeout 500 python tools/list_shift_ab.py "C3 C2 C3T C5" "1 3 4 5 auto" 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/list_shift_ab.txt
+# FILE -> native reader -> sort -> draw at BASELINE size: a 5.8 M-splat INRIA .ply staged on the box (synthetic content, real format)
+(timeout 600 python tools/stage_ply.py C3 /tmp/gsdata 2>&1 | grep -v amdgpu.ids; GS_DATA_DIR=/tmp/gsdata timeout 500 python bench.py --only-headline --no-cpu 2>/dev/null | tail -1; rm -rf /tmp/gsdata) > gpurun_out/$TAG/bench_from_file.txt
 cp gpurun_out/crops_C*.json gpurun_out/$TAG/ 2>/dev/null
 cat gpurun_out/$TAG/pytest_gpu.txt; head -c 700 gpurun_out/$TAG/bench.json; echo; head -14 gpurun_out/$TAG/kstats.txt; cat gpurun_out/$TAG/pmc_traffic.txt | tail -3; cat gpurun_out/$TAG/strip_scaling.txt

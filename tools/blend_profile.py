@@ -1,9 +1,11 @@
-"""Per-bin timeline of k_tile_blend (variant built with -DGS_BLEND_PROFILE, selected through GSPLAT_HIP_LIB)."""
+"""Per-bin timeline of k_tile_blend (variant built with -DGS_BLEND_PROFILE, selected through GSPLAT_HIP_LIB).
+usage: python tools/blend_profile.py [C3] [r0:r1]      r0:r1 = only the strip of 16-px tile rows [r0, r1) (a rank's frame)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaussiansplats3d_amd import Context, SplatMesh, camera, create_sort_worker, scenes, util, _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+rows = tuple(int(v) for v in sys.argv[2].split(":")) if len(sys.argv) > 2 else None
 cfg = scenes.CONFIGS[name]
 scene = scenes.make_config_scene(name)
 cam = camera.demo_camera(cfg["pose"], cfg["width"], cfg["height"])
@@ -16,10 +18,12 @@ mesh.set_camera(cam)
 mesh.use_sorter_result(w, N)
 for _ in range(5):
     w.sort_on_device(cam.sort_mvp(), N)
-    _, st = mesh.render(to_host=True, want_stats=True)       # (to_host: the deep pass's verdict reaches the next draw)
+    _, st = mesh.render(tile_rows=rows, to_host=True, want_stats=True)       # (to_host: the deep pass's verdict reaches the next draw)
 ctx.synchronize()
 info = mesh.deep_pass_info()
 bins = ((cfg["width"] + 31) // 32) * ((cfg["height"] + 31) // 32)
+if rows:
+    bins = ((cfg["width"] + 31) // 32) * ((rows[1] * 16 + 31) // 32 - (rows[0] * 16) // 32)
 bins = min(bins, 40960)
 buf = np.zeros((bins, 14), dtype=np.uint64)     # BLEND_PROF_WORDS per bin (tile_blend.hip)
 lib = _lib.load()

@@ -43,10 +43,14 @@ def oracle_inputs(scene):
 def compare_frames(got_u8, fb_f32, ambig, label="", strict=False):
     """The stated framebuffer tolerance:
        * >= 99.9 % of channel values within 1/255 of the fp32 oracle,
-       * every pixel within 2/255 - including the pixels the oracle flags as discard-ambiguous (some splat had
+       * every pixel within 2/255 - except the pixels the oracle flags as discard-ambiguous (some splat had
          |A - 8| <= 1e-3 there: the hard `A > 8 -> discard` edge may flip under fp32 reassociation and jump by up to
-         exp(-4)*alpha = 4.67/255).  Rounds 1-3 allowed those 6/255; no frame of any test or crop ever used the slack
-         (carve_out_pixels = 0 in every report), so it is gone: the message still reports the ambiguous pixels' worst error.
+         exp(-4)*alpha = 4.67/255).  Rounds 1-3 allowed those pixels 6/255; no frame of any test or crop ever used the slack
+         (carve_out_pixels = 0 in every report), and round 4 first removed it.  tools/soak.py then drew 1000 scenes on
+         seeds nobody had looked at: 998 within 2/255 everywhere, and two frames with ONE ambiguous pixel each at 2.53 and 2.66 of
+         1/255 (profiles/r04z_soak_long.txt, seeds 5222 and 5595) - the flip the analysis predicts.  So the ambiguous pixels get
+         the ANALYTICAL bound, 255 * exp(-4) = 4.67 (not the old round number), every other pixel stays at 2/255, and the message
+         reports how many pixels needed more than 2/255 (carve_out_pixels).
     strict=True (the full-size crop tests): every channel of every pixel within 1/255, ambiguous or not."""
     ref = np.clip(fb_f32, 0.0, 1.0) * 255.0
     err = np.abs(got_u8.astype(np.float32) - ref)           # in 1/255 units, vs the unquantised oracle
@@ -63,6 +67,6 @@ def compare_frames(got_u8, fb_f32, ambig, label="", strict=False):
         assert max(worst_clear, worst_amb) <= 1.0 + 0.5 and carve == 0, msg
     assert frac_1 >= 0.999, msg
     assert worst_clear <= 2.0 + 0.5, msg
-    assert worst_amb <= 2.0 + 0.5, msg
+    assert worst_amb <= 255.0 * float(np.exp(-4.0)) + 0.5, msg
     assert psnr >= 50.0, msg
     return msg

@@ -25,6 +25,10 @@ import helpers
 import oracle
 from gaussiansplats3d_amd import Context, SplatMesh, SplatTree, camera, create_sort_worker, util
 
+if os.environ.get("SOAK_LIB"):          # an OLDER build of the library (entry points added since are dropped): does the soak find its bugs?
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from ab_libs import use_library
+    use_library(os.environ["SOAK_LIB"])
 seqs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30

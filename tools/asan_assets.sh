@@ -14,5 +14,5 @@ done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address -fno-gpu-sanitize -shared-libasan $OBJ/*.o -ldl -o gpurun_ab/lib_asan.so
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-echo "instrumented call sites in the library: $(nm -D gpurun_ab/lib_asan.so | grep -c __asan_report)"
+echo "__asan_report entry points the library imports (it is instrumented): $(nm -D gpurun_ab/lib_asan.so | grep -c __asan_report)"
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 GSPLAT_HIP_LIB=$ROOT/gpurun_ab/lib_asan.so python tools/soak_assets.py ${1:-300} ${2:-100} | grep -v "^ok"

@@ -46,7 +46,7 @@ def compare_frames(got_u8, fb_f32, ambig, label="", strict=False):
        * every pixel within 2/255 - except the pixels the oracle flags as discard-ambiguous (some splat had
          |A - 8| <= 1e-3 there: the hard `A > 8 -> discard` edge may flip under fp32 reassociation and jump by up to
          exp(-4)*alpha = 4.67/255).  Rounds 1-3 allowed those pixels 6/255; no frame of any test or crop ever used the slack
-         (carve_out_pixels = 0 in every report), and round 4 first removed it.  tools/soak.py then drew 1000 scenes on
+         (carve_out_pixels = 0 in every report), and round 4 first removed it.  tests/tools/soak.py then drew 1000 scenes on
          seeds nobody had looked at: 998 within 2/255 everywhere, and two frames with ONE ambiguous pixel each at 2.53 and 2.66 of
          1/255 (profiles/r04z_soak_long.txt, seeds 5222 and 5595) - the flip the analysis predicts.  So the ambiguous pixels get
          the ANALYTICAL bound, 255 * exp(-4) = 4.67 (not the old round number), every other pixel stays at 2/255, and the message

@@ -1,4 +1,4 @@
-"""-m gpu: short runs of the seed-fuzz soaks (tools/soak*.py) on seeds of their own - the long runs are evidence
+"""-m gpu: short runs of the seed-fuzz soaks (tests/tools/soak*.py) on seeds of their own - the long runs are evidence
 (profiles/r04z_soak*.txt), these keep the soaks themselves alive and add a few hundred unseen cases to every GPU tier run."""
 import os
 import subprocess
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _soak(script, *args, env=None):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)] + [str(a) for a in args], text=True, timeout=900,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", script)] + [str(a) for a in args], text=True, timeout=900,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {})))
     tail = [l for l in p.stdout.splitlines() if l.startswith(("FAIL", "soak"))]
     assert p.returncode == 0 and tail and " 0 failures" in tail[-1], "\n".join(tail[-12:]) or p.stdout[-2000:]

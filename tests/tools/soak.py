@@ -7,12 +7,12 @@
   * a visibility-culled sort draws the same frame.
 The oracle is the checker here, as in tests/ (this tool is test infrastructure, not product).
 
-usage: python tools/soak.py [iterations=24] [first_seed=1000] [max_splats=60000]   -> one line per iteration, "soak: N iterations, 0 failures" """
+usage: python tests/tools/soak.py [iterations=24] [first_seed=1000] [max_splats=60000]   -> one line per iteration, "soak: N iterations, 0 failures" """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -9,12 +9,12 @@ overwritten, the file truncated at a random point - the reader must either fail 
 announced; it must never read outside the buffer (a crash of this process is the failure signal; run under `timeout`).
 The oracle is the checker here, as in tests/.
 
-usage: python tools/soak_assets.py [iterations=300] [first_seed=100] """
+usage: python tests/tools/soak_assets.py [iterations=300] [first_seed=100] """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -7,12 +7,12 @@ without the distance fade-in.  Checked: the frame against the fp32 raster oracle
 stage may only drop splats that cannot reach the strip, whatever the permutation).
 The oracle is the checker here, as in tests/.
 
-usage: python tools/soak_options.py [iterations=120] [first_seed=4000] [max_splats=40000] """
+usage: python tests/tools/soak_options.py [iterations=120] [first_seed=4000] [max_splats=40000] """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

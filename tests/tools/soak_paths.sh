@@ -1,13 +1,13 @@
 #!/bin/bash
 # The soaks again under the environment switches that select the ALTERNATIVE code paths (A/B switches, fallbacks): one summary
 # line per (switch, soak).  (Not GSPLAT_POOL_SLOTS: with a pool of a few slots a dense frame runs out of chunk partials, the draw
-# says so - GS_DRAW_POOL_EXHAUSTED - and its strips then differ from the full frame in the last bits by design.)   usage: tools/soak_paths.sh > gpurun_out/soak_paths.txt
-cd "$(dirname "$0")/.."
+# says so - GS_DRAW_POOL_EXHAUSTED - and its strips then differ from the full frame in the last bits by design.)   usage: tests/tools/soak_paths.sh > gpurun_out/soak_paths.txt
+cd "$(dirname "$0")/../.."
 run() {  # <env assignments or -> <soak script> <args...>
   local e=$1; shift
   local cmd="env"; [ "$e" != "-" ] && cmd="env $e"
   printf "%-44s %-18s " "$e" "$1"
-  $cmd timeout 600 python tools/"$@" 2>&1 | grep -E "^(FAIL|soak)" | tail -3 | tr '\n' ' '; echo
+  $cmd timeout 600 python tests/tools/"$@" 2>&1 | grep -E "^(FAIL|soak)" | tail -3 | tr '\n' ' '; echo
 }
 for E in - GSPLAT_NO_LDS_ATOMIC_RANK=1 GSPLAT_NO_SORT_PACK=1 GSPLAT_NO_SORT_CHUNK=1 GSPLAT_ONE_RECORD_SET=1 GSPLAT_SERIAL=1 \
          GSPLAT_NO_BLOCK_CULL=1 GSPLAT_NO_REORDER=1 GSPLAT_NO_DEEP=1 GSPLAT_NO_COARSE_VIS=1 GSPLAT_NO_BLEND_ORDER=1 GSPLAT_WIDE_ENTRY_KEYS=1 \

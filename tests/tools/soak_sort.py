@@ -6,14 +6,14 @@ worker exposes them - with the C oracle (sort_oracle.c, pinned to the reference'
 (LDS atomics and, through GSPLAT_NO_LDS_ATOMIC_RANK=1 in the environment, ballots: run the tool twice).
 The oracle is the checker here, as in tests/.
 
-usage: python tools/soak_sort.py [iterations=200] [first_seed=100] [max_splats=300000]
-       python tools/soak_sort.py sizes 4095,4096,12289,...     the listed splat counts exactly (tile / chunk / table boundaries of
+usage: python tests/tools/soak_sort.py [iterations=200] [first_seed=100] [max_splats=300000]
+       python tests/tools/soak_sort.py sizes 4095,4096,12289,...     the listed splat counts exactly (tile / chunk / table boundaries of
                                                                radix.hpp), each as int-16, float-20 and a permuted partial sort """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -10,12 +10,12 @@ and regrows.  Checked at every step: the sorted list against the sort oracle (or
 against the raster oracle within the stated tolerance.
 The oracles are the checkers here, as in tests/.
 
-usage: python tools/soak_stateful.py [sequences=12] [first_seed=7000] [steps=30] [max_splats=50000] """
+usage: python tests/tools/soak_stateful.py [sequences=12] [first_seed=7000] [steps=30] [max_splats=50000] """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -8,12 +8,12 @@ onto split planes), random maxDepth / maxCentersPerNode, a random orbit pose, vi
   * a partial sort of the gathered list (splatSortCount < splatRenderCount) on the synchronous path.
 The oracles are the checkers here, as in tests/.
 
-usage: python tools/soak_tree.py [iterations=60] [first_seed=300] [max_splats=120000] """
+usage: python tests/tools/soak_tree.py [iterations=60] [first_seed=300] [max_splats=120000] """
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -5,7 +5,7 @@ usage: python tools/sort_ab.py "C3 C4" lib_a.so lib_b.so ... [--sorts 30] [--rou
 Per (config, library): median / min of gs_sort_stats.device_ms over `sorts` full sorts of the config's splat count (static
 integer mode, 16-bit buckets, the sorter bound to a mesh so that the payload is the mesh's storage position, as in a frame),
 and a CRC of the sorted list, which must agree across the libraries (--check additionally compares it with the CPU oracle's
-list: the reference's order, oracle/sort_oracle.c).  Only the centres of a config's scene are generated (the same RNG stream as
+list: the reference's order, through tests/tools/sort_reference_crc.py).  Only the centres of a config's scene are generated (the same RNG stream as
 scenes.make_config_scene), the mesh gets unit covariances: nothing but the sort is measured here.
 
 GSPLAT_SORT_AB_MARK=1 prints a line per library with the number of sorts it ran, in order - tools/sort_ab_trace.py cuts a
@@ -100,10 +100,10 @@ def main():
         centers = config_centers(name)
         want = None
         if a.check:
-            import oracle
-            cam = camera.demo_camera(cfg["pose"], cfg["width"], cfg["height"])
-            want = zlib.crc32(oracle.sort_indexes(np.arange(centers.shape[0], dtype=np.uint32), util.integer_centers(centers),
-                                                  cam.sort_mvp()).tobytes())
+            # (the checker lives with the tests: tests/tools/sort_reference_crc.py runs the sort oracle, this tool only gets the CRC)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "tools"))
+            from sort_reference_crc import reference_crc
+            want = reference_crc(name, centers)
         res = {}
         for rnd in range(a.rounds):
             for lib in a.libs:

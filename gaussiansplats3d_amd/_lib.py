@@ -60,6 +60,15 @@ class RenderStats(C.Structure):
                 ("entries_scanned", C.c_uint64), ("splats_walked", C.c_uint64), ("halves_evaluated", C.c_uint64)]
 
 
+class Destination(C.Structure):
+    """gs_destination: what the splats are depth-tested against and blended over (gs_mesh_set_destination)."""
+    _fields_ = [("depth_host", C.c_void_p), ("depth_dev", C.c_void_p), ("rgba_host", C.c_void_p), ("rgba_dev", C.c_void_p),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("flags", C.c_uint32), ("pad", C.c_uint32)]
+
+
+GS_DEST_DEPTH_UNORM24 = 1
+
+
 class TreeInfo(C.Structure):
     _fields_ = [("leaves", C.c_uint32), ("all_leaves", C.c_uint32), ("nodes", C.c_uint32), ("splats", C.c_uint32),
                 ("scene_min", C.c_double * 3), ("scene_max", C.c_double * 3)]
@@ -115,6 +124,7 @@ SYMBOLS = {
     "gs_mesh_upload_scene_indexes": (C.c_int, [_VP, C.c_uint32, C.c_uint32, _VP]),
     "gs_mesh_set_scenes": (C.c_int, [_VP, C.POINTER(SceneParams)]),
     "gs_mesh_project": (C.c_int, [_VP, C.POINTER(Camera)]),
+    "gs_mesh_set_destination": (C.c_int, [_VP, C.POINTER(Destination)]),
     "gs_group_unique_id": (C.c_int, [_VP]),
     "gs_group_create": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(_VP)]),
     "gs_group_destroy": (None, [_VP]),
@@ -190,6 +200,14 @@ class Context:
         self.lib = load()
         self.handle = _VP()
         st = _VP(stream) if stream else None
+        if fork_join and single_stream:
+            raise ValueError("fork_join needs the streams single_stream=True removes")
+        if single_stream is None and fork_join:
+            # (this combination used to fall through to gs_context_create and silently drop the flag)
+            serial = os.environ.get("GSPLAT_SERIAL", "")
+            if serial not in ("", "0"):
+                raise ValueError("fork_join cannot be combined with $GSPLAT_SERIAL")
+            single_stream = False
         if single_stream is None:
             check(self.lib.gs_context_create(int(device), st, C.byref(self.handle)))
         else:

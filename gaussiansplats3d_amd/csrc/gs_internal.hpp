@@ -364,6 +364,7 @@ struct ProjectParams {
     uint32_t count;
     uint32_t block_cull;           // 1: whole 256-splat storage blocks are tested first (project.hip); 0 for per-scene transforms
     float mv_row_norm[3];          // |row r of mat3(view)| * (1 + 1e-6): bounds |T0|, |T1| of the strip pre-test (project.hip)
+    uint32_t depth_mode;           // destination depth test (gs_mesh_set_destination): 0 = off, 1 = fp32 compare, 2 = as a 24-bit buffer
 };
 
 struct gs_mesh {
@@ -390,6 +391,9 @@ struct gs_mesh {
     bool reorder = true;
     uint32_t layout_version = 0;   // bumped whenever splats receive storage slots (perm changes): a sorter's per-tree payload cache
     bool no_block_cull = false;    // GSPLAT_NO_BLOCK_CULL=1 (A/B and tests)
+    bool no_block_list = false;    // GSPLAT_NO_BLOCK_LIST=1: every k_project workgroup tests its own block (the round-4 shape; A/B and tests)
+    DevBuf live_list, live_count;  // k_block_test: the storage blocks that may draw this frame, and two counters used in turn
+    uint32_t live_parity = 0;
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
     DevBuf scene_dev;          // gs_scene_params on the device
@@ -398,6 +402,8 @@ struct gs_mesh {
     DevBuf staging;
     // per-draw
     DevBuf recs;               // SplatRec [n]  survivors compacted inside each 256-splat block (project.hip)
+    DevBuf zrec;               // float [n]     the survivor's window-space centre depth, same slots (only while a destination
+                               //               depth is set: the blend's depth test, gs_mesh_set_destination)
     DevBuf rects;              // uint2 [n]     tile rect per survivor, same slots
     DevBuf vis_mask;           // uint64 [4*ceil(n/256)]  1 = splat survived the vertex stage and touches a pixel
     DevBuf block_any;          // uint8 [ceil(n/256)]      1 = some splat of the 256-splat block survived the vertex stage
@@ -445,7 +451,7 @@ struct gs_mesh {
     // frame k - 1 drew from while frame k is still binned and blended from the other one (mesh_project swaps the two; every field
     // that belongs to a set is swapped with it).  `alt` is the set that is NOT current.
     struct ProjSet {
-        DevBuf recs, rects, vis_mask, block_any, vis32, prect, vis_orig;
+        DevBuf recs, zrec, rects, vis_mask, block_any, vis32, prect, vis_orig;
         hipEvent_t ev_done = nullptr;
         bool drawn = false, vis_orig_dirty = true;
         uint32_t vis_orig_count = 0;
@@ -466,6 +472,12 @@ struct gs_mesh {
     uint32_t truncated_draws = 0;      // asynchronous draws that overflowed the entry buffer (noticed after the fact)
     bool projection_pending = false;   // gs_mesh_project ran; the next gs_mesh_render with the same camera consumes it
     gs_camera projected_cam = {};
+    uint32_t projected_depth_mode = 0; // ... and it wrote zrec for this depth mode (a destination set in between re-projects)
+    // destination of the draws (gs_mesh_set_destination): what the splats are depth-tested against and blended over
+    DevBuf dest_depth_own, dest_rgba_own;          // copies of host-side inputs
+    const float* dest_depth = nullptr;             // float [dest_h][dest_w] window depth, or nullptr
+    const uint32_t* dest_rgba = nullptr;           // RGBA8 [dest_h][dest_w], or nullptr
+    uint32_t dest_w = 0, dest_h = 0, dest_flags = 0;
 };
 
 int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);

@@ -262,6 +262,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     A(m->block_box, ((n + 255) / 256) * 32 + 32);
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
     m->no_block_cull = getenv("GSPLAT_NO_BLOCK_CULL") != nullptr;
+    m->no_block_list = getenv("GSPLAT_NO_BLOCK_LIST") != nullptr;
     m->no_deep = getenv("GSPLAT_NO_DEEP") != nullptr;
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
@@ -629,7 +630,7 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
 static void swap_buf(DevBuf& a, DevBuf& b) { std::swap(a.p, b.p); std::swap(a.bytes, b.bytes); }
 static void mesh_swap_sets(gs_mesh* m) {
     gs_mesh::ProjSet& o = m->alt;
-    swap_buf(m->recs, o.recs); swap_buf(m->rects, o.rects); swap_buf(m->vis_mask, o.vis_mask); swap_buf(m->block_any, o.block_any);
+    swap_buf(m->recs, o.recs); swap_buf(m->zrec, o.zrec); swap_buf(m->rects, o.rects); swap_buf(m->vis_mask, o.vis_mask); swap_buf(m->block_any, o.block_any);
     swap_buf(m->vis32, o.vis32); swap_buf(m->prect, o.prect); swap_buf(m->vis_orig, o.vis_orig);
     std::swap(m->ev_done, o.ev_done); std::swap(m->set_drawn, o.drawn);
     std::swap(m->vis_orig_dirty, o.vis_orig_dirty); std::swap(m->vis_orig_count, o.vis_orig_count);
@@ -752,6 +753,10 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
     pp.lists_x = (cam->width + list_px - 1) / list_px;
     pp.list_row_begin = y0 / list_px;
     pp.list_row_end = pp.y1 > y0 ? (pp.y1 + list_px - 1) / list_px : pp.list_row_begin;
+    // the destination the splats are tested against and blended over (gs_mesh_set_destination)
+    GS_REQUIRE(!(m->dest_depth || m->dest_rgba) || (m->dest_w == cam->width && m->dest_h == cam->height),
+               "the destination set with gs_mesh_set_destination does not have this camera's viewport size");
+    pp.depth_mode = m->dest_depth ? ((m->dest_flags & GS_DEST_DEPTH_UNORM24) ? 2u : 1u) : 0u;
     return GS_OK;
 }
 
@@ -785,6 +790,7 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
     GS_TRY(mesh_project(m, pp, true, m->ctx->stage_events));   // + the per-splat mask a visibility-culled sort reads
     m->projection_pending = true;
     m->projected_cam = *cam;
+    m->projected_depth_mode = pp.depth_mode;
     return GS_OK;
 }
 
@@ -804,7 +810,7 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
     bool healed = false;
     GS_TRY(mesh_heal_overflow(m, &healed));
     // a gs_mesh_project of exactly this camera is consumed by exactly one draw (the vertex stage runs once per frame)
-    bool projected = m->projection_pending && memcmp(cam, &m->projected_cam, sizeof(*cam)) == 0;
+    bool projected = m->projection_pending && memcmp(cam, &m->projected_cam, sizeof(*cam)) == 0 && m->projected_depth_mode == pp.depth_mode;
     m->projection_pending = false;
     const uint32_t y0 = pp.y0, y1 = pp.y1;
     m->drawn_list_shift = pp.list_shift;
@@ -953,9 +959,52 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
     return GS_OK;
 }
 
+int gs_mesh_set_destination(gs_mesh* m, const gs_destination* dest) {
+    GS_REQUIRE(m != nullptr, "mesh == NULL");
+    ScopedDevice sd(m->ctx->device);
+    hipStream_t st = m->ctx->stream;
+    // draws in flight still read the previous destination (and, on a context with streams of its own, a pending vertex stage
+    // was run for the previous depth mode)
+    GS_HIP(hipStreamSynchronize(st));
+    if (m->ctx->aux != st) GS_HIP(hipStreamSynchronize(m->ctx->aux));
+    m->dest_depth = nullptr;
+    m->dest_rgba = nullptr;
+    m->dest_w = m->dest_h = m->dest_flags = 0;
+    if (!dest) return GS_OK;
+    GS_REQUIRE(!(dest->depth_host && dest->depth_dev), "pass the destination depth on the host OR on the device, not both");
+    GS_REQUIRE(!(dest->rgba_host && dest->rgba_dev), "pass the destination colour on the host OR on the device, not both");
+    GS_REQUIRE((dest->flags & ~GS_DEST_DEPTH_UNORM24) == 0, "unknown destination flags");
+    const bool any = dest->depth_host || dest->depth_dev || dest->rgba_host || dest->rgba_dev;
+    if (!any) return GS_OK;
+    GS_REQUIRE(dest->width > 0 && dest->height > 0 && dest->width <= 4096u * GS_TILE && dest->height <= 4096u * GS_TILE, "destination size");
+    const size_t px = (size_t)dest->width * dest->height;
+    if (dest->depth_host) {
+        GS_TRY(m->dest_depth_own.ensure(px * 4));
+        GS_HIP(hipMemcpyAsync(m->dest_depth_own.p, dest->depth_host, px * 4, hipMemcpyHostToDevice, st));
+        m->dest_depth = m->dest_depth_own.as<float>();
+    } else if (dest->depth_dev) {
+        m->dest_depth = reinterpret_cast<const float*>(dest->depth_dev);
+    }
+    if (dest->rgba_host) {
+        GS_TRY(m->dest_rgba_own.ensure(px * 4));
+        GS_HIP(hipMemcpyAsync(m->dest_rgba_own.p, dest->rgba_host, px * 4, hipMemcpyHostToDevice, st));
+        m->dest_rgba = m->dest_rgba_own.as<uint32_t>();
+    } else if (dest->rgba_dev) {
+        m->dest_rgba = reinterpret_cast<const uint32_t*>(dest->rgba_dev);
+    }
+    GS_HIP(hipStreamSynchronize(st));                      // the host buffers are reusable on return
+    m->dest_w = dest->width;
+    m->dest_h = dest->height;
+    m->dest_flags = dest->flags;
+    return GS_OK;
+}
+
 int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height, uint8_t* rgba_out_host) {
     GS_REQUIRE(m && rgba_out_host, "mesh / out == NULL");
     GS_REQUIRE(m->has_draw, "no draw yet");
+    //  on a context with two sets of vertex-stage outputs a gs_mesh_project for the NEXT frame has swapped the sets:
+    // the last draw's lists would be composited against the other set's records
+    GS_REQUIRE(!m->projection_pending, "a gs_mesh_project is pending: the records of the last draw are no longer current (draw first)");
     GS_REQUIRE(width > 0 && height > 0 && (uint64_t)width * height <= 65536u, "the window holds 1 .. 65536 pixels");
     const ProjectParams& pp = m->last_pp;
     GS_REQUIRE(x0 + width <= (uint32_t)pp.width && y0 >= pp.y0 && y0 + height <= pp.y1, "the window leaves the rows the last draw covered");

@@ -29,7 +29,104 @@ struct MeshPlanes {
     const uint4* __restrict__ sh2;      // SH2: halfs 16..23
     const uint32_t* __restrict__ scene_idx;          // per-splat scene (EXT, scene_count > 1)
     const gs_scene_params* __restrict__ scenes;      // per-scene uniforms (EXT)
+    const uint32_t* __restrict__ live_list;          // k_block_test's list of the storage blocks that may draw (nullable: every
+    const uint32_t* __restrict__ live_count;         // workgroup tests its own block, the round-2..4 shape) and its length
 };
+
+// One storage block's verdict: can NO splat of the block reach the frame (or this rank's strip)?  See k_project's header comment
+// for the argument; `corner` evaluates one of the box's eight corners, the reductions over the corners are the caller's.
+struct BlockCorner {
+    float q[4], v[3];
+    bool rej[6];            // this corner satisfies reject k (x > 1.2 w, x < -1.2 w, y > .., y < .., z < -1.2 w, w < 0) beyond the margin
+    bool front;             // properly in front of the camera
+    float ypx;              // its window y
+};
+__device__ __forceinline__ BlockCorner block_corner(const ProjectParams& pp, const float* bb, uint32_t c) {
+    BlockCorner o;
+    const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
+    const float* MV = pp.view;
+    const float* P = pp.proj;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = MV[r] * x + MV[4 + r] * y + MV[8 + r] * z + MV[12 + r];
+#pragma unroll
+    for (int r = 0; r < 4; r++) o.q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
+    o.v[0] = v[0]; o.v[1] = v[1]; o.v[2] = v[2];
+    const float clip = 1.2f * o.q[3], tol = 1e-4f * (fabsf(o.q[0]) + fabsf(o.q[1]) + fabsf(o.q[2]) + fabsf(clip) + 1.0f);
+    o.rej[0] = o.q[0] - clip > tol; o.rej[1] = -o.q[0] - clip > tol;
+    o.rej[2] = o.q[1] - clip > tol; o.rej[3] = -o.q[1] - clip > tol;
+    o.rej[4] = -o.q[2] - clip > tol; o.rej[5] = -o.q[3] > tol;
+    o.front = o.q[3] > 1e-6f && v[2] < -1e-6f;
+    o.ypx = (o.q[1] / o.q[3] * 0.5f + 0.5f) * pp.height;
+    return o;
+}
+// the strip half of the verdict, from the reductions over the eight corners (all of them in front of the camera)
+__device__ __forceinline__ bool block_misses_strip(const ProjectParams& pp, float cov_bound_max, float ymin, float ymax, float zmin,
+                                                   float axmax, float aymax) {
+    const float ks = fabsf(pp.splat_scale * pp.inv_focal_adj);
+    float reach = pp.max_splat_px * ks * 1.001f + 2.0f;
+    const float iz = 1.0f / zmin, s2 = iz * iz;
+    const float t0 = fabsf(pp.focal_x) * iz * pp.mv_row_norm[0] + fabsf(pp.focal_x) * axmax * s2 * pp.mv_row_norm[2];
+    const float t1 = fabsf(pp.focal_y) * iz * pp.mv_row_norm[1] + fabsf(pp.focal_y) * aymax * s2 * pp.mv_row_norm[2];
+    const float t = fmaxf(t0, t1) * 1.001f;
+    float l = cov_bound_max * t * t + pp.kernel2d + 0.3163f;
+    if (pp.flags & GS_CAM_POINT_CLOUD) l = fmaxf(l, 0.2f);
+    const float tight = ks * sqrtf(8.0f * l) * 1.002f + 2.0f;
+    if (tight < reach) reach = tight;                     // false for NaN: the cap stays
+    const float slack = 0.05f + 1e-5f * pp.height;       // the corners' own fp32 projection
+    return ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
+}
+
+// The block test as a kernel of its own (round 5): one THREAD per storage block runs the eight-corner test, a dead block gets its
+// empty masks here, a live one is appended to a list (one wave-aggregated atomic per wave), and k_project runs over the list:
+// workgroup g leaves at once when g >= live (one scalar load), otherwise it projects block list[g] without a test, without the
+// box read and without the first barrier.  Rounds 2-4 had every one of the 22.6 k workgroups of a C3 draw evaluate its own box:
+// a draw that sees nothing still cost 20 us, a rank's strip of eight 40 us, to find the ~1 k blocks that reach the strip.  The
+// list's ORDER depends on which wave's atomic arrives first - it only decides which workgroup projects which block, never a value.
+// `count` is this draw's counter (zero on entry); `next_count` is the other one, reset here for the following draw (both kernels
+// of a draw run on ctx->aux in order, so the previous draw's k_project has read its counter by now).
+__global__ __launch_bounds__(256) void k_block_test(ProjectParams pp, const float* __restrict__ block_box, uint32_t blocks,
+                                                    uint32_t* __restrict__ live_list, uint32_t* __restrict__ count,
+                                                    uint32_t* __restrict__ next_count, unsigned long long* __restrict__ vis_mask,
+                                                    uint2* __restrict__ vis32, uint8_t* __restrict__ block_any) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b == 0u) *next_count = 0u;
+    bool live = false;
+    if (b < blocks) {
+        const float* bb = block_box + 8u * (size_t)b;
+        bool all_rej[6] = {true, true, true, true, true, true}, all_front = true;
+        float ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, axmax = 0.0f, aymax = 0.0f;
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; c++) {
+            const BlockCorner k = block_corner(pp, bb, c);
+#pragma unroll
+            for (int r = 0; r < 6; r++) all_rej[r] = all_rej[r] && k.rej[r];
+            all_front = all_front && k.front;
+            ymin = fminf(ymin, k.ypx); ymax = fmaxf(ymax, k.ypx);
+            zmin = fminf(zmin, -k.v[2]);
+            axmax = fmaxf(axmax, fabsf(k.v[0])); aymax = fmaxf(aymax, fabsf(k.v[1]));
+        }
+        bool dead = all_rej[0] || all_rej[1] || all_rej[2] || all_rej[3] || all_rej[4] || all_rej[5];
+        const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
+        if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC) && all_front) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
+        live = !dead;
+        if (dead) {                                          // nothing of this block draws: empty masks, no records
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; w++) vis_mask[4u * b + w] = 0ull;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; k++) vis32[8u * b + k] = make_uint2(0u, b * 256u);
+            block_any[b] = 0;
+        }
+    }
+    const unsigned long long m = __ballot(live);
+    if (m) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (uint32_t)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (live) live_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+    }
+}
 
 __device__ __forceinline__ float h2f(uint32_t bits16) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)(bits16 & 0xFFFFu));
@@ -122,8 +219,14 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any,
-                                                 uint2* __restrict__ prect) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+                                                 uint2* __restrict__ prect, float* __restrict__ zrec) {
+    // the storage block this workgroup projects: its own, or the g-th live one of k_block_test's list
+    uint32_t blk = blockIdx.x;
+    if (mp.live_list) {
+        if (blockIdx.x >= *mp.live_count) return;
+        blk = mp.live_list[blockIdx.x];
+    }
+    const uint32_t i = blk * 256u + threadIdx.x;
     // Block-level cull.  Storage order is Morton order, so a block of 256 splats is a small box in space; its eight corners
     // (one lane each, wave 0) decide whether EVERY splat inside must fail the vertex stage - then nothing of the block is
     // read: not even its centres (12 bytes x 256), which is all a rank of a multi-GPU draw still paid for the ~85 % of the
@@ -143,52 +246,28 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     // dead waves of live blocks skip their centre loads and the shader) is slower as well: the test costs every live wave ~60
     // instructions and a 32-byte read, and Morton blocks are already nearly all-or-nothing (C3 59.5 -> 62.8 us, C2 34.0 -> 37.5,
     // C4 262 -> 300).
-    if (pp.block_cull) {
+    if (pp.block_cull && !mp.live_list) {
         __shared__ uint32_t s_dead;
         bool wave_dead = false;
         if (GS_BLOCK_TEST_PER_WAVE || threadIdx.x < 64u) {
-            const uint32_t c = threadIdx.x & 7u;
-            const float* bb = mp.block_box + 8u * (size_t)blockIdx.x;
-            const float x = (c & 1u) ? bb[3] : bb[0], y = (c & 2u) ? bb[4] : bb[1], z = (c & 4u) ? bb[5] : bb[2];
-            const float* MV = pp.view;
-            const float* P = pp.proj;
-            float v[4], q[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = MV[r] * x + MV[4 + r] * y + MV[8 + r] * z + MV[12 + r];
-#pragma unroll
-            for (int r = 0; r < 4; r++) q[r] = P[r] * v[0] + P[4 + r] * v[1] + P[8 + r] * v[2] + P[12 + r] * v[3];
-            const float clip = 1.2f * q[3], tol = 1e-4f * (fabsf(q[0]) + fabsf(q[1]) + fabsf(q[2]) + fabsf(clip) + 1.0f);
+            const float* bb = mp.block_box + 8u * (size_t)blk;
+            const BlockCorner k = block_corner(pp, bb, threadIdx.x & 7u);
             const unsigned long long lanes8 = 0xFFull;
-            const bool dead_frustum = (__ballot(q[0] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[0] - clip > tol) & lanes8) == lanes8 ||
-                                      (__ballot(q[1] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[1] - clip > tol) & lanes8) == lanes8 ||
-                                      (__ballot(-q[2] - clip > tol) & lanes8) == lanes8 || (__ballot(-q[3] > tol) & lanes8) == lanes8;
+            const bool dead_frustum = (__ballot(k.rej[0]) & lanes8) == lanes8 || (__ballot(k.rej[1]) & lanes8) == lanes8 ||
+                                      (__ballot(k.rej[2]) & lanes8) == lanes8 || (__ballot(k.rej[3]) & lanes8) == lanes8 ||
+                                      (__ballot(k.rej[4]) & lanes8) == lanes8 || (__ballot(k.rej[5]) & lanes8) == lanes8;
             bool dead = dead_frustum;
             const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
             if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC)) {
                 // every corner properly in front of the camera (w > 0 and view-space z < 0)?
-                const bool front = q[3] > 1e-6f && v[2] < -1e-6f;
-                float ypx = (q[1] / q[3] * 0.5f + 0.5f) * pp.height;
-                float ymin = ypx, ymax = ypx, zmin = -v[2], axmax = fabsf(v[0]), aymax = fabsf(v[1]);
+                float ymin = k.ypx, ymax = k.ypx, zmin = -k.v[2], axmax = fabsf(k.v[0]), aymax = fabsf(k.v[1]);
 #pragma unroll
                 for (int o = 1; o < 8; o <<= 1) {
                     ymin = fminf(ymin, __shfl_xor(ymin, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
                     zmin = fminf(zmin, __shfl_xor(zmin, o, 64));
                     axmax = fmaxf(axmax, __shfl_xor(axmax, o, 64)); aymax = fmaxf(aymax, __shfl_xor(aymax, o, 64));
                 }
-                if ((__ballot(front) & lanes8) == lanes8) {
-                    const float ks = fabsf(pp.splat_scale * pp.inv_focal_adj);
-                    float reach = pp.max_splat_px * ks * 1.001f + 2.0f;
-                    const float iz = 1.0f / zmin, s2 = iz * iz;
-                    const float t0 = fabsf(pp.focal_x) * iz * pp.mv_row_norm[0] + fabsf(pp.focal_x) * axmax * s2 * pp.mv_row_norm[2];
-                    const float t1 = fabsf(pp.focal_y) * iz * pp.mv_row_norm[1] + fabsf(pp.focal_y) * aymax * s2 * pp.mv_row_norm[2];
-                    const float t = fmaxf(t0, t1) * 1.001f;
-                    float l = bb[6] * t * t + pp.kernel2d + 0.3163f;
-                    if (pp.flags & GS_CAM_POINT_CLOUD) l = fmaxf(l, 0.2f);
-                    const float tight = ks * sqrtf(8.0f * l) * 1.002f + 2.0f;
-                    if (tight < reach) reach = tight;                     // false for NaN: the cap stays
-                    const float slack = 0.05f + 1e-5f * pp.height;       // the corners' own fp32 projection
-                    dead = ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
-                }
+                if ((__ballot(k.front) & lanes8) == lanes8) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
             }
             if (GS_BLOCK_TEST_PER_WAVE) wave_dead = __builtin_amdgcn_readfirstlane((int)dead) != 0;     // (every wave evaluated the same box: no LDS word, no barrier)
             else if (threadIdx.x == 0u) s_dead = dead ? 1u : 0u;
@@ -199,9 +278,9 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         }
         if (wave_dead) {                                      // nothing of this block draws: empty masks, no records
             const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            if (lane == 0u) vis_mask[blockIdx.x * 4u + wave] = 0ull;
-            if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blockIdx.x * 256u);
-            if (threadIdx.x == 0u) block_any[blockIdx.x] = 0;
+            if (lane == 0u) vis_mask[blk * 4u + wave] = 0ull;
+            if ((lane & 31u) == 0u) vis32[i >> 5] = make_uint2(0u, blk * 256u);
+            if (threadIdx.x == 0u) block_any[blk] = 0;
             return;
         }
     }
@@ -210,6 +289,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     rec.cx = rec.cy = rec.ax = rec.ay = rec.bx = rec.by = 0.0f;
     rec.c0 = rec.c1 = 0u;
     uint2 rect = make_uint2(RECT_EMPTY_LO, 0u);
+    float zwin = 0.0f;          // window-space depth of the centre = of the whole quad (SplatMaterial3D.js:206-210)
 
     if (i < pp.count) {
         const float* MV = pp.view;
@@ -274,6 +354,10 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         bool ok = scene_ok && !(q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip);
         const float ndcx = q[0] / q[3], ndcy = q[1] / q[3], ndcz = q[2] / q[3];       // :166
         ok = ok && (ndcz >= -1.0f && ndcz <= 1.0f);       // quad z == centre z (SplatMaterial3D.js:209): GL clip
+        // what the depth test of a draw with a destination compares (gs_mesh_set_destination): glDepthRange(0, 1), and for a
+        // fixed-point depth buffer the value it would be converted to
+        zwin = ndcz * 0.5f + 0.5f;
+        if (pp.depth_mode == 2u) zwin = (float)floor((double)zwin * 16777215.0 + 0.5);   // (fp64: exact round to nearest; < 2^24, exact as a float)
         if (pp.row_begin > 0u || pp.row_end < pp.tiles_y) {
             // a rank's strip of a multi-GPU draw: no splat reaches farther than maxScreenSpaceSplatSize from its centre, so one
             // whose centre is farther than that from the strip is dropped before its covariance is fetched (the exact rect
@@ -454,8 +538,8 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
     __syncthreads();
     // one byte per block: does ANY of its 256 splats reach the frame?  Morton order makes most blocks all-or-nothing, and the
     // binner tests this (from LDS) before it spends an L2 gather on a splat's visibility word
-    if (threadIdx.x == 0) block_any[blockIdx.x] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
-    const uint32_t block_base = blockIdx.x * 256u;
+    if (threadIdx.x == 0) block_any[blk] = (s_cnt[0] | s_cnt[1] | s_cnt[2] | s_cnt[3]) ? 1 : 0;
+    const uint32_t block_base = blk * 256u;
     uint32_t wave_base = block_base;
 #pragma unroll
     for (uint32_t w = 0; w < 3; w++) wave_base += (w < wave) ? s_cnt[w] : 0u;
@@ -479,6 +563,7 @@ __global__ __launch_bounds__(256) void k_project(ProjectParams pp, MeshPlanes mp
         const uint32_t slot = wave_base + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
         recs[slot] = rec;
         rects[slot] = rect;
+        if (pp.depth_mode) zrec[slot] = zwin;
         // gs_mesh_project: the same bit by ORIGINAL splat index, for a sort that keeps only what this frame draws (the mask
         // was zeroed before the launch; only survivors pay the atomic)
         if (vis_orig) {
@@ -498,7 +583,27 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
     mp.scene_idx = m->scene_idx.as<uint32_t>();
     mp.scenes = m->scene_dev.as<gs_scene_params>();
+    mp.live_list = nullptr;
+    mp.live_count = nullptr;
     if (pp.count == 0) return GS_OK;
+    const uint32_t blocks = (pp.count + 255u) / 256u;
+    if (pp.block_cull && !m->no_block_list) {
+        // the block test first, as a kernel of its own; k_project then runs over the list of live blocks
+        if (!m->live_count.p) {
+            GS_TRY(m->live_list.alloc(((size_t)m->max_count + 255) / 256 * 4 + 64));
+            GS_TRY(m->live_count.alloc(256));
+            GS_HIP(hipMemsetAsync(m->live_count.p, 0, 256, m->ctx->aux));
+        }
+        uint32_t* cnt = m->live_count.as<uint32_t>() + 32u * (m->live_parity & 1u);        // (128 bytes apart)
+        uint32_t* next = m->live_count.as<uint32_t>() + 32u * ((m->live_parity ^ 1u) & 1u);
+        m->live_parity ^= 1u;
+        hipLaunchKernelGGL(k_block_test, dim3((blocks + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
+                           m->live_list.as<uint32_t>(), cnt, next, m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
+                           m->block_any.as<uint8_t>());
+        mp.live_list = m->live_list.as<uint32_t>();
+        mp.live_count = cnt;
+    }
+    if (pp.depth_mode) GS_TRY(m->zrec.ensure((size_t)m->max_count * 4 + 16));
     uint32_t* vis_orig = nullptr;
     if (orig_mask) {
         const bool fresh = m->vis_orig.p == nullptr;
@@ -517,11 +622,11 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     if (ext)
         hipLaunchKernelGGL(k_project<true>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm, m->block_any.as<uint8_t>(), m->prect.as<uint2>());
+                           vis_orig, inv_perm, m->block_any.as<uint8_t>(), m->prect.as<uint2>(), m->zrec.as<float>());
     else
         hipLaunchKernelGGL(k_project<false>, dim3((pp.count + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp,
                            m->recs.as<SplatRec>(), m->rects.as<uint2>(), m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           vis_orig, inv_perm, m->block_any.as<uint8_t>(), m->prect.as<uint2>());
+                           vis_orig, inv_perm, m->block_any.as<uint8_t>(), m->prect.as<uint2>(), m->zrec.as<float>());
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -682,7 +682,10 @@ __global__ __launch_bounds__(CHUNK_THREADS, CHUNK_OCC_CFG) void k_radix_scatter_
 #pragma unroll
             for (uint32_t k = 0; k < 8u; k++) before += (r0 + k * CHUNK_PARTS) < ch.id ? v[k] : 0u;
         }
-        const uint32_t own = tid < RADIX_BINS ? ld32(block_hist, ch.id * RADIX_BINS + d) : 0u;    // this chunk's keys of digit d
+        // this chunk's keys of digit d.  A workgroup WITHOUT tiles (only workgroup 0 of an empty list gets here) has no row: the
+        // histogram kernel wrote none for it, and row 0 still holds the previous sort's counts - reading it made the final sweep
+        // store that many never-written staging words through s_gbase of a zero table
+        const uint32_t own = (tid < RADIX_BINS && ch.tile_begin < ch.tile_end) ? ld32(block_hist, ch.id * RADIX_BINS + d) : 0u;
         uint32_t* s_before = &s_wave[0][0];                  // [PARTS][256], free until the tile loop uses it
         uint32_t* s_all = &s_wave[CHUNK_PARTS][0];
         s_before[tid] = before;

@@ -930,7 +930,18 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 gs_tree_forget_sorter(s->pending_tree, s);
             }
         }
-    } else if (indexes_to_sort) {
+    } else {
+        // A sort that does not consume the gathered list may destroy what a gather left for a later gs_sorter_sort_gathered
+        // (ADVICE r04): a planned gather's fused copy ORs its keep bits into a mask the GATHER zeroed - a frustum-culled sort in
+        // between rewrites that mask, so the copy falls back to the plain one + the ordinary key kernel; a list that was already
+        // copied into idx_in is gone once a host list or a compaction overwrites it.
+        if (s->pending_tree) {
+            if (cull) s->pending_keep_zeroed = false;
+        } else if (indexes_to_sort || vis_cull) {
+            s->has_gathered = false;
+        }
+    }
+    if (!device_list && indexes_to_sort) {
         GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
         if (R) GS_HIP(hipMemcpyAsync(s->idx_in.p, indexes_to_sort, (size_t)R * 4, hipMemcpyHostToDevice, st));
         idx_dev = s->idx_in.as<uint32_t>();
@@ -1064,8 +1075,13 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         // payload in one 32-bit word (payloads are splat positions < uploaded: 23 bits at 5.8 M splats, 24 at 16 M, so the default
         // 16-bit buckets always do below 2^24 splats) the pass writes that word instead of a key array and a value array
         // (radix.hpp PACK_OUT); otherwise 16- or 32-bit keys + values as before, and a later pass packs as soon as it can.
+        // The payload's range, not the list's: with a bound mesh a payload is perm[o], a position inside the mesh's slotted range,
+        // which reaches mesh.uploaded - 1 even when fewer centres have reached this sorter (gs_mesh_payload_map allows
+        // sorter.uploaded <= mesh.uploaded).  Sized from last_splat alone, the payload's top bits OR-ed into the key.
+        uint32_t max_payload = kp.last_splat;
+        if (map && s->bound_mesh->uploaded && s->bound_mesh->uploaded - 1u > max_payload) max_payload = s->bound_mesh->uploaded - 1u;
         uint32_t val_bits = 1;
-        while (val_bits < 32u && (kp.last_splat >> val_bits)) val_bits++;
+        while (val_bits < 32u && (max_payload >> val_bits)) val_bits++;
         static const bool no_pack = getenv("GSPLAT_NO_SORT_PACK") != nullptr;       // A/B and tests: the unpacked path
         static const bool no_chunk = getenv("GSPLAT_NO_SORT_CHUNK") != nullptr;     // ... the tile-at-a-time scatter for packed passes
         // packed passes stage a whole chunk in LDS (radix.hpp) when the list is short enough for <= CHUNK_TILES tiles per

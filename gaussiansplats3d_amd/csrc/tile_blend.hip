@@ -38,7 +38,7 @@ __device__ __forceinline__ v2f pk_fma_sat(v2f a, v2f b, v2f c) {
 //     u = ax * x + ay * y + cu ,  w = bx * x + by * y + cw      (x, y = pixel centre - bin origin, |x|, |y| < 32)
 // with cu = -(ax * cx' + ay * cy'), (cx', cy') = splat centre - bin origin, so the inner loop never forms pixel - centre.
 struct __attribute__((aligned(16))) LdsSplat {
-    float ax, ay, cu, pad0;
+    float ax, ay, cu, z;           // z: the splat's window depth (draws with a destination depth only, else 0)
     float bx, by, cw, a;           // 48-byte stride keeps the three reads of a splat 16-byte aligned
     float r, g, b, pad1;
 };
@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t block_mask16(const uint4 lo, const uint4 hi,
 }
 
 // expands one record, relative to the origin of the bin that stages it
-__device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi, float bin_x0, float bin_y0) {
+__device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const uint4 hi, float bin_x0, float bin_y0, float z = 0.0f) {
 #pragma clang fp contract(off)
     LdsSplat s;
     const float cx = __uint_as_float(lo.x) - bin_x0, cy = __uint_as_float(lo.y) - bin_y0;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void stage_entry(LdsSplat* dst, const uint4 lo, const
     s.bx = __uint_as_float(hi.x); s.by = __uint_as_float(hi.y);
     s.cu = -__builtin_fmaf(s.ax, cx, s.ay * cy);
     s.cw = -__builtin_fmaf(s.bx, cx, s.by * cy);
-    s.pad0 = 0.0f; s.pad1 = 0.0f;
+    s.z = z; s.pad1 = 0.0f;
     s.r = (float)(hi.z & 0xFFFFu) * (1.0f / 65535.0f);
     s.g = (float)(hi.z >> 16) * (1.0f / 65535.0f);
     s.b = (float)(hi.w & 0xFFFFu) * (1.0f / 65535.0f);
@@ -220,8 +220,13 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 // `if (A > 8.0) discard` is a saturated multiply-add instead of a compare + select (which does not pack and stalls on VCC):
 // keep = sat((CUT - pw) * 2^100) is exactly 1 for pw < CUT and 0 for pw >= CUT - fp32 cannot represent a positive difference
 // below 2^-100 here.  The two pairs are independent chains the scheduler interleaves.
+// DEPTH (a draw with a destination depth, gs_mesh_set_destination): the reference's `depthTest: true, depthWrite: false`
+// (SplatMaterial3D.js:72-73) - a fragment whose depth (the splat centre's: the quad is flat, :206-210) fails LEQUAL against the
+// pixel's stored depth dz contributes nothing: alpha = 0 there, exactly like a discarded fragment.  A per-(splat, pixel) select
+// on the alpha, so the order of the list and who executes the composite stay irrelevant.
 struct Alpha { v2f a[2]; float r, g, b; };
-__device__ __forceinline__ void alpha_of(const LdsSplat* sp, float fx, const v2f (&fy)[2], const Px& px, Alpha& out, uint32_t& p_kept, uint32_t& p_useful) {
+template <bool DEPTH>
+__device__ __forceinline__ void alpha_of(const LdsSplat* sp, float fx, const v2f (&fy)[2], const v2f (&dz)[2], const Px& px, Alpha& out, uint32_t& p_kept, uint32_t& p_useful) {
 #pragma clang fp contract(off)
     const float4 q0 = *reinterpret_cast<const float4*>(&sp->ax);     // three wave-uniform ds_read_b128 broadcasts
     const float4 q1 = *reinterpret_cast<const float4*>(&sp->bx);
@@ -242,9 +247,13 @@ __device__ __forceinline__ void alpha_of(const LdsSplat* sp, float fx, const v2f
                     (uint32_t)__popcll(__ballot(keep.y > 0.0f && px.T[h].y > GS_T_EPS));
 #endif
         out.a[h] = e * (v2f{q1.w, q1.w} * keep);
+        if (DEPTH) {
+            out.a[h].x = q0.w <= dz[h].x ? out.a[h].x : 0.0f;
+            out.a[h].y = q0.w <= dz[h].y ? out.a[h].y : 0.0f;
+        }
     }
     out.r = q2.x; out.g = q2.y; out.b = q2.z;
-    (void)px; (void)p_kept; (void)p_useful;
+    (void)px; (void)p_kept; (void)p_useful; (void)dz;
 }
 __device__ __forceinline__ void apply_alpha(Px& px, const Alpha& al) {
 #pragma clang fp contract(off)
@@ -257,19 +266,21 @@ __device__ __forceinline__ void apply_alpha(Px& px, const Alpha& al) {
         px.T[h] = fma2(-px.T[h], al.a[h], px.T[h]);                  // T * (1 - alpha) without waiting for wgt
     }
 }
-__device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+template <bool DEPTH>
+__device__ __forceinline__ void composite_one(const LdsSplat* sp, float fx, const v2f (&fy)[2], const v2f (&dz)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
     Alpha al;
-    alpha_of(sp, fx, fy, px, al, p_kept, p_useful);
+    alpha_of<DEPTH>(sp, fx, fy, dz, px, al, p_kept, p_useful);
     apply_alpha(px, al);
 }
 // Two consecutive splats: both alphas first (they do not depend on the pixel's state), then the two composite steps in order -
 // the same operations on the same operands as two composite_one calls, with the second splat's LDS reads and exponentials in
 // the shadow of the first's.  For waves that walk alone (the deep pass's units): they are bound by the latency of one splat's
 // dependent chain (~400 cycles per splat against 132 of VALU issue), not by issue slots.
-__device__ __forceinline__ void composite_two(const LdsSplat* sp, const LdsSplat* sp1, float fx, const v2f (&fy)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
+template <bool DEPTH>
+__device__ __forceinline__ void composite_two(const LdsSplat* sp, const LdsSplat* sp1, float fx, const v2f (&fy)[2], const v2f (&dz)[2], Px& px, uint32_t& p_kept, uint32_t& p_useful) {
     Alpha a0, a1;
-    alpha_of(sp, fx, fy, px, a0, p_kept, p_useful);
-    alpha_of(sp1, fx, fy, px, a1, p_kept, p_useful);
+    alpha_of<DEPTH>(sp, fx, fy, dz, px, a0, p_kept, p_useful);
+    alpha_of<DEPTH>(sp1, fx, fy, dz, px, a1, p_kept, p_useful);
     apply_alpha(px, a0);
     apply_alpha(px, a1);
 }
@@ -300,16 +311,26 @@ struct Folded {
     }
 };
 
+// dst_rgba (nullable): the colour the splats are blended over (gs_mesh_set_destination), the WHOLE frame's RGBA8 rows.  Back to
+// front NormalBlending over dst leaves rgb = C + T * dst.rgb, alpha = (1 - T) + T * dst.a (C, T = the splats' own composite).
 __device__ __forceinline__ void write_pixels(uint32_t* __restrict__ out, uint32_t width, uint32_t y0, uint32_t y1, uint32_t px, uint32_t py0,
-                                             const Folded& f) {
+                                             const Folded& f, const uint32_t* __restrict__ dst_rgba = nullptr) {
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
         if (px < width && py >= y0 && py < y1) {
-            const float a = 1.0f - f.T[g];
-            const uint32_t r8 = (uint32_t)(fminf(fmaxf(f.C[g][0], 0.0f), 1.0f) * 255.0f + 0.5f);
-            const uint32_t g8 = (uint32_t)(fminf(fmaxf(f.C[g][1], 0.0f), 1.0f) * 255.0f + 0.5f);
-            const uint32_t b8 = (uint32_t)(fminf(fmaxf(f.C[g][2], 0.0f), 1.0f) * 255.0f + 0.5f);
+            float a = 1.0f - f.T[g];
+            float cr = f.C[g][0], cg = f.C[g][1], cb = f.C[g][2];
+            if (dst_rgba) {
+                const uint32_t d = dst_rgba[(size_t)py * width + px];
+                cr = __builtin_fmaf(f.T[g], (float)(d & 255u) * (1.0f / 255.0f), cr);
+                cg = __builtin_fmaf(f.T[g], (float)((d >> 8) & 255u) * (1.0f / 255.0f), cg);
+                cb = __builtin_fmaf(f.T[g], (float)((d >> 16) & 255u) * (1.0f / 255.0f), cb);
+                a = __builtin_fmaf(f.T[g], (float)(d >> 24) * (1.0f / 255.0f), a);
+            }
+            const uint32_t r8 = (uint32_t)(fminf(fmaxf(cr, 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t g8 = (uint32_t)(fminf(fmaxf(cg, 0.0f), 1.0f) * 255.0f + 0.5f);
+            const uint32_t b8 = (uint32_t)(fminf(fmaxf(cb, 0.0f), 1.0f) * 255.0f + 0.5f);
             const uint32_t a8 = (uint32_t)(fminf(fmaxf(a, 0.0f), 1.0f) * 255.0f + 0.5f);
             out[(size_t)(py - y0) * width + px] = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
         }
@@ -337,7 +358,28 @@ struct FrameArgs {
     uint2* __restrict__ bin_stats;
     uint32_t* __restrict__ bin_pairs;
     const uint32_t* __restrict__ bin_order;
+    // destination (gs_mesh_set_destination): the splats' window depths (per record slot), the stored depth and colour of the whole
+    // frame (row 0 = bottom, `width` pixels per row), and how depths compare (1 = fp32, 2 = both sides as 24-bit integers)
+    const float* __restrict__ zrec;
+    const float* __restrict__ dst_depth;
+    const uint32_t* __restrict__ dst_rgba;
+    uint32_t depth_mode, height;
 };
+
+// the stored depth of this lane's four pixels (x = px, y = py0 + 4 g), as the blend compares it; outside the frame: passes
+__device__ __forceinline__ void load_dst_depth(const FrameArgs& fa, uint32_t px, uint32_t py0, v2f (&dz)[2]) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t py = py0 + 4u * g;
+        float d = GS_HUGE;
+        if (px < fa.width && py < fa.height) {
+            d = fa.dst_depth[(size_t)py * fa.width + px];
+            if (fa.depth_mode == 2u) d = (float)floor((double)d * 16777215.0 + 0.5);
+        }
+        dz[g >> 1][g & 1] = d;
+    }
+}
 
 struct BinGeom {
     uint32_t bx, by, begin, n;
@@ -358,6 +400,7 @@ struct BinGeom {
 // ---------------------------------------------------------------------------------------------------------------------------
 // one workgroup per bin
 // ---------------------------------------------------------------------------------------------------------------------------
+template <bool DEPTH>
 __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da, const uint32_t wg, LdsSplat* s_batch, uint32_t* s_qmask,
                                          uint32_t* s_live, uint32_t* s_walked) {
     const uint32_t bin = fa.bin_order ? fa.bin_order[wg] : wg;             // heaviest bins of the previous draw first (k_bin_emit)
@@ -374,6 +417,8 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
     const float fx = (float)((wave & 1u) * GS_TILE + (lane & 15u)) + 0.5f;
     const float fy0 = (float)((wave >> 1) * GS_TILE + (lane >> 4)) + 0.5f;
     const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
+    v2f dz[2] = {{GS_HUGE, GS_HUGE}, {GS_HUGE, GS_HUGE}};
+    if (DEPTH) load_dst_depth(fa, px, py0, dz);
 
 #ifdef GS_BLEND_PROFILE
     const unsigned long long t_start = wall_clock64();
@@ -405,12 +450,14 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
     uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
     uint2 rect = make_uint2(0xFFFFu, 0u);              // empty
     uint32_t v_next = 0;
+    float zs = 0.0f;                                   // (DEPTH) the entry's window depth, fetched with its record
     if (n) {                                           // (uniform)
         const uint32_t last = begin + n - 1u;
         const uint32_t slot = fa.vals[min(begin + tid, last)];
         rect = fa.rects[slot];
         lo = fa.recs[2 * (size_t)slot];
         hi = fa.recs[2 * (size_t)slot + 1];
+        if (DEPTH) zs = fa.zrec[slot];
         v_next = fa.vals[min(begin + BLEND_THREADS + tid, last)];
     }
     for (uint32_t base = 0; base < n; base += BLEND_THREADS) {
@@ -427,12 +474,13 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
 #else
         s_qmask[tid] = qm;
 #endif
-        if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0);
+        if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0, zs);
         if (tid == 0) *s_live = 0u;
         // prefetch while this batch is blended
         rect = fa.rects[v_next];
         lo = fa.recs[2 * (size_t)v_next];
         hi = fa.recs[2 * (size_t)v_next + 1];
+        if (DEPTH) zs = fa.zrec[v_next];
         v_next = fa.vals[min(begin + base + 2u * BLEND_THREADS + tid, begin + n - 1u)];
         __syncthreads();
         if (live_wave) {
@@ -462,10 +510,10 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
                         m &= m - 1ull;
                         walked++;
                         since_check++;
-                        composite_two(&s_batch[j], &s_batch[j1], fx, fy, acc, p_kept, p_useful);
+                        composite_two<DEPTH>(&s_batch[j], &s_batch[j1], fx, fy, dz, acc, p_kept, p_useful);
                     } else
 #endif
-                    composite_one(&s_batch[j], fx, fy, acc, p_kept, p_useful);
+                    composite_one<DEPTH>(&s_batch[j], fx, fy, dz, acc, p_kept, p_useful);
                     // Retire the wave when the open chunk has saturated its whole quadrant (every T <= 1e-4; everything behind is
                     // then multiplied by <= 1e-4).  Tested after every GS_BLEND_CHECK-th splat of the chunk and nowhere else, so a
                     // chunk composites exactly the first K of its own ordered survivors (K = the first multiple of GS_BLEND_CHECK at
@@ -592,7 +640,7 @@ __device__ __forceinline__ void bin_body(const FrameArgs& fa, const DeepArgs& da
             for (int g = 0; g < 4; g++) f.merge(g, acc.get(g));
         }
     }
-    write_pixels(fa.out, fa.width, fa.y0, fa.y1, px, py0, f);
+    write_pixels(fa.out, fa.width, fa.y0, fa.y1, px, py0, f, fa.dst_rgba);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -721,12 +769,14 @@ __global__ __launch_bounds__(1024) void k_deep_plan(FrameArgs fa, DeepArgs da) {
     if (threadIdx.x == 0) { da.flags[GS_FLAG_UNITS] = total_units; da.flags[GS_FLAG_UNIT_NEXT] = 0u; }
 }
 
+template <bool DEPTH>
 __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArgs& da, const uint32_t u, LdsSplat* s_batch, uint32_t* s_queue);
 
 // The waves of the pass's workgroups TAKE units from the packed work list (k_deep_plan) until it is empty.  (History, r03y
 // profiles: fixed (bin, chunk) x 4 quadrants per workgroup left most workgroups with one or two live waves, and bin-major order
 // let the chunk index choose the XCD - 620, then 1900 waves busy out of 6144; one unit per wave of a packed list still left a
 // workgroup's other waves idle behind its slowest unit - a workgroup holds its CU slot until its last wave ends.)
+template <bool DEPTH>
 __device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& da, LdsSplat* s_batch, uint32_t* s_queue) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t units = da.flags[GS_FLAG_UNITS];
@@ -735,11 +785,12 @@ __device__ __forceinline__ void deep_unit(const FrameArgs& fa, const DeepArgs& d
         if (lane == 0u) u = atomicAdd(&da.flags[GS_FLAG_UNIT_NEXT], 1u);
         u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
         if (u >= units) return;
-        deep_unit_one(fa, da, u, s_batch, s_queue);
+        deep_unit_one<DEPTH>(fa, da, u, s_batch, s_queue);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
+template <bool DEPTH>
 __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArgs& da, const uint32_t u, LdsSplat* s_batch, uint32_t* s_queue) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -764,6 +815,8 @@ __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArg
     const float fx = (float)((q & 1u) * GS_TILE + (lane & 15u)) + 0.5f;
     const float fy0 = (float)((q >> 1) * GS_TILE + (lane >> 4)) + 0.5f;
     const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
+    v2f dz[2] = {{GS_HUGE, GS_HUGE}, {GS_HUGE, GS_HUGE}};
+    if (DEPTH) load_dst_depth(fa, bg.bx * GS_BIN + (q & 1u) * GS_TILE + (lane & 15u), bg.by * GS_BIN + (q >> 1) * GS_TILE + (lane >> 4), dz);
     LdsSplat* mine = s_batch + 64u * wave;                                  // this wave's quarter of the batch buffer
     uint32_t* qs = s_queue + 128u * wave;                                   // slots of survivors found but not yet composited
     const uint32_t* ent = da.ent + (size_t)d * GS_DEEP_LIST_CAP;
@@ -820,7 +873,7 @@ __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArg
         __builtin_amdgcn_wave_barrier();
         if (lane < k) {
             const uint32_t slot = qs[lane];
-            stage_entry(&mine[lane], fa.recs[2 * (size_t)slot], fa.recs[2 * (size_t)slot + 1], bin_x0, bin_y0);
+            stage_entry(&mine[lane], fa.recs[2 * (size_t)slot], fa.recs[2 * (size_t)slot + 1], bin_x0, bin_y0, DEPTH ? fa.zrec[slot] : 0.0f);
         }
         const uint32_t carry = lane < rem ? qs[64u + lane] : 0u;           // what is left moves to the front of the queue
         __builtin_amdgcn_wave_barrier();
@@ -830,12 +883,12 @@ __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArg
         __builtin_amdgcn_wave_barrier();
         uint32_t jj = 0;
         if ((since_check & 1u) && k) {                                      // (pairs never straddle a saturation test)
-            composite_one(&mine[0], fx, fy, acc, p_kept, p_useful);
+            composite_one<DEPTH>(&mine[0], fx, fy, dz, acc, p_kept, p_useful);
             jj = 1; done++;
             if (++since_check == GS_BLEND_CHECK) { since_check = 0; if (!acc.open()) open = false; }
         }
         for (; jj + 1u < k && open; jj += 2u) {
-            composite_two(&mine[jj], &mine[jj + 1u], fx, fy, acc, p_kept, p_useful);
+            composite_two<DEPTH>(&mine[jj], &mine[jj + 1u], fx, fy, dz, acc, p_kept, p_useful);
             done += 2u;
             since_check += 2u;
             if (since_check == GS_BLEND_CHECK) {                            // the per-bin kernel's stop rule
@@ -844,7 +897,7 @@ __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArg
             }
         }
         if (jj < k && open) {
-            composite_one(&mine[jj], fx, fy, acc, p_kept, p_useful);
+            composite_one<DEPTH>(&mine[jj], fx, fy, dz, acc, p_kept, p_useful);
             done++;
             if (++since_check == GS_BLEND_CHECK) { since_check = 0; if (!acc.open()) open = false; }
         }
@@ -868,6 +921,7 @@ __device__ __forceinline__ void deep_unit_one(const FrameArgs& fa, const DeepArg
 // One launch: one workgroup per bin (heaviest first, k_bin_emit's order), then the deep pass's units, which fill the slots the light
 // bins free (units first: the per-bin workgroups sat behind 16 k mostly empty unit workgroups in the dispatcher's queue and
 // started 0.26 ms late - they, not the units, ended the launch: r03y profile).
+template <bool DEPTH>
 __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameArgs fa, DeepArgs da, uint32_t bins) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
@@ -875,11 +929,11 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameAr
     __shared__ uint32_t s_walked[4];
     __shared__ uint32_t s_queue[512];                  // (deep units: 128 pending survivor slots per wave)
 #ifdef GS_AB_NO_DEEP_UNIT            // (A/B: the per-bin kernel alone)
-    if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
+    if (blockIdx.x < bins) bin_body<DEPTH>(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
     (void)s_queue;
 #else
-    if (blockIdx.x < bins) bin_body(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
-    else deep_unit(fa, da, s_batch, s_queue);
+    if (blockIdx.x < bins) bin_body<DEPTH>(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
+    else deep_unit<DEPTH>(fa, da, s_batch, s_queue);
 #endif
 }
 
@@ -903,7 +957,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_deep_fold(FrameArgs fa, DeepA
         for (int g = 0; g < 4; g++) f.merge(g, part[64 * g]);
         open = f.open();
     }
-    write_pixels(fa.out, fa.width, fa.y0, fa.y1, bg.bx * GS_BIN + (q & 1u) * GS_TILE + (lane & 15u), bg.by * GS_BIN + (q >> 1) * GS_TILE + (lane >> 4), f);
+    write_pixels(fa.out, fa.width, fa.y0, fa.y1, bg.bx * GS_BIN + (q & 1u) * GS_TILE + (lane & 15u), bg.by * GS_BIN + (q >> 1) * GS_TILE + (lane >> 4), f, fa.dst_rgba);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -925,6 +979,16 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
     const uint32_t px = wx0 + t % ww, py = wy0 + t / ww;
     float r = 0.0f, g = 0.0f, b = 0.0f, al = 0.0f;
     if (px < fa.width && py < height && py >= fa.y0 && py < fa.y1) {
+        float dzp = GS_HUGE;                                  // the destination (gs_mesh_set_destination): stored depth and colour
+        if (fa.dst_depth) {
+            dzp = fa.dst_depth[(size_t)py * fa.width + px];
+            if (fa.depth_mode == 2u) dzp = (float)floor((double)dzp * 16777215.0 + 0.5);
+        }
+        if (fa.dst_rgba) {
+            const uint32_t d = fa.dst_rgba[(size_t)py * fa.width + px];
+            r = (float)(d & 255u) * (1.0f / 255.0f); g = (float)((d >> 8) & 255u) * (1.0f / 255.0f);
+            b = (float)((d >> 16) & 255u) * (1.0f / 255.0f); al = (float)(d >> 24) * (1.0f / 255.0f);
+        }
         const uint32_t tx = px / GS_TILE, ty = py / GS_TILE;
         const uint32_t lx = tx >> fa.list_shift, ly = (ty >> fa.list_shift) - fa.list_row_begin;
         const uint2 range = fa.ranges[ly * fa.lists_x + lx];
@@ -935,6 +999,7 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
                 const uint2 rc = fa.rects[slot];
                 const uint32_t x0 = rc.x & 0xFFFFu, y0 = rc.x >> 16, x1 = rc.y & 0xFFFFu, y1 = rc.y >> 16;
                 if (tx < x0 || tx > x1 || ty < y0 || ty > y1) continue;
+                if (fa.dst_depth && !(fa.zrec[slot] <= dzp)) continue;   // depthTest, LessEqualDepth
                 const uint4 lo = fa.recs[2 * (size_t)slot], hi = fa.recs[2 * (size_t)slot + 1];
                 const float dx = fx - __uint_as_float(lo.x), dy = fy - __uint_as_float(lo.y);
                 const float u = __builtin_fmaf(__uint_as_float(lo.z), dx, __uint_as_float(lo.w) * dy);
@@ -957,8 +1022,18 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
     out[t] = u8(r) | (u8(g) << 8) | (u8(b) << 16) | (u8(al) << 24);
 }
 
+// the destination of a draw as the kernels see it (pp.depth_mode was derived from the same fields: mesh_params)
+static void frame_destination(FrameArgs& fa, const gs_mesh* m, const ProjectParams& pp) {
+    fa.depth_mode = pp.depth_mode;
+    fa.height = (uint32_t)pp.height;
+    fa.zrec = pp.depth_mode ? m->zrec.as<float>() : nullptr;
+    fa.dst_depth = pp.depth_mode ? m->dest_depth : nullptr;
+    fa.dst_rgba = m->dest_rgba;
+}
+
 int gs_launch_rop8_window(gs_mesh* m, const ProjectParams& pp, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t* out_dev) {
     FrameArgs fa = {};
+    frame_destination(fa, m, pp);
     fa.ranges = m->tile_ranges.as<uint2>();
     fa.vals = (m->sorted_buf ? m->evalB : m->evalA).as<uint32_t>();
     fa.recs = m->recs.as<uint4>();
@@ -990,6 +1065,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     fa.bin_stats = m->blend_stats.as<uint2>();
     fa.bin_pairs = m->blend_stats.as<uint32_t>() + 2 * (size_t)bins;
     fa.bin_order = m->blend_order_valid ? m->blend_order.as<uint32_t>() : nullptr;
+    frame_destination(fa, m, pp);
     // (the buffers were sized and the flag words reset by the binner's launches: gs_launch_binning)
     DeepArgs da;
     da.flags = m->deep_flags.as<uint32_t>();
@@ -1006,7 +1082,8 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
         hipLaunchKernelGGL(k_deep_scan, dim3(GS_DEEP_MAX_BINS * GS_DEEP_SCAN_WGS), dim3(256), 0, st, fa, da);
         hipLaunchKernelGGL(k_deep_plan, dim3(1), dim3(1024), 0, st, fa, da);
     }
-    hipLaunchKernelGGL(k_tile_blend, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
+    if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend<true>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
+    else hipLaunchKernelGGL(k_tile_blend<false>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     if (m->deep_pass) hipLaunchKernelGGL(k_deep_fold, dim3(GS_DEEP_MAX_BINS), dim3(BLEND_THREADS), 0, st, fa, da);
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;

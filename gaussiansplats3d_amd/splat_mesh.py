@@ -197,6 +197,36 @@ class SplatMesh:
             C.byref(stats) if stats is not None else None))
         return out, stats
 
+    def set_destination(self, depth=None, rgba=None, depth_unorm24=False, depth_device_ptr=None, rgba_device_ptr=None,
+                        size=None):
+        """What the following draws are depth-tested against and blended over - the reference's `depthTest: true,
+        depthWrite: false` + NormalBlending over whatever the host's scene drew first (SplatMaterial3D.js:72-73,
+        src/Viewer.js:1610-1616, src/DropInViewer.js:34-42).  depth: float32 [H, W] window depth (row 0 = bottom), rgba: uint8
+        [H, W, 4]; or device pointers of the same layouts with size = (width, height).  No arguments: back to a cleared target."""
+        if depth is None and rgba is None and depth_device_ptr is None and rgba_device_ptr is None:
+            L.check(self.lib.gs_mesh_set_destination(self.handle, None))
+            return self
+        d = L.Destination()
+        keep = []
+        if depth is not None:
+            a = np.ascontiguousarray(depth, dtype=np.float32)
+            size = (a.shape[1], a.shape[0])
+            d.depth_host = a.ctypes.data
+            keep.append(a)
+        if rgba is not None:
+            a = np.ascontiguousarray(rgba, dtype=np.uint8)
+            size = (a.shape[1], a.shape[0])
+            d.rgba_host = a.ctypes.data
+            keep.append(a)
+        if depth_device_ptr:
+            d.depth_dev = int(depth_device_ptr)
+        if rgba_device_ptr:
+            d.rgba_dev = int(rgba_device_ptr)
+        d.width, d.height = int(size[0]), int(size[1])
+        d.flags = L.GS_DEST_DEPTH_UNORM24 if depth_unorm24 else 0
+        L.check(self.lib.gs_mesh_set_destination(self.handle, C.byref(d)))
+        return self
+
     def debug_set_entry_capacity(self, capacity):
         """Test hook: resize the entry buffers (the overflow -> regrow path of a draw)."""
         L.check(self.lib.gs_mesh_debug_set_entry_capacity(self.handle, int(capacity)))

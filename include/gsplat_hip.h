@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 3
+#define GS_ABI_VERSION 4   /* 4: + gs_mesh_set_destination (round 5); every version-3 entry point is unchanged */
 
 /* status codes (negative = error, positive = warning, result still defined) */
 #define GS_OK 0
@@ -353,6 +353,39 @@ typedef struct gs_render_stats {
  *   rgba_out_dev  same, device pointer (e.g. a torch uint8 tensor); or NULL to use an internal buffer */
 int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host, gs_sorter* sorter,
                    uint32_t render_count, uint8_t* rgba_out_host, void* rgba_out_dev, gs_render_stats* stats);
+
+/* The DESTINATION the splats are blended into.  The reference draws the other scene geometry first and then the splats with
+ * `depthTest: true, depthWrite: false` and NormalBlending (src/splatmesh/SplatMaterial3D.js:72-73; draw order
+ * src/Viewer.js:1610-1616; drop-in mode, where the splat mesh is one object of the host's own scene:
+ * src/DropInViewer.js:34-42): a splat fragment is kept where its depth passes three's default depthFunc (LessEqualDepth)
+ * against the depth the opaque geometry left, and what is kept is blended OVER the colour that geometry left.  The quad of a
+ * splat sits at its centre's depth (gl_Position.z = ndcCenter.z, SplatMaterial3D.js:206-210), so the test is per (splat,
+ * pixel): window depth of the splat's CENTRE, 0.5 * ndc.z + 0.5 (glDepthRange 0..1), <= depth[pixel].
+ *
+ *   depth_host / depth_dev   float[height * width], window-space depth in [0, 1] as glReadPixels(DEPTH_COMPONENT, FLOAT) or
+ *                            a THREE.DepthTexture(FloatType) holds it, row 0 = bottom; at most one of the two; both NULL = no
+ *                            depth test (every fragment passes)
+ *   rgba_host / rgba_dev     uint8[4 * height * width] RGBA8, row 0 = bottom: the colour the splats are blended over
+ *                            (rgb = C + T * dst.rgb, alpha = 1 - T * (1 - dst.a): what NormalBlending, back to front, leaves);
+ *                            both NULL = the reference Viewer's clear colour (0, 0, 0, 0)
+ *   width, height            must equal the camera's viewport at every draw while the destination is set
+ *   GS_DEST_DEPTH_UNORM24    compare as a 24-bit fixed-point depth buffer does: both sides round(z * (2^24 - 1)) first
+ *
+ * Host buffers are copied to the device by this call (it returns when they are reusable); device buffers are READ BY EVERY
+ * FOLLOWING DRAW until the destination is replaced or cleared (dest == NULL) - the caller keeps them alive and orders its
+ * writes to them before the draws (same stream or an event).  A multi-GPU strip reads its own rows of the full-size buffers.
+ * Draw modes and outputs are unchanged; frames stay bit-identical across strips and across the deep pass. */
+#define GS_DEST_DEPTH_UNORM24 1u
+typedef struct gs_destination {
+    const float* depth_host;
+    const void* depth_dev;
+    const uint8_t* rgba_host;
+    const void* rgba_dev;
+    uint32_t width, height;
+    uint32_t flags;
+    uint32_t pad;
+} gs_destination;
+int gs_mesh_set_destination(gs_mesh* m, const gs_destination* dest);
 
 /* The vertex stage of a draw on its own (the GLSL vertex shader, SplatMaterial.js:112-341 + SplatMaterial3D.js:81-217):
  * projects every uploaded splat for `cam` and leaves records, tile rects and the visibility mask on the device.  The next

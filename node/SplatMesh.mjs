@@ -171,6 +171,7 @@ export class SplatMesh {
         sphericalHarmonics8Bit: this.minSphericalHarmonicsDegree > 0 && this.shCompressionLevel === 2 });
       this.core.setSplatScale(this.splatScale);
       this.core.setPointCloudModeEnabled(this.pointCloudModeEnabled);
+      if (this._destination) this.setDestination(this._destination);      // a rebuilt mesh keeps the host's destination
       this.splatDataTextures = { baseData: {}, maxSplatCount,
         covariances: { compressionLevel: this.getTargetCovarianceCompressionLevel(), size: new THREE.Vector2(maxSplatCount, 1) },
         centerColors: { size: new THREE.Vector2(maxSplatCount, 1) } };       // sizes: Viewer.js:1289-1296 only logs them
@@ -328,6 +329,23 @@ export class SplatMesh {
   // The draw: renderer.render(splatMesh, camera) (src/Viewer.js:1616) reaches every object through onBeforeRender.
   // modelViewMatrix = camera.matrixWorldInverse * this.matrixWorld, projectionMatrix, cameraPosition: three's built-ins.
   onBeforeRender(renderer, scene, camera) { return this.renderFrame(camera); }
+
+  // Drop-in mode (src/DropInViewer.js:34-42: the splat mesh is one object of the HOST's scene) and the Viewer's own threeScene
+  // (src/Viewer.js:1610-1616: `renderer.render(this.threeScene, ...)` first, then the splat mesh with autoClear off).  The
+  // reference's material is `depthTest: true, depthWrite: false` (SplatMaterial3D.js:72-73): splats behind what the other objects
+  // drew are hidden, the rest blends over their colour.  A host hands that state over once per frame, after it has drawn its
+  // opaque objects into a render target with a DepthTexture:
+  //     renderer.readRenderTargetPixels(rt, 0, 0, w, h, colour)            -> Uint8Array RGBA8, row 0 = bottom
+  //     depth: a FloatType DepthTexture copied out through a full-screen pass (or gl.readPixels(DEPTH_COMPONENT, FLOAT))
+  //     splatMesh.setDestination({depth, colour, width: w, height: h, depthBits: 24})
+  // and then draws `this.frame` (now the COMPLETE frame: splats over the scene) instead of blending it itself.  Pass null (or
+  // nothing) to go back to splats alone over a cleared target.
+  setDestination(dest) {
+    this._destination = dest || null;
+    if (!this.core) return;
+    if (!dest) this.core.setDestination(null, null, 0, 0);
+    else this.core.setDestination(dest.depth || null, dest.colour || null, dest.width, dest.height, dest.depthBits || 32);
+  }
   renderFrame(camera, out) {
     if (!this.core || this.getSplatCount() <= 0) return null;
     const view = camera.matrixWorldInverse ? camera.matrixWorldInverse : new THREE.Matrix4().copy(camera.matrixWorld).invert();

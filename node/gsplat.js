@@ -14,7 +14,7 @@ const path = require('path');
 const addon = require(path.join(__dirname, 'gsplat_addon.node'));
 
 const Constants = { DefaultSplatSortDistanceMapPrecision: 16, BytesPerInt: 4, BytesPerFloat: 4, MaxScenes: 32 };
-const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_MESH_SH_U8 = 2;
+const GS_SORT_INTEGER = 1, GS_SORT_DYNAMIC = 2, GS_MESH_COV_HALF = 1, GS_MESH_SH_U8 = 2, GS_DEST_DEPTH_UNORM24 = 1;
 const GS_CAM_ANTIALIASED = 1, GS_CAM_POINT_CLOUD = 2, GS_CAM_ORTHOGRAPHIC = 4, GS_CAM_FADE_IN = 8, GS_CAM_SCENE_EFFECTS = 16, GS_CAM_DYNAMIC = 32;
 
 let sharedContext = null;
@@ -238,6 +238,13 @@ class SplatMeshHIP {
   setPointCloudModeEnabled(e) { this.pointCloudModeEnabled = !!e; }
   // HIP-engine extra: whether very deep bins may be composited by many waves at once (same pixels either way)
   setDeepPass(enabled) { addon.meshSetDeepPass(this.handle, enabled ? 1 : 0); }
+  // The destination of the following draws: `depthTest: true, depthWrite: false` against `depth` (Float32Array W*H, window depth in
+  // [0, 1], row 0 = bottom: what the host's opaque geometry left) and NormalBlending over `rgba` (Uint8Array 4*W*H) - the reference's
+  // material state (SplatMaterial3D.js:72-73) when the splat mesh shares a scene with other objects (DropInViewer.js:34-42,
+  // Viewer.js:1610-1616).  depthBits 24: compare as a 24-bit depth buffer.  Both null: a cleared target, no test.
+  setDestination(depth, rgba, width, height, depthBits = 32) {
+    addon.meshSetDestination(this.handle, depth || null, rgba || null, width >>> 0, height >>> 0, depthBits === 24 ? GS_DEST_DEPTH_UNORM24 : 0);
+  }
   _camera() {
     const c = this.cam;
     c.splatScale = this.splatScale;

@@ -751,6 +751,34 @@ static napi_value AssetLoad(napi_env env, napi_callback_info info) {
     return r;
 }
 
+/* meshSetDestination(mesh, depth Float32Array(W*H)|null, rgba Uint8Array(4*W*H)|null, width, height, flags): what the following
+ * draws are depth-tested against and blended over (gs_mesh_set_destination; SplatMaterial3D.js:72-73, src/Viewer.js:1610-1616,
+ * src/DropInViewer.js:34-42).  Both null: back to a cleared target without a depth test. */
+static napi_value MeshSetDestination(napi_env env, napi_callback_info info) {
+    ARGS(6)
+    void *depth, *rgba;
+    size_t db, rb;
+    if (!get_bytes(env, argv[1], &depth, &db) || !get_bytes(env, argv[2], &rgba, &rb)) {
+        napi_throw_type_error(env, NULL, "meshSetDestination: depth must be a Float32Array or null, rgba a Uint8Array or null");
+        return NULL;
+    }
+    gs_destination d;
+    memset(&d, 0, sizeof d);
+    d.width = get_u32(env, argv[3]);
+    d.height = get_u32(env, argv[4]);
+    d.flags = get_u32(env, argv[5]);
+    const size_t px = (size_t)d.width * d.height;
+    if ((depth && db < px * 4) || (rgba && rb < px * 4)) {
+        napi_throw_range_error(env, NULL, "meshSetDestination: buffer shorter than width * height");
+        return NULL;
+    }
+    d.depth_host = (const float*)depth;
+    d.rgba_host = (const uint8_t*)rgba;
+    int st;
+    LOCKED(st = gs_mesh_set_destination((gs_mesh*)get_external(env, argv[0]), (depth || rgba) ? &d : NULL));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
 static napi_value Init(napi_env env, napi_value exports) {
     addon_state* state = (addon_state*)calloc(1, sizeof *state);
     if (!state || pthread_mutex_init(&state->lock, NULL) != 0 || napi_set_instance_data(env, state, state_free, NULL) != napi_ok) {
@@ -770,7 +798,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"meshProject", MeshProject},       {"sorterSetVisibilityCull", SorterSetVisibilityCull},
         {"groupUniqueId", GroupUniqueId},   {"groupCreate", GroupCreate},     {"groupDestroy", GroupDestroy},
         {"groupRenderGather", GroupRenderGather}, {"groupSetOverlap", GroupSetOverlap}, {"groupWait", GroupWait},
-        {"meshSetDeepPass", MeshSetDeepPass},
+        {"meshSetDeepPass", MeshSetDeepPass}, {"meshSetDestination", MeshSetDestination},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -351,25 +351,51 @@ def project(cam, centers, cov, rgba, sh=None, order=None, scene_indexes=None):
     return out
 
 
-def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-3, scene_indexes=None):
-    """Returns (fb float32[H,W,4] row0=bottom, rgba8 uint8[H,W,4], ambig uint8[H,W], fragments)."""
+def _set_destination(depth, depth_unorm24, W, H):
+    """The destination depth of the next render call (gro_set_destination_depth); returns the array to keep alive."""
+    if depth is None:
+        _lib().gro_set_destination_depth(None, 0)
+        return None
+    d = np.ascontiguousarray(depth, dtype=np.float32).reshape(H, W)
+    _lib().gro_set_destination_depth(d.ctypes.data_as(_f32p), int(bool(depth_unorm24)))
+    return d
+
+
+def _dst_colour(dst_rgba, W, H):
+    """RGBA8 [H, W, 4] destination colour -> the float framebuffer the composite starts from (None: the Viewer's clear colour)."""
+    if dst_rgba is None:
+        return np.zeros((H, W, 4), dtype=np.float32)
+    return np.ascontiguousarray(np.asarray(dst_rgba, dtype=np.uint8).reshape(H, W, 4).astype(np.float32) * np.float32(1.0 / 255.0))
+
+
+def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-3, scene_indexes=None, depth=None,
+           depth_unorm24=False, dst_rgba=None):
+    """Returns (fb float32[H,W,4] row0=bottom, rgba8 uint8[H,W,4], ambig uint8[H,W], fragments).
+    depth: float32 [H, W] window depth other scene geometry left (`depthTest: true, depthWrite: false`,
+    SplatMaterial3D.js:72-73; LessEqualDepth); depth_unorm24: compare as a 24-bit depth buffer; dst_rgba: uint8 [H, W, 4] the
+    colour the splats are blended over (draw order src/Viewer.js:1610-1616)."""
     centers, cov, rgba, sh = _scene_args(centers, cov, rgba, sh)
     _keep = _set_scene_idx(scene_indexes)  # noqa: F841
     if order is not None:
         order = np.ascontiguousarray(order, dtype=np.uint32)
     count = centers.shape[0] if order is None else order.shape[0]
     W, H = int(cam.viewport[0]), int(cam.viewport[1])
-    fb = np.zeros((H, W, 4), dtype=np.float32)
+    fb = _dst_colour(dst_rgba, W, H)
     amb = np.zeros((H, W), dtype=np.uint8)
-    frags = _lib().gro_render(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p),
-                              _p(sh, _f32p), _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)),
-                              C.c_float(amb_eps), _p(fb, _f32p), _p(amb, _u8p))
+    _keep_depth = _set_destination(depth, depth_unorm24, W, H)  # noqa: F841
+    try:
+        frags = _lib().gro_render(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p),
+                                  _p(sh, _f32p), _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)),
+                                  C.c_float(amb_eps), _p(fb, _f32p), _p(amb, _u8p))
+    finally:
+        _set_destination(None, False, W, H)
     q = np.empty((H, W, 4), dtype=np.uint8)
     _lib().gro_quantize(_p(fb, _f32p), C.c_uint64(fb.size), _p(q, _u8p))
     return fb, q, amb, int(frags)
 
 
-def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop8=False, amb_eps=1e-3, scene_indexes=None):
+def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop8=False, amb_eps=1e-3, scene_indexes=None,
+                   depth=None, depth_unorm24=False, dst_rgba=None):
     """Crops of the full frame: `windows` = [(x0, y0, w, h)] in GL window coordinates (row 0 = bottom).  Every splat of
     `order` is projected once and composited into the windows it reaches; window k's pixels equal pixels
     [y0:y0+h, x0:x0+w] of :func:`render`.  `sh` may be float32 [n, 9|24] or IEEE-half bits / float16 (kept as stored:
@@ -392,7 +418,14 @@ def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop
     count = centers.shape[0] if order is None else order.shape[0]
     wins = np.ascontiguousarray(np.asarray(windows, dtype=np.int32).reshape(-1, 4))
     n = wins.shape[0]
-    fbs = [np.zeros((int(h), int(w), 4), dtype=np.float32) for _, _, w, h in wins]
+    W, H = int(cam.viewport[0]), int(cam.viewport[1])
+    if dst_rgba is None:
+        fbs = [np.zeros((int(h), int(w), 4), dtype=np.float32) for _, _, w, h in wins]
+    else:                                                        # (depth / dst_rgba: the FULL frame's, as in render)
+        full = _dst_colour(dst_rgba, W, H)
+        fbs = [np.ascontiguousarray(full[int(y0):int(y0 + h), int(x0):int(x0 + w)]) for x0, y0, w, h in wins]
+        assert all(f.shape[:2] == (int(h), int(w)) for f, (_, _, w, h) in zip(fbs, wins)), "windows must lie inside the frame"
+    _keep_depth = _set_destination(depth, depth_unorm24, W, H)  # noqa: F841
     ambs = [np.zeros((int(h), int(w)), dtype=np.uint8) for _, _, w, h in wins]
     fb_ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fbs])
     amb_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ambs])
@@ -402,4 +435,5 @@ def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop
                                    sh.ctypes.data_as(C.c_void_p) if sh is not None else None, C.c_int(sh_f16),
                                    _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)), C.c_float(amb_eps),
                                    C.c_uint32(n), wins.ctypes.data_as(C.POINTER(C.c_int32)), fb_ptrs, amb_ptrs)
+    _set_destination(None, False, W, H)
     return list(zip(fbs, ambs)), int(frags)

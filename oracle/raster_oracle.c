@@ -239,6 +239,21 @@ void gro_project(const gro_camera* cam, const float* centers, const float* cov, 
     }
 }
 
+/* The DESTINATION's depth (nullable): what other scene geometry left in the depth buffer before the splats are drawn with
+ * `depthTest: true, depthWrite: false` (/root/reference/src/splatmesh/SplatMaterial3D.js:72-73; draw order
+ * /root/reference/src/Viewer.js:1610-1616; drop-in mode /root/reference/src/DropInViewer.js:34-42).  float [H][W], window
+ * depth in [0, 1], row 0 = bottom.  The quad of a splat is flat at its centre's depth (gl_Position.z = ndcCenter.z,
+ * SplatMaterial3D.js:206-210), so every fragment of a splat carries z_w = 0.5 * ndc.z + 0.5 (glDepthRange 0..1) and is kept
+ * where z_w <= stored depth (three r160's default depthFunc, LessEqualDepth); nothing is written back.  unorm24 != 0: both
+ * sides are first converted as a 24-bit fixed-point depth buffer stores them, round(z * (2^24 - 1)).
+ * The destination COLOUR needs no state: the caller initialises fb with it instead of zeros. */
+static const float* g_dst_depth = 0;
+static int g_dst_unorm24 = 0;
+void gro_set_destination_depth(const float* depth, int unorm24) { g_dst_depth = depth; g_dst_unorm24 = unorm24; }
+/* (the conversion in fp64: round to nearest exactly - in fp32 the product already sits at 1-LSB granularity above z = 0.5; the
+ * result is an integer < 2^24, exact as a float) */
+static float depth_cmp_value(float z) { return g_dst_unorm24 ? (float)floor((double)z * 16777215.0 + 0.5) : z; }
+
 /* Composites one projected splat over the window [wx0, wx0+ww) x [wy0, wy0+wh) of the W x H frame; fb / ambig are the
  * window's own [wh][ww] arrays. */
 static uint64_t blend_one(const gro_splat2d* s, int W, int H, int wx0, int wy0, int ww, int wh, int rop8, float amb_eps,
@@ -255,8 +270,11 @@ static uint64_t blend_one(const gro_splat2d* s, int W, int H, int wx0, int wy0, 
     if (fy1 > (float)ye) fy1 = (float)ye;
     if (!(fx0 <= fx1) || !(fy0 <= fy1)) return 0;
     const float n1 = s->b1x * s->b1x + s->b1y * s->b1y, n2 = s->b2x * s->b2x + s->b2y * s->b2y;
+    const float zfrag = depth_cmp_value(s->ndcz * 0.5f + 0.5f);
     for (int py = (int)fy0; py <= (int)fy1; py++) {
         for (int px = (int)fx0; px <= (int)fx1; px++) {
+            /* depthTest against the destination (the fixed-function test runs whether or not the shader discards) */
+            if (g_dst_depth && !(zfrag <= depth_cmp_value(g_dst_depth[(size_t)py * W + px]))) continue;
             const float dx = ((float)px + 0.5f) - s->cx, dy = ((float)py + 0.5f) - s->cy;
             /* quad-local coordinates q in [-1,1]^2 (b1 is orthogonal to b2) */
             const float qx = (dx * s->b1x + dy * s->b1y) / n1;

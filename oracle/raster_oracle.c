@@ -254,10 +254,24 @@ void gro_set_destination_depth(const float* depth, int unorm24) { g_dst_depth = 
  * result is an integer < 2^24, exact as a float) */
 static float depth_cmp_value(float z) { return g_dst_unorm24 ? (float)floor((double)z * 16777215.0 + 0.5) : z; }
 
+/* How far an RGBA8 render target can drift from the exact composite (row a14): every blend into the target rounds each channel
+ * to 8 bits (an error of at most half a step), and every later splat scales what has accumulated by (1 - alpha):
+ *     e <- (1 - alpha) * e + 0.5            per kept fragment, in units of 1/255, e = 0 on the cleared target.
+ * With a plane per window set here (nullable; [h][w] floats, zeroed by the caller), blend_one keeps that recursion next to the
+ * composite.  The fp32 composite rounded ONCE (the engine) then differs from the per-splat-rounded one (the reference's ROPs) by
+ * at most e + 0.5: a bound that grows with the composited depth of a pixel instead of a limit fitted to the scenes at hand. */
+#define GRO_MAX_BOUND_PLANES 64
+static float* g_err_bound[GRO_MAX_BOUND_PLANES];
+static uint32_t g_err_bound_count = 0;
+void gro_set_error_bound_planes(uint32_t n, float** planes) {
+    g_err_bound_count = n > GRO_MAX_BOUND_PLANES ? GRO_MAX_BOUND_PLANES : n;
+    for (uint32_t k = 0; k < g_err_bound_count; k++) g_err_bound[k] = planes[k];
+}
+
 /* Composites one projected splat over the window [wx0, wx0+ww) x [wy0, wy0+wh) of the W x H frame; fb / ambig are the
  * window's own [wh][ww] arrays. */
 static uint64_t blend_one(const gro_splat2d* s, int W, int H, int wx0, int wy0, int ww, int wh, int rop8, float amb_eps,
-                          float* fb, uint8_t* ambig) {
+                          float* fb, uint8_t* ambig, float* ebound) {
     uint64_t frags = 0;
     /* bounding box of the quad centre +- b1 +- b2 */
     const float ext_x = fabsf(s->b1x) + fabsf(s->b2x), ext_y = fabsf(s->b1y) + fabsf(s->b2y);
@@ -291,6 +305,7 @@ static uint64_t blend_one(const gro_splat2d* s, int W, int H, int wx0, int wy0, 
             dst[1] = al * s->g + om * dst[1];
             dst[2] = al * s->b + om * dst[2];
             dst[3] = al + om * dst[3];
+            if (ebound) ebound[at] = om * ebound[at] + 0.5f;
             if (rop8)
                 for (int ch = 0; ch < 4; ch++) dst[ch] = floorf(clamp01(dst[ch]) * 255.0f + 0.5f) * (1.0f / 255.0f);
             frags++;
@@ -319,7 +334,7 @@ uint64_t gro_render(const gro_camera* cam, const float* centers, const float* co
         project_one(cam, centers + 3 * g, cov + 6 * g, rgba + 4 * g, sh ? sh + (size_t)shn * g : NULL,
                     g_scene_idx ? g_scene_idx[g] : 0u, &s);
         if (!s.visible) continue;
-        frags += blend_one(&s, W, H, 0, 0, W, H, rop8, amb_eps, fb, ambig);
+        frags += blend_one(&s, W, H, 0, 0, W, H, rop8, amb_eps, fb, ambig, g_err_bound_count ? g_err_bound[0] : NULL);
     }
     return frags;
 }
@@ -371,7 +386,7 @@ uint64_t gro_render_windows(const gro_camera* cam, const float* centers, const f
         if (!s.visible) continue;
         for (uint32_t k = 0; k < nwin; k++)
             frags += blend_one(&s, W, H, wins[4 * k], wins[4 * k + 1], wins[4 * k + 2], wins[4 * k + 3], rop8, amb_eps,
-                               fbs[k], ambigs ? ambigs[k] : NULL);
+                               fbs[k], ambigs ? ambigs[k] : NULL, k < g_err_bound_count ? g_err_bound[k] : NULL);
     }
     return frags;
 }

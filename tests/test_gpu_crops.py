@@ -107,12 +107,13 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
     sh = scene.sh if scene.sh_degree else None
     boxes = [w[1:] for w in wins]
     crops, frags = oracle.render_windows(ocam, c, cov, rgba, sh, order, boxes)
-    crops8, _ = oracle.render_windows(ocam, c, cov, rgba, sh, order, boxes, rop8=True)
+    bounds = []                                      # per window: how far per-splat RGBA8 rounding can drift from the exact composite
+    crops8, _ = oracle.render_windows(ocam, c, cov, rgba, sh, order, boxes, rop8=True, error_bounds=bounds)
     assert frags > 1000
     report = {"config": tag, "width": W, "height": H, "splats": n, "visible": int(stats.visible_splats),
               "list_bin_px": int(stats.list_bin_px), "oracle_fragments": frags, "windows": []}
     amb_pixels = 0
-    for (name, x0, y0, w, h), (fb, amb), (fb8, _) in zip(wins, crops, crops8):
+    for (name, x0, y0, w, h), (fb, amb), (fb8, _), ebound in zip(wins, crops, crops8, bounds):
         got = frame[y0:y0 + h, x0:x0 + w]
         msg = helpers.compare_frames(got, fb, amb, f"{tag} {name} @({x0},{y0})", strict=True)
         assert got[..., 3].any(), f"{tag} {name}: the window is empty, it checks nothing"
@@ -134,13 +135,21 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
                                   "rop8_gap_max": round(float(gap.max()), 3), "rop8_gap_mean": round(float(gap.mean()), 4),
                                   "rop8_path_equal_frac": round(rop8_equal, 5), "rop8_path_max": rop8_max,
                                   "engine_vs_rop8_max": round(float(ours.max()), 3),
-                                  "engine_vs_rop8_mean": round(float(ours.mean()), 4)})
+                                  "engine_vs_rop8_mean": round(float(ours.mean()), 4),
+                                  "rop8_bound_max": round(float(ebound.max()) + ENGINE_SLACK, 3),
+                                  "rop8_bound_headroom_min": round(float((ebound[..., None] + ENGINE_SLACK - ours).min()), 3)})
         print(msg, "| rop8 gap max %.2f mean %.3f (1/255 units) | rop8 path: %.4f equal, max %.0f" % (gap.max(), gap.mean(), rop8_equal, rop8_max))
         # The reference's real target is RGBA8 and rounds after every splat (SplatMaterial3D.js:65-75); the engine composites in
         # fp32 and rounds once.  The distance between the two is not an engine error, but it is GATED so that it cannot grow
         # unnoticed: worst 3-4 and mean 0.3-0.9 of 1/255 on every window of rounds 2-3 (profiles/r03z_crops_*.json).
-        assert ours.max() <= 4.0 and ours.mean() <= 1.0, \
-            f"{tag} {name}: engine vs the RGBA8-ROP-emulating oracle: max {ours.max():.2f} mean {ours.mean():.3f} (limits 4 / 1.0 of 1/255)"
+        # Round 5: the limit is DERIVED per pixel instead of fitted (round 4's flat "max 4" sat exactly on C3T's and C3S's worst
+        # pixel): every blend into RGBA8 rounds by <= 0.5 and later splats scale the accumulated error by (1 - alpha), so the
+        # ROP-emulating oracle sits within e = sum_k 0.5 * T_k of the exact composite (raster_oracle.c keeps the recursion
+        # e <- (1 - alpha) e + 0.5 per pixel), and the engine - the fp32 composite rounded once - within 0.5 + its own measured
+        # distance to the fp32 oracle (<= 0.52 on every crop, gated above by strict=True).
+        excess = ours - (ebound[..., None] + ENGINE_SLACK)
+        assert excess.max() <= 0.0 and ours.mean() <= 1.0, \
+            f"{tag} {name}: engine vs the RGBA8-ROP-emulating oracle: {excess.max():+.2f} beyond the per-pixel bound (max diff {ours.max():.2f}, mean {ours.mean():.3f}; mean limit 1.0 of 1/255)"
     report["ambiguous_pixels_total"] = amb_pixels
     report["entries_scanned"] = int(stats.entries_scanned)
     report["splats_walked"] = int(stats.splats_walked)
@@ -149,6 +158,9 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
     worker.terminate()
     mesh.dispose()
     return report
+
+
+ENGINE_SLACK = 1.05        # the engine's own final rounding (0.5) + its strict-gated distance to the fp32 oracle (<= 0.5) + fp32 noise
 
 
 def _write_report(name, report):
@@ -194,3 +206,39 @@ def test_c3s_capture_like_1080p_crops_match_oracle(ctx):
     """Surface-like stand-in: flat anisotropic splats on 2-D manifolds, 40 % of them nearly transparent, camera outside the
     object (scenes.capture_like)."""
     _crop_parity(ctx, "C3S", 8)
+
+
+def test_c3_whole_frame_at_480x270_matches_oracle(ctx):
+    """The crops above cover 8 windows of 64 x 64 px per configuration (1.6 % of a 1080p frame).  This closes "some tile nobody
+    cropped" from the other side: EVERY pixel of a frame of the whole C3 scene (all 5.8 M splats, SH-2, the demo pose), at a
+    resolution the fp32 oracle can rasterise in full - 480 x 270, where a pixel sees about sixteen times the splats of a 1080p
+    pixel - against the oracle, the device's own sorted order checked against the pinned sort oracle first."""
+    scene = scenes.make_config_scene("C3")
+    W, H = 480, 270
+    cam = camera.demo_camera(scenes.CONFIGS["C3"]["pose"], W, H)
+    n = scene.count
+    ci = util.integer_centers(scene.centers)
+    worker = create_sort_worker(ctx, n)
+    worker.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+    mesh = SplatMesh(ctx, n, scene.sh_degree, scene.cov_half)
+    mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh if scene.sh_degree else None)
+    mesh.set_camera(cam)
+    mvp = cam.sort_mvp()
+    worker.sort_on_device(mvp, n)
+    mesh.use_sorter_result(worker, n)
+    worker.sort_on_device(mvp, n)
+    frame, stats = mesh.render()
+    order = oracle.sort_indexes(np.arange(n, dtype=np.uint32), ci, mvp)
+    np.testing.assert_array_equal(worker.debug_read(2, n), order)
+    c, cov, rgba, _ = helpers.oracle_inputs(scene)
+    ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, W, H, scene.sh_degree, scene.sh_degree)
+    (fb, amb), = oracle.render_windows(ocam, c, cov, rgba, scene.sh if scene.sh_degree else None, order, [(0, 0, W, H)])[0]
+    msg = helpers.compare_frames(frame, fb, amb, "C3 whole frame 480x270")
+    err = np.abs(frame.astype(np.float32) - np.clip(fb, 0, 1) * 255.0)
+    _write_report("whole_frame_C3_480x270.json", {"config": "C3 at 480x270, every pixel", "splats": n, "visible": int(stats.visible_splats),
+                                                  "parity": msg, "worst_1_255": round(float(err.max()), 3),
+                                                  "pixels_beyond_1_255": int((err.max(axis=-1) > 1.5).sum()), "pixels": W * H,
+                                                  "ambiguous_pixels": int(amb.sum())})
+    print(msg)
+    worker.terminate()
+    mesh.dispose()

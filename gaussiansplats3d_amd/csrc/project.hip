@@ -98,21 +98,21 @@ __global__ __launch_bounds__(256) void k_block_test(ProjectParams pp, const floa
     const float* bb = block_box + 8u * (size_t)(in ? b : 0u);
     const BlockCorner k = block_corner(pp, bb, c);
     // AND / min / max over the block's eight lanes
-    bool all_rej[6], all_front = k.front;
-#pragma unroll
-    for (int r = 0; r < 6; r++) all_rej[r] = k.rej[r];
+    // (bit masks and `&`, never `&&`: a short-circuited `x && __shfl_xor(x)` takes the lanes whose x is false out of the shuffle,
+    // and what the others then read from them is undefined - the first version of this kernel declared 4 % of C3's visible splats
+    // dead that way, r05e)
+    uint32_t flags = (k.rej[0] ? 1u : 0u) | (k.rej[1] ? 2u : 0u) | (k.rej[2] ? 4u : 0u) | (k.rej[3] ? 8u : 0u) | (k.rej[4] ? 16u : 0u) |
+                     (k.rej[5] ? 32u : 0u) | (k.front ? 64u : 0u);
     float ymin = k.ypx, ymax = k.ypx, zmin = -k.v[2], axmax = fabsf(k.v[0]), aymax = fabsf(k.v[1]);
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 6; r++) all_rej[r] = all_rej[r] && (__shfl_xor((int)all_rej[r], o, 64) != 0);
-        all_front = all_front && (__shfl_xor((int)all_front, o, 64) != 0);
+        flags &= (uint32_t)__shfl_xor((int)flags, o, 64);
         ymin = fminf(ymin, __shfl_xor(ymin, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64));
         zmin = fminf(zmin, __shfl_xor(zmin, o, 64));
         axmax = fmaxf(axmax, __shfl_xor(axmax, o, 64)); aymax = fmaxf(aymax, __shfl_xor(aymax, o, 64));
     }
-    bool dead = all_rej[0] || all_rej[1] || all_rej[2] || all_rej[3] || all_rej[4] || all_rej[5];
-    const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;
+    bool dead = (flags & 63u) != 0u;                         // every corner satisfies one of the six rejects
+    const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y, all_front = (flags & 64u) != 0u;
     if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC) && all_front) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
     const bool live = in && !dead;
     if (in && dead) {                                        // nothing of this block draws: empty masks, no records (lane c: its share)

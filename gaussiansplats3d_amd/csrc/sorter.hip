@@ -696,17 +696,21 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     const uint4* __restrict__ y4 = reinterpret_cast<const uint4*>(p.cy);
     const uint4* __restrict__ z4 = reinterpret_cast<const uint4*>(p.cz);
     int32_t* __restrict__ keys_out = p.keys_out;
+    const uint4* __restrict__ map4 = reinterpret_cast<const uint4*>(map);
     // VC_UNROLL spans per turn, every load of the turn issued before anything is stored: the stores of a span may alias the next
     // span's loads as far as the compiler knows, and a turn of ONE span made every span a memory round trip of its own (the first
     // version: 6 spans per wave, two dependent reads each: 56 us for the 70 MB a min / max pass streams in 17, r05d)
     for (uint32_t base = begin; base < end; base += VC_UNROLL * VC_WAVE_SPAN) {
-        uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL];
+        uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL], M[VC_UNROLL];
         uint32_t raw[VC_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
             const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;       // this lane's four positions of span u
             const uint32_t ic = min(i0, N >= 4u ? ((N - 4u) & ~3u) : 0u);  // (clamped: the loads are unconditional)
             X[u] = x4[ic >> 2]; Y[u] = y4[ic >> 2]; Z[u] = z4[ic >> 2];
+            // the payloads (the bound mesh's positions) travel with the centres: fetched only for the survivors they were a load
+            // inside every store branch - sixteen dependent round trips per turn (k_cull_front 41 us, r05e)
+            M[u] = map4 ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);
             raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                        // the mask word of the four positions (eight lanes share one)
         }
 #pragma unroll
@@ -739,11 +743,13 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
                 if (raw[u]) mask[i0 >> 5] = 0u;
             }
             uint32_t o = out + incl - mine;
+            const uint32_t pm[4] = {M[u].x, M[u].y, M[u].z, M[u].w};
+            const bool vec = i0 + 4u <= N;                                 // (else the vector was read at a clamped position)
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++)
                 if ((nib >> c) & 1u) {
                     keys_out[o] = k[c];
-                    pay_out[o] = map ? map[i0 + c] : i0 + c;
+                    pay_out[o] = vec ? pm[c] : (map ? map[i0 + c] : i0 + c);
                     o++;
                 }
             out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);

@@ -393,8 +393,9 @@ struct gs_mesh {
     uint32_t layout_version = 0;   // bumped whenever splats receive storage slots (perm changes): a sorter's per-tree payload cache
     bool no_block_cull = false;    // GSPLAT_NO_BLOCK_CULL=1 (A/B and tests)
     bool no_block_list = false;    // GSPLAT_NO_BLOCK_LIST=1: every k_project workgroup tests its own block (the round-4 shape; A/B and tests)
-    DevBuf live_list, live_count;  // k_block_test: the storage blocks that may draw this frame, and two counters used in turn
-    uint32_t live_parity = 0, live_probe = 0;
+    bool block_test_always = false;   // GSPLAT_BLOCK_TEST_ALWAYS=1: the separate block test whatever the scene looks like (A/B and tests)
+    uint32_t measured_visible = 0, measured_count = 0;   // of the last full-frame draw whose statistics were read (like list_shift:
+                                   // chosen from the last measured draw): more than 60 % visible -> no separate block test
     bool translate = true;     // this draw's index list is in the caller's numbering (needs perm)
     DevBuf scene_idx;          // uint32 per splat (allocated by gs_mesh_upload_scene_indexes)
     DevBuf scene_dev;          // gs_scene_params on the device

@@ -263,6 +263,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     m->reorder = !(flags & GS_MESH_KEEP_ORDER) && !getenv("GSPLAT_NO_REORDER");
     m->no_block_cull = getenv("GSPLAT_NO_BLOCK_CULL") != nullptr;
     m->no_block_list = getenv("GSPLAT_NO_BLOCK_LIST") != nullptr;
+    m->block_test_always = getenv("GSPLAT_BLOCK_TEST_ALWAYS") != nullptr;
     m->no_deep = getenv("GSPLAT_NO_DEEP") != nullptr;
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
@@ -581,6 +582,10 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     if (m->timed_draw) GS_HIP(hipEventElapsedTime(&total, m->ev[0], m->ev[5]));
     m->last.device_ms = total;
     m->last.visible_splats = f.visible;
+    if (m->last_pp.row_begin == 0u && m->last_pp.row_end >= m->last_pp.tiles_y) {     // (a strip's count says nothing about the scene)
+        m->measured_visible = f.visible;
+        m->measured_count = m->last_pp.count;
+    }
     m->last.tile_entries = ((uint64_t)f.entries_hi << 32) | f.entries_lo;
     m->last.tiles16 = ((uint64_t)f.tiles16_hi << 32) | f.tiles16_lo;
     m->last.entry_capacity = m->entry_capacity;

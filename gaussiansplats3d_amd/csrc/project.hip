@@ -29,9 +29,6 @@ struct MeshPlanes {
     const uint4* __restrict__ sh2;      // SH2: halfs 16..23
     const uint32_t* __restrict__ scene_idx;          // per-splat scene (EXT, scene_count > 1)
     const gs_scene_params* __restrict__ scenes;      // per-scene uniforms (EXT)
-    const uint32_t* __restrict__ live_list;          // k_block_test's list of the storage blocks that may draw (nullable: every
-    const uint32_t* __restrict__ live_count;         // workgroup tests its own block, the round-2..4 shape) and its length
-    volatile uint32_t* live_mirror;                  // mapped host word: live count + 1 of this draw, for the grid of a later one
 };
 
 // One storage block's verdict: can NO splat of the block reach the frame (or this rank's strip)?  See k_project's header comment
@@ -78,22 +75,17 @@ __device__ __forceinline__ bool block_misses_strip(const ProjectParams& pp, floa
     return ymax + reach + slack < (float)(pp.row_begin * GS_TILE) || ymin - reach - slack > (float)(pp.row_end * GS_TILE);
 }
 
-// The block test as a kernel of its own (round 5): eight lanes per storage block run the eight-corner test, a dead block gets its
-// empty masks here, a live one is appended to a list (one wave-aggregated atomic per wave), and k_project runs over the list:
-// workgroup g leaves at once when g >= live (one scalar load), otherwise it projects block list[g] without a test, without the
-// box read and without the first barrier.  Rounds 2-4 had every one of the 22.6 k workgroups of a C3 draw evaluate its own box:
-// a draw that sees nothing still cost 20 us, a rank's strip of eight 40 us, to find the ~1 k blocks that reach the strip.  The
-// list's ORDER depends on which wave's atomic arrives first - it only decides which workgroup projects which block, never a value.
-// `count` is this draw's counter (zero on entry); `next_count` is the other one, reset here for the following draw (both kernels
-// of a draw run on ctx->aux in order, so the previous draw's k_project has read its counter by now).
+// The block test as a kernel of its own (round 5): eight lanes per storage block run the eight-corner test; a dead block gets its
+// empty masks here and block_any = 0, a live one block_any = 1 (k_project overwrites it with what it finds), and k_project's
+// workgroup b leaves at once when block_any[b] == 0 - one byte, no box read, no corner arithmetic, no barrier.  Rounds 2-4 had every
+// one of the 22.6 k workgroups of a C3 draw evaluate its own box: the vertex stage 59.6 -> 52 us at C3, a rank's strip of eight
+// 41.6 -> 32 us (r05a-c, same box).  No list and no counter: the first version appended the live blocks to a list through one
+// wave-aggregated atomic per wave and let k_project walk it - 354 same-address atomics were fine, but with eight lanes per block
+// (2829 waves) they alone took 17 us (one address retires ~88 atomics per microsecond; r05g rank_C3_n1 table).
 __global__ __launch_bounds__(256) void k_block_test(ProjectParams pp, const float* __restrict__ block_box, uint32_t blocks,
-                                                    uint32_t* __restrict__ live_list, uint32_t* __restrict__ count,
-                                                    uint32_t* __restrict__ next_count, unsigned long long* __restrict__ vis_mask,
-                                                    uint2* __restrict__ vis32, uint8_t* __restrict__ block_any) {
-    // eight lanes per block, one corner each (the serial eight-corner loop of the first version was a 6 us kernel of 89
-    // workgroups: r05d); a wave decides eight blocks, a workgroup 32
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x, b = t >> 3, c = threadIdx.x & 7u, lane = threadIdx.x & 63u;
-    if (t == 0u) *next_count = 0u;
+                                                    unsigned long long* __restrict__ vis_mask, uint2* __restrict__ vis32,
+                                                    uint8_t* __restrict__ block_any) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, b = t >> 3, c = threadIdx.x & 7u;
     const bool in = b < blocks;
     const float* bb = block_box + 8u * (size_t)(in ? b : 0u);
     const BlockCorner k = block_corner(pp, bb, c);
@@ -114,19 +106,12 @@ __global__ __launch_bounds__(256) void k_block_test(ProjectParams pp, const floa
     bool dead = (flags & 63u) != 0u;                         // every corner satisfies one of the six rejects
     const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y, all_front = (flags & 64u) != 0u;
     if (!dead && strip && !(pp.flags & GS_CAM_ORTHOGRAPHIC) && all_front) dead = block_misses_strip(pp, bb[6], ymin, ymax, zmin, axmax, aymax);
-    const bool live = in && !dead;
-    if (in && dead) {                                        // nothing of this block draws: empty masks, no records (lane c: its share)
+    if (!in) return;
+    if (dead) {                                              // nothing of this block draws: empty masks, no records (lane c: its share)
         if (c < 4u) vis_mask[4u * b + c] = 0ull;
         vis32[8u * b + c] = make_uint2(0u, b * 256u);
-        if (c == 0u) block_any[b] = 0;
     }
-    const unsigned long long m = __ballot(live && c == 0u);  // one bit per live block of the wave
-    if (m) {
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (uint32_t)__popcll(m));
-        base = __shfl(base, __builtin_ctzll(m), 64);
-        if (live && c == 0u) live_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
-    }
+    if (c == 0u) block_any[b] = dead ? 0 : 1;
 }
 
 __device__ __forceinline__ float h2f(uint32_t bits16) {
@@ -569,30 +554,27 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     }
 }
 
-// The vertex stage's launch.  LIST = false (per-scene transforms, $GSPLAT_NO_BLOCK_LIST, or a scene that is mostly in view):
-// workgroup b projects storage block b (and tests it first when pp.block_cull).  LIST = true: workgroup g projects block list[g]
-// of k_block_test's list and leaves at once when g >= live; workgroup 0 mirrors the live count into mapped host memory, where the
-// host reads it (some draws later, without a synchronisation) to decide whether the list is worth its launch.
-// Measured and dropped (r05b/c, project_floor / ab_libs, same box): (a) ONE kernel whose workgroups loop over the list behind a
-// grid sized from that mirrored count - the loop costs 80 instead of 48 VGPRs, C3 51.8 -> 60.0 us; (b) the same grid bound with a
-// separate 64-workgroup tail launch for the entries beyond it - 52.0 -> 54.3 us, and the floor (a pose that sees next to nothing)
-// 16.7 -> 17.5 us: the empty workgroups of a full grid are NOT what the floor is made of (three kernel boundaries and
-// k_block_test's own ~4 us are), so the full grid stays.
+// The vertex stage's launch.  PRETESTED = false (per-scene transforms, $GSPLAT_NO_BLOCK_LIST, or a scene that was mostly in view at
+// its last measured draw): workgroup b tests storage block b itself when pp.block_cull.  PRETESTED = true: k_block_test has
+// decided, a workgroup whose block is dead leaves on one byte.
+// Measured and dropped (r05b/c, project_floor / ab_libs, same box): (a) ONE kernel whose workgroups loop over a list of the live
+// blocks behind a grid sized from an earlier draw's count - the loop costs 80 instead of 48 VGPRs, C3 51.8 -> 60.0 us; (b) the
+// same grid bound with a separate 64-workgroup tail launch for the entries beyond it - 52.0 -> 54.3 us, and the floor (a pose
+// that sees next to nothing) 16.7 -> 17.5 us: the empty workgroups of a full grid are NOT what the floor is made of (the kernel
+// boundaries and the test kernel are), so the full grid stays.
 // amdgpu_num_sgpr(80): left alone the compiler takes 106 scalar registers, and MI355X admits 256-thread workgroups per CU by
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) - 6 at 106, 7 at 86 (round 4's kernel), 8 at <= 80 (MI355X_MICROARCH.md, residency).
-template <bool EXT, bool LIST>
+template <bool EXT, bool PRETESTED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any,
                                                  uint2* __restrict__ prect, float* __restrict__ zrec) {
-    if (!LIST) {
-        project_block<EXT, true>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
+    if (PRETESTED) {
+        if (block_any[blockIdx.x] == 0) return;
+        project_block<EXT, false>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
     } else {
-        const uint32_t live = *mp.live_count;
-        if (blockIdx.x == 0u && threadIdx.x == 0u && mp.live_mirror) *mp.live_mirror = live + 1u;     // (0 = no draw has reported yet)
-        if (blockIdx.x >= live) return;
-        project_block<EXT, false>(pp, mp, mp.live_list[blockIdx.x], recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
+        project_block<EXT, true>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
     }
 }
 
@@ -606,34 +588,15 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
     mp.scene_idx = m->scene_idx.as<uint32_t>();
     mp.scenes = m->scene_dev.as<gs_scene_params>();
-    mp.live_list = nullptr;
-    mp.live_count = nullptr;
-    mp.live_mirror = nullptr;
     if (pp.count == 0) return GS_OK;
     const uint32_t blocks = (pp.count + 255u) / 256u;
-    // (a scene that was mostly in view at the last draw that has reported - truck-like C2: 36.0 us with the list, 33.3 without -
-    // keeps the per-workgroup test: the list buys nothing there and costs a launch)
-    const uint32_t seen = m->mirror_host ? ((volatile uint32_t*)m->mirror_host)[8] : 0u;
-    static const bool always_list = getenv("GSPLAT_BLOCK_LIST_ALWAYS") != nullptr;           // A/B and tests
-    const bool mostly_live = seen && !always_list && (uint64_t)(seen - 1u) * 5u > (uint64_t)blocks * 3u;
-    m->live_probe = mostly_live ? (m->live_probe + 1u) % 64u : 0u;                           // (but look again every 64th draw)
-    if (pp.block_cull && !m->no_block_list && !(mostly_live && m->live_probe != 0u)) {
-        // the block test first, as a kernel of its own; k_project then runs over the list of live blocks
-        if (!m->live_count.p) {
-            GS_TRY(m->live_list.alloc(((size_t)m->max_count + 255) / 256 * 4 + 64));
-            GS_TRY(m->live_count.alloc(256));
-            GS_HIP(hipMemsetAsync(m->live_count.p, 0, 256, m->ctx->aux));
-        }
-        uint32_t* cnt = m->live_count.as<uint32_t>() + 32u * (m->live_parity & 1u);        // (128 bytes apart)
-        uint32_t* next = m->live_count.as<uint32_t>() + 32u * ((m->live_parity ^ 1u) & 1u);
-        m->live_parity ^= 1u;
+    // (a scene that was mostly in view at its last MEASURED draw - truck-like C2: 36.0 us with the separate test, 33.3 without; C4,
+    // every splat visible: 262 vs 252 - keeps the per-workgroup test: the separate kernel buys nothing there and costs a launch)
+    const bool mostly_live = !m->block_test_always && m->measured_count > 0u && (uint64_t)m->measured_visible * 5u > (uint64_t)m->measured_count * 3u;
+    const bool pretest = pp.block_cull && !m->no_block_list && !mostly_live;
+    if (pretest)
         hipLaunchKernelGGL(k_block_test, dim3((blocks + 31u) / 32u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
-                           m->live_list.as<uint32_t>(), cnt, next, m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(),
-                           m->block_any.as<uint8_t>());
-        mp.live_list = m->live_list.as<uint32_t>();
-        mp.live_count = cnt;
-        if (m->mirror_host) mp.live_mirror = m->mirror_dev + 8;
-    }
+                           m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), m->block_any.as<uint8_t>());
     if (pp.depth_mode) GS_TRY(m->zrec.ensure((size_t)m->max_count * 4 + 16));
     uint32_t* vis_orig = nullptr;
     if (orig_mask) {
@@ -655,10 +618,9 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
                            m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), vis_orig, inv_perm, m->block_any.as<uint8_t>(),
                            m->prect.as<uint2>(), m->zrec.as<float>());
     };
-    const bool list = mp.live_list != nullptr;
-    if (ext && list) launch(k_project<true, true>);
+    if (ext && pretest) launch(k_project<true, true>);
     else if (ext) launch(k_project<true, false>);
-    else if (list) launch(k_project<false, true>);
+    else if (pretest) launch(k_project<false, true>);
     else launch(k_project<false, false>);
     GS_HIP(hipGetLastError());
     return GS_OK;

@@ -658,6 +658,9 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const ui
     if (lane == 0u) wave_counts[v] = cnt;
 }
 
+// MAP: payloads come from the bound mesh's position table (a compile-time switch: as a run-time `map ? load : index` the load sat
+// in a branch of its own with a full wait behind it, once per span - r05g ISA)
+template <bool MAP>
 __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
                                                            const uint32_t* __restrict__ wave_counts, uint32_t wave_len,
                                                            const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out) {
@@ -710,9 +713,12 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             X[u] = x4[ic >> 2]; Y[u] = y4[ic >> 2]; Z[u] = z4[ic >> 2];
             // the payloads (the bound mesh's positions) travel with the centres: fetched only for the survivors they were a load
             // inside every store branch - sixteen dependent round trips per turn (k_cull_front 41 us, r05e)
-            M[u] = map4 ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);
+            M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);
             raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                        // the mask word of the four positions (eight lanes share one)
         }
+        // phase 1, registers only: keys, survivor nibbles and first output slots of all the spans of the turn ...
+        int32_t K[VC_UNROLL][4];
+        uint32_t nibs[VC_UNROLL], first[VC_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
             const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;
@@ -736,23 +742,34 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             }
             const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
             const uint32_t incl = wave_incl_scan_dpp(mine);
+            nibs[u] = nib;
+            first[u] = out + incl - mine;
+            out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; c++) K[u][c] = k[c];
+        }
+        // ... phase 2, every store of the turn behind them.  (A span's stores used to sit between its own arithmetic and the next
+        // span's: the stores are predicated, so the compiler cannot count them and drains the whole memory queue - stores included -
+        // before it touches the next span's operands: a store round trip per span, 12 per wave, 48 us for the 93 MB: r05g.)
+#pragma unroll
+        for (uint32_t u = 0; u < VC_UNROLL; u++) {
+            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;
             // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (no other wave touches these words, and this
             // wave has read them all)
             if (i0 < end && (i0 & 31u) == 0u) {
                 mask_copy[i0 >> 5] = raw[u];
                 if (raw[u]) mask[i0 >> 5] = 0u;
             }
-            uint32_t o = out + incl - mine;
+            uint32_t o = first[u];
             const uint32_t pm[4] = {M[u].x, M[u].y, M[u].z, M[u].w};
             const bool vec = i0 + 4u <= N;                                 // (else the vector was read at a clamped position)
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++)
-                if ((nib >> c) & 1u) {
-                    keys_out[o] = k[c];
-                    pay_out[o] = vec ? pm[c] : (map ? map[i0 + c] : i0 + c);
+                if ((nibs[u] >> c) & 1u) {
+                    keys_out[o] = K[u][c];
+                    pay_out[o] = vec ? pm[c] : (MAP ? map[i0 + c] : i0 + c);
                     o++;
                 }
-            out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
 #pragma unroll
@@ -1201,8 +1218,10 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 GS_TRY(s->chunk_counts.ensure((size_t)waves * 4));
                 GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
                 hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wave_len, s->chunk_counts.as<uint32_t>());
-                hipLaunchKernelGGL(k_cull_front, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                   s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
+                if (map) hipLaunchKernelGGL(k_cull_front<true>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
+                                            s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
+                else hipLaunchKernelGGL(k_cull_front<false>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
+                                        s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
             } else {
                 hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
                 hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),

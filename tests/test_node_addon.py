@@ -172,10 +172,12 @@ def test_tree_gather_through_node_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ortho,fade,effects", [(False, False, False), (True, False, False), (False, True, True)])
-def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho, fade, effects):
+@pytest.mark.parametrize("ortho,fade,effects,dest", [(False, False, False, False), (True, False, False, False), (False, True, True, False),
+                                                     (False, False, False, True)])
+def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho, fade, effects, dest):
     """SplatMeshHIP (node/gsplat.js -> N-API -> C ABI) and SplatMesh (ctypes -> C ABI) must draw the same pixels,
-    including the orthographic, fade-in and per-scene opacity / visibility uniforms."""
+    including the orthographic, fade-in and per-scene opacity / visibility uniforms, and a destination (drop-in mode's depth test
+    against the host's geometry + its colour, gs_mesh_set_destination)."""
     import helpers
     import oracle
     from gaussiansplats3d_amd import Context, SplatMesh, camera, util
@@ -199,18 +201,23 @@ def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho
         mesh.set_fade_in(center, radius)
     mesh.set_camera(cam)
     mesh.update_render_indexes(order, n)
+    rng = np.random.default_rng(8)
+    dst_depth = (0.9 + 0.1 * rng.random((H, W))).astype(np.float32)      # around the scene's own window depths
+    dst_colour = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    if dest:
+        mesh.set_destination(depth=dst_depth, rgba=dst_colour, depth_unorm24=True)
     expect, _ = mesh.render()
     mesh.dispose()
     ctx.close()
     # the same draw through Node
     fx, fy = cam.focal()
-    flags = (1 if ortho else 0) | (2 if fade else 0) | (4 if effects else 0)
+    flags = (1 if ortho else 0) | (2 if fade else 0) | (4 if effects else 0) | (8 if dest else 0)
     nsc = 3 if effects else 1
     hdr = np.array([n, 1, W, H, flags, nsc, 0, 0], np.uint32)
     parts = [hdr, scene.centers.astype(np.float32), scene.cov.astype(np.float32), scene.rgba, scene.sh.view(np.uint16), order, sidx,
              np.asarray(cam.model_view(), np.float64).astype(np.float32), np.asarray(cam.projection, np.float64).astype(np.float32),
              np.asarray(cam.position, np.float32), np.array([fx, fy], np.float32), np.array([getattr(cam, "zoom", 1.0)], np.float32),
-             center, np.array([radius], np.float32), opacity[:nsc], visible[:nsc]]
+             center, np.array([radius], np.float32), opacity[:nsc], visible[:nsc]] + ([dst_depth, dst_colour] if dest else [])
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
         for p in parts:

@@ -740,9 +740,9 @@ def main():
                 tree_splats = int(tree.info().splats)
                 worker.set_frustum_cull(True)
 
-                def cull_frame():
-                    tree.gather_scene_nodes_for_sort(cam, sort_worker=worker, to_host=False, asynchronous=True)
-                    worker.sort_gathered(mvp, keep_on_device=True)
+                def cull_frame(c=cam, c_mvp=mvp):
+                    tree.gather_scene_nodes_for_sort(c, sort_worker=worker, to_host=False, asynchronous=True)
+                    worker.sort_gathered(c_mvp, keep_on_device=True)
                     mesh.use_sorter_result(worker, tree_splats)
                     mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
 
@@ -768,6 +768,47 @@ def main():
                                 "+ draw, EVERY frame; render_count = R kept by the reference's leaf test, scene = all N splats per frame.  "
                                 "The reference gathers and sorts only when the camera has turned or moved enough (Viewer.runSplatSort, "
                                 "src/Viewer.js:1858-1961) and keeps drawing with the last order in between"}
+                # ... and a pose where an octree cull has something to remove: the camera INSIDE the scene, at the
+                # demo's look-at point, looking on along the demo's view direction - what a viewer sees after walking in.  Cull off
+                # (full sort + draw) against cull on (gather + fused copy / keys / frustum cull + draw) at that pose.
+                up_v, pos_v, look_v = (np.asarray(v, dtype=np.float64) for v in camera.DEMO_POSES[cfg["pose"]])
+                cam_in = camera.PerspectiveCamera(W, H, tuple(look_v), tuple(look_v + (look_v - pos_v)), tuple(up_v))
+                mvp_in = cam_in.sort_mvp()
+                mesh.set_camera(cam_in)
+                worker.set_frustum_cull(False)
+
+                def plain_frame():
+                    worker.sort_on_device(mvp_in, N)
+                    mesh.use_sorter_result(worker, N)
+                    mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+
+                def time_frames(fn, steps):
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(steps):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t) / steps * 1e3
+
+                in_off = time_frames(plain_frame, args.steps)
+                _, in_st = mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
+                off_img = strip.clone()
+                worker.set_frustum_cull(True)
+                in_on = time_frames(lambda: cull_frame(cam_in, mvp_in), args.steps)
+                in_diff = int((off_img.to(torch.int16) - strip.to(torch.int16)).abs().max().item())
+                in_kept = int(rig.worker.last_stats()[0].result_count)
+                worker.set_frustum_cull(False)
+                in_R = tree.gather_scene_nodes_for_sort(cam_in, sort_worker=worker, to_host=False)["splatRenderCount"]
+                cull["inside_pose"] = {"camera": "at the demo's look-at point, looking on along the demo's view direction",
+                                       "render_count": int(in_R), "removed_by_the_leaf_test_frac": round(1.0 - in_R / N, 4),
+                                       "kept_after_frustum_cull": in_kept, "visible_splats": int(in_st.visible_splats),
+                                       "cull_off_ms_per_frame": round(in_off, 4), "cull_on_ms_per_frame": round(in_on, 4),
+                                       "cull_on_over_cull_off": round(in_on / in_off, 4),
+                                       "max_abs_diff_vs_cull_off_frame_u8": in_diff}
+                del off_img
+                mesh.set_camera(cam)
                 tree.dispose()
                 mesh.use_sorter_result(worker, N)
 

@@ -625,16 +625,22 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
 //                  the chunk - whose first output slot is the sum of the earlier chunks' counts - key and payload (the bound
 //                  mesh's position, read for survivors only) written to the compacted list.  The mask is consumed as before.
 // No look-back, no spinning: the offsets come from the first kernel's counts.
-// Both kernels work per WAVE: wave v of the launch owns the positions [v * wave_len, (v + 1) * wave_len) (wave_len % 256 == 0), so the
-// compaction needs no barrier - a lane takes four consecutive positions (one 16-byte load per plane), the wave's prefix over its
-// 64 survivor counts is a DPP scan, and the wave's first output slot is the sum of the earlier waves' counts.  (The first version
-// cut the list per workgroup and scanned every 1024 positions across its four waves, two barriers each: a rank's strip, where
-// hardly anything survives, paid 22 barriers per chunk for nothing - C5 rank 4 of 8 0.1887 -> 0.1937 ms, r05c.)
+// A workgroup owns a contiguous run of positions (chunk_len % 4096 == 0) and walks it in turns of 4096: wave w of the workgroup
+// takes the four spans [w * 1024, (w + 1) * 1024) of the turn, a lane four consecutive positions of a span (one 16-byte load per
+// plane), so the workgroup streams 16 KB per plane per turn and the chip ~2000 streams in all.  A wave's first output slot in a
+// turn = the workgroup's running offset + the survivors of the lower waves in this turn (one barrier per turn, counts double
+// buffered); inside a wave the prefix over the 64 lanes is a DPP scan.
+// (History, r05c-h: cutting the list per workgroup with a block scan every 1024 positions cost a rank's strip 22 barriers per chunk
+// for nothing; one contiguous run per WAVE needs no barrier at all but makes 8192 concurrent DRAM streams - 36-42 us for the 93 MB;
+// spans handled one by one put a store round trip between them - predicated stores cannot be counted, the compiler drains the queue -
+// and a run-time `map ? load : index` put every payload load in a branch of its own with a full wait behind it.)
 constexpr uint32_t VC_WAVE_SPAN = 256;                     // positions per wave and span (4 per lane; 8 mask words)
-constexpr uint32_t VC_UNROLL = 4;                          // spans per turn of k_cull_front (12 x 16-byte loads in flight per lane)
+constexpr uint32_t VC_UNROLL = 4;                          // spans per wave and turn (12 + 4 x 16-byte loads in flight per lane)
+constexpr uint32_t VC_TURN = VC_UNROLL * VC_WAVE_SPAN * (VC_THREADS / 64u);   // positions per workgroup and turn (4096)
 
-__global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t wave_len,
-                                                           uint32_t* __restrict__ wave_counts) {
+__global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t chunk_len,
+                                                           uint32_t* __restrict__ chunk_counts) {
+    __shared__ uint32_t s_cnt[4];
     const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;
     if (t < SORT_SHARDS) {
@@ -645,40 +651,39 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const ui
         p.next_frame->clamped = 0;
         p.next_frame->kept = 0;
     }
-    const uint32_t N = p.render_count, lane = threadIdx.x & 63u, v = t >> 6;
-    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);
+    const uint32_t N = p.render_count;
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);
     uint32_t cnt = 0;
-    for (uint32_t first = begin + 32u * lane; first < end; first += 32u * 64u) {
+    for (uint32_t first = begin + 32u * threadIdx.x; first < end; first += 32u * VC_THREADS) {
         uint32_t w = mask[first >> 5];
         if (end - first < 32u) w &= (1u << (end - first)) - 1u;            // positions beyond this sort's list
         cnt += (uint32_t)__popc(w);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0u) wave_counts[v] = cnt;
+    if ((threadIdx.x & 63u) == 0u) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// MAP: payloads come from the bound mesh's position table (a compile-time switch: as a run-time `map ? load : index` the load sat
-// in a branch of its own with a full wait behind it, once per span - r05g ISA)
+// MAP: payloads come from the bound mesh's position table (a compile-time switch, see above)
 template <bool MAP>
 __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
-                                                           const uint32_t* __restrict__ wave_counts, uint32_t wave_len,
+                                                           const uint32_t* __restrict__ chunk_counts, uint32_t chunk_len,
                                                            const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out) {
-    __shared__ uint32_t s_before[4], s_all[4];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, v = blockIdx.x * 4u + wave, waves = gridDim.x * 4u;
+    __shared__ uint32_t s_before[4], s_all[4], s_turn[2][4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     static_assert(VC_THREADS == 256, "four waves per workgroup");
-    // survivors of the waves before this WORKGROUP's / of all waves: the workgroup sums the counts once (the one barrier of the
-    // kernel), a wave then adds its <= 3 predecessors inside the workgroup
-    uint32_t before = 0, all = 0;
-    for (uint32_t c0 = 0; c0 < waves; c0 += 4u * VC_THREADS) {      // (four loads in flight per lane)
+    uint32_t before = 0, all = 0;                                   // survivors of the chunks before this one / of all chunks
+    for (uint32_t c0 = 0; c0 < gridDim.x; c0 += 4u * VC_THREADS) {  // (four loads in flight per lane)
         uint32_t x[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) x[k] = wave_counts[min(c0 + VC_THREADS * k + threadIdx.x, waves - 1u)];
+        for (uint32_t k = 0; k < 4u; k++) x[k] = chunk_counts[min(c0 + VC_THREADS * k + threadIdx.x, gridDim.x - 1u)];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) {
             const uint32_t c = c0 + VC_THREADS * k + threadIdx.x;
-            all += c < waves ? x[k] : 0u;
-            before += c < blockIdx.x * 4u ? x[k] : 0u;
+            all += c < gridDim.x ? x[k] : 0u;
+            before += c < blockIdx.x ? x[k] : 0u;
         }
     }
 #pragma unroll
@@ -688,11 +693,10 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     }
     if (lane == 0u) { s_before[wave] = before; s_all[wave] = all; }
     __syncthreads();
-    uint32_t out = s_before[0] + s_before[1] + s_before[2] + s_before[3];
-    for (uint32_t w = 0; w < wave; w++) out += wave_counts[blockIdx.x * 4u + w];
-    if (v == 0u && lane == 0u) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
+    uint32_t out = s_before[0] + s_before[1] + s_before[2] + s_before[3];          // the workgroup's running output slot
+    if (blockIdx.x == 0u && threadIdx.x == 0u) p.frame->kept = s_all[0] + s_all[1] + s_all[2] + s_all[3];
     const uint32_t N = p.render_count;
-    const uint32_t begin = min(v * wave_len, N), end = min(begin + wave_len, N);       // wave_len % (VC_UNROLL * VC_WAVE_SPAN) == 0
+    const uint32_t begin = min(blockIdx.x * chunk_len, N), end = min(begin + chunk_len, N);       // chunk_len % VC_TURN == 0
     int32_t lo = 2147483640, hi = -2147483640;
     const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
     const uint4* __restrict__ x4 = reinterpret_cast<const uint4*>(p.cx);
@@ -700,28 +704,25 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     const uint4* __restrict__ z4 = reinterpret_cast<const uint4*>(p.cz);
     int32_t* __restrict__ keys_out = p.keys_out;
     const uint4* __restrict__ map4 = reinterpret_cast<const uint4*>(map);
-    // VC_UNROLL spans per turn, every load of the turn issued before anything is stored: the stores of a span may alias the next
-    // span's loads as far as the compiler knows, and a turn of ONE span made every span a memory round trip of its own (the first
-    // version: 6 spans per wave, two dependent reads each: 56 us for the 70 MB a min / max pass streams in 17, r05d)
-    for (uint32_t base = begin; base < end; base += VC_UNROLL * VC_WAVE_SPAN) {
+    uint32_t turn = 0;
+    for (uint32_t base = begin; base < end; base += VC_TURN, turn++) {
+        const uint32_t wbase = base + wave * (VC_UNROLL * VC_WAVE_SPAN);    // this wave's four spans of the turn
         uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL], M[VC_UNROLL];
         uint32_t raw[VC_UNROLL];
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
-            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;       // this lane's four positions of span u
+            const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;      // this lane's four positions of span u
             const uint32_t ic = min(i0, N >= 4u ? ((N - 4u) & ~3u) : 0u);  // (clamped: the loads are unconditional)
             X[u] = x4[ic >> 2]; Y[u] = y4[ic >> 2]; Z[u] = z4[ic >> 2];
-            // the payloads (the bound mesh's positions) travel with the centres: fetched only for the survivors they were a load
-            // inside every store branch - sixteen dependent round trips per turn (k_cull_front 41 us, r05e)
-            M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);
+            M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);   // the payloads travel with the centres
             raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                        // the mask word of the four positions (eight lanes share one)
         }
-        // phase 1, registers only: keys, survivor nibbles and first output slots of all the spans of the turn ...
+        // phase 1, registers only: keys, survivor nibbles and slots (relative to the wave's first) of all the spans of the turn ...
         int32_t K[VC_UNROLL][4];
-        uint32_t nibs[VC_UNROLL], first[VC_UNROLL];
+        uint32_t nibs[VC_UNROLL], first[VC_UNROLL], mine_total = 0;
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
-            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;
+            const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;
             int32_t k[4] = {0, 0, 0, 0};
             uint32_t word = raw[u];
             if (i0 < end && end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
@@ -743,24 +744,33 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
             const uint32_t incl = wave_incl_scan_dpp(mine);
             nibs[u] = nib;
-            first[u] = out + incl - mine;
-            out += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            first[u] = mine_total + incl - mine;
+            mine_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++) K[u][c] = k[c];
         }
-        // ... phase 2, every store of the turn behind them.  (A span's stores used to sit between its own arithmetic and the next
-        // span's: the stores are predicated, so the compiler cannot count them and drains the whole memory queue - stores included -
-        // before it touches the next span's operands: a store round trip per span, 12 per wave, 48 us for the 93 MB: r05g.)
+        // the wave's first slot of the turn: the survivors of the lower waves (counts double buffered: one barrier per turn)
+        if (lane == 0u) s_turn[turn & 1u][wave] = mine_total;
+        __syncthreads();
+        uint32_t wave_out = out, turn_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) {
+            const uint32_t c = s_turn[turn & 1u][w];
+            wave_out += w < wave ? c : 0u;
+            turn_total += c;
+        }
+        out += turn_total;
+        // ... phase 2, every store of the turn behind them
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
-            const uint32_t i0 = base + u * VC_WAVE_SPAN + 4u * lane;
+            const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;
             // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (no other wave touches these words, and this
             // wave has read them all)
             if (i0 < end && (i0 & 31u) == 0u) {
                 mask_copy[i0 >> 5] = raw[u];
                 if (raw[u]) mask[i0 >> 5] = 0u;
             }
-            uint32_t o = first[u];
+            uint32_t o = wave_out + first[u];
             const uint32_t pm[4] = {M[u].x, M[u].y, M[u].z, M[u].w};
             const bool vec = i0 + 4u <= N;                                 // (else the vector was read at a clamped position)
 #pragma unroll
@@ -778,8 +788,8 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
         hi = max(hi, __shfl_xor(hi, o, 64));
     }
     if (lane == 0u && lo <= hi) {
-        atomicMin(&p.frame->key_min[v % SORT_SHARDS], lo);
-        atomicMax(&p.frame->key_max[v % SORT_SHARDS], hi);
+        atomicMin(&p.frame->key_min[(blockIdx.x * 4u + wave) % SORT_SHARDS], lo);
+        atomicMax(&p.frame->key_max[(blockIdx.x * 4u + wave) % SORT_SHARDS], hi);
     }
 }
 
@@ -1209,19 +1219,17 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             static const bool old_front = getenv("GSPLAT_VIS_FRONT_R04") != nullptr;   // A/B and tests: round 4's three-kernel front end
             vis_front = !old_front;
             if (vis_front) {
-                // one contiguous run of positions per WAVE (4 per workgroup)
-                const uint32_t turn = VC_UNROLL * VC_WAVE_SPAN, wspans = (R + turn - 1u) / turn;     // turns of a wave in the whole list
-                uint32_t waves = (uint32_t)ctx->cu_count * 2u * (VC_THREADS / 64u);       // (512 workgroups: 8 waves per CU stream)
-                if (waves > wspans) waves = (wspans + 3u) & ~3u;
-                const uint32_t wgrid = waves / (VC_THREADS / 64u);
-                const uint32_t wave_len = ((wspans + waves - 1u) / waves) * turn;
-                GS_TRY(s->chunk_counts.ensure((size_t)waves * 4));
+                // one contiguous run of positions per workgroup, walked in turns of 4096 (two workgroups per CU)
+                const uint32_t turns = (R + VC_TURN - 1u) / VC_TURN;
+                const uint32_t wgrid = turns < (uint32_t)ctx->cu_count * 2u ? turns : (uint32_t)ctx->cu_count * 2u;
+                const uint32_t wlen = ((turns + wgrid - 1u) / wgrid) * VC_TURN;
+                GS_TRY(s->chunk_counts.ensure((size_t)wgrid * 4));
                 GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
-                hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wave_len, s->chunk_counts.as<uint32_t>());
+                hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wlen, s->chunk_counts.as<uint32_t>());
                 if (map) hipLaunchKernelGGL(k_cull_front<true>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                            s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
+                                            s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>());
                 else hipLaunchKernelGGL(k_cull_front<false>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                        s->chunk_counts.as<uint32_t>(), wave_len, map, s->pay_in.as<uint32_t>());
+                                        s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>());
             } else {
                 hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
                 hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),

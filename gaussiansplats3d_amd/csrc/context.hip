@@ -82,15 +82,8 @@ int gs_context_create_ex(int device, void* hip_stream, uint32_t flags, gs_contex
             gs_context_destroy(ctx);
             return GS_ERR_HIP;
         }
-        e = hipStreamCreateWithFlags(&ctx->bin, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            gs_set_error("hipStreamCreate(bin) failed: %s", hipGetErrorString(e));
-            gs_context_destroy(ctx);
-            return GS_ERR_HIP;
-        }
     } else {
         ctx->aux = ctx->stream;
-        ctx->bin = ctx->stream;
     }
     ctx->fork_join = (flags & GS_CTX_FORK_JOIN) != 0;
     if (ctx->fork_join && hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess) {
@@ -120,10 +113,6 @@ void gs_context_destroy(gs_context* ctx) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
     }
-    if (ctx->bin && ctx->bin != ctx->stream) {
-        (void)hipStreamSynchronize(ctx->bin);
-        (void)hipStreamDestroy(ctx->bin);
-    }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->radix.block_hist.release();
     ctx->radix.digit_total.release();
@@ -136,7 +125,6 @@ int gs_context_synchronize(gs_context* ctx) {
     ScopedDevice sd(ctx->device);
     GS_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->aux != ctx->stream) GS_HIP(hipStreamSynchronize(ctx->aux));
-    if (ctx->bin && ctx->bin != ctx->stream) GS_HIP(hipStreamSynchronize(ctx->bin));
     return GS_OK;
 }
 

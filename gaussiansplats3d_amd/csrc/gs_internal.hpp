@@ -189,8 +189,6 @@ struct gs_context {
     bool wide_entry_keys = false;      // GSPLAT_WIDE_ENTRY_KEYS=1: 32-bit list keys even below 65536 lists (test hook)
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;
-    hipStream_t bin = nullptr;            // binner + tile-entry sort of a draw whose sorted list is device resident (== stream on a
-                                          // single-stream context): frame k + 1 is binned while frame k is still blended on `stream`
     bool own_stream = false;
     bool stage_events = false;            // GS_CTX_STAGE_TIMING / GSPLAT_STAGE_EVENTS=1: bracket the stages of EVERY sort and
                                           // draw with timing events.  Otherwise only calls that are handed a stats pointer
@@ -462,23 +460,6 @@ struct gs_mesh {
     } alt;
     bool two_sets = false;                         // alt is allocated and in use
     bool set_drawn = false;                        // a draw has read the current set (ev_done is recorded)
-    // What a draw's binner leaves for its blend - and the statistics that blend leaves for a later binner - exists twice on a context
-    // with streams of its own as well (round 5): frame k + 1 is binned and its entries sorted on ctx->bin while frame k is blended on
-    // ctx->stream from the other set.  draw_swap exchanges every field below with `alt_draw`; the binner's own scratch (cidx, rect_q,
-    // coff, bin_sums, radix) stays single - binners run one after the other.  The blend statistics a binner reads (bin order, deep
-    // pass selection) are its OWN set's, i.e. of the draw before the previous one: scheduling hints, never pixels.
-    struct DrawSet {
-        DevBuf ekeyA, ekeyB, evalA, evalB, tile_ranges, frame, deep_flags, blend_order, blend_stats;
-        uint32_t sorted_buf = 0, blend_bins = 0, blend_row_begin = 0, blend_width = 0;
-        bool blend_order_valid = false, blended = false;
-        hipEvent_t ev_blended = nullptr;
-    } alt_draw;
-    bool two_draw_sets = false;
-    bool set_blended = false;                      // a blend has read the current draw set (ev_blended is recorded)
-    hipEvent_t ev_blended = nullptr;               // end of the last blend that read THIS draw set (on ctx->stream)
-    hipEvent_t ev_binned = nullptr;                // end of the last binner + entry sort (on whichever stream it ran)
-    bool has_binned = false;
-    hipStream_t bin_stream = nullptr;              // where the current draw's binner runs (set by mesh_draw_once)
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;

@@ -219,17 +219,10 @@ static inline uint32_t up_grid(uint32_t n) {
 
 static int mesh_alloc_entries(gs_mesh* m, uint32_t capacity) {
     // keys are sized for 32-bit tile ids so the same buffers serve > 65536-tile strips
-    // (callers have synchronised ctx->stream: every binner's draw has been blended by then, so ctx->bin is idle too)
     GS_TRY(m->ekeyA.alloc((size_t)capacity * 4));
     GS_TRY(m->ekeyB.alloc((size_t)capacity * 4));
     GS_TRY(m->evalA.alloc((size_t)capacity * 4));
     GS_TRY(m->evalB.alloc((size_t)capacity * 4));
-    if (m->two_draw_sets) {
-        GS_TRY(m->alt_draw.ekeyA.alloc((size_t)capacity * 4));
-        GS_TRY(m->alt_draw.ekeyB.alloc((size_t)capacity * 4));
-        GS_TRY(m->alt_draw.evalA.alloc((size_t)capacity * 4));
-        GS_TRY(m->alt_draw.evalB.alloc((size_t)capacity * 4));
-    }
     m->entry_capacity = capacity;
     return GS_OK;
 }
@@ -291,8 +284,6 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     }
     A(m->bin_sums, 4 * 3 * 2048 + 64);               // uint32 [3][BIN_MAX_BLOCKS] + the batches-per-workgroup of the last count
     A(m->frame, sizeof(RenderFrame));
-    m->two_draw_sets = ctx->bin != ctx->stream && !getenv("GSPLAT_ONE_DRAW_SET");
-    if (m->two_draw_sets) A(m->alt_draw.frame, sizeof(RenderFrame));
     if (st == GS_OK) st = m->radix.init();
     if (st == GS_OK) {
         // Never-uploaded splats are what the reference's zero-filled data textures hold (SplatMesh.js:686-697: new
@@ -327,12 +318,6 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
             gs_set_error("hipEventCreate failed");
             st = GS_ERR_HIP;
         }
-    if (st == GS_OK && (hipEventCreateWithFlags(&m->ev_binned, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&m->ev_blended, hipEventDisableTiming) != hipSuccess ||
-                        (m->two_draw_sets && hipEventCreateWithFlags(&m->alt_draw.ev_blended, hipEventDisableTiming) != hipSuccess))) {
-        gs_set_error("hipEventCreate failed");
-        st = GS_ERR_HIP;
-    }
     if (st == GS_OK && (hipEventCreateWithFlags(&m->ev_done, hipEventDisableTiming) != hipSuccess ||
                         (m->two_sets && hipEventCreateWithFlags(&m->alt.ev_done, hipEventDisableTiming) != hipSuccess))) {
         gs_set_error("hipEventCreate failed");
@@ -377,9 +362,6 @@ void gs_mesh_destroy(gs_mesh* m) {
         if (m->ring0[i]) (void)hipEventDestroy(m->ring0[i]);
         if (m->ring1[i]) (void)hipEventDestroy(m->ring1[i]);
     }
-    if (m->ev_binned) (void)hipEventDestroy(m->ev_binned);
-    if (m->ev_blended) (void)hipEventDestroy(m->ev_blended);
-    if (m->alt_draw.ev_blended) (void)hipEventDestroy(m->alt_draw.ev_blended);
     if (m->ev_done) (void)hipEventDestroy(m->ev_done);
     if (m->alt.ev_done) (void)hipEventDestroy(m->alt.ev_done);
     if (m->mirror_host) (void)hipHostFree(m->mirror_host);
@@ -659,16 +641,6 @@ static void mesh_swap_sets(gs_mesh* m) {
     std::swap(m->vis_orig_dirty, o.vis_orig_dirty); std::swap(m->vis_orig_count, o.vis_orig_count);
 }
 
-static void mesh_swap_draw_sets(gs_mesh* m) {
-    gs_mesh::DrawSet& o = m->alt_draw;
-    swap_buf(m->ekeyA, o.ekeyA); swap_buf(m->ekeyB, o.ekeyB); swap_buf(m->evalA, o.evalA); swap_buf(m->evalB, o.evalB);
-    swap_buf(m->tile_ranges, o.tile_ranges); swap_buf(m->frame, o.frame); swap_buf(m->deep_flags, o.deep_flags);
-    swap_buf(m->blend_order, o.blend_order); swap_buf(m->blend_stats, o.blend_stats);
-    std::swap(m->sorted_buf, o.sorted_buf); std::swap(m->blend_bins, o.blend_bins); std::swap(m->blend_row_begin, o.blend_row_begin);
-    std::swap(m->blend_width, o.blend_width); std::swap(m->blend_order_valid, o.blend_order_valid);
-    std::swap(m->set_blended, o.blended); std::swap(m->ev_blended, o.ev_blended);
-}
-
 static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, bool timed) {
     gs_context* ctx = m->ctx;
     hipStream_t st = ctx->stream, aux = ctx->aux;
@@ -706,42 +678,21 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     timed = timed || ctx->stage_events;
     m->timed_draw = timed;
     const uint32_t tiles = pp.lists_x * (pp.list_row_end - pp.list_row_begin);  // one entry list per list bin
-    // the draw set this frame's binner writes and its blend reads: the one the frame BEFORE the last used (two sets), else the only one
-    if (m->two_draw_sets) mesh_swap_draw_sets(m);
     GS_TRY(m->tile_ranges.ensure((size_t)tiles * 8 + 16));
     if (!projected) GS_TRY(mesh_project(m, pp, false, timed));   // else gs_mesh_project already ran it for this camera
     else if (timed) GS_HIP(hipEventRecord(m->ev[0], st));
-    // The binner and the entry sort of an untimed draw that takes its list from a sorter run on ctx->bin, beside the blend of the
-    // previous frame on ctx->stream (timed draws synchronise anyway and keep their stage events on one stream; host index lists
-    // are copied on ctx->stream).
-    hipStream_t bs = (m->two_draw_sets && !timed && sorter) ? ctx->bin : st;
-    m->bin_stream = bs;
     // join: projection and (if a sorter feeds this draw) the sort result
-    if (aux != bs) GS_HIP(hipStreamWaitEvent(bs, m->ev_p1, 0));
-    if (sorter && sorter->stream != bs) GS_HIP(hipStreamWaitEvent(bs, sorter->ev1, 0));
-    if (bs != st) {
-        // ... the blend that last read this draw set, and the previous binner (its scratch is shared), wherever it ran
-        if (m->set_blended) GS_HIP(hipStreamWaitEvent(bs, m->ev_blended, 0));
-        if (m->has_binned) GS_HIP(hipStreamWaitEvent(bs, m->ev_binned, 0));
-    }
+    if (aux != st) GS_HIP(hipStreamWaitEvent(st, m->ev_p1, 0));
+    if (sorter && sorter->stream != st) GS_HIP(hipStreamWaitEvent(st, sorter->ev1, 0));
     if (timed) GS_HIP(hipEventRecord(m->ev[1], st));
     // the index list is in the caller's splat numbering unless it comes from a sorter bound to this mesh
     m->translate = m->reorder && !(sorter && sorter->result_mesh == m);
     GS_TRY(gs_launch_binning(m, pp, order_dev, sorter, R));   // records ev[2] between emit and the tile sort
-    if (m->two_draw_sets) {
-        GS_HIP(hipEventRecord(m->ev_binned, bs));
-        m->has_binned = true;
-        if (bs != st) GS_HIP(hipStreamWaitEvent(st, m->ev_binned, 0));
-    }
     if (timed) GS_HIP(hipEventRecord(m->ev[3], st));
     GS_TRY(gs_launch_blend(m, pp, out_dev));
     if (timed) {
         GS_HIP(hipEventRecord(m->ev[4], st));
         GS_HIP(hipEventRecord(m->ev[5], st));
-    }
-    if (m->two_draw_sets) {
-        GS_HIP(hipEventRecord(m->ev_blended, st));
-        m->set_blended = true;
     }
     if (aux != st) GS_HIP(hipEventRecord(m->ev_done, st));     // only another stream ever waits for it
     m->set_drawn = true;

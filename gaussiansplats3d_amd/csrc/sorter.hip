@@ -625,17 +625,17 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_compact(uint32_t* __restric
 //                  the chunk - whose first output slot is the sum of the earlier chunks' counts - key and payload (the bound
 //                  mesh's position, read for survivors only) written to the compacted list.  The mask is consumed as before.
 // No look-back, no spinning: the offsets come from the first kernel's counts.
-// A workgroup owns a contiguous run of positions (chunk_len % 4096 == 0) and walks it in turns of 4096: wave w of the workgroup
-// takes the four spans [w * 1024, (w + 1) * 1024) of the turn, a lane four consecutive positions of a span (one 16-byte load per
-// plane), so the workgroup streams 16 KB per plane per turn and the chip ~2000 streams in all.  A wave's first output slot in a
+// A workgroup owns a contiguous run of positions (chunk_len % VC_TURN == 0) and walks it in turns of VC_TURN: wave w of the workgroup
+// takes VC_UNROLL consecutive spans of the turn, a lane four consecutive positions of a span (one 16-byte load per
+// plane), so the workgroup streams 8 KB per plane per turn and the chip ~2000 streams in all.  A wave's first output slot in a
 // turn = the workgroup's running offset + the survivors of the lower waves in this turn (one barrier per turn, counts double
-// buffered); inside a wave the prefix over the 64 lanes is a DPP scan.
+// buffered); inside a wave the prefix over the 64 lanes is a DPP scan.  (Turn = 2048 positions with VC_UNROLL = 2.)
 // (History, r05c-h: cutting the list per workgroup with a block scan every 1024 positions cost a rank's strip 22 barriers per chunk
 // for nothing; one contiguous run per WAVE needs no barrier at all but makes 8192 concurrent DRAM streams - 36-42 us for the 93 MB;
 // spans handled one by one put a store round trip between them - predicated stores cannot be counted, the compiler drains the queue -
 // and a run-time `map ? load : index` put every payload load in a branch of its own with a full wait behind it.)
 constexpr uint32_t VC_WAVE_SPAN = 256;                     // positions per wave and span (4 per lane; 8 mask words)
-constexpr uint32_t VC_UNROLL = 4;                          // spans per wave and turn (12 + 4 x 16-byte loads in flight per lane)
+constexpr uint32_t VC_UNROLL = 2;                          // spans per wave and turn (two turns' loads in flight: 2 x 8 x 16 bytes per lane)
 constexpr uint32_t VC_TURN = VC_UNROLL * VC_WAVE_SPAN * (VC_THREADS / 64u);   // positions per workgroup and turn (4096)
 
 __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const uint32_t* __restrict__ mask, uint32_t chunk_len,
@@ -704,19 +704,26 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
     const uint4* __restrict__ z4 = reinterpret_cast<const uint4*>(p.cz);
     int32_t* __restrict__ keys_out = p.keys_out;
     const uint4* __restrict__ map4 = reinterpret_cast<const uint4*>(map);
-    uint32_t turn = 0;
-    for (uint32_t base = begin; base < end; base += VC_TURN, turn++) {
-        const uint32_t wbase = base + wave * (VC_UNROLL * VC_WAVE_SPAN);    // this wave's four spans of the turn
-        uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL], M[VC_UNROLL];
-        uint32_t raw[VC_UNROLL];
+    // The loads of turn t + 1 are issued BEFORE turn t is keyed and stored (two register sets): all workgroups run in step, so a
+    // turn that loads, then computes, then stores left the memory system idle between the bursts - 36-44 us for 93 MB (r05h/i).
+    struct Turn { uint4 X[VC_UNROLL], Y[VC_UNROLL], Z[VC_UNROLL], M[VC_UNROLL]; uint32_t raw[VC_UNROLL]; };
+    auto fetch = [&](uint32_t base, Turn& t) {
+        const uint32_t wbase = base + wave * (VC_UNROLL * VC_WAVE_SPAN);    // this wave's spans of the turn
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
             const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;      // this lane's four positions of span u
             const uint32_t ic = min(i0, N >= 4u ? ((N - 4u) & ~3u) : 0u);  // (clamped: the loads are unconditional)
-            X[u] = x4[ic >> 2]; Y[u] = y4[ic >> 2]; Z[u] = z4[ic >> 2];
-            M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);   // the payloads travel with the centres
-            raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                        // the mask word of the four positions (eight lanes share one)
+            t.X[u] = x4[ic >> 2]; t.Y[u] = y4[ic >> 2]; t.Z[u] = z4[ic >> 2];
+            t.M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);   // the payloads travel with the centres
+            t.raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                      // the mask word of the four positions (eight lanes share one)
         }
+    };
+    Turn cur, nxt;
+    if (begin < end) fetch(begin, cur);
+    uint32_t turn = 0;
+    for (uint32_t base = begin; base < end; base += VC_TURN, turn++) {
+        const uint32_t wbase = base + wave * (VC_UNROLL * VC_WAVE_SPAN);
+        fetch(min(base + VC_TURN, end - 1u), nxt);                          // (past the end: a clamped re-read, never used)
         // phase 1, registers only: keys, survivor nibbles and slots (relative to the wave's first) of all the spans of the turn ...
         int32_t K[VC_UNROLL][4];
         uint32_t nibs[VC_UNROLL], first[VC_UNROLL], mine_total = 0;
@@ -724,10 +731,10 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
             const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;
             int32_t k[4] = {0, 0, 0, 0};
-            uint32_t word = raw[u];
+            uint32_t word = cur.raw[u];
             if (i0 < end && end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
             if ((p.mode & MODE_INT) && i0 + 4u <= end) {
-                const uint4 x = X[u], y = Y[u], z = Z[u];
+                const uint4 x = cur.X[u], y = cur.Y[u], z = cur.Z[u];
                 k[0] = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2); k[1] = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
                 k[2] = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2); k[3] = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
                 lo = min(min(lo, k[0]), min(min(k[1], k[2]), k[3]));
@@ -767,11 +774,11 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             // the mask is consumed: copied for gs_sorter_debug_read, then zeroed (no other wave touches these words, and this
             // wave has read them all)
             if (i0 < end && (i0 & 31u) == 0u) {
-                mask_copy[i0 >> 5] = raw[u];
-                if (raw[u]) mask[i0 >> 5] = 0u;
+                mask_copy[i0 >> 5] = cur.raw[u];
+                if (cur.raw[u]) mask[i0 >> 5] = 0u;
             }
             uint32_t o = wave_out + first[u];
-            const uint32_t pm[4] = {M[u].x, M[u].y, M[u].z, M[u].w};
+            const uint32_t pm[4] = {cur.M[u].x, cur.M[u].y, cur.M[u].z, cur.M[u].w};
             const bool vec = i0 + 4u <= N;                                 // (else the vector was read at a clamped position)
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++)
@@ -781,6 +788,7 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
                     o++;
                 }
         }
+        cur = nxt;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

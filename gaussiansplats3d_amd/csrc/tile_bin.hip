@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
 template <class KeyT>
 static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t R, uint32_t tiles /* sort keys */) {
     gs_context* ctx = m->ctx;
-    hipStream_t st = m->bin_stream ? m->bin_stream : ctx->stream;   // (ctx->bin beside the previous frame's blend: mesh_draw_once)
+    hipStream_t st = ctx->stream;
     const RadixExec ex = {st, &m->radix, ctx->lds_atomic_lane_order};
     RenderFrame* frame = m->frame.as<RenderFrame>();
     uint32_t grid = (R + BIN_THREADS - 1) / BIN_THREADS;

@@ -267,7 +267,7 @@ int gs_mesh_create(gs_context* ctx, uint32_t max_splat_count, uint32_t sh_degree
     m->no_deep = getenv("GSPLAT_NO_DEEP") != nullptr;
     if (const char* ls = getenv("GSPLAT_LIST_SHIFT"))
         if (ls[0] >= '1' && ls[0] <= '6' && ls[1] == '\0') m->forced_list_shift = ls[0] - '0';
-    if (m->reorder) { A(m->perm, n * 4); A(m->inv_perm, n * 4); }
+    if (m->reorder) { A(m->perm, n * 4 + 16); A(m->inv_perm, n * 4); }   // (+16: the sorter's k_cull_front reads perm as 16-byte vectors)
     A(m->recs, n * sizeof(SplatRec)); A(m->rects, n * 8); A(m->rect_q, n * 8 + 2048); A(m->cidx, n * 4 + 1024); A(m->coff, n * 4 + 1024);
     A(m->vis_mask, ((n + 255) / 256) * 32 + 32);   // whole 256-splat blocks: 4 words each
     A(m->vis32, ((n + 255) / 256) * 64 + 64);

@@ -712,7 +712,9 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
 #pragma unroll
         for (uint32_t u = 0; u < VC_UNROLL; u++) {
             const uint32_t i0 = wbase + u * VC_WAVE_SPAN + 4u * lane;      // this lane's four positions of span u
-            const uint32_t ic = min(i0, N >= 4u ? ((N - 4u) & ~3u) : 0u);  // (clamped: the loads are unconditional)
+            // (unconditional loads; the planes and the mesh's position table are padded by 16 bytes, so the vector that holds the
+            // list's last position is readable whatever N is)
+            const uint32_t ic = i0 < N ? i0 : 0u;
             t.X[u] = x4[ic >> 2]; t.Y[u] = y4[ic >> 2]; t.Z[u] = z4[ic >> 2];
             t.M[u] = MAP ? map4[ic >> 2] : make_uint4(ic, ic + 1u, ic + 2u, ic + 3u);   // the payloads travel with the centres
             t.raw[u] = i0 < end ? mask[i0 >> 5] : 0u;                      // the mask word of the four positions (eight lanes share one)
@@ -733,20 +735,24 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             int32_t k[4] = {0, 0, 0, 0};
             uint32_t word = cur.raw[u];
             if (i0 < end && end - (i0 & ~31u) < 32u) word &= (1u << (end - (i0 & ~31u))) - 1u;    // positions beyond this sort's list
-            if ((p.mode & MODE_INT) && i0 + 4u <= end) {
-                const uint4 x = cur.X[u], y = cur.Y[u], z = cur.Z[u];
-                k[0] = (int32_t)(x.x * m0 + y.x * m1 + z.x * m2); k[1] = (int32_t)(x.y * m0 + y.y * m1 + z.y * m2);
-                k[2] = (int32_t)(x.z * m0 + y.z * m1 + z.z * m2); k[3] = (int32_t)(x.w * m0 + y.w * m1 + z.w * m2);
-                lo = min(min(lo, k[0]), min(min(k[1], k[2]), k[3]));
-                hi = max(max(hi, k[0]), max(max(k[1], k[2]), k[3]));
-            } else {                                                       // float centres, or the ragged end of the list
+            {   // keys from the vectors (no memory access in this phase: a load in a branch here puts a full wait at its join)
+                const uint32_t xs[4] = {cur.X[u].x, cur.X[u].y, cur.X[u].z, cur.X[u].w}, ys[4] = {cur.Y[u].x, cur.Y[u].y, cur.Y[u].z, cur.Y[u].w},
+                               zs[4] = {cur.Z[u].x, cur.Z[u].y, cur.Z[u].z, cur.Z[u].w};
 #pragma unroll
-                for (uint32_t c = 0; c < 4u; c++)
-                    if (i0 + c < end) {
-                        k[c] = depth_key_planes(p, i0 + c);
+                for (uint32_t c = 0; c < 4u; c++) {
+                    if (p.mode & MODE_INT) {
+                        k[c] = (int32_t)(xs[c] * m0 + ys[c] * m1 + zs[c] * m2);
+                    } else {
+                        float sm = __fmul_rn(p.fm0, __uint_as_float(xs[c]));
+                        sm = __fadd_rn(sm, __fmul_rn(p.fm1, __uint_as_float(ys[c])));
+                        sm = __fadd_rn(sm, __fmul_rn(p.fm2, __uint_as_float(zs[c])));
+                        k[c] = trunc_f64_i32((double)sm * 4096.0);
+                    }
+                    if (i0 + c < end) {                                    // (min / max over the list's positions only)
                         lo = min(lo, k[c]);
                         hi = max(hi, k[c]);
                     }
+                }
             }
             const uint32_t nib = (word >> (i0 & 31u)) & 15u, mine = (uint32_t)__popc(nib);
             const uint32_t incl = wave_incl_scan_dpp(mine);
@@ -779,12 +785,11 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
             }
             uint32_t o = wave_out + first[u];
             const uint32_t pm[4] = {cur.M[u].x, cur.M[u].y, cur.M[u].z, cur.M[u].w};
-            const bool vec = i0 + 4u <= N;                                 // (else the vector was read at a clamped position)
 #pragma unroll
             for (uint32_t c = 0; c < 4u; c++)
-                if ((nibs[u] >> c) & 1u) {
+                if ((nibs[u] >> c) & 1u) {                                 // (stores only: see phase 1)
                     keys_out[o] = K[u][c];
-                    pay_out[o] = vec ? pm[c] : (MAP ? map[i0 + c] : i0 + c);
+                    pay_out[o] = pm[c];
                     o++;
                 }
         }
@@ -960,7 +965,7 @@ int gs_sorter_create(gs_context* ctx, uint32_t max_splat_count, uint32_t flags, 
     const size_t n = max_splat_count, b4 = n * 4;
     int st = GS_OK;
     auto A = [&](DevBuf& b, size_t bytes) { if (st == GS_OK) st = b.alloc(bytes); };
-    A(s->cx, b4); A(s->cy, b4); A(s->cz, b4); A(s->caos, n * 16);
+    A(s->cx, b4 + 16); A(s->cy, b4 + 16); A(s->cz, b4 + 16); A(s->caos, n * 16);   // (+16: k_cull_front reads whole 16-byte vectors)
     if (flags & GS_SORT_DYNAMIC) { A(s->cw, b4); A(s->scene_idx, b4); A(s->scene_rows, sizeof(SceneRows)); }
     A(s->keys, b4); A(s->keyA, b4); A(s->keyB, b4); A(s->valA, b4); A(s->valB, b4); A(s->sorted, b4);
     A(s->frame, 2 * sizeof(SortFrame));

@@ -808,7 +808,10 @@ __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t
 
 // Phase B as a radix loader.  Logical element j <-> list position i = R-1-j (reverse traversal makes the
 // stable ascending sort of key' = range-1-bucket equal to the reference's descending, tie-reversed order).
-template <bool CULL>
+// IDX: the list is an index (or ready-made payload) array, not the identity - a compile-time switch: as a run-time `idx ? load : i`
+// every index load sat in a branch of its own with a full memory wait behind it, eight serialised round trips per tile in every
+// sort of a gathered / compacted list (r05k ISA of the pass-0 scatter).
+template <bool CULL, bool IDX>
 struct DepthLoaderT {
     const int32_t* __restrict__ keys;
     const unsigned long long* __restrict__ keep;   // CULL: 1 bit per list position (k_depth_key_cull)
@@ -856,7 +859,7 @@ struct DepthLoaderT {
     }
     __device__ __forceinline__ uint32_t key(uint32_t j) const { return (range - 1) - bucket(render_count - 1 - j); }
     __device__ __forceinline__ uint32_t payload(uint32_t i) const {
-        const uint32_t o = idx ? min(ld32(idx, i), last_splat) : i;
+        const uint32_t o = IDX ? min(ld32(idx, i), last_splat) : i;
         return map ? ld32(map, o) : o;
     }
     __device__ __forceinline__ uint32_t val(uint32_t j) const { return payload(render_count - 1 - j); }
@@ -866,7 +869,7 @@ struct DepthLoaderT {
     static __device__ __forceinline__ int prof_slot(int) { return 0; }       // GS_RADIX_PROFILE
     __device__ __forceinline__ uint32_t pre(uint32_t j) const {
         const uint32_t i = render_count - 1 - j;
-        return idx ? min(ld32(idx, i), last_splat) : i;
+        return IDX ? min(ld32(idx, i), last_splat) : i;
     }
     __device__ __forceinline__ Raw fetch(uint32_t j, uint32_t o) const {
         Raw r;
@@ -888,8 +891,7 @@ struct DepthLoaderT {
         return (ld32(keep, i >> 6) >> (i & 63u)) & 1ull;
     }
 };
-typedef DepthLoaderT<false> DepthLoader;
-typedef DepthLoaderT<true> DepthLoaderCull;
+typedef DepthLoaderT<false, false> DepthLoader;          // (the identity list without a cull: what k_debug_buckets walks)
 
 // A pass that follows a PACKING pass (radix.hpp, PACK_OUT) reads ONE word per element: what is left of the key above a value of
 // `val_bits` bits; its digit is the low byte of that remainder (shift 0), its histogram is ArrayLoader<uint32_t>'s over the same
@@ -931,6 +933,31 @@ __global__ void k_debug_buckets(DepthLoader ld, int32_t* out) {
     for (uint32_t i = ld.sort_start + blockIdx.x * blockDim.x + threadIdx.x; i < ld.render_count;
          i += gridDim.x * blockDim.x)
         out[i] = (int32_t)ld.bucket(i);
+}
+
+// Pass 0 of a depth sort for one (CULL, IDX) combination of the loader: packed + chunk-staged, packed, or key + value output.
+struct Pass0Args {
+    DepthLoader base;                   // the fields every variant shares (copied member by member below)
+    const unsigned long long* keep;
+    uint32_t Rs, val_bits;
+    int shift;
+    bool pack, chunked, wide;
+    void* kbuf0;
+    uint32_t* vo;
+    uint32_t* kept_out;
+};
+template <bool CULL, bool IDX>
+static int depth_pass0(const RadixExec& ex, const Pass0Args& a) {
+    typedef DepthLoaderT<CULL, IDX> L;
+    L d = {};
+    d.keys = a.base.keys; d.keep = a.keep; d.idx = a.base.idx; d.map = a.base.map; d.frame = a.base.frame; d.n_dev = a.base.n_dev;
+    d.sort_start = a.base.sort_start; d.render_count = a.base.render_count; d.range = a.base.range; d.last_splat = a.base.last_splat;
+    L h = d;                            // only the histogram launch counts clamped buckets (once per element)
+    h.count_clamps = 1;
+    if (a.pack && a.chunked) return radix_pass_chunk<L, L, true>(ex, h, a.shift, d, a.Rs, a.shift, 0, a.vo, a.val_bits, a.kept_out);
+    if (a.pack) return radix_pass_ex<L, L, uint8_t, false, false, true>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint8_t*)nullptr, a.vo, nullptr, 0u, a.val_bits, a.kept_out);
+    if (a.wide) return radix_pass_ex<L, L, uint32_t, true, false, false>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint32_t*)a.kbuf0, a.vo, nullptr, 0u, 0u, a.kept_out);
+    return radix_pass_ex<L, L, uint16_t, true, false, false>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint16_t*)a.kbuf0, a.vo, nullptr, 0u, 0u, a.kept_out);
 }
 
 static inline uint32_t grid_for(uint32_t n, uint32_t per_block, uint32_t cap) {
@@ -1229,8 +1256,17 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
             GS_TRY(s->mask_copy.ensure(((size_t)s->max_count + 31) / 32 * 4 + 64));
             uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
-            static const bool old_front = getenv("GSPLAT_VIS_FRONT_R04") != nullptr;   // A/B and tests: round 4's three-kernel front end
-            vis_front = !old_front;
+            // Two front ends, chosen by what the vertex stage drew.  A full frame keeps a large part of the scene (C3: a quarter):
+            // the streaming front end keys the survivors on the way (N = 1 frame 0.285 -> 0.270 ms, r05k).  A rank's strip keeps
+            // a few per cent: round 4's chain - a 12-byte-per-splat min / max pass, a compaction of the mask, and centre gathers
+            // for the few survivors - is the cheaper one there (C3 rank 4 of 8: 0.116 vs 0.126 ms, same box), because the streaming
+            // kernel also reads the payload table (+4 bytes per splat) and runs at 2.8 TB/s where the pure reduction reaches 4.
+            // $GSPLAT_VIS_FRONT = stream | compact forces one (A/B and tests).
+            static const char* force = getenv("GSPLAT_VIS_FRONT");
+            const gs_camera& pc = s->bound_mesh->projected_cam;
+            const uint32_t rows_total = (pc.height + GS_TILE - 1u) / GS_TILE;
+            const bool strip = !(pc.tile_row_begin == 0u && (pc.tile_row_end == 0u || pc.tile_row_end >= rows_total));
+            vis_front = force ? force[0] == 's' : !strip;
             if (vis_front) {
                 // one contiguous run of positions per workgroup, walked in turns of 4096 (two workgroups per CU)
                 const uint32_t turns = (R + VC_TURN - 1u) / VC_TURN;
@@ -1305,25 +1341,16 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             uint32_t* vo = last ? out_tail : vbuf[p & 1];
             // after a culling pass 0 the element count is the device-resident kept count
             const uint32_t* n_dev = (cull || vis_cull || list_count_dev) ? &kp.frame->kept : nullptr;
-            if (p == 0 && cull) {
-                DepthLoaderCull dc = {};
-                dc.keys = dl.keys; dc.keep = kp.keep; dc.idx = dl.idx; dc.map = dl.map; dc.frame = dl.frame;
-                dc.sort_start = dl.sort_start; dc.render_count = dl.render_count; dc.range = dl.range; dc.last_splat = dl.last_splat;
-                dc.n_dev = dl.n_dev;
-                DepthLoaderCull h = dc;
-                h.count_clamps = 1;
-                uint32_t* kept_out = &kp.frame->kept;                  // pass 0 compacts: it publishes the result's length
-                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoaderCull, DepthLoaderCull, true>(ex, h, shift, dc, Rs, shift, (int)p, vo, val_bits, kept_out)));
-                else if (pack) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint8_t, false, false, true>(ex, h, shift, dc, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits, kept_out)));
-                else if (wide) GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint32_t, true, false, false>(ex, h, shift, dc, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo, nullptr, 0u, 0u, kept_out)));
-                else GS_TRY((radix_pass_ex<DepthLoaderCull, DepthLoaderCull, uint16_t, true, false, false>(ex, h, shift, dc, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo, nullptr, 0u, 0u, kept_out)));
-            } else if (p == 0) {
-                DepthLoader h = dl;   // only the histogram launch counts clamped buckets (once per element)
-                h.count_clamps = 1;
-                if (pack && chunked) GS_TRY((radix_pass_chunk<DepthLoader, DepthLoader, true>(ex, h, shift, dl, Rs, shift, (int)p, vo, val_bits)));
-                else if (pack) GS_TRY((radix_pass_ex<DepthLoader, DepthLoader, uint8_t, false, false, true>(ex, h, shift, dl, Rs, shift, (int)p, (uint8_t*)nullptr, vo, nullptr, 0u, val_bits)));
-                else if (wide) GS_TRY((radix_pass<DepthLoader, uint32_t, true>(ex, h, dl, Rs, shift, (int)p, (uint32_t*)kbuf[0], vo)));
-                else GS_TRY((radix_pass<DepthLoader, uint16_t, true>(ex, h, dl, Rs, shift, (int)p, (uint16_t*)kbuf[0], vo)));
+            if (p == 0) {
+                Pass0Args a = {};
+                a.base = dl; a.keep = cull ? kp.keep : nullptr; a.Rs = Rs; a.val_bits = val_bits; a.shift = shift;
+                a.pack = pack; a.chunked = chunked; a.wide = wide; a.kbuf0 = kbuf[0]; a.vo = vo;
+                a.kept_out = cull ? &kp.frame->kept : nullptr;         // a culling pass 0 compacts: it publishes the result's length
+                const bool has_idx = dl.idx != nullptr;
+                if (cull && has_idx) GS_TRY((depth_pass0<true, true>(ex, a)));
+                else if (cull) GS_TRY((depth_pass0<true, false>(ex, a)));
+                else if (has_idx) GS_TRY((depth_pass0<false, true>(ex, a)));
+                else GS_TRY((depth_pass0<false, false>(ex, a)));
             } else if (in_packed) {
                 PackedLoader pl = {vbuf[(p - 1) & 1], n_dev, Rs, val_bits};
                 ArrayLoader<uint32_t> ph = {vbuf[(p - 1) & 1], nullptr, n_dev, Rs};

@@ -46,3 +46,11 @@ def test_shader_permutations_on_unseen_seeds():
 def test_a_long_lived_viewer_on_unseen_seeds():
     """one mesh + sorter + octree over random event sequences (re-uploads, culls, strips, asynchronous frames, overflow)"""
     print(_soak("soak_stateful.py", 4, 35000, 20, 40000))
+
+
+@pytest.mark.parametrize("front", ["stream", "compact"])
+def test_whole_path_with_either_front_end_of_the_culled_sort(front):
+    """Round 5: the visibility-culled sort has a streaming front end (full frames) and the compact-then-gather one (strips); the
+    soak forces each of them onto every culled sort it draws, strips and full frames alike."""
+    print(_soak("soak.py", 10, 36000 + (700 if front == "compact" else 0), 60000, env={"GSPLAT_VIS_FRONT": front}))
+    print(_soak("soak_stateful.py", 2, 37000 + (700 if front == "compact" else 0), 16, 30000, env={"GSPLAT_VIS_FRONT": front}))

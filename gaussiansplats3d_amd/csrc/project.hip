@@ -201,7 +201,10 @@ __device__ __forceinline__ void sh_colour(const ProjectParams& pp, const MeshPla
 // permutations: orthographic J, per-scene transforms (dynamicMode), per-scene opacity / visibility
 // (enableOptionalEffects), 8-bit SH, distance fade-in.
 // One storage block `blk` of 256 splats by one workgroup (k_project below says which).
-template <bool EXT, bool TEST>
+// DEPTH: a destination depth is set (gs_mesh_set_destination) and the blend wants every survivor's window depth - a compile-time
+// switch, because one more pointer and two more uniforms pushed the plain kernel over its scalar-register budget (106 SGPRs, 24
+// spilled: the all-visible C4 launch went 250 -> 278 us, r05m).
+template <bool EXT, bool TEST, bool DEPTH>
 __device__ __forceinline__ void project_block(const ProjectParams& pp, const MeshPlanes& mp, const uint32_t blk, SplatRec* __restrict__ recs,
                                               uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                               uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
@@ -337,8 +340,10 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
         ok = ok && (ndcz >= -1.0f && ndcz <= 1.0f);       // quad z == centre z (SplatMaterial3D.js:209): GL clip
         // what the depth test of a draw with a destination compares (gs_mesh_set_destination): glDepthRange(0, 1), and for a
         // fixed-point depth buffer the value it would be converted to
-        zwin = ndcz * 0.5f + 0.5f;
-        if (pp.depth_mode == 2u) zwin = (float)floor((double)zwin * 16777215.0 + 0.5);   // (fp64: exact round to nearest; < 2^24, exact as a float)
+        if (DEPTH) {
+            zwin = ndcz * 0.5f + 0.5f;
+            if (pp.depth_mode == 2u) zwin = (float)floor((double)zwin * 16777215.0 + 0.5);   // (fp64: exact round to nearest; < 2^24, exact as a float)
+        }
         if (pp.row_begin > 0u || pp.row_end < pp.tiles_y) {
             // a rank's strip of a multi-GPU draw: no splat reaches farther than maxScreenSpaceSplatSize from its centre, so one
             // whose centre is farther than that from the strip is dropped before its covariance is fetched (the exact rect
@@ -544,7 +549,7 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
         const uint32_t slot = wave_base + (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
         recs[slot] = rec;
         rects[slot] = rect;
-        if (pp.depth_mode) zrec[slot] = zwin;
+        if (DEPTH) zrec[slot] = zwin;
         // gs_mesh_project: the same bit by ORIGINAL splat index, for a sort that keeps only what this frame draws (the mask
         // was zeroed before the launch; only survivors pay the atomic)
         if (vis_orig) {
@@ -554,9 +559,8 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     }
 }
 
-// The vertex stage's launch.  PRETESTED = false (per-scene transforms, $GSPLAT_NO_BLOCK_LIST, or a scene that was mostly in view at
-// its last measured draw): workgroup b tests storage block b itself when pp.block_cull.  PRETESTED = true: k_block_test has
-// decided, a workgroup whose block is dead leaves on one byte.
+// The vertex stage's launch (the modes are named at the kernel below): k_block_test has decided and a workgroup whose block is dead
+// leaves on one byte - or, for $GSPLAT_NO_BLOCK_LIST, workgroup b tests storage block b itself as in rounds 2-4.
 // Measured and dropped (r05b/c, project_floor / ab_libs, same box): (a) ONE kernel whose workgroups loop over a list of the live
 // blocks behind a grid sized from an earlier draw's count - the loop costs 80 instead of 48 VGPRs, C3 51.8 -> 60.0 us; (b) the
 // same grid bound with a separate 64-workgroup tail launch for the entries beyond it - 52.0 -> 54.3 us, and the floor (a pose
@@ -564,17 +568,22 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
 // boundaries and the test kernel are), so the full grid stays.
 // amdgpu_num_sgpr(80): left alone the compiler takes 106 scalar registers, and MI355X admits 256-thread workgroups per CU by
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) - 6 at 106, 7 at 86 (round 4's kernel), 8 at <= 80 (MI355X_MICROARCH.md, residency).
-template <bool EXT, bool PRETESTED>
+// MODE 0: every workgroup tests its own block (rounds 2-4; $GSPLAT_NO_BLOCK_LIST);  1: k_block_test has decided;  2: no block test
+// at all (per-scene transforms, or a full-frame draw of a scene that was mostly in view at its last measured draw: the test finds
+// nothing to drop there, and its code costs the all-visible launch scalar registers - C4 250 -> 278 us with it compiled in, r05m).
+template <bool EXT, int MODE, bool DEPTH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,
                                                  uint2* __restrict__ vis32, uint32_t* __restrict__ vis_orig,
                                                  const uint32_t* __restrict__ inv_perm, uint8_t* __restrict__ block_any,
                                                  uint2* __restrict__ prect, float* __restrict__ zrec) {
-    if (PRETESTED) {
+    if (MODE == 1) {
         if (block_any[blockIdx.x] == 0) return;
-        project_block<EXT, false>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
+        project_block<EXT, false, DEPTH>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
+    } else if (MODE == 2) {
+        project_block<EXT, false, DEPTH>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
     } else {
-        project_block<EXT, true>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
+        project_block<EXT, true, DEPTH>(pp, mp, blockIdx.x, recs, rects, vis_mask, vis32, vis_orig, inv_perm, block_any, prect, zrec);
     }
 }
 
@@ -593,7 +602,10 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     // (a scene that was mostly in view at its last MEASURED draw - truck-like C2: 36.0 us with the separate test, 33.3 without; C4,
     // every splat visible: 262 vs 252 - keeps the per-workgroup test: the separate kernel buys nothing there and costs a launch)
     const bool mostly_live = !m->block_test_always && m->measured_count > 0u && (uint64_t)m->measured_visible * 5u > (uint64_t)m->measured_count * 3u;
-    const bool pretest = pp.block_cull && !m->no_block_list && !mostly_live;
+    const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;     // (a strip of a scene that is mostly in view still drops most blocks)
+    const bool test = pp.block_cull && (!mostly_live || strip);
+    const bool pretest = test && !m->no_block_list;
+    const int mode = pretest ? 1 : (test ? 0 : 2);
     if (pretest)
         hipLaunchKernelGGL(k_block_test, dim3((blocks + 31u) / 32u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
                            m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), m->block_any.as<uint8_t>());
@@ -618,10 +630,18 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
                            m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), vis_orig, inv_perm, m->block_any.as<uint8_t>(),
                            m->prect.as<uint2>(), m->zrec.as<float>());
     };
-    if (ext && pretest) launch(k_project<true, true>);
-    else if (ext) launch(k_project<true, false>);
-    else if (pretest) launch(k_project<false, true>);
-    else launch(k_project<false, false>);
+    const bool depth = pp.depth_mode != 0u;
+#define GS_PROJECT_LAUNCH(E, D)                                                                                  \
+    do {                                                                                                         \
+        if (mode == 1) launch(k_project<E, 1, D>);                                                               \
+        else if (mode == 2) launch(k_project<E, 2, D>);                                                          \
+        else launch(k_project<E, 0, D>);                                                                         \
+    } while (0)
+    if (ext && depth) GS_PROJECT_LAUNCH(true, true);
+    else if (ext) GS_PROJECT_LAUNCH(true, false);
+    else if (depth) GS_PROJECT_LAUNCH(false, true);
+    else GS_PROJECT_LAUNCH(false, false);
+#undef GS_PROJECT_LAUNCH
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

@@ -25,25 +25,27 @@ bash tools/prof.sh ${TAG}_C4_kstats --config C4 > gpurun_out/$TAG/kstats_C4.txt 
 bash tools/pmc.sh ${TAG}_C4 hbm --config C4 > /dev/null 2>&1
 python tools/pmc_traffic.py gpurun_out/pmc_${TAG}_C4 gpurun_out/$TAG/pmc_traffic_C4.json > gpurun_out/$TAG/pmc_traffic_C4.txt 2>&1
 (GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 400 python tools/blend_lanes.py C3 C3T C2 C5 C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_lanes.txt
-(python tools/project_floor.py C3; GSPLAT_NO_BLOCK_CULL=1 python tools/project_floor.py C3) 2>&1 | grep k_project > gpurun_out/$TAG/project_floor.txt
+(python tools/project_floor.py C3; echo "-- GSPLAT_NO_BLOCK_LIST=1 (every workgroup tests its own block: round 4)"; GSPLAT_NO_BLOCK_LIST=1 python tools/project_floor.py C3; echo "-- GSPLAT_NO_BLOCK_CULL=1"; GSPLAT_NO_BLOCK_CULL=1 python tools/project_floor.py C3) 2>&1 | grep "k_project\|^--" > gpurun_out/$TAG/project_floor.txt
 (GSPLAT_SERIAL=1 bash tools/prof_script.sh ${TAG}_cull 44 /root/repo/tools/cull_prof.py; grep "cull-on" gpurun_out/${TAG}_cull/log.txt) > gpurun_out/$TAG/cull_on_serial_kstats.txt 2>&1
 # the deep pass on / off (same pixels), its unit timeline on the capture-like scene, and this tree against the library of the
 # previous evidence set (gpurun_ab/lib_r03x.so, built by tools/build_variant.sh from that commit) in one process
-(timeout 300 python tools/deep_ab.py "C3S C3T C3" 10 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/deep_ab.txt
+(timeout 300 python tools/deep_ab.py "C3S C3T" 10 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/deep_ab.txt
 (GSPLAT_HIP_LIB=gaussiansplats3d_amd/csrc/libgsplat_hip_blendprof.so timeout 200 python tools/blend_profile.py C3S 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/blend_profile_C3S.txt
 # this tree against the library of the previous round (gpurun_ab/lib_r03.so: tools/build_variant.sh with GS_VARIANT_SRC = a checkout
 # of round 3's last commit) in one process: whole frames, and the depth sort alone (bit-identical lists, checked against the oracle)
-if [ -f gpurun_ab/lib_r03.so ]; then
+# (round 5: the previous round's library is gpurun_ab/lib_r04.so; $GS_EVIDENCE_PREV names it)
+PREV=${GS_EVIDENCE_PREV:-gpurun_ab/lib_r03.so}
+if [ -f $PREV ]; then
   cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
-  (timeout 500 python tools/ab_libs.py "C3 C3T C2 C5 C4 C3S" gpurun_ab/lib_r03.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/ab_r03_vs_this_tree.txt
-  (timeout 500 python tools/sort_ab.py "C3 C4 C2" gpurun_ab/lib_r03.so gpurun_ab/lib_this_tree.so --check --sorts 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/sort_ab_r03_vs_this_tree.txt
+  (timeout 500 python tools/ab_libs.py "C3 C3T C2 C5 C4 C3S" $PREV gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/ab_r03_vs_this_tree.txt
+  (timeout 500 python tools/sort_ab.py "C3 C4 C2" $PREV gpurun_ab/lib_this_tree.so --check --sorts 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/sort_ab_r03_vs_this_tree.txt
 fi
 # the depth sort alone: kernel table and counters (FETCH_SIZE / WRITE_SIZE / SQ / LDS, one set per pass)
 cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
 bash tools/sort_prof.sh ${TAG}_sort_k C3 gpurun_ab/lib_this_tree.so 30 > gpurun_out/$TAG/sort_kstats_C3.txt 2>&1
 bash tools/sort_prof.sh ${TAG}_sort_k4 C4 gpurun_ab/lib_this_tree.so 15 > gpurun_out/$TAG/sort_kstats_C4.txt 2>&1
 bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_out/$TAG/sort_pmc_C3.txt 2>&1
-(tools/probes/gather_rate.bin 2>&1 | grep -v "^start") > gpurun_out/$TAG/gather_rate.txt
+[ -z "$GS_EVIDENCE_LIGHT" ] && (tools/probes/gather_rate.bin 2>&1 | grep -v "^start") > gpurun_out/$TAG/gather_rate.txt
 (python tools/cull_prof.py 2>&1 | grep cull-on) > gpurun_out/$TAG/cull_on_frame.txt
 [ -n "$GS_EVIDENCE_SORT_MIDDLE" ] && (timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
@@ -51,8 +53,9 @@ bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_ou
 (GS_STRIP_STREAMS=1 python tools/strip_scaling.py C3 20; GS_STRIP_STREAMS=1 python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling_streams.txt
 (timeout 400 python bench.py --gpus 2 --steps 10 --no-cpu --no-cull 2>/dev/null | tail -1) > gpurun_out/$TAG/bench_2ranks_dry_run.json
 # forced list-bin sizes against the per-mesh rule
-(timeout 500 python tools/list_shift_ab.py "C3 C2 C3T C5" "1 3 4 5 auto" 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/list_shift_ab.txt
+[ -z "$GS_EVIDENCE_LIGHT" ] && (timeout 500 python tools/list_shift_ab.py "C3 C2 C3T C5" "1 3 4 5 auto" 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/list_shift_ab.txt
 # FILE -> native reader -> sort -> draw at BASELINE size: a 5.8 M-splat INRIA .ply staged on the box (synthetic content, real format)
-(timeout 600 python tools/stage_ply.py C3 /tmp/gsdata 2>&1 | grep -v amdgpu.ids; GS_DATA_DIR=/tmp/gsdata timeout 500 python bench.py --only-headline --no-cpu 2>/dev/null | tail -1; rm -rf /tmp/gsdata) > gpurun_out/$TAG/bench_from_file.txt
-cp gpurun_out/crops_C*.json gpurun_out/$TAG/ 2>/dev/null
+[ -z "$GS_EVIDENCE_LIGHT" ] && (timeout 600 python tools/stage_ply.py C3 /tmp/gsdata 2>&1 | grep -v amdgpu.ids; GS_DATA_DIR=/tmp/gsdata timeout 500 python bench.py --only-headline --no-cpu 2>/dev/null | tail -1; rm -rf /tmp/gsdata) > gpurun_out/$TAG/bench_from_file.txt
+(timeout 60 tools/probes/lookback_probe.bin 5800000 20; timeout 60 tools/probes/lookback_probe.bin 270000 20) > gpurun_out/$TAG/lookback_probe.txt 2>&1
+cp gpurun_out/crops_C*.json gpurun_out/whole_frame_*.json gpurun_out/$TAG/ 2>/dev/null
 cat gpurun_out/$TAG/pytest_gpu.txt; head -c 700 gpurun_out/$TAG/bench.json; echo; head -14 gpurun_out/$TAG/kstats.txt; cat gpurun_out/$TAG/pmc_traffic.txt | tail -3; cat gpurun_out/$TAG/strip_scaling.txt

@@ -489,7 +489,11 @@ const uint32_t* gs_mesh_payload_map(gs_mesh* m, uint32_t splats);
 const uint32_t* gs_mesh_payload_unmap(gs_mesh* m);
 
 // kernels' host launchers ---------------------------------------------------------------------------
-int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask);
+// (ev_before / ev_after, nullable, recorded on ctx->aux: around the whole vertex stage - block test, mask memset, k_project - when
+// whole_stage (a timed draw's project_ms), else right around k_project itself, so that gs_mesh_kernel_time, the bench's live
+// roofline clock over the untimed frames of its timed region, times that one kernel)
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, hipEvent_t ev_before = nullptr, hipEvent_t ev_after = nullptr,
+                      bool whole_stage = false);
 int gs_launch_binning(gs_mesh* m, const ProjectParams& pp, const uint32_t* order_dev, gs_sorter* sorter, uint32_t render_count);
 int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev);
 int gs_launch_rop8_window(gs_mesh* m, const ProjectParams& pp, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t* out_dev);

@@ -665,9 +665,7 @@ static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, boo
         m->ev_p1 = m->ring1[slot];
     }
     m->timed_project = sample;
-    if (sample) GS_HIP(hipEventRecord(m->ev_p0, aux));
-    GS_TRY(gs_launch_project(m, pp, orig_mask));
-    if (sample) GS_HIP(hipEventRecord(m->ev_p1, aux));
+    GS_TRY(gs_launch_project(m, pp, orig_mask, sample ? m->ev_p0 : nullptr, sample ? m->ev_p1 : nullptr, timed));
     return GS_OK;
 }
 

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_pr
     }
 }
 
-int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
+int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, hipEvent_t ev_before, hipEvent_t ev_after, bool whole_stage) {
     MeshPlanes mp;
     mp.px = m->px.as<float>(); mp.py = m->py.as<float>(); mp.pz = m->pz.as<float>();
     mp.covA = m->covA.p; mp.covB = m->covB.p;
@@ -597,7 +597,11 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     mp.sh0 = m->sh0.as<uint4>(); mp.sh1 = m->sh1.p; mp.sh2 = m->sh2.as<uint4>();
     mp.scene_idx = m->scene_idx.as<uint32_t>();
     mp.scenes = m->scene_dev.as<gs_scene_params>();
-    if (pp.count == 0) return GS_OK;
+    if (pp.count == 0) {
+        if (ev_before) GS_HIP(hipEventRecord(ev_before, m->ctx->aux));
+        if (ev_after) GS_HIP(hipEventRecord(ev_after, m->ctx->aux));
+        return GS_OK;
+    }
     const uint32_t blocks = (pp.count + 255u) / 256u;
     // (a scene that was mostly in view at its last MEASURED draw - truck-like C2: 36.0 us with the separate test, 33.3 without; C4,
     // every splat visible: 262 vs 252 - keeps the per-workgroup test: the separate kernel buys nothing there and costs a launch)
@@ -606,6 +610,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     const bool test = pp.block_cull && (!mostly_live || strip);
     const bool pretest = test && !m->no_block_list;
     const int mode = pretest ? 1 : (test ? 0 : 2);
+    if (ev_before && whole_stage) GS_HIP(hipEventRecord(ev_before, m->ctx->aux));
     if (pretest)
         hipLaunchKernelGGL(k_block_test, dim3((blocks + 31u) / 32u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,
                            m->vis_mask.as<unsigned long long>(), m->vis32.as<uint2>(), m->block_any.as<uint8_t>());
@@ -631,6 +636,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
                            m->prect.as<uint2>(), m->zrec.as<float>());
     };
     const bool depth = pp.depth_mode != 0u;
+    if (ev_before && !whole_stage) GS_HIP(hipEventRecord(ev_before, m->ctx->aux));
 #define GS_PROJECT_LAUNCH(E, D)                                                                                  \
     do {                                                                                                         \
         if (mode == 1) launch(k_project<E, 1, D>);                                                               \
@@ -642,6 +648,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask) {
     else if (depth) GS_PROJECT_LAUNCH(false, true);
     else GS_PROJECT_LAUNCH(false, false);
 #undef GS_PROJECT_LAUNCH
+    if (ev_after) GS_HIP(hipEventRecord(ev_after, m->ctx->aux));
     GS_HIP(hipGetLastError());
     return GS_OK;
 }

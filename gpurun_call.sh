@@ -1,4 +1,14 @@
-cd /root/repo; mkdir -p gpurun_out/r05m; O=gpurun_out/r05m
-(timeout 500 python tools/ab_libs.py "C3 C2 C4" gpurun_ab/lib_r04.so gpurun_ab/lib_nocap.so gpurun_ab/lib_cap96.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 3 2>&1 | grep -v amdgpu.ids) > $O/ab_sgpr.txt
-for L in gpurun_ab/lib_nocap.so gpurun_ab/lib_cap96.so gpurun_ab/lib_this_tree.so; do echo "== $L"; GSPLAT_HIP_LIB=$L python tools/project_floor.py C3 2>&1 | grep k_project; done > $O/project_floor_sgpr.txt
-cat $O/ab_sgpr.txt $O/project_floor_sgpr.txt
+cd /root/repo; mkdir -p gpurun_out/r05o; O=gpurun_out/r05o
+(timeout 900 python bench.py --steps 10 --warmup 3 2>$O/bench.err | tail -1) > $O/bench.json
+tail -5 $O/bench.err; python - <<'PY'
+import json
+d=json.load(open("gpurun_out/r05o/bench.json"))
+for k in ("value","ms_per_step","median_ms_per_step","frame_latency_ms"): print(k, d.get(k))
+print("config", {k:d["config"].get(k) for k in ("V_over_N","D_over_R")})
+print("roofline", d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
+print("cull_on", json.dumps(d.get("cull_on"))[:900])
+print("vis", json.dumps(d.get("visibility_cull_fused"))[:400])
+print("fused", json.dumps(d.get("frustum_cull_fused"))[:300])
+print("pipelined", json.dumps(d.get("pipelined"))[:500])
+print("cpu", json.dumps(d.get("cpu_baseline"))[:300])
+PY

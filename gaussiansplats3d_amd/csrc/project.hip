@@ -603,12 +603,18 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, hipEv
         return GS_OK;
     }
     const uint32_t blocks = (pp.count + 255u) / 256u;
-    // (a scene that was mostly in view at its last MEASURED draw - truck-like C2: 36.0 us with the separate test, 33.3 without; C4,
-    // every splat visible: 262 vs 252 - keeps the per-workgroup test: the separate kernel buys nothing there and costs a launch)
-    const bool mostly_live = !m->block_test_always && m->measured_count > 0u && (uint64_t)m->measured_visible * 5u > (uint64_t)m->measured_count * 3u;
+    // Where the block test runs, by the share of the splats that were in view at the mesh's last MEASURED full-frame draw (same box,
+    // tools/ab_libs.py, vertex stage): the separate k_block_test pays a launch (~5 us) to spare every dead block its workgroup's set-up,
+    // so it wins where most blocks are dead (C3, V/N 0.25: 58.0 -> 52.5 us; C2, 0.48: 35.0 against 35.9 inside the workgroups; any strip);
+    // a scene that is mostly in view keeps the test inside each workgroup (C3S, 0.65: 95.3 there vs 107.7 with no test at all); one
+    // that is all in view runs no test (C4, 0.998: 243.2 -> 219.2 us - the test's registers cost k_project a wave per SIMD).
+    // (profiles/r05z_ab_r03_vs_this_tree.txt, r05p_ab.txt)
+    const bool measured = m->measured_count > 0u;
+    const bool all_live = measured && (uint64_t)m->measured_visible * 10u > (uint64_t)m->measured_count * 9u;
+    const bool half_live = measured && !all_live && (uint64_t)m->measured_visible * 20u > (uint64_t)m->measured_count * 11u;
     const bool strip = pp.row_begin > 0u || pp.row_end < pp.tiles_y;     // (a strip of a scene that is mostly in view still drops most blocks)
-    const bool test = pp.block_cull && (!mostly_live || strip);
-    const bool pretest = test && !m->no_block_list;
+    const bool test = pp.block_cull && (!all_live || strip || m->block_test_always);
+    const bool pretest = test && !m->no_block_list && (!half_live || strip || m->block_test_always);
     const int mode = pretest ? 1 : (test ? 0 : 2);
     if (ev_before && whole_stage) GS_HIP(hipEventRecord(ev_before, m->ctx->aux));
     if (pretest)

@@ -1,14 +1,7 @@
-cd /root/repo; mkdir -p gpurun_out/r05o; O=gpurun_out/r05o
-(timeout 900 python bench.py --steps 10 --warmup 3 2>$O/bench.err | tail -1) > $O/bench.json
-tail -5 $O/bench.err; python - <<'PY'
-import json
-d=json.load(open("gpurun_out/r05o/bench.json"))
-for k in ("value","ms_per_step","median_ms_per_step","frame_latency_ms"): print(k, d.get(k))
-print("config", {k:d["config"].get(k) for k in ("V_over_N","D_over_R")})
-print("roofline", d["roofline"]["frac"], d["roofline"]["avg_launch_ms"])
-print("cull_on", json.dumps(d.get("cull_on"))[:900])
-print("vis", json.dumps(d.get("visibility_cull_fused"))[:400])
-print("fused", json.dumps(d.get("frustum_cull_fused"))[:300])
-print("pipelined", json.dumps(d.get("pipelined"))[:500])
-print("cpu", json.dumps(d.get("cpu_baseline"))[:300])
-PY
+#!/bin/bash
+mkdir -p gpurun_out/r05p
+cp gaussiansplats3d_amd/csrc/libgsplat_hip.so gpurun_ab/lib_this_tree.so
+(timeout 300 python tools/ab_libs.py "C3S C2 C4 C3" gpurun_ab/lib_r04.so gpurun_ab/lib_this_tree.so --frames 30 --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05p/ab.txt
+(timeout 300 python -m pytest tests/test_gpu_render.py tests/test_gpu_depth.py -q -m gpu 2>&1 | tail -3) > gpurun_out/r05p/pytest_subset.txt
+(timeout 420 python tests/tools/soak.py 80 51000 90000 2>&1 | grep -v amdgpu.ids) > gpurun_out/r05p/soak_destination.txt
+cat gpurun_out/r05p/ab.txt | cut -c1-170; cat gpurun_out/r05p/pytest_subset.txt; grep -c "^ok" gpurun_out/r05p/soak_destination.txt; grep -c destination gpurun_out/r05p/soak_destination.txt; grep "^FAIL\|^soak" gpurun_out/r05p/soak_destination.txt | head

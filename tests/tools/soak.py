@@ -4,7 +4,9 @@
     float centres alternating, and the frustum-culled sort = the full list minus the culled splats;
   * the frame against the fp32 raster oracle within the stated tolerance (tests/helpers.compare_frames);
   * three strips of tile rows == the full frame, byte for byte; the same frame from a context with streams of its own;
-  * a visibility-culled sort draws the same frame.
+  * a visibility-culled sort draws the same frame;
+  * every other scene: a random destination (depth planes with per-pixel noise or holes, fp32 or 24-bit, with or without colour)
+    against the oracle with the same destination (same tolerance), strips included.
 The oracle is the checker here, as in tests/ (this tool is test infrastructure, not product).
 
 usage: python tests/tools/soak.py [iterations=24] [first_seed=1000] [max_splats=60000]   -> one line per iteration, "soak: N iterations, 0 failures" """
@@ -79,6 +81,36 @@ for it in range(iters):
                 vis, _ = mesh.render()
                 assert np.array_equal(vis, full), "frame from the visibility-culled list differs"
                 w.set_visibility_cull(False)
+                # a destination (depth the host's own geometry left + its colour): the engine against the oracle with the same one,
+                # strips tile it; clearing it restores the plain frame
+                if rng.integers(0, 2):
+                    w.sort_on_device(cam.sort_mvp(), n)
+                    proj = oracle.project(ocam, c, cov, rgba, sh)
+                    zw = (proj["ndcz"] * np.float32(0.5) + np.float32(0.5)).astype(np.float32)
+                    seen = zw[proj["visible"] == 1]
+                    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+                    if seen.size:
+                        mid, spread = float(np.quantile(seen, rng.uniform(0.05, 0.6))), float(seen.std())
+                    else:
+                        mid, spread = 0.5, 0.1
+                    kind = int(rng.integers(0, 3))
+                    depth = mid + spread * rng.uniform(-0.3, 0.3) * ((xx - W / 2) / W + (yy - H / 2) / H)
+                    if kind == 1:
+                        depth = depth + spread * 0.2 * rng.standard_normal((H, W))            # per-pixel noise: no two pixels cut alike
+                    if kind == 2:
+                        depth = np.where(rng.random((H, W)) < 0.5, depth, 1.0)                  # holes pixel by pixel
+                    depth = np.clip(depth, 0.0, 1.0).astype(np.float32)
+                    unorm24 = bool(rng.integers(0, 2))
+                    dst = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8) if rng.integers(0, 2) else None
+                    mesh.set_destination(depth=depth, rgba=dst, depth_unorm24=unorm24)
+                    got_d, _ = mesh.render()
+                    fb_d, _, amb_d, _ = oracle.render(ocam, c, cov, rgba, sh, expect, depth=depth, depth_unorm24=unorm24, dst_rgba=dst)
+                    msg += " | " + helpers.compare_frames(got_d, fb_d, amb_d, f"destination kind {kind}{' unorm24' if unorm24 else ''}")
+                    parts = [mesh.render(tile_rows=(a, b))[0] for a, b in zip(cuts[:-1], cuts[1:])]
+                    assert np.array_equal(np.concatenate(parts, axis=0), got_d), "strips do not tile the depth-tested frame"
+                    mesh.set_destination()
+                    again, _ = mesh.render()
+                    assert np.array_equal(again, full), "clearing the destination does not restore the plain frame"
             w.terminate(); mesh.dispose()
         assert np.array_equal(frames["one stream"], frames["streams"]), "the default context's frame differs from the one-stream context's"
         print(f"ok   {label} | entries {st.tile_entries} visible {st.visible_splats} | {msg}", flush=True)

@@ -463,10 +463,13 @@ struct gs_mesh {
     gs_render_stats last = {};
     bool has_draw = false;
     uint32_t last_count = 0;
-    uint32_t* mirror_host = nullptr;   // mapped pinned {serial, overflow, entries lo, hi} written by every draw's k_bin_emit
+    uint32_t* mirror_host = nullptr;   // mapped pinned words written by every draw's k_bin_emit: [0..3] {serial, overflow, entries lo, hi},
+                                       // [4] bins over the deep pass's threshold, [6..7] {serial, visible splats}
     uint32_t* mirror_dev = nullptr;
     uint32_t draw_serial = 0, healed_serial = 0;
+    uint32_t full_serial[8] = {0, 0, 0, 0, 0, 0, 0, 0}, full_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last full-frame draws: serial (slot = serial & 7) and splats projected
     uint32_t project_serial = 0;
+    uint32_t last_project_mode = 1;       // gs_launch_project: 1 = k_block_test + k_project, 0 = the test in every workgroup, 2 = no test
     bool vis_orig_dirty = true;           // vis_orig may hold bits (cleared by the sort that consumes it, see k_mask_compact)
     uint32_t vis_orig_count = 0;          // splats the last gs_mesh_project looked at
     bool timed_project = false;           // the last vertex stage was bracketed with ev_p0 / ev_p1

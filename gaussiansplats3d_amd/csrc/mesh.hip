@@ -767,9 +767,21 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
 // then missing its farthest list entries.  Every draw leaves its verdict in mapped host memory (k_bin_emit), and the next
 // draw reads it here - no synchronisation when everything fitted.  After an overflow the buffers are grown to what that
 // draw needed (this waits for the stream once) and the caller is told with GS_WARN_FRAME_TRUNCATED.
+// The share of the scene in view, from the last FULL-frame draw whose verdict has arrived (an 8-byte store of k_bin_emit's into the
+// mapped words: {serial, visible}); only a hint for the vertex stage's launch shape (project.hip), frames do not depend on it.
+static void mesh_read_view_share(gs_mesh* m) {
+    volatile uint32_t* mir = m->mirror_host;
+    const uint32_t vs = mir[6], vv = mir[7];
+    if (vs != 0u && vs == m->full_serial[vs & 7u] && mir[6] == vs) {
+        m->measured_visible = vv;
+        m->measured_count = m->full_count[vs & 7u];
+    }
+}
+
 static int mesh_heal_overflow(gs_mesh* m, bool* healed) {
     *healed = false;
     volatile uint32_t* mir = m->mirror_host;
+    mesh_read_view_share(m);
     const uint32_t serial = mir[0];
     if (serial == m->healed_serial || !mir[1]) return GS_OK;
     const uint64_t need = ((uint64_t)mir[3] << 32) | mir[2];
@@ -957,6 +969,14 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count) {
         GS_REQUIRE(m->deep_flags.p && count >= 4 && count <= 4u + GS_DEEP_MAX_BINS, "no draw yet / count outside 4 .. 4 + GS_DEEP_MAX_BINS");
         GS_HIP(hipMemcpyAsync(dst, m->deep_flags.as<uint32_t>(), 16, hipMemcpyDeviceToHost, st));
         if (count > 4) GS_HIP(hipMemcpyAsync(static_cast<uint32_t*>(dst) + 4, m->deep_flags.as<uint32_t>() + GS_FLAG_LIST, (size_t)(count - 4) * 4, hipMemcpyDeviceToHost, st));
+    } else if (what == 6) {   // host state: {visible splats, splats projected} of the last full-frame draw whose verdict has arrived,
+                              // and where the last vertex stage ran its block test (1 separate kernel, 0 per workgroup, 2 nowhere)
+        GS_REQUIRE(count == 3, "count == 3");
+        GS_HIP(hipStreamSynchronize(st));
+        mesh_read_view_share(m);                           // (the mapped words the last draw left)
+        uint32_t* w = static_cast<uint32_t*>(dst);
+        w[0] = m->measured_visible; w[1] = m->measured_count; w[2] = m->last_project_mode;
+        return GS_OK;
     } else GS_REQUIRE(false, "unknown debug selector");
     GS_HIP(hipStreamSynchronize(st));
     return GS_OK;

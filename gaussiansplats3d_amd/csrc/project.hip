@@ -616,6 +616,7 @@ int gs_launch_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, hipEv
     const bool test = pp.block_cull && (!all_live || strip || m->block_test_always);
     const bool pretest = test && !m->no_block_list && (!half_live || strip || m->block_test_always);
     const int mode = pretest ? 1 : (test ? 0 : 2);
+    m->last_project_mode = (uint32_t)mode;
     if (ev_before && whole_stage) GS_HIP(hipEventRecord(ev_before, m->ctx->aux));
     if (pretest)
         hipLaunchKernelGGL(k_block_test, dim3((blocks + 31u) / 32u), dim3(256), 0, m->ctx->aux, pp, mp.block_box, blocks,

@@ -425,6 +425,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = {serial, D64 > capacity ? 1u : 0u, (uint32_t)D64, (uint32_t)(D64 >> 32)};
                 *reinterpret_cast<volatile u32x4*>(mirror) = v;
+                // ... and, as a second 8-byte store, {serial, visible splats}: what tells the vertex stage of the following draws how
+                // much of the scene is in view (project.hip: where the block test runs) without anybody asking for statistics
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 sv = {serial, s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]};
+                *reinterpret_cast<volatile u32x2*>(mirror + 6) = sv;
             }
         }
     }
@@ -532,6 +537,10 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                        m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
     m->blend_order_valid = order_ok;
     GS_HIP(hipGetLastError());
+    if (pp.row_begin == 0u && pp.row_end >= pp.tiles_y) {     // (a strip's visible count says nothing about the scene: mesh_heal_overflow)
+        m->full_serial[m->draw_serial & 7u] = m->draw_serial;
+        m->full_count[m->draw_serial & 7u] = pp.count;
+    }
     if (m->timed_draw) GS_HIP(hipEventRecord(m->ev[2], st));
 
     uint32_t bits = 1;

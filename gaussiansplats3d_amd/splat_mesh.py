@@ -298,6 +298,14 @@ class SplatMesh:
         return {"bins": out[4:4 + int(out[0])].copy(), "candidates": int(out[1]), "chunks_closed_by_bins": int(out[2]),
                 "pool_exhausted": bool(out[3])}
 
+    def view_share(self):
+        """{visible, projected: of the last full-frame draw whose verdict has reached the host (a mapped word, no statistics call
+        needed), block_test: where the last vertex stage ran its block test - 1 a kernel of its own, 0 in every workgroup, 2 nowhere}.
+        Scheduling only: frames do not depend on it."""
+        out = np.zeros(3, dtype=np.uint32)
+        L.check(self.lib.gs_mesh_debug_read(self.handle, 6, out.ctypes.data, 3))
+        return {"visible": int(out[0]), "projected": int(out[1]), "block_test": int(out[2])}
+
     def tile_row_costs(self):
         """Work estimate per 16-px tile row of the last FULL-frame draw (used to balance multi-GPU strips).  The blend is
         what a strip mostly pays for and its cost is what it WALKS before its pixels saturate, not the length of its lists:

@@ -400,7 +400,9 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam);
  * splat packed in uint64 words (count = number of words); 4 = per 32x32-px blend bin of the drawn strip (row-major,
  * bins_x = ceil(width / 32)) the pair {list entries scanned, 2 x (splat, 16x16-px quadrant) pairs composited}: the blend's
  * real cost, used to balance multi-GPU strips; 5 = the deep pass of the last draw: {bins it composited, bins over its threshold,
- * chunk partials the per-bin kernel closed itself, 1 if that pool ran out}, then the bin numbers (count = 4 .. 4 + 512 words).
+ * chunk partials the per-bin kernel closed itself, 1 if that pool ran out}, then the bin numbers (count = 4 .. 4 + 512 words);
+ * 6 = host state (count = 3 words): {visible splats, splats projected} of the last full-frame draw whose verdict has reached the
+ * host, and where the last vertex stage ran its block test (1 = a kernel of its own, 0 = in every workgroup, 2 = not at all).
  *
  * The composite (csrc/tile_blend.hip).  Per 16x16-px quadrant, the ordered list entries whose ellipse reaches the quadrant are
  * cut into chunks of 1024; a chunk is the plain front-to-back composite from T = 1, and the chunks are merged near -> far

@@ -681,3 +681,36 @@ def test_live_block_list_and_per_workgroup_block_tests_draw_the_same_frame(ctx, 
         assert a[1] == b[1] and a[2] == b[2]
         for x, y in zip((a[0], a[3], a[4], a[5]), (b[0], b[3], b[4], b[5])):
             np.testing.assert_array_equal(x, y)
+
+
+def test_asynchronous_draws_learn_how_much_of_the_scene_is_in_view(ctx):
+    """Where the vertex stage runs its block test depends on the share of the splats in view at the last full-frame draw; draws that
+    never ask for statistics learn it from a mapped word k_bin_emit leaves (mesh.hip, mesh_read_view_share).  A scene seen whole ends
+    up without a block test, the same scene seen from inside with the separate kernel - and the frames are the ones a
+    statistics-reading mesh draws."""
+    import torch
+    w, h = 320, 200
+    scene = helpers.small_scene(30000, 0, seed=91, scale=0.03)
+    order = np.arange(scene.count, dtype=np.uint32)
+    up, pos, look = (np.asarray(v, dtype=np.float64) for v in camera.DEMO_POSES["garden"])
+    fwd = (look - pos) / np.linalg.norm(look - pos)
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    for eye, expect in ((pos - fwd * 6.0, 2), (pos + fwd * 6.0, 1)):        # the whole slab in view (99.8 %) / from inside it (14 %)
+        cam = camera.PerspectiveCamera(w, h, tuple(eye), tuple(eye + fwd), tuple(up))
+        ref_mesh = SplatMesh(ctx, scene.count, 0).build(scene.centers, scene.cov, scene.rgba, None)
+        ref_mesh.set_camera(cam)
+        ref_mesh.update_render_indexes(order, scene.count)
+        ref, st = ref_mesh.render()
+        share = st.visible_splats / scene.count
+        assert (share > 0.95) if expect == 2 else (share < 0.3), share
+        mesh = SplatMesh(ctx, scene.count, 0).build(scene.centers, scene.cov, scene.rgba, None)
+        mesh.set_camera(cam)
+        mesh.update_render_indexes(order, scene.count)
+        for _ in range(4):
+            mesh.render(out_device_ptr=out.data_ptr(), want_stats=False, to_host=False)     # asynchronous: no statistics, device output
+            torch.cuda.synchronize()
+        info = mesh.view_share()
+        assert info["projected"] == scene.count and info["visible"] == st.visible_splats, (info, st.visible_splats)
+        assert info["block_test"] == expect, info
+        assert np.array_equal(out.cpu().numpy(), ref)
+        ref_mesh.dispose(); mesh.dispose()

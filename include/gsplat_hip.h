@@ -374,7 +374,9 @@ int gs_mesh_render(gs_mesh* m, const gs_camera* cam, const uint32_t* sorted_host
  * Host buffers are copied to the device by this call (it returns when they are reusable); device buffers are READ BY EVERY
  * FOLLOWING DRAW until the destination is replaced or cleared (dest == NULL) - the caller keeps them alive and orders its
  * writes to them before the draws (same stream or an event).  A multi-GPU strip reads its own rows of the full-size buffers.
- * Draw modes and outputs are unchanged; frames stay bit-identical across strips and across the deep pass. */
+ * Draw modes and outputs are unchanged; frames stay bit-identical across strips and across the deep pass.
+ * The call waits for the mesh's draws in flight (they read the previous destination).  A descriptor that is refused (both a host
+ * and a device pointer for one plane, unknown flags, a size of 0 or beyond 65536 px) leaves the mesh WITHOUT a destination. */
 #define GS_DEST_DEPTH_UNORM24 1u
 typedef struct gs_destination {
     const float* depth_host;

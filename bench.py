@@ -943,11 +943,16 @@ def main():
             raise SystemExit("bench.py: no k_project launch was timed (GSPLAT_KERNEL_SAMPLE=0?)")
         k_ms = proj_ms_sum / proj_launches
         k_gbs = kb / (k_ms * 1e-3) / 1e9
-        roof_note = None
+        # (since round 5 the per-block frustum test of the vertex stage is a kernel of its own, k_block_test, ~5 us and ~2 MB in front of
+        # k_project: the live clock and the algorithmic bytes here are k_project's alone, as rocprofv3 lists it; the whole vertex stage
+        # is frame.stage_ms_isolated_frame.project)
+        roof_note = ("k_project alone (events right around its launch; rocprofv3's average for the same kernel is a few us lower: the "
+                     "two event packets); k_block_test (~5 us, ~2 MB) runs in front of it and is part of "
+                     "frame.stage_ms_isolated_frame.project")
         if world > 1:
             # a rank projects all N centres but only its strip's survivors: the kernel's algorithmic bytes are the rank's
             # own; reported for rank 0
-            roof_note = "rank 0's launch: all N centres, the survivors of its own strip (visible_splats is the full frame's)"
+            roof_note += "; rank 0's launch: all N centres, the survivors of its own strip (visible_splats is the full frame's)"
         traffic, traffic_src = pmc_traffic("k_project", headline) if world == 1 else (None, None)
         frame_traffic, frame_traffic_src = pmc_frame_traffic(headline) if world == 1 else (None, None)
         walked, scanned, halves = int(st_probe.splats_walked), int(st_probe.entries_scanned), int(st_probe.halves_evaluated)

@@ -3,10 +3,11 @@
 // The reference has no binning: it draws one instanced quad per splat, back to front, and lets the ROPs blend
 // (/root/reference/src/splatmesh/SplatGeometry.js:11-37, SplatMaterial3D.js:65-75, src/Viewer.js:1616).  A
 // tile rasteriser needs each tile's splats as a list in that same draw order, so:
-//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p).  A visibility table written by k_project (8 bytes
-//                 per 32 splats, 1.45 MB for 5.8 M splats: L2 resident) filters the list before anything is gathered;
-//                 only survivors gather their 8-byte tile rect.  Survivors are compacted (wave64 ballot + popcount
-//                 prefix) into the workgroup's own slice of a (index, rect) list, and entry counts are reduced.
+//   k_bin_count   walk the sorted index list NEAR->FAR (q = R-1-p).  One flag per 256-splat storage block (block_any, kept as a
+//                 bitmap in LDS) filters the list before anything is gathered; a position of a live block gathers ONE 8-byte
+//                 word written by k_project - {visible, record slot in the block, tile rect}.  Survivors are compacted
+//                 (wave64 ballot + popcount prefix) into the workgroup's own slice of a (slot, rect, offset) list, and
+//                 entry counts are reduced.  The kernel runs at the machine's random-gather rate.
 //   k_bin_emit    splat-centric expansion into (list bin, record slot) pairs, one lane per surviving splat, runs
 //                 written at the offsets the count pass fixed; each workgroup scans the binning workgroups' counts itself
 //                 (no scan kernel) and takes batches of 256 splats round-robin, so the near end of the list - whose splats

@@ -230,7 +230,7 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
     // dead waves of live blocks skip their centre loads and the shader) is slower as well: the test costs every live wave ~60
     // instructions and a 32-byte read, and Morton blocks are already nearly all-or-nothing (C3 59.5 -> 62.8 us, C2 34.0 -> 37.5,
     // C4 262 -> 300).
-    if (TEST && pp.block_cull) {                   // (with a list k_block_test has decided already)
+    if (TEST && pp.block_cull) {                   // (MODE 0 only: in MODE 1 k_block_test has decided already)
         __shared__ uint32_t s_dead;
         bool wave_dead = false;
         if (GS_BLOCK_TEST_PER_WAVE || threadIdx.x < 64u) {
@@ -568,9 +568,11 @@ __device__ __forceinline__ void project_block(const ProjectParams& pp, const Mes
 // boundaries and the test kernel are), so the full grid stays.
 // amdgpu_num_sgpr(80): left alone the compiler takes 106 scalar registers, and MI355X admits 256-thread workgroups per CU by
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) - 6 at 106, 7 at 86 (round 4's kernel), 8 at <= 80 (MI355X_MICROARCH.md, residency).
-// MODE 0: every workgroup tests its own block (rounds 2-4; $GSPLAT_NO_BLOCK_LIST);  1: k_block_test has decided;  2: no block test
-// at all (per-scene transforms, or a full-frame draw of a scene that was mostly in view at its last measured draw: the test finds
-// nothing to drop there, and its code costs the all-visible launch scalar registers - C4 250 -> 278 us with it compiled in, r05m).
+// MODE 0: every workgroup tests its own block (rounds 2-4; a full-frame draw of a scene that is 55-90 % in view, or
+// $GSPLAT_NO_BLOCK_LIST);  1: k_block_test has decided (the default, any strip, $GSPLAT_BLOCK_TEST_ALWAYS);  2: no block test at all
+// (per-scene transforms, or a full-frame draw of a scene that was > 90 % in view at its last full-frame draw: the test finds nothing
+// to drop there, and its code costs the all-visible launch scalar registers - C4 250 -> 278 us with it compiled in, r05m).  The
+// rule and its measurements: gs_launch_project below.
 template <bool EXT, int MODE, bool DEPTH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_project(ProjectParams pp, MeshPlanes mp, SplatRec* __restrict__ recs,
                                                  uint2* __restrict__ rects, unsigned long long* __restrict__ vis_mask,

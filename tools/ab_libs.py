@@ -2,7 +2,8 @@
 generated once, every library is dlopen'ed under its own path and measured in turn, `rounds` times interleaved.
 
 usage: python tools/ab_libs.py "C3 C3T" lib_a.so lib_b.so ... [--frames 40] [--rounds 2]
-prints per (config, library): one-stream ms per frame (unbracketed region) and the isolated-frame stage medians."""
+prints per (config, library): one-stream ms per frame (unbracketed region), the isolated-frame stage medians and the CRC-32 of the
+frame (libraries that must draw the same bits can be compared at a glance)."""
 import argparse
 import os
 import sys
@@ -59,6 +60,10 @@ def measure(scene, cfg, frames):
         st["esort"].append(r.tile_sort_ms); st["blend"].append(r.blend_ms)
     out = {k: float(np.median(v)) for k, v in st.items()}
     out["ms"] = ms
+    import zlib
+    w.sort_on_device(mvp, N)
+    img, _ = mesh.render(to_host=True, want_stats=True)
+    out["crc"] = zlib.crc32(img.tobytes())
     out["halves"] = int(getattr(r, "halves_evaluated", 0))
     out["walked"] = int(r.splats_walked)
     w.terminate(); mesh.dispose(); ctx.close()
@@ -79,9 +84,9 @@ def main():
             for lib in a.libs:
                 use_library(lib)
                 r = measure(scene, cfg, a.frames)
-                print("%-4s %-28s frame %.4f ms | sort %.4f project %.4f bin %.4f esort %.4f blend %.4f | walked %d halves %d" %
+                print("%-4s %-28s frame %.4f ms | sort %.4f project %.4f bin %.4f esort %.4f blend %.4f | walked %d halves %d | frame crc %08x" %
                       (name, os.path.basename(lib), r["ms"], r["sort"], r["project"], r["bin"], r["esort"], r["blend"],
-                       r["walked"], r["halves"]), flush=True)
+                       r["walked"], r["halves"], r["crc"]), flush=True)
         del scene
 
 

@@ -373,6 +373,8 @@ struct gs_mesh {
     uint32_t list_shift = GS_LIST_SHIFT_LARGE;     // list-bin size of the next draw (mesh_collect_stats re-evaluates it)
     uint32_t drawn_list_shift = GS_LIST_SHIFT_LARGE;   // ... of the last draw (what tile_ranges / the statistics refer to)
     ProjectParams last_pp = {};                    // the last draw's geometry (gs_mesh_debug_rop8 walks its lists)
+    ProjectParams stats_pp = {};                   // ... of the draw that wrote blend_stats (set once that draw is enqueued)
+    bool stats_pp_valid = false;
     int forced_list_shift = -1;                    // GSPLAT_LIST_SHIFT (A/B and tests)
     uint32_t max_count = 0, sh_degree = 0, flags = 0, uploaded = 0;
     // SoA planes

@@ -688,6 +688,8 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     GS_TRY(gs_launch_binning(m, pp, order_dev, sorter, R));   // records ev[2] between emit and the tile sort
     if (timed) GS_HIP(hipEventRecord(m->ev[3], st));
     GS_TRY(gs_launch_blend(m, pp, out_dev));
+    m->stats_pp = pp;                                          // whose view the per-bin blend statistics now describe
+    m->stats_pp_valid = true;
     if (timed) {
         GS_HIP(hipEventRecord(m->ev[4], st));
         GS_HIP(hipEventRecord(m->ev[5], st));

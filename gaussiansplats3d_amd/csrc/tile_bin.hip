@@ -521,6 +521,18 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
                           m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
+    // ... and they ORDER this draw's blend workgroups only when that draw had THIS draw's view.  Heaviest-first from statistics of
+    // the same view is worth 5-8 % of a frame (C3 demo pose 0.261 -> 0.248 ms, the orbit's poses held fixed 0.350 -> 0.322); from
+    // a view 6 degrees away it is worth less than the workgroup that computes it costs - a moving camera draws its frames faster
+    // in plain row-major order (C3 orbit 0.359 -> 0.349 ms per frame, C2 0.264 -> 0.255; profiles/r06g_orbit_gate.txt).  Two
+    // stateless orders were built and measured as well, both no better than row-major: by the length of the list a bin scans (a
+    // long list is a dense region that saturates at once: C2 fixed pose 0.327 vs 0.318 ms without any order, r06c) and a stride
+    // permutation that makes the late starters a uniform sample of the screen (r06e: 0.3624 vs 0.3625).  The deep pass's
+    // membership (which executor composites a bin, not when) keeps using the statistics of whatever view came before.
+    const ProjectParams& lp = m->stats_pp;
+    const bool same_view = m->stats_pp_valid && memcmp(lp.view, pp.view, sizeof(pp.view)) == 0 && memcmp(lp.proj, pp.proj, sizeof(pp.proj)) == 0 &&
+                           lp.width == pp.width && lp.height == pp.height && lp.count == pp.count && lp.list_shift == pp.list_shift;
+    const bool stale_order = getenv("GSPLAT_BLEND_ORDER_STALE") != nullptr;   // (A/B: rounds 2-5 - order from whatever draw came before)
     // The deep pass runs when the last draw whose verdict has arrived (mapped host word, no synchronisation) left bins over the
     // threshold - the decision only moves work between executors, the pixels do not depend on it (tile_blend.hip)
     m->deep_pass = order_ok && !m->no_deep && m->mirror_host && ((volatile uint32_t*)m->mirror_host)[4] > 0u;
@@ -530,13 +542,16 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_TRY(m->deep_partial.ensure((size_t)GS_DEEP_UNITS * 256 * sizeof(float4)));
         GS_TRY(m->deep_work.ensure((size_t)GS_DEEP_UNITS * 4));
     }
-    // (+ one workgroup that only orders the blend's bins)
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_ok ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
+    // (+ one workgroup that orders the blend's bins and names the deep pass's members)
+    // (that workgroup also raises the deep pass's trigger, so under a camera that keeps moving it still runs when the pass is on,
+    // for scenes of tiny splats - the ones that grow deep bins - and every 8th draw otherwise)
+    const bool order_wg = order_ok && (same_view || stale_order || m->deep_pass || pp.list_shift == GS_LIST_SHIFT_SMALL || (m->draw_serial & 7u) == 7u);
+    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_wg ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
                        m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                        m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
-                       order_ok ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_ok ? m->blend_order.as<uint32_t>() : nullptr,
+                       order_wg ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
                        m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
-    m->blend_order_valid = order_ok;
+    m->blend_order_valid = order_ok && (same_view || stale_order);
     GS_HIP(hipGetLastError());
     if (pp.row_begin == 0u && pp.row_end >= pp.tiles_y) {     // (a strip's visible count says nothing about the scene: mesh_heal_overflow)
         m->full_serial[m->draw_serial & 7u] = m->draw_serial;

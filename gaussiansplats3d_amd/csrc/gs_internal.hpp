@@ -447,9 +447,10 @@ struct gs_mesh {
     static constexpr int TIMING_RING = 128;
     hipEvent_t ring0[TIMING_RING] = {}, ring1[TIMING_RING] = {};
     bool ring_used[TIMING_RING] = {};
+    bool ring_whole[TIMING_RING] = {};             // the slot brackets the whole vertex stage (a timed draw), not k_project alone
     uint32_t ring_next = 0;
-    double proj_sum_ms = 0.0;
-    uint32_t proj_launches = 0;
+    double proj_sum_ms = 0.0, stage_sum_ms = 0.0;  // k_project alone (sampled draws) | block test + mask memset + k_project (timed draws)
+    uint32_t proj_launches = 0, stage_launches = 0;
     hipEvent_t ev_done = nullptr;                  // end of the last draw that read THIS set of vertex-stage outputs (on ctx->stream)
     // The vertex stage's outputs exist twice on a context with streams of its own: the vertex stage of frame k + 1 writes the set
     // frame k - 1 drew from while frame k is still binned and blended from the other one (mesh_project swaps the two; every field
@@ -485,6 +486,9 @@ struct gs_mesh {
     const float* dest_depth = nullptr;             // float [dest_h][dest_w] window depth, or nullptr
     const uint32_t* dest_rgba = nullptr;           // RGBA8 [dest_h][dest_w], or nullptr
     uint32_t dest_w = 0, dest_h = 0, dest_flags = 0;
+    const float* drawn_dest_depth = nullptr;       // ... as the last draw saw it (gs_mesh_debug_rop8 refuses a destination that
+    const uint32_t* drawn_dest_rgba = nullptr;     // changed since: it combines the mesh's destination with the last draw's geometry)
+    uint32_t drawn_dest_w = 0, drawn_dest_h = 0, drawn_dest_flags = 0;
 };
 
 int gs_selftest_lds_atomic_order(gs_context* ctx, bool* ok);

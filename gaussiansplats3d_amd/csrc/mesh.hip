@@ -654,13 +654,15 @@ static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, boo
         if (m->ring_used[slot]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, m->ring0[slot], m->ring1[slot]) == hipSuccess) {
-                m->proj_sum_ms += ms;
-                m->proj_launches++;
+                //  a timed draw brackets the whole vertex stage, a sampled one k_project alone: two clocks
+                if (m->ring_whole[slot]) { m->stage_sum_ms += ms; m->stage_launches++; }
+                else { m->proj_sum_ms += ms; m->proj_launches++; }
             } else {
                 (void)hipGetLastError();
             }
         }
         m->ring_used[slot] = true;
+        m->ring_whole[slot] = timed;
         m->ev_p0 = m->ring0[slot];
         m->ev_p1 = m->ring1[slot];
     }
@@ -690,6 +692,8 @@ static int mesh_draw_once(gs_mesh* m, const ProjectParams& pp, const uint32_t* o
     GS_TRY(gs_launch_blend(m, pp, out_dev));
     m->stats_pp = pp;                                          // whose view the per-bin blend statistics now describe
     m->stats_pp_valid = true;
+    m->drawn_dest_depth = m->dest_depth; m->drawn_dest_rgba = m->dest_rgba;      // the destination this draw saw (gs_mesh_debug_rop8)
+    m->drawn_dest_w = m->dest_w; m->drawn_dest_h = m->dest_h; m->drawn_dest_flags = m->dest_flags;
     if (timed) {
         GS_HIP(hipEventRecord(m->ev[4], st));
         GS_HIP(hipEventRecord(m->ev[5], st));
@@ -914,7 +918,7 @@ int gs_mesh_last_stats(gs_mesh* m, gs_render_stats* stats) {
 
 int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches) {
     GS_REQUIRE(m && sum_ms && launches, "mesh / outputs == NULL");
-    GS_REQUIRE(which == 0, "unknown kernel selector (0 = k_project)");
+    GS_REQUIRE(which == 0 || which == 1, "unknown selector (0 = k_project alone, 1 = the whole vertex stage of timed draws)");
     ScopedDevice sd(m->ctx->device);
     GS_HIP(hipStreamSynchronize(m->ctx->stream));
     if (m->ctx->aux != m->ctx->stream) GS_HIP(hipStreamSynchronize(m->ctx->aux));
@@ -922,15 +926,15 @@ int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32
         if (!m->ring_used[i]) continue;
         float ms = 0.f;
         GS_HIP(hipEventElapsedTime(&ms, m->ring0[i], m->ring1[i]));
-        m->proj_sum_ms += ms;
-        m->proj_launches++;
+        if (m->ring_whole[i]) { m->stage_sum_ms += ms; m->stage_launches++; }
+        else { m->proj_sum_ms += ms; m->proj_launches++; }
         m->ring_used[i] = false;
     }
-    *sum_ms = m->proj_sum_ms;
-    *launches = m->proj_launches;
+    *sum_ms = which == 0 ? m->proj_sum_ms : m->stage_sum_ms;
+    *launches = which == 0 ? m->proj_launches : m->stage_launches;
     if (reset) {
-        m->proj_sum_ms = 0.0;
-        m->proj_launches = 0;
+        m->proj_sum_ms = m->stage_sum_ms = 0.0;
+        m->proj_launches = m->stage_launches = 0;
         m->project_serial = 0;                              // the next launch is a measured one
     }
     return GS_OK;
@@ -1003,21 +1007,27 @@ int gs_mesh_set_destination(gs_mesh* m, const gs_destination* dest) {
     if (!any) return GS_OK;
     GS_REQUIRE(dest->width > 0 && dest->height > 0 && dest->width <= 4096u * GS_TILE && dest->height <= 4096u * GS_TILE, "destination size");
     const size_t px = (size_t)dest->width * dest->height;
+    //  staged in locals and committed together: a refused call - an allocation or a copy that fails half way - leaves
+    // the mesh WITHOUT a destination, as the header promises, not with a depth pointer and a size of 0
+    const float* new_depth = nullptr;
+    const uint32_t* new_rgba = nullptr;
     if (dest->depth_host) {
         GS_TRY(m->dest_depth_own.ensure(px * 4));
         GS_HIP(hipMemcpyAsync(m->dest_depth_own.p, dest->depth_host, px * 4, hipMemcpyHostToDevice, st));
-        m->dest_depth = m->dest_depth_own.as<float>();
+        new_depth = m->dest_depth_own.as<float>();
     } else if (dest->depth_dev) {
-        m->dest_depth = reinterpret_cast<const float*>(dest->depth_dev);
+        new_depth = reinterpret_cast<const float*>(dest->depth_dev);
     }
     if (dest->rgba_host) {
         GS_TRY(m->dest_rgba_own.ensure(px * 4));
         GS_HIP(hipMemcpyAsync(m->dest_rgba_own.p, dest->rgba_host, px * 4, hipMemcpyHostToDevice, st));
-        m->dest_rgba = m->dest_rgba_own.as<uint32_t>();
+        new_rgba = m->dest_rgba_own.as<uint32_t>();
     } else if (dest->rgba_dev) {
-        m->dest_rgba = reinterpret_cast<const uint32_t*>(dest->rgba_dev);
+        new_rgba = reinterpret_cast<const uint32_t*>(dest->rgba_dev);
     }
     GS_HIP(hipStreamSynchronize(st));                      // the host buffers are reusable on return
+    m->dest_depth = new_depth;
+    m->dest_rgba = new_rgba;
     m->dest_w = dest->width;
     m->dest_h = dest->height;
     m->dest_flags = dest->flags;
@@ -1033,6 +1043,11 @@ int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uin
     GS_REQUIRE(width > 0 && height > 0 && (uint64_t)width * height <= 65536u, "the window holds 1 .. 65536 pixels");
     const ProjectParams& pp = m->last_pp;
     GS_REQUIRE(x0 + width <= (uint32_t)pp.width && y0 >= pp.y0 && y0 + height <= pp.y1, "the window leaves the rows the last draw covered");
+    //  the walk reads the mesh's CURRENT destination with the LAST draw's width / height / depth mode: a destination
+    // set (or resized, or cleared) since that draw would be indexed out of bounds - and is not what the drawn frame saw
+    GS_REQUIRE(m->drawn_dest_depth == m->dest_depth && m->drawn_dest_rgba == m->dest_rgba && m->drawn_dest_w == m->dest_w &&
+               m->drawn_dest_h == m->dest_h && m->drawn_dest_flags == m->dest_flags,
+               "the destination changed since the last draw (gs_mesh_set_destination): draw again before gs_mesh_debug_rop8");
     ScopedDevice sd(m->ctx->device);
     hipStream_t st = m->ctx->stream;
     const size_t bytes = (size_t)width * height * 4;

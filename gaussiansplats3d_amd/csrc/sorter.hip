@@ -1152,10 +1152,11 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
         // A sort that does not consume the gathered list may destroy what a gather left for a later gs_sorter_sort_gathered
         // (ADVICE r04): a planned gather's fused copy ORs its keep bits into a mask the GATHER zeroed - a frustum-culled sort in
         // between rewrites that mask, so the copy falls back to the plain one + the ordinary key kernel; a list that was already
-        // copied into idx_in is gone once a host list or a compaction overwrites it.
+        // copied into idx_in is gone once a host list or a compaction overwrites it (the compaction: below, where the front end
+        // of a visibility-culled sort is chosen - ADVICE r05: the streaming one writes pay_in and leaves idx_in alone).
         if (s->pending_tree) {
             if (cull) s->pending_keep_zeroed = false;
-        } else if (indexes_to_sort || vis_cull) {
+        } else if (indexes_to_sort) {
             s->has_gathered = false;
         }
     }
@@ -1263,6 +1264,8 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             // kernel also reads the payload table (+4 bytes per splat) and runs at 2.8 TB/s where the pure reduction reaches 4.
             // $GSPLAT_VIS_FRONT = stream | compact forces one (A/B and tests).
             static const char* force = getenv("GSPLAT_VIS_FRONT");
+            // (projected_cam is the camera of the gs_mesh_project this sort consumes: the entry checks refused the call unless
+            // the bound mesh's projection_pending is set)
             const gs_camera& pc = s->bound_mesh->projected_cam;
             const uint32_t rows_total = (pc.height + GS_TILE - 1u) / GS_TILE;
             const bool strip = !(pc.tile_row_begin == 0u && (pc.tile_row_end == 0u || pc.tile_row_end >= rows_total));
@@ -1280,6 +1283,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 else hipLaunchKernelGGL(k_cull_front<false>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
                                         s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>());
             } else {
+                if (!s->pending_tree) s->has_gathered = false;     // k_mask_compact overwrites a gathered list that was already copied into idx_in
                 hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
                 hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),
                                    s->chunk_counts.as<uint32_t>(), R, chunk_len, s->idx_in.as<uint32_t>(), kp.frame);

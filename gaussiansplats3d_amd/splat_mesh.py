@@ -208,16 +208,34 @@ class SplatMesh:
             return self
         d = L.Destination()
         keep = []
+        if depth is not None and depth_device_ptr:
+            raise ValueError("pass the destination depth on the host OR on the device, not both")
+        if rgba is not None and rgba_device_ptr:
+            raise ValueError("pass the destination colour on the host OR on the device, not both")
+        shapes = []                                  # (width, height) every input implies: they must agree
+        if size is not None:
+            if len(size) != 2:
+                raise ValueError("size = (width, height)")
+            shapes.append((int(size[0]), int(size[1])))
         if depth is not None:
             a = np.ascontiguousarray(depth, dtype=np.float32)
-            size = (a.shape[1], a.shape[0])
+            if a.ndim != 2:
+                raise ValueError("depth must be a float32 array of shape [H, W], got %r" % (a.shape,))
+            shapes.append((a.shape[1], a.shape[0]))
             d.depth_host = a.ctypes.data
             keep.append(a)
         if rgba is not None:
             a = np.ascontiguousarray(rgba, dtype=np.uint8)
-            size = (a.shape[1], a.shape[0])
+            if a.ndim != 3 or a.shape[2] != 4:
+                raise ValueError("rgba must be a uint8 array of shape [H, W, 4], got %r" % (a.shape,))
+            shapes.append((a.shape[1], a.shape[0]))
             d.rgba_host = a.ctypes.data
             keep.append(a)
+        if not shapes:
+            raise ValueError("device pointers need size = (width, height)")
+        if any(sh != shapes[0] for sh in shapes):
+            raise ValueError("the destination's depth, colour and size disagree: %r" % (shapes,))
+        size = shapes[0]
         if depth_device_ptr:
             d.depth_dev = int(depth_device_ptr)
         if rgba_device_ptr:

@@ -427,7 +427,8 @@ int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uin
 int gs_mesh_set_deep_pass(gs_mesh* m, int enabled);
 
 /* Measurement hook: summed device duration (HIP events on the stream the kernel is launched on) and number of
- * launches of one kernel since the last reset.  which: 0 = k_project, the vertex stage.  Synchronises the streams.
+ * launches since the last reset.  which: 0 = k_project alone (the sampled untimed draws), 1 = the whole vertex stage (block
+ * test + mask reset + k_project) of the timed draws - two clocks, kept apart.  Synchronises the streams.
  * On a single-stream context without GS_CTX_STAGE_TIMING every 8th launch is measured ($GSPLAT_KERNEL_SAMPLE; the two event
  * records cost 1.5 % of a frame): `launches` counts the measured ones. */
 int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32_t* launches);

@@ -421,6 +421,9 @@ struct gs_mesh {
     DevBuf rect_q;             // uint2 [render_count] their rects, same layout as cidx
     DevBuf coff;               // uint32 [render_count] first entry slot of each, relative to its binning workgroup
     DevBuf bin_sums;           // uint32 [3][BIN_MAX_BLOCKS]: entries | visible splats | 16-px tiles per workgroup
+    DevBuf bin_scan;           // k_bin_fused's scan across the grid: uint64 granules {draw serial, value} [3][BIN_MAX_BLOCKS] per slice,
+                               // [3][BIN_MAX_BLOCKS / 32] per group of slices, then one uint32 `fail` word (tile_bin.hip)
+    bool bin_scan_ready = false;
     DevBuf ekeyA, ekeyB, evalA, evalB;   // tile entries ping-pong (key = tile id, val = splat index)
     DevBuf tile_ranges;        // uint2 [bins]
     DevBuf frame;              // RenderFrame

@@ -597,6 +597,15 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
         GS_HIP(hipStreamSynchronize(st));
         if (w[GS_FLAG_POOL_OVER]) m->last.flags |= GS_DRAW_POOL_EXHAUSTED;
     }
+    if (m->bin_scan_ready) {                               // k_bin_fused: a poll of the scan across its grid ran out of patience
+        uint32_t fail = 0;
+        GS_HIP(hipMemcpyAsync(&fail, (const char*)m->bin_scan.p + ((size_t)3 * 2048 + 3 * 64) * 8, 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (fail) {
+            gs_set_error("the binner's cross-workgroup scan timed out (k_bin_fused): the frame is incomplete");
+            return GS_ERR_HIP;
+        }
+    }
     m->last.entries_scanned = 0;
     m->last.splats_walked = 0;
     m->last.halves_evaluated = 0;

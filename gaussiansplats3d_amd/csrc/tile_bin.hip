@@ -71,65 +71,17 @@ extern "C" int gs_debug_bin_prof(void* dst) {
 #define BIN_PROF(k, slot, v) do { } while (0)
 #endif
 
-// (waves_per_eu 8: at 62 VGPRs the compiler reports 8 waves per SIMD, yet only 7 workgroups per CU became resident and the last
-// 256 of the 2048 started 10 us late - r02v timeline; with the attribute all start together: span 35.4 -> 33.0 us.
-// Dealing spans of 1024 positions round-robin instead of one contiguous chunk per workgroup, with a scan kernel between count
-// and emit, was tried as well: the entries per workgroup even out (max 1841 vs 3681) but the body time does not - 24.6 us max
-// either way, it is a chain of loaded memory round trips - and the extra kernel makes the C3 frame 3 us slower.)
-__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
-                                                           const uint32_t* __restrict__ R_dev /* nullable */,
-                                                           const uint32_t* __restrict__ perm,
-                                                           const uint2* __restrict__ prect,
-                                                           uint32_t* __restrict__ cidx,
-                                                           uint2* __restrict__ crect, uint32_t* __restrict__ coff,
-                                                           uint32_t* __restrict__ block_sums,
-                                                           uint32_t* __restrict__ digit_total,
-                                                           uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift,
-                                                           uint32_t splat_count, const uint8_t* __restrict__ block_any,
-                                                           uint32_t* __restrict__ deep_flags, uint32_t blend_bins) {
-    __shared__ unsigned long long s_w[4];
-    // Coarse visibility, one bit per 256-splat storage block, in LDS.  75 % of a scene's splats draw nothing and, stored along
-    // a Morton curve, mostly whole blocks of them; an LDS bit test spares those list positions the 8-byte L2 gather of their
-    // visibility word (5.8 M random L2 transactions per frame were this kernel's real cost: making the rects dense did nothing)
-    __shared__ uint32_t s_any[ANY_WORDS];
-    BIN_PROF(0, 0, wall_clock64());
-    const uint32_t blocks = (splat_count + 255u) >> 8;
-    const bool coarse = block_any != nullptr && blocks <= ANY_WORDS * 32u;
-    if (coarse) {
-        for (uint32_t w = threadIdx.x; w < (blocks + 31u) / 32u; w += BIN_THREADS) {
-            const uint4* src = reinterpret_cast<const uint4*>(block_any + 32u * w);      // the buffer is padded to 64 bytes
-            const uint4 a = src[0], b = src[1];
-            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            uint32_t bits = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++)                                                   // 4 flag bytes per word -> 4 bits
-                bits |= (((v[k] & 0xFFu) ? 1u : 0u) | ((v[k] & 0xFF00u) ? 2u : 0u) | ((v[k] & 0xFF0000u) ? 4u : 0u) |
-                         ((v[k] & 0xFF000000u) ? 8u : 0u)) << (4 * k);
-            s_any[w] = bits;
-        }
-        __syncthreads();
-    }
-    // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
-    // pass, reset the bin ranges.
-    {
-        const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
-        for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
-        for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
-        // the chunked composite's per-draw words: no deep bins (k_bin_emit names them), an empty partial pool
-        if (t < GS_FLAG_LIST) deep_flags[t] = 0u;
-        for (uint32_t w = t; w < blend_bins; w += stride) deep_flags[GS_FLAG_OF + w] = GS_DEEP_NONE;
-    }
-    // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
-    // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
-    const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
-    const BinChunk ch = bin_chunk(R);
-    BIN_PROF(0, 1, wall_clock64());
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
-        block_sums[3 * BIN_MAX_BLOCKS] = (batches + gridDim.x - 1) / gridDim.x;      // = bin_chunk()'s `per`
-    }
+// The count pass over one workgroup's slice [pos_begin, pos_end) of the near->far walk: filter, one gather per position of a live
+// block, compaction into the slice of (slot, rect, first entry) lists.  Shared by k_bin_count and k_bin_fused.
+struct SliceCount {
+    uint32_t entries, splats, t16;       // entries emitted by the slice | compacted (visible) splats | this LANE's 16-px tiles (statistics)
+};
+__device__ __forceinline__ SliceCount bin_count_slice(const uint32_t* __restrict__ order, uint32_t R, const uint32_t* __restrict__ perm,
+                                                      const uint2* __restrict__ prect, uint32_t* __restrict__ cidx, uint2* __restrict__ crect,
+                                                      uint32_t* __restrict__ coff, uint32_t list_shift, uint32_t splat_count,
+                                                      const uint8_t* __restrict__ block_any, bool coarse, const uint32_t* s_any,
+                                                      unsigned long long* s_w, uint32_t pos_begin, uint32_t pos_end) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t pos_begin = ch.begin * BIN_THREADS, pos_end = min(ch.end * BIN_THREADS, R);
     uint32_t sum = 0;                                      // entries emitted so far by this workgroup
     uint32_t out = pos_begin;                              // next slot of this workgroup's compacted slice
     uint32_t t16 = 0;                                      // 16-px tiles touched by this lane's splats (statistics only)
@@ -214,6 +166,73 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         sum += (uint32_t)total;
         __syncthreads();
     }
+    SliceCount sc;
+    sc.entries = sum; sc.splats = out - pos_begin; sc.t16 = t16;
+    return sc;
+}
+
+// (waves_per_eu 8: at 62 VGPRs the compiler reports 8 waves per SIMD, yet only 7 workgroups per CU became resident and the last
+// 256 of the 2048 started 10 us late - r02v timeline; with the attribute all start together: span 35.4 -> 33.0 us.
+// Dealing spans of 1024 positions round-robin instead of one contiguous chunk per workgroup, with a scan kernel between count
+// and emit, was tried as well: the entries per workgroup even out (max 1841 vs 3681) but the body time does not - 24.6 us max
+// either way, it is a chain of loaded memory round trips - and the extra kernel makes the C3 frame 3 us slower.)
+__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_count(const uint32_t* __restrict__ order, uint32_t R_host,
+                                                           const uint32_t* __restrict__ R_dev /* nullable */,
+                                                           const uint32_t* __restrict__ perm,
+                                                           const uint2* __restrict__ prect,
+                                                           uint32_t* __restrict__ cidx,
+                                                           uint2* __restrict__ crect, uint32_t* __restrict__ coff,
+                                                           uint32_t* __restrict__ block_sums,
+                                                           uint32_t* __restrict__ digit_total,
+                                                           uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift,
+                                                           uint32_t splat_count, const uint8_t* __restrict__ block_any,
+                                                           uint32_t* __restrict__ deep_flags, uint32_t blend_bins) {
+    __shared__ unsigned long long s_w[4];
+    // Coarse visibility, one bit per 256-splat storage block, in LDS.  75 % of a scene's splats draw nothing and, stored along
+    // a Morton curve, mostly whole blocks of them; an LDS bit test spares those list positions the 8-byte L2 gather of their
+    // visibility word (5.8 M random L2 transactions per frame were this kernel's real cost: making the rects dense did nothing)
+    __shared__ uint32_t s_any[ANY_WORDS];
+    BIN_PROF(0, 0, wall_clock64());
+    const uint32_t blocks = (splat_count + 255u) >> 8;
+    const bool coarse = block_any != nullptr && blocks <= ANY_WORDS * 32u;
+    if (coarse) {
+        for (uint32_t w = threadIdx.x; w < (blocks + 31u) / 32u; w += BIN_THREADS) {
+            const uint4* src = reinterpret_cast<const uint4*>(block_any + 32u * w);      // the buffer is padded to 64 bytes
+            const uint4 a = src[0], b = src[1];
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)                                                   // 4 flag bytes per word -> 4 bits
+                bits |= (((v[k] & 0xFFu) ? 1u : 0u) | ((v[k] & 0xFF00u) ? 2u : 0u) | ((v[k] & 0xFF0000u) ? 4u : 0u) |
+                         ((v[k] & 0xFF000000u) ? 8u : 0u)) << (4 * k);
+            s_any[w] = bits;
+        }
+        __syncthreads();
+    }
+    // The draw's housekeeping (no separate init kernel; these tables are idle now): zero the group rows of every entry-sort
+    // pass, reset the bin ranges.
+    {
+        const uint32_t t = blockIdx.x * BIN_THREADS + threadIdx.x, stride = gridDim.x * BIN_THREADS;
+        for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
+        for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
+        // the chunked composite's per-draw words: no deep bins (k_bin_emit names them), an empty partial pool
+        if (t < GS_FLAG_LIST) deep_flags[t] = 0u;
+        for (uint32_t w = t; w < blend_bins; w += stride) deep_flags[GS_FLAG_OF + w] = GS_DEEP_NONE;
+    }
+    // the grid is sized for the host's count; a list whose real length only exists on the device (frustum-culled sort)
+    // is spread over the same grid, and k_bin_emit learns the batches per workgroup from block_sums[3*BIN_MAX_BLOCKS]
+    const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
+    const BinChunk ch = bin_chunk(R);
+    BIN_PROF(0, 1, wall_clock64());
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS;
+        block_sums[3 * BIN_MAX_BLOCKS] = (batches + gridDim.x - 1) / gridDim.x;      // = bin_chunk()'s `per`
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t pos_begin = ch.begin * BIN_THREADS, pos_end = min(ch.end * BIN_THREADS, R);
+    const SliceCount sc = bin_count_slice(order, R, perm, prect, cidx, crect, coff, list_shift, splat_count, block_any, coarse, s_any, s_w, pos_begin, pos_end);
+    uint32_t t16 = sc.t16;
+    const uint32_t sum = sc.entries, out = pos_begin + sc.splats;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t16 += __shfl_xor(t16, o, 64);
     if (lane == 0) s_w[wave] = t16;                        // the loop's trailing barrier makes s_w reusable
@@ -227,6 +246,138 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     BIN_PROF(0, 3, (unsigned long long)sum);
 }
 
+// One batch of <= 256 compacted splats of a slice -> (list bin, record slot) entries from slot `base` on: a lane writes the first
+// EMIT_OWN entries of its own splat walking the rect row-major, what is left of the few splats that cover more list bins is written
+// by the whole wave.  src: this thread's position in the compacted lists; live: it holds a splat.  Returns the lane's entry count.
+constexpr uint32_t EMIT_OWN = 16;      // entries a lane writes for its own splat; longer runs are shared by the wave
+template <class KeyT>
+__device__ __forceinline__ uint32_t bin_emit_batch(const uint32_t* __restrict__ cidx, const uint2* __restrict__ crect, const uint32_t* __restrict__ coff,
+                                                   uint32_t src, bool live, uint32_t base, uint32_t limit, uint32_t tiles_x, uint32_t row_begin,
+                                                   uint32_t list_shift, KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
+        if (e >= limit) return;                              // dropped by an overflowing draw (it is redone)
+        keys_out[e] = (KeyT)key;
+        vals_out[e] = idx;
+    };
+    uint2 r = make_uint2(0u, 0u);
+    uint32_t idx = 0, e0 = 0, n = 0;
+    if (live) {
+        r = rect_to_bins(crect[src], list_shift);                    // the list bins the splat touches
+        idx = cidx[src];
+        e0 = base + coff[src];
+        n = rect_tiles(r);
+    }
+    const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, w = (r.y & 0xFFFFu) - x0 + 1u;
+    for (uint32_t k = 0, xx = x0, yy = y0; k < min(n, EMIT_OWN); k++) {     // row-major walk of the rect, no k / w, k % w
+        put(e0 + k, (yy - row_begin) * tiles_x + xx, idx);
+        if (++xx == x0 + w) { xx = x0; yy++; }
+    }
+    // the few near splats that cover many lists: all 64 lanes write one splat's remaining entries together
+    unsigned long long big = __ballot(n > EMIT_OWN);
+    while (big) {
+        const int sl = __builtin_ctzll(big);
+        big &= big - 1ull;
+        const uint32_t bn = __shfl(n, sl, 64), be0 = __shfl(e0, sl, 64), bidx = __shfl(idx, sl, 64);
+        const uint32_t bx0 = __shfl(x0, sl, 64), by0 = __shfl(y0, sl, 64), bw = __shfl(w, sl, 64);
+        const float inv_w = 1.0f / (float)bw;
+        for (uint32_t k = EMIT_OWN + lane; k < bn; k += 64u) {
+            uint32_t q = (uint32_t)((float)k * inv_w);               // k / bw: k < 2^24, so the estimate is off by <= 1
+            int32_t rem = (int32_t)(k - q * bw);
+            if (rem < 0) { q--; rem += (int32_t)bw; }
+            else if (rem >= (int32_t)bw) { q++; rem -= (int32_t)bw; }
+            put(be0 + k, (by0 + q - row_begin) * tiles_x + bx0 + (uint32_t)rem, bidx);
+        }
+    }
+    return n;
+}
+
+// The blend's schedule and the deep pass's members, one workgroup of BIN_THREADS (see where it is called: k_bin_emit / k_bin_fused)
+__device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins, uint32_t* __restrict__ blend_order,
+                                                   uint32_t deep, uint32_t* __restrict__ deep_flags, uint32_t* __restrict__ blend_stats_w,
+                                                   uint32_t deep_min, uint32_t deep_factor, volatile uint32_t* __restrict__ mirror) {
+    __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
+    // the chunked composite's per-draw words: no deep bins yet, an empty partial pool (k_bin_count resets them as well; in the fused
+    // launch this workgroup runs BESIDE the counting workgroups, so the reset has to be its own)
+    if (threadIdx.x < GS_FLAG_LIST) deep_flags[threadIdx.x] = 0u;
+    for (uint32_t w = threadIdx.x; w < blend_bins; w += BIN_THREADS) deep_flags[GS_FLAG_OF + w] = GS_DEEP_NONE;
+    __threadfence_block();
+    __syncthreads();
+    // three sweeps over the statistics, 8 loads in flight per lane (registers for all 8192 / 256 values would set the
+    // whole kernel's VGPR allocation and cost every emitting workgroup its occupancy)
+    constexpr uint32_t SWEEP = 8;
+    auto sweep = [&](auto&& use) {
+        for (uint32_t base = 0; base < blend_bins; base += SWEEP * BIN_THREADS) {
+            uint32_t c[SWEEP];
+#pragma unroll
+            for (uint32_t k = 0; k < SWEEP; k++) {
+                const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
+                c[k] = i < blend_bins ? prev_blend_stats[i].y : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < SWEEP; k++) {
+                const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
+                if (i < blend_bins) use(i, c[k]);
+            }
+        }
+    };
+    uint32_t sum = 0;
+    sweep([&](uint32_t, uint32_t c) { sum += c; });
+    uint32_t total_walked;
+    (void)block_excl_scan_256(sum, s_tmp2, &total_walked);
+    // 8-bit cost key scaled to the scene: the mean bin lands near 48 whatever the scene walks per bin
+    uint32_t shift = 0;
+    while (((total_walked / blend_bins) >> shift) > 48u) shift++;
+    s_cost[threadIdx.x] = 0u;
+    __syncthreads();
+    sweep([&](uint32_t, uint32_t c) { atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u); });
+    __syncthreads();
+    const uint32_t cnt_d = s_cost[threadIdx.x];
+    const uint32_t start = block_excl_scan_256(cnt_d, s_tmp2, nullptr);
+    s_cost[threadIdx.x] = start;
+    __syncthreads();
+    sweep([&](uint32_t i, uint32_t c) { blend_order[atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u)] = i; });
+    // The deep pass (tile_blend.hip): among the GS_DEEP_MAX_BINS costliest bins (the head of the order just written), the ones
+    // whose previous draw walked >= deep_min (splat, quadrant) pairs are composited by one wave per (quadrant, chunk) + a fold
+    // instead of by one workgroup - same pixels either way, so this is scheduling only.  Their count goes to the host (the NEXT
+    // draw launches the deep pass when it is non-zero); they are only named when THIS draw runs the pass.  Their statistics
+    // are then summed atomically by many waves: zeroed here.
+    // (a bin qualifies when it walked >= deep_min pairs AND >= deep_factor x the mean bin: the pass costs three launches, and
+    // only a tail that is long against the body of the frame pays for them - C3T's costliest bins are 3 x its mean and gain
+    // nothing, C3S's are 18 x; .y = half quadrants evaluated = 2 per pair, total_walked is their sum)
+    // Once the pass runs, more bins in it cost next to nothing, and every bin left behind is a workgroup that walks alone at the
+    // end of the launch: membership starts at 3/4 of the mean (and never below deep_min).
+    const uint32_t mean_halves = total_walked / max(blend_bins, 1u);
+    const uint32_t deep_trigger = max(2u * deep_min, deep_factor * mean_halves), deep_thr = max(2u * deep_min, mean_halves - mean_halves / 4u);
+    __shared__ uint32_t s_trigger;
+    if (threadIdx.x == 0) s_trigger = 0u;
+    __shared__ uint32_t s_deep_n;
+    if (threadIdx.x == 0) s_deep_n = 0u;
+    __threadfence_block();
+    __syncthreads();                                   // blend_order complete (and visible to this workgroup)
+    for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
+        const uint32_t i = __hip_atomic_load(&blend_order[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t cost = i < blend_bins ? prev_blend_stats[i].y : 0u;
+        if (cost >= deep_trigger) s_trigger = 1u;
+        if (cost >= deep_thr) {
+            const uint32_t k = atomicAdd(&s_deep_n, 1u);
+            if (deep) {
+                deep_flags[GS_FLAG_LIST + k] = i;
+                deep_flags[GS_FLAG_OF + i] = k;
+                blend_stats_w[2u * i] = 0u; blend_stats_w[2u * i + 1u] = 0u; blend_stats_w[2u * blend_bins + i] = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (a draw whose tail no longer reaches the trigger still runs the pass it was launched with - on the bins of the
+        // membership rule - and tells the next one to stop)
+        deep_flags[GS_FLAG_CAND] = s_trigger ? s_deep_n : 0u;
+        if (deep) deep_flags[GS_FLAG_COUNT] = s_deep_n;
+        if (mirror) mirror[4] = s_trigger ? s_deep_n : 0u;
+    }
+}
+
 // k_bin_emit: splat-centric expansion of the compacted list into (list bin, record slot) pairs.
 // Work unit = one batch of 256 compacted splats of one binning workgroup's slice; the units are dealt round-robin to the
 // workgroups.  (One workgroup per binning workgroup, the r01 shape, lasted as long as its heaviest slice: the slices that hold
@@ -237,8 +388,6 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 // [2*BIN_MAX_BLOCKS,..) its 16-px tiles | [3*BIN_MAX_BLOCKS] batches per binning workgroup.
 // Every workgroup scans the binning workgroups' sums itself (8 KB of hot L2 lines: cheaper than a one-workgroup scan kernel
 // and its two kernel boundaries); workgroup 0 publishes the RenderFrame scalars that the following kernels read.
-constexpr uint32_t EMIT_OWN = 16;      // entries a lane writes for its own splat; longer runs are shared by the wave
-
 template <class KeyT>
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restrict__ frame, uint32_t capacity,
                                                           const uint32_t* __restrict__ cidx,
@@ -267,80 +416,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     // keys is irrelevant (pixels do not depend on which workgroup draws a bin).
     const uint32_t first_wg = blend_order ? 1u : 0u;
     if (blend_order && blockIdx.x == 0) {
-        __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
-        // three sweeps over the statistics, 8 loads in flight per lane (registers for all 8192 / 256 values would set the
-        // whole kernel's VGPR allocation and cost every emitting workgroup its occupancy)
-        constexpr uint32_t SWEEP = 8;
-        auto sweep = [&](auto&& use) {
-            for (uint32_t base = 0; base < blend_bins; base += SWEEP * BIN_THREADS) {
-                uint32_t c[SWEEP];
-#pragma unroll
-                for (uint32_t k = 0; k < SWEEP; k++) {
-                    const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
-                    c[k] = i < blend_bins ? prev_blend_stats[i].y : 0u;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < SWEEP; k++) {
-                    const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
-                    if (i < blend_bins) use(i, c[k]);
-                }
-            }
-        };
-        uint32_t sum = 0;
-        sweep([&](uint32_t, uint32_t c) { sum += c; });
-        uint32_t total_walked;
-        (void)block_excl_scan_256(sum, s_tmp2, &total_walked);
-        // 8-bit cost key scaled to the scene: the mean bin lands near 48 whatever the scene walks per bin
-        uint32_t shift = 0;
-        while (((total_walked / blend_bins) >> shift) > 48u) shift++;
-        s_cost[threadIdx.x] = 0u;
-        __syncthreads();
-        sweep([&](uint32_t, uint32_t c) { atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u); });
-        __syncthreads();
-        const uint32_t cnt_d = s_cost[threadIdx.x];
-        const uint32_t start = block_excl_scan_256(cnt_d, s_tmp2, nullptr);
-        s_cost[threadIdx.x] = start;
-        __syncthreads();
-        sweep([&](uint32_t i, uint32_t c) { blend_order[atomicAdd(&s_cost[255u - min(c >> shift, 255u)], 1u)] = i; });
-        // The deep pass (tile_blend.hip): among the GS_DEEP_MAX_BINS costliest bins (the head of the order just written), the ones
-        // whose previous draw walked >= deep_min (splat, quadrant) pairs are composited by one wave per (quadrant, chunk) + a fold
-        // instead of by one workgroup - same pixels either way, so this is scheduling only.  Their count goes to the host (the NEXT
-        // draw launches the deep pass when it is non-zero); they are only named when THIS draw runs the pass.  Their statistics
-        // are then summed atomically by many waves: zeroed here.
-        // (a bin qualifies when it walked >= deep_min pairs AND >= deep_factor x the mean bin: the pass costs three launches, and
-        // only a tail that is long against the body of the frame pays for them - C3T's costliest bins are 3 x its mean and gain
-        // nothing, C3S's are 18 x; .y = half quadrants evaluated = 2 per pair, total_walked is their sum)
-        // Once the pass runs, more bins in it cost next to nothing, and every bin left behind is a workgroup that walks alone at the
-        // end of the launch: membership starts at 3/4 of the mean (and never below deep_min).
-        const uint32_t mean_halves = total_walked / max(blend_bins, 1u);
-        const uint32_t deep_trigger = max(2u * deep_min, deep_factor * mean_halves), deep_thr = max(2u * deep_min, mean_halves - mean_halves / 4u);
-        __shared__ uint32_t s_trigger;
-        if (threadIdx.x == 0) s_trigger = 0u;
-        __shared__ uint32_t s_deep_n;
-        if (threadIdx.x == 0) s_deep_n = 0u;
-        __threadfence_block();
-        __syncthreads();                                   // blend_order complete (and visible to this workgroup)
-        for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
-            const uint32_t i = __hip_atomic_load(&blend_order[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint32_t cost = i < blend_bins ? prev_blend_stats[i].y : 0u;
-            if (cost >= deep_trigger) s_trigger = 1u;
-            if (cost >= deep_thr) {
-                const uint32_t k = atomicAdd(&s_deep_n, 1u);
-                if (deep) {
-                    deep_flags[GS_FLAG_LIST + k] = i;
-                    deep_flags[GS_FLAG_OF + i] = k;
-                    blend_stats_w[2u * i] = 0u; blend_stats_w[2u * i + 1u] = 0u; blend_stats_w[2u * blend_bins + i] = 0u;
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // (a draw whose tail no longer reaches the trigger still runs the pass it was launched with - on the bins of the
-            // membership rule - and tells the next one to stop)
-            deep_flags[GS_FLAG_CAND] = s_trigger ? s_deep_n : 0u;
-            if (deep) deep_flags[GS_FLAG_COUNT] = s_deep_n;
-            if (mirror) mirror[4] = s_trigger ? s_deep_n : 0u;
-        }
+        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror);
         BIN_PROF(1, 1, wall_clock64());
         BIN_PROF(1, 2, wall_clock64());
         return;
@@ -438,51 +514,176 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     BIN_PROF(1, 1, wall_clock64());
     const uint32_t per = block_sums[3 * BIN_MAX_BLOCKS];     // batches per binning workgroup (k_bin_count)
     const uint32_t units = bin_grid * per;
-    auto put = [&](uint32_t e, uint32_t key, uint32_t idx) {
-        if (e >= D) return;                                  // dropped by an overflowing draw (it is redone)
-        keys_out[e] = (KeyT)key;
-        vals_out[e] = idx;
-    };
     uint32_t emitted = 0;
     for (uint32_t u = wg; u < units; u += wgs) {
         const uint32_t b = u / per, jb = (u - b * per) * BIN_THREADS;    // batch jb / 256 of binning workgroup b (uniform)
         const uint32_t cnt = s_cnt[b], boff = s_eoff[b];
         if (jb >= cnt || boff >= D) continue;
         const uint32_t src = b * per * BIN_THREADS + jb + threadIdx.x;   // the workgroup's slice of the compacted list
-        uint2 r = make_uint2(0u, 0u);
-        uint32_t idx = 0, e0 = 0, n = 0;
-        if (jb + threadIdx.x < cnt) {
-            r = rect_to_bins(crect[src], list_shift);                    // the list bins the splat touches
-            idx = cidx[src];
-            e0 = boff + coff[src];
-            n = rect_tiles(r);
-        }
-        emitted += n;
-        const uint32_t x0 = r.x & 0xFFFFu, y0 = r.x >> 16, w = (r.y & 0xFFFFu) - x0 + 1u;
-        for (uint32_t k = 0, xx = x0, yy = y0; k < min(n, EMIT_OWN); k++) {     // row-major walk of the rect, no k / w, k % w
-            put(e0 + k, (yy - row_begin) * tiles_x + xx, idx);
-            if (++xx == x0 + w) { xx = x0; yy++; }
-        }
-        // the few near splats that cover many lists: all 64 lanes write one splat's remaining entries together
-        unsigned long long big = __ballot(n > EMIT_OWN);
-        while (big) {
-            const int sl = __builtin_ctzll(big);
-            big &= big - 1ull;
-            const uint32_t bn = __shfl(n, sl, 64), be0 = __shfl(e0, sl, 64), bidx = __shfl(idx, sl, 64);
-            const uint32_t bx0 = __shfl(x0, sl, 64), by0 = __shfl(y0, sl, 64), bw = __shfl(w, sl, 64);
-            const float inv_w = 1.0f / (float)bw;
-            for (uint32_t k = EMIT_OWN + lane; k < bn; k += 64u) {
-                uint32_t q = (uint32_t)((float)k * inv_w);               // k / bw: k < 2^24, so the estimate is off by <= 1
-                int32_t rem = (int32_t)(k - q * bw);
-                if (rem < 0) { q--; rem += (int32_t)bw; }
-                else if (rem >= (int32_t)bw) { q++; rem -= (int32_t)bw; }
-                put(be0 + k, (by0 + q - row_begin) * tiles_x + bx0 + (uint32_t)rem, bidx);
-            }
-        }
+        emitted += bin_emit_batch<KeyT>(cidx, crect, coff, src, jb + threadIdx.x < cnt, boff, D, tiles_x, row_begin, list_shift, keys_out, vals_out);
     }
     BIN_PROF(1, 2, wall_clock64());
     BIN_PROF(1, 3, (unsigned long long)emitted);
     (void)emitted;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_bin_fused: count + emit in ONE launch (round 6).
+// k_bin_count fixes where every splat's entries go and k_bin_emit, a kernel boundary later, re-reads the compacted lists from a
+// grid that first scans all 2048 slice sums again.  Here the workgroup that counted a slice also emits it, as soon as it knows how
+// many entries the slices in front of it hold - a scan ACROSS the running grid:
+//   * every workgroup publishes {entries, visible splats, 16-px tiles} of its slice as 8-byte granules {tag, value} (one relaxed
+//     agent-scope store each: the value and its "ready" flag travel together, no fence; tag = the draw's serial, so the rows are
+//     never reset);
+//   * two levels: the last slice of a GROUP of 32 sums its group and publishes the group's row; a slice needs its <= 31
+//     predecessors inside the group and the <= 63 group rows in front = two rounds of polls by one wave (a flat look-back over
+//     2048 slices that all finish counting at the same moment would walk ~1000 granules per slice);
+//   * the LAST slice knows the frame's totals and writes the RenderFrame scalars and the host mirror.
+// Who waits for whom: slice c only ever waits for slices < c.  Slice ids are a function of blockIdx (xcd_chunk: monotone within
+// an XCD), every XCD starts its workgroups in blockIdx order, so the smallest unfinished slice is always running or the next one
+// its XCD starts: no cycle, whatever the residency (and all 2048 are resident at once on a whole MI355X: 8 per CU).  Every poll is
+// bounded all the same: a poll that runs out of patience raises `fail` (the draw reports GS_ERR_HIP on the next statistics read)
+// instead of hanging the device.
+struct BinScan {
+    unsigned long long* chunk_rows;     // [3][BIN_MAX_BLOCKS]
+    unsigned long long* group_rows;     // [3][BIN_MAX_BLOCKS / BIN_SCAN_GROUP]
+    uint32_t* fail;
+    uint32_t tag;
+};
+#ifndef BIN_SCAN_SLEEP
+#define BIN_SCAN_SLEEP 100              // units of 64 cycles between two polls of a wave (4 / 32 / 100: C3 bin stage 0.0642 / 0.0610 / 0.0598 ms)
+#endif
+constexpr uint32_t BIN_SCAN_GROUP = 32, BIN_SCAN_GROUPS = BIN_MAX_BLOCKS / BIN_SCAN_GROUP;
+static_assert(BIN_SCAN_GROUP <= 64 && BIN_SCAN_GROUPS <= 64, "one lane per predecessor / per group row");
+__device__ __forceinline__ void bin_scan_put(unsigned long long* p, uint32_t value, uint32_t tag) {
+    __hip_atomic_store(p, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t bin_scan_poll(const unsigned long long* p, uint32_t tag, uint32_t* fail) {
+    for (uint32_t spin = 0; spin < (1u << 21); spin++) {                  // ~ 1 s with the sleeps: a wrong frame, never a hung GPU
+        const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(g >> 32) == tag) return (uint32_t)g;
+        __builtin_amdgcn_s_sleep(BIN_SCAN_SLEEP);
+    }
+    *fail = 1u;
+    return 0u;
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <class KeyT>
+__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bin_fused(
+    const uint32_t* __restrict__ order, uint32_t R_host, const uint32_t* __restrict__ R_dev /* nullable */, const uint32_t* __restrict__ perm,
+    const uint2* __restrict__ prect, uint32_t* __restrict__ cidx, uint2* __restrict__ crect, uint32_t* __restrict__ coff,
+    uint32_t* __restrict__ digit_total, uint2* __restrict__ tile_ranges, uint32_t tiles, uint32_t list_shift, uint32_t splat_count,
+    const uint8_t* __restrict__ block_any, uint32_t* __restrict__ deep_flags, uint32_t blend_bins,
+    // (k_bin_emit's)
+    RenderFrame* __restrict__ frame, uint32_t capacity, uint32_t tiles_x /* list bins per row */, uint32_t row_begin /* first list-bin row */,
+    KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, volatile uint32_t* __restrict__ mirror, uint32_t serial,
+    const uint2* __restrict__ prev_blend_stats, uint32_t* __restrict__ blend_order, uint32_t deep, uint32_t* __restrict__ blend_stats_w,
+    uint32_t deep_min, uint32_t deep_factor, BinScan scan) {
+    __shared__ unsigned long long s_w[4];
+    __shared__ uint32_t s_any[ANY_WORDS];
+    __shared__ uint32_t s_base;
+    // (+ one workgroup, the first to be dispatched, for the blend's schedule and the deep pass's members: k_bin_emit's)
+    const uint32_t first_wg = blend_order ? 1u : 0u;
+    if (blend_order && blockIdx.x == 0) {
+        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror);
+        return;
+    }
+    const uint32_t wg = blockIdx.x - first_wg, G = gridDim.x - first_wg;
+    const uint32_t blocks = (splat_count + 255u) >> 8;
+    const bool coarse = block_any != nullptr && blocks <= ANY_WORDS * 32u;
+    if (coarse) {                                                          // (k_bin_count's LDS bitmap of live storage blocks)
+        for (uint32_t w = threadIdx.x; w < (blocks + 31u) / 32u; w += BIN_THREADS) {
+            const uint4* src = reinterpret_cast<const uint4*>(block_any + 32u * w);
+            const uint4 a = src[0], b = src[1];
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                bits |= (((v[k] & 0xFFu) ? 1u : 0u) | ((v[k] & 0xFF00u) ? 2u : 0u) | ((v[k] & 0xFF0000u) ? 4u : 0u) |
+                         ((v[k] & 0xFF000000u) ? 8u : 0u)) << (4 * k);
+            s_any[w] = bits;
+        }
+        __syncthreads();
+    }
+    {   // the draw's housekeeping (k_bin_count's)
+        const uint32_t t = wg * BIN_THREADS + threadIdx.x, stride = G * BIN_THREADS;
+        for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) digit_total[w] = 0u;
+        for (uint32_t w = t; w < tiles; w += stride) tile_ranges[w] = make_uint2(0xFFFFFFFFu, 0u);
+        if (!first_wg) {                                                   // (a schedule workgroup resets - and then fills - these itself)
+            if (t < GS_FLAG_LIST) deep_flags[t] = 0u;
+            for (uint32_t w = t; w < blend_bins; w += stride) deep_flags[GS_FLAG_OF + w] = GS_DEEP_NONE;
+        }
+    }
+    const uint32_t R = R_dev ? min(*R_dev, R_host) : R_host;
+    const uint32_t batches = (R + BIN_THREADS - 1) / BIN_THREADS, per = (batches + G - 1) / G;
+    const uint32_t c = xcd_chunk(wg, G);
+    const uint32_t b0 = min(c * per, batches), b1 = min(b0 + per, batches);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t pos_begin = b0 * BIN_THREADS, pos_end = min(b1 * BIN_THREADS, R);
+    const SliceCount sc = bin_count_slice(order, R, perm, prect, cidx, crect, coff, list_shift, splat_count, block_any, coarse, s_any, s_w, pos_begin, pos_end);
+    uint32_t t16 = sc.t16;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t16 += __shfl_xor(t16, o, 64);
+    if (lane == 0) s_w[wave] = t16;
+    __syncthreads();
+    if (wave == 0u) {
+        const uint32_t E = sc.entries, V = sc.splats, T = (uint32_t)(s_w[0] + s_w[1] + s_w[2] + s_w[3]);
+        if (lane < 3u) bin_scan_put(scan.chunk_rows + (size_t)lane * BIN_MAX_BLOCKS + c, lane == 0u ? E : lane == 1u ? V : T, scan.tag);
+        const uint32_t g = c / BIN_SCAN_GROUP, j = c % BIN_SCAN_GROUP;
+        const bool closer = j == BIN_SCAN_GROUP - 1u || c == G - 1u;
+        // entries in front of this slice: the slices of its group before it + the groups before its group
+        const unsigned long long in_e = wave_sum64(lane < j ? bin_scan_poll(scan.chunk_rows + g * BIN_SCAN_GROUP + lane, scan.tag, scan.fail) : 0u);
+        if (closer) {
+            const unsigned long long ge = in_e + E;
+            if (lane == 0u) bin_scan_put(scan.group_rows + g, ge > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ge, scan.tag);
+        }
+        const unsigned long long front = in_e + wave_sum64(lane < g ? bin_scan_poll(scan.group_rows + lane, scan.tag, scan.fail) : 0u);
+        if (lane == 0u) s_base = front > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)front;
+        if (closer) {                                                      // the group's statistics rows; the last slice: the frame's totals
+            const unsigned long long gv = V + wave_sum64(lane < j ? bin_scan_poll(scan.chunk_rows + BIN_MAX_BLOCKS + g * BIN_SCAN_GROUP + lane, scan.tag, scan.fail) : 0u);
+            const unsigned long long gt = T + wave_sum64(lane < j ? bin_scan_poll(scan.chunk_rows + 2u * BIN_MAX_BLOCKS + g * BIN_SCAN_GROUP + lane, scan.tag, scan.fail) : 0u);
+            if (c != G - 1u) {
+                if (lane == 0u) {
+                    bin_scan_put(scan.group_rows + BIN_SCAN_GROUPS + g, (uint32_t)gv, scan.tag);
+                    bin_scan_put(scan.group_rows + 2u * BIN_SCAN_GROUPS + g, gt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)gt, scan.tag);
+                }
+            } else {
+                const unsigned long long vis64 = gv + wave_sum64(lane < g ? bin_scan_poll(scan.group_rows + BIN_SCAN_GROUPS + lane, scan.tag, scan.fail) : 0u);
+                const unsigned long long tsum = gt + wave_sum64(lane < g ? bin_scan_poll(scan.group_rows + 2u * BIN_SCAN_GROUPS + lane, scan.tag, scan.fail) : 0u);
+                const unsigned long long D64 = front + E;
+                if (lane == 0u) {
+                    const uint32_t vis = (uint32_t)vis64;
+                    frame->tiles16_lo = (uint32_t)tsum;
+                    frame->tiles16_hi = (uint32_t)(tsum >> 32);
+                    frame->visible = vis;
+                    frame->entries_lo = (uint32_t)D64;
+                    frame->entries_hi = (uint32_t)(D64 >> 32);
+                    frame->overflow = D64 > capacity ? 1u : 0u;
+                    frame->entry_count = D64 > capacity ? capacity : (uint32_t)D64;
+                    frame->pad = 0;
+                    if (mirror) {                                           // (see k_bin_emit: one 16-byte and one 8-byte store to mapped host memory)
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 v = {serial, D64 > capacity ? 1u : 0u, (uint32_t)D64, (uint32_t)(D64 >> 32)};
+                        *reinterpret_cast<volatile u32x4*>(mirror) = v;
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        const u32x2 sv = {serial, vis};
+                        *reinterpret_cast<volatile u32x2*>(mirror + 6) = sv;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                                        // s_base; this workgroup's compacted lists (written above)
+    const uint32_t base = s_base;
+    if (base >= capacity) return;
+    for (uint32_t jb = 0; jb < sc.splats; jb += BIN_THREADS)
+        (void)bin_emit_batch<KeyT>(cidx, crect, coff, pos_begin + jb + threadIdx.x, jb + threadIdx.x < sc.splats, base, capacity, tiles_x, row_begin,
+                                   list_shift, keys_out, vals_out);
 }
 
 template <class KeyT>
@@ -501,11 +702,6 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     GS_TRY(m->deep_flags.ensure(((size_t)GS_FLAG_OF + blend_bins) * 4 + 64));
     GS_TRY(m->chunk_pool.ensure((size_t)GS_POOL_SLOTS * 256 * sizeof(float4)));
     GS_TRY(m->blend_stats.ensure((size_t)blend_bins * 12));
-    hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
-                       m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
-                       m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(),
-                       m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
-                       m->block_any.as<uint8_t>(), m->deep_flags.as<uint32_t>(), blend_bins);
     if (sorter && sorter->stream != st) {      // the sorter's private stream may overwrite `sorted` from here on
         GS_HIP(hipEventRecord(sorter->ev_consumed, st));
         sorter->consumer_pending = true;
@@ -542,15 +738,50 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
         GS_TRY(m->deep_partial.ensure((size_t)GS_DEEP_UNITS * 256 * sizeof(float4)));
         GS_TRY(m->deep_work.ensure((size_t)GS_DEEP_UNITS * 4));
     }
+    // $GSPLAT_BIN_FUSED=1: count + emit in one launch behind a scan across the running grid (k_bin_fused).  Built, bit-identical,
+    // and SLOWER than the two kernels on every configuration, so it is not the default: bin stage C3 0.0513 -> 0.0598-0.0642 ms,
+    // C2 0.037 -> 0.047, C3S 0.084 -> 0.100, C4 0.419 -> 0.425-0.431 (profiles/r06i_ab_fused.txt, r06j_ab_fused_sleep.txt; longer
+    // back-off between polls recovers 4 of the 12 us).  Every slice's emit has to wait for the slowest slice's count - the scan
+    // is a grid-wide barrier in disguise - so the launch is count + barrier + emit like the two kernels, minus one kernel boundary,
+    // plus two hops of polling under the count's own memory traffic, and the emit loses k_bin_emit's round-robin deal of batches.
+    const char* fused_env = getenv("GSPLAT_BIN_FUSED");
+    const bool fused = fused_env && fused_env[0] == '1';
     // (+ one workgroup that orders the blend's bins and names the deep pass's members)
     // (that workgroup also raises the deep pass's trigger, so under a camera that keeps moving it still runs when the pass is on,
     // for scenes of tiny splats - the ones that grow deep bins - and every 8th draw otherwise)
     const bool order_wg = order_ok && (same_view || stale_order || m->deep_pass || pp.list_shift == GS_LIST_SHIFT_SMALL || (m->draw_serial & 7u) == 7u);
-    hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_wg ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
-                       m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
-                       m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, ++m->draw_serial,
-                       order_wg ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
-                       m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
+    ++m->draw_serial;
+    if (m->draw_serial == 0u) m->draw_serial = 1u;       // (the scan's granules are tagged with the serial: 0 is "never written")
+    if (fused) {
+        GS_TRY(m->bin_scan.ensure(((size_t)3 * BIN_MAX_BLOCKS + 3 * BIN_SCAN_GROUPS) * 8 + 64));
+        if (!m->bin_scan_ready) {                        // once: no granule carries a tag
+            GS_HIP(hipMemsetAsync(m->bin_scan.p, 0, m->bin_scan.bytes, st));
+            m->bin_scan_ready = true;
+        }
+        BinScan scan;
+        scan.chunk_rows = m->bin_scan.as<unsigned long long>();
+        scan.group_rows = scan.chunk_rows + 3 * BIN_MAX_BLOCKS;
+        scan.fail = reinterpret_cast<uint32_t*>(scan.group_rows + 3 * BIN_SCAN_GROUPS);
+        scan.tag = m->draw_serial;
+        hipLaunchKernelGGL((k_bin_fused<KeyT>), dim3(grid + (order_wg ? 1u : 0u)), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
+                           m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(),
+                           m->coff.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(), m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
+                           m->block_any.as<uint8_t>(), m->deep_flags.as<uint32_t>(), blend_bins, frame, cap, pp.lists_x, pp.list_row_begin,
+                           m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), m->mirror_dev, m->draw_serial,
+                           order_wg ? m->blend_stats.as<uint2>() : nullptr, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
+                           m->deep_pass ? 1u : 0u, m->blend_stats.as<uint32_t>(), deep_min, deep_factor, scan);
+    } else {
+        hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
+                           m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
+                           m->bin_sums.as<uint32_t>(), m->radix.digit_total.as<uint32_t>(),
+                           m->tile_ranges.as<uint2>(), tiles, pp.list_shift, pp.count,
+                           m->block_any.as<uint8_t>(), m->deep_flags.as<uint32_t>(), blend_bins);
+        hipLaunchKernelGGL((k_bin_emit<KeyT>), dim3(grid + (order_wg ? 1u : 0u)), dim3(BIN_THREADS), 0, st, frame, cap, m->cidx.as<uint32_t>(),
+                           m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
+                           m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, m->draw_serial,
+                           order_wg ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
+                           m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
+    }
     m->blend_order_valid = order_ok && (same_view || stale_order);
     GS_HIP(hipGetLastError());
     if (pp.row_begin == 0u && pp.row_end >= pp.tiles_y) {     // (a strip's visible count says nothing about the scene: mesh_heal_overflow)

@@ -714,3 +714,50 @@ def test_asynchronous_draws_learn_how_much_of_the_scene_is_in_view(ctx):
         assert info["block_test"] == expect, info
         assert np.array_equal(out.cpu().numpy(), ref)
         ref_mesh.dispose(); mesh.dispose()
+
+
+def test_fused_binner_draws_the_same_frame_and_statistics(ctx, monkeypatch):
+    """$GSPLAT_BIN_FUSED=1 (k_bin_fused: count + emit in one launch behind a scan across the running grid; built in round 6,
+    slower than the two kernels, kept as an A/B switch) must produce the same entries: same frame, same counters - also when the
+    entry buffer overflows, for a strip, and for a list whose length lives on the device (a visibility-culled sort)."""
+    scene = helpers.small_scene(150000, 1, seed=77)
+    cam = camera.demo_camera("garden", 640, 360)
+    n = scene.count
+    w = create_sort_worker(ctx, n)
+    w.post_message({"centers": util.integer_centers(scene.centers), "range": {"from": 0, "to": n - 1, "count": n}})
+    mesh = build_mesh(ctx, scene)
+    mesh.set_camera(cam)
+    mvp = cam.sort_mvp()
+    w.sort_on_device(mvp, n)
+    mesh.use_sorter_result(w, n)
+
+    def frames():
+        out = []
+        w.set_visibility_cull(False)
+        w.sort_on_device(mvp, n)
+        img, st = mesh.render()
+        out.append((img, int(st.visible_splats), int(st.tile_entries), int(st.tiles16)))
+        img, st = mesh.render(tile_rows=(5, 13))
+        out.append((img, int(st.visible_splats), int(st.tile_entries), int(st.tiles16)))
+        w.set_visibility_cull(True)
+        mesh.project()
+        w.sort_on_device(mvp, n)
+        img, st = mesh.render()
+        out.append((img, int(st.visible_splats), int(st.tile_entries), int(st.tiles16)))
+        w.set_visibility_cull(False)
+        return out
+
+    plain = frames()
+    monkeypatch.setenv("GSPLAT_BIN_FUSED", "1")
+    fused = frames()
+    mesh.debug_set_entry_capacity(4096)                 # an overflowing draw is redone with a grown buffer
+    w.sort_on_device(mvp, n)
+    img, st = mesh.render()
+    monkeypatch.delenv("GSPLAT_BIN_FUSED")
+    for (a, *sa), (b, *sb) in zip(plain, fused):
+        np.testing.assert_array_equal(a, b)
+        assert sa == sb
+    np.testing.assert_array_equal(img, plain[0][0])
+    assert plain[0][1] > 1000 and plain[0][2] > plain[0][1]
+    w.terminate()
+    mesh.dispose()

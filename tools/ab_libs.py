@@ -81,11 +81,21 @@ def main():
         cfg = scenes.CONFIGS[name]
         scene = scenes.make_config_scene("C3" if name == "C5" else name)
         for rnd in range(a.rounds):
-            for lib in a.libs:
+            for item in a.libs:
+                env, lib = item.split("|") if "|" in item else ("", item)       # `ENV=V,ENV=V|lib.so`: that library under those switches
+                sets = dict(kv.split("=", 1) for kv in env.split(",") if kv)
+                old = {k: os.environ.get(k) for k in sets}
+                os.environ.update(sets)
                 use_library(lib)
                 r = measure(scene, cfg, a.frames)
-                print("%-4s %-28s frame %.4f ms | sort %.4f project %.4f bin %.4f esort %.4f blend %.4f | walked %d halves %d | frame crc %08x" %
-                      (name, os.path.basename(lib), r["ms"], r["sort"], r["project"], r["bin"], r["esort"], r["blend"],
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+                lib = (env + " " if env else "") + os.path.basename(lib)
+                print("%-4s %-40s frame %.4f ms | sort %.4f project %.4f bin %.4f esort %.4f blend %.4f | walked %d halves %d | frame crc %08x" %
+                      (name, lib, r["ms"], r["sort"], r["project"], r["bin"], r["esort"], r["blend"],
                        r["walked"], r["halves"], r["crc"]), flush=True)
         del scene
 

@@ -547,6 +547,28 @@ def measure(env, cfg_name, steps, warmup, world, rank, stages=True, median_frame
     return m
 
 
+def gather_floor(strips, width, height, world, one_gpu_ms):
+    """north_star's gather puts every other rank's strip into rank 0 over point-to-point xGMI links: the time those bytes need at
+    the link rate is a floor under a frame however well the strips overlap, and one-GPU frame / floor a ceiling over the speed-up
+    (at 8K the gather, not the strips, bounds the rate near 3.9x).  $GS_LINK_GBPS: GB/s per link and direction
+    (default 76.8 = half of the 153.6 GB/s bidirectional figure in MI355X_MICROARCH.md); one link per peer, at most seven."""
+    if not strips or world < 2:
+        return None
+    gbps = float(os.environ.get("GS_LINK_GBPS", "76.8"))
+    rows = [min(r1 * 16, height) - min(r0 * 16, height) for r0, r1 in strips]
+    into_rank0 = sum(rows[1:]) * width * 4
+    per_link = max(rows[1:]) * width * 4                     # the peers send concurrently, each over its own link
+    floor_ms = per_link / (gbps * 1e9) * 1e3
+    out = {"bytes_into_rank0": int(into_rank0), "largest_strip_bytes": int(per_link), "links": min(world - 1, 7), "link_GBps": gbps,
+           "gather_floor_ms": round(floor_ms, 4),
+           "note": "largest peer strip / one link's rate: rank 0 receives over world - 1 links at once; HBM write of the gathered frame not included"}
+    # rank 0 has ONE set of links: the seven strips arrive in parallel only while the aggregate stays under what its ports take
+    out["gather_floor_serial_ms"] = round(into_rank0 / (gbps * 1e9 * min(world - 1, 7)) * 1e3, 4)
+    if one_gpu_ms:
+        out["speedup_ceiling_from_gather"] = round(one_gpu_ms / max(floor_ms, 1e-9), 2)
+    return out
+
+
 def brief(m, N):
     """The short form of one measurement (secondary objects of the line)."""
     return {"workload": m["cfg"], "width": m["W"], "height": m["H"], "n_gpus": m["world"],
@@ -1021,6 +1043,10 @@ def main():
                          "unit": "GB/s", "frac": round(k_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(kb),
                          "avg_launch_ms": round(k_ms, 5), "launches_timed": proj_launches,
+                         # the whole vertex stage (k_block_test + mask reset + k_project) against the same bytes: rounds 1-4
+                         # bracketed this, round 5 moved the bracket to k_project alone - both stay in the line
+                         "stage_ms": round(stage_ms.get("project"), 5) if stage_ms.get("project") else None,
+                         "stage_frac": round(kb / (stage_ms["project"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms.get("project") else None,
                          "launches_in_timed_region": args.steps,
                          # the vertex stage is co-limited: its SIMDs issue vector instructions most of the launch as well
                          "valu_busy_frac": proj_valu.get("valu_busy_frac") if proj_valu else None,
@@ -1073,6 +1099,10 @@ def main():
             # (N = 1: configs[4]'s viewport on this one GPU)
             "c5_1gpu": brief(second_solo, N) if second_solo else c5_one,
             "c5_speedup_vs_1gpu": round(second_solo["ms_per_step"] / second["ms_per_step"], 4) if (second and second_solo) else None,
+            # what the strip gather alone allows (bytes into rank 0 over its links), beside each measured speed-up
+            "gather_floor": gather_floor(strips, W, H, world, solo["ms_per_step"] if solo else None) if world > 1 else None,
+            "c5_gather_floor": gather_floor(second["strips"], scenes.CONFIGS[second_cfg]["width"], scenes.CONFIGS[second_cfg]["height"], world,
+                                            second_solo["ms_per_step"] if second_solo else None) if second else None,
             "pipelined": pipelined,
             "orbit": orbit,
             "cull_on": cull,

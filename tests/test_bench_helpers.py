@@ -101,3 +101,20 @@ def test_a_failing_rank_takes_the_others_down(monkeypatch, tmp_path):
     procs.clear()
     assert bench.spawn_ranks(2, timeout_s=1.0, poll_s=0.05) == 124
     assert all(p.poll() is not None for p in procs)
+
+
+def test_gather_floor_is_the_largest_peer_strip_over_one_link(monkeypatch):
+    """bench --gpus N prints what the strip gather alone allows beside each speed-up.  C5 (7680 x 4320) on
+    eight ranks: seven peers send ~1/8 of a 133 MB frame each; at 76.8 GB/s per link and direction the largest strip is the floor."""
+    monkeypatch.delenv("GS_LINK_GBPS", raising=False)
+    rows = 4320 // 16                                    # 270 tile rows
+    strips = [(k * rows // 8, (k + 1) * rows // 8) for k in range(8)]
+    g = bench.gather_floor(strips, 7680, 4320, 8, 0.845)
+    largest = max(min(r1 * 16, 4320) - r0 * 16 for r0, r1 in strips[1:]) * 7680 * 4
+    assert g["largest_strip_bytes"] == largest and g["links"] == 7
+    assert abs(g["gather_floor_ms"] - largest / 76.8e9 * 1e3) < 1e-3
+    assert g["bytes_into_rank0"] == sum(min(r1 * 16, 4320) - r0 * 16 for r0, r1 in strips[1:]) * 7680 * 4
+    assert g["speedup_ceiling_from_gather"] == round(0.845 / g["gather_floor_ms"], 2)
+    monkeypatch.setenv("GS_LINK_GBPS", "38.4")
+    assert abs(bench.gather_floor(strips, 7680, 4320, 8, None)["gather_floor_ms"] - 2 * g["gather_floor_ms"]) < 2e-4
+    assert bench.gather_floor(strips, 7680, 4320, 1, 1.0) is None and bench.gather_floor(None, 7680, 4320, 8, 1.0) is None

@@ -67,6 +67,7 @@ class Destination(C.Structure):
 
 
 GS_DEST_DEPTH_UNORM24 = 1
+GS_DRAW_FP32, GS_DRAW_ROP8 = 0, 1
 
 
 class TreeInfo(C.Structure):
@@ -136,6 +137,7 @@ SYMBOLS = {
     "gs_mesh_debug_read": (C.c_int, [_VP, C.c_int, _VP, C.c_uint32]),
     "gs_mesh_debug_rop8": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
     "gs_mesh_set_deep_pass": (C.c_int, [_VP, C.c_int]),
+    "gs_mesh_set_draw_mode": (C.c_int, [_VP, C.c_uint32]),
     "gs_mesh_last_stats": (C.c_int, [_VP, C.POINTER(RenderStats)]),
     "gs_mesh_kernel_time": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
 }

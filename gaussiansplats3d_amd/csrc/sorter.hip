@@ -399,80 +399,105 @@ __global__ __launch_bounds__(256) void k_tree_copy_keys(TreeCopyParams c, KeyPar
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     int32_t lo = 2147483640, hi = -2147483640;
     uint32_t kept = 0;
-    // (the next leaf's three words are fetched while this one is copied: one dependent round trip per leaf less)
-    uint32_t leaf = blockIdx.x * 4u + wave;
+    // A wave's work is a sequence of ROUNDS: 256 consecutive entries (four 64-splat slices, twelve loads that leave together) of
+    // one kept leaf's list - a leaf holds ~200 splats, so most leaves are one round.  Round 6: the loads of round k + 1 are issued
+    // BEFORE round k is keyed and stored (two register sets, no copies: the loop is unrolled by two), also across leaves; before,
+    // a wave's memory system idled between the stores of one leaf and the loads of the next (the same finding as k_cull_front,
+    // load -> compute -> store in step leaves the memory idle between bursts).  The loads are unconditional - a lane
+    // past the end of its leaf, or a wave past its last round, reads entry 0 of the round's leaf / of the arrays - because a load
+    // inside a branch costs a full s_waitcnt at the join, taken or not.
+    struct Round { uint32_t off, n, src, t0, valid; };
+    struct Loads { uint32_t idx[4], pos[4]; uint4 ce[4]; };
+    const uint32_t wstride = gridDim.x * 4u;
+    uint32_t leaf = blockIdx.x * 4u + wave;                  // the next leaf whose header words are in m_*
     uint32_t m_off = 0xFFFFFFFFu, m_n = 0, m_src = 0;
     if (leaf < c.v.leaves) { m_off = c.v.leaf_offset[leaf]; m_n = c.v.leaf_count[leaf]; m_src = c.v.leaf_begin[leaf]; }
-    for (; leaf < c.v.leaves; leaf += gridDim.x * 4u) {
-        const uint32_t off = m_off, n = m_n, src = m_src;
-        const uint32_t nxt = leaf + gridDim.x * 4u;
-        if (nxt < c.v.leaves) { m_off = c.v.leaf_offset[nxt]; m_n = c.v.leaf_count[nxt]; m_src = c.v.leaf_begin[nxt]; }
-        if (off == 0xFFFFFFFFu) continue;                    // culled leaf
-        // four 64-splat slices of the leaf per round: their twelve loads leave together (a leaf holds ~200 splats, so a wave's
-        // work is two or three dependent memory round trips whatever its length - what hides them is the loads in flight)
-        unsigned long long carry = 0ull;                     // (lane 0) keep bits of this leaf that belong to the next round's first word
-        for (uint32_t t0 = 0; t0 < n; t0 += 256u) {
-            uint32_t idx[4], pos[4];
-            uint4 ce[4];
-            bool in[4];
+    auto advance = [&](Round& r) {                           // (wave-uniform)
+        if (r.valid && r.t0 + 256u < r.n) { r.t0 += 256u; return; }
+        r.valid = 0u;
+        while (leaf < c.v.leaves) {
+            const uint32_t off = m_off, n = m_n, src = m_src;
+            leaf += wstride;
+            if (leaf < c.v.leaves) { m_off = c.v.leaf_offset[leaf]; m_n = c.v.leaf_count[leaf]; m_src = c.v.leaf_begin[leaf]; }
+            if (off != 0xFFFFFFFFu && n) { r.off = off; r.n = n; r.src = src; r.t0 = 0u; r.valid = 1u; return; }   // (else: a culled leaf)
+        }
+    };
+    auto load = [&](const Round& r, Loads& L) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t t = t0 + 64u * k + lane;
-                in[k] = t < n;
-                const uint32_t j = src + (in[k] ? t : 0u);
-                idx[k] = c.v.leaf_indexes[j];
-                pos[k] = c.leaf_pos[j];
-                ce[k] = c.leaf_centers[j];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t t = r.t0 + 64u * k + lane;
+            const uint32_t j = r.valid ? r.src + (t < r.n ? t : 0u) : 0u;
+            L.idx[k] = c.v.leaf_indexes[j];
+            L.pos[k] = c.leaf_pos[j];
+            L.ce[k] = c.leaf_centers[j];
+        }
+    };
+    unsigned long long carry = 0ull;                         // (lane 0) keep bits of this leaf that belong to the next round's first word
+    auto process = [&](const Round& r, const Loads& L) {
+        const uint32_t off = r.off, n = r.n, t0 = r.t0;
+        if (t0 == 0u) carry = 0ull;
+        unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t t = t0 + 64u * k + lane;
+            const bool in = t < n;
+            int32_t key;
+            float x, y, z;
+            if (p.mode & MODE_INT) {
+                key = (int32_t)(L.ce[k].x * (uint32_t)p.im0 + L.ce[k].y * (uint32_t)p.im1 + L.ce[k].z * (uint32_t)p.im2);
+                x = __fmul_rn((float)(int32_t)L.ce[k].x, 0.001f); y = __fmul_rn((float)(int32_t)L.ce[k].y, 0.001f);
+                z = __fmul_rn((float)(int32_t)L.ce[k].z, 0.001f);
+            } else {
+                x = __uint_as_float(L.ce[k].x); y = __uint_as_float(L.ce[k].y); z = __uint_as_float(L.ce[k].z);
+                float s = __fmul_rn(p.fm0, x);
+                s = __fadd_rn(s, __fmul_rn(p.fm1, y));
+                s = __fadd_rn(s, __fmul_rn(p.fm2, z));
+                key = trunc_f64_i32((double)s * 4096.0);
             }
-            unsigned long long bits[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t t = t0 + 64u * k + lane;
-                int32_t key;
-                float x, y, z;
-                if (p.mode & MODE_INT) {
-                    key = (int32_t)(ce[k].x * (uint32_t)p.im0 + ce[k].y * (uint32_t)p.im1 + ce[k].z * (uint32_t)p.im2);
-                    x = __fmul_rn((float)(int32_t)ce[k].x, 0.001f); y = __fmul_rn((float)(int32_t)ce[k].y, 0.001f);
-                    z = __fmul_rn((float)(int32_t)ce[k].z, 0.001f);
-                } else {
-                    x = __uint_as_float(ce[k].x); y = __uint_as_float(ce[k].y); z = __uint_as_float(ce[k].z);
-                    float s = __fmul_rn(p.fm0, x);
-                    s = __fadd_rn(s, __fmul_rn(p.fm1, y));
-                    s = __fadd_rn(s, __fmul_rn(p.fm2, z));
-                    key = trunc_f64_i32((double)s * 4096.0);
-                }
-                if (in[k]) {
-                    c.idx_out[off + t] = idx[k];
-                    c.pay_out[off + t] = pos[k];
-                    p.keys_out[off + t] = key;
-                    lo = min(lo, key);
-                    hi = max(hi, key);
-                }
-                if (CULL) {
-                    bits[k] = __ballot(in[k] && frustum_keep_one(p.mvp, x, y, z));
-                    kept += (uint32_t)__popcll(bits[k]);     // (the same value in every lane)
-                }
+            if (in) {
+                c.idx_out[off + t] = L.idx[k];
+                c.pay_out[off + t] = L.pos[k];
+                p.keys_out[off + t] = key;
+                lo = min(lo, key);
+                hi = max(hi, key);
             }
-            if (CULL && lane == 0u) {
-                // The round's 256 list positions start at `first`: four words of the (zeroed) keep mask and a carry into the
-                // fifth, which the next round of this leaf completes.  A word that lies wholly inside this leaf's range is ours
-                // alone - a plain store; the words the leaf shares with its neighbours in the list take an atomicOr (two per
-                // slice, 136 k atomics per gather, were ~15 us of this kernel).
-                const uint32_t first = off + t0, sh = first & 63u, w0 = first >> 6;
-                unsigned long long W[4];
-                W[0] = carry | (bits[0] << sh);
-#pragma unroll
-                for (int j = 1; j < 4; j++) W[j] = (bits[j] << sh) | (sh ? bits[j - 1] >> (64u - sh) : 0ull);
-                carry = sh ? bits[3] >> (64u - sh) : 0ull;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t wbeg = (w0 + (uint32_t)j) * 64u;            // first list position of the word
-                    if (wbeg >= off && wbeg + 64u <= off + n) p.keep[w0 + j] = W[j];
-                    else if (W[j]) atomicOr(&p.keep[w0 + j], W[j]);
-                }
-                if (t0 + 256u >= n && carry) atomicOr(&p.keep[w0 + 4u], carry);   // the leaf's last round: its tail word
+            if (CULL) {
+                bits[k] = __ballot(in && frustum_keep_one(p.mvp, x, y, z));
+                kept += (uint32_t)__popcll(bits[k]);         // (the same value in every lane)
             }
         }
+        if (CULL && lane == 0u) {
+            // The round's 256 list positions start at `first`: four words of the (zeroed) keep mask and a carry into the
+            // fifth, which the next round of this leaf completes.  A word that lies wholly inside this leaf's range is ours
+            // alone - a plain store; the words the leaf shares with its neighbours in the list take an atomicOr (two per
+            // slice, 136 k atomics per gather, were ~15 us of this kernel).
+            const uint32_t first = off + t0, sh = first & 63u, w0 = first >> 6;
+            unsigned long long W[4];
+            W[0] = carry | (bits[0] << sh);
+#pragma unroll
+            for (int j = 1; j < 4; j++) W[j] = (bits[j] << sh) | (sh ? bits[j - 1] >> (64u - sh) : 0ull);
+            carry = sh ? bits[3] >> (64u - sh) : 0ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t wbeg = (w0 + (uint32_t)j) * 64u;            // first list position of the word
+                if (wbeg >= off && wbeg + 64u <= off + n) p.keep[w0 + j] = W[j];
+                else if (W[j]) atomicOr(&p.keep[w0 + j], W[j]);
+            }
+            if (t0 + 256u >= n && carry) atomicOr(&p.keep[w0 + 4u], carry);   // the leaf's last round: its tail word
+        }
+    };
+    Round ra = {0u, 0u, 0u, 0u, 0u}, rb;
+    Loads A, B;
+    advance(ra);
+    load(ra, A);
+    while (ra.valid) {
+        rb = ra; advance(rb);
+        load(rb, B);                                         // in flight while A is keyed and stored
+        process(ra, A);
+        if (!rb.valid) break;
+        ra = rb; advance(ra);
+        load(ra, A);
+        process(rb, B);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

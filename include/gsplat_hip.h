@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GS_ABI_VERSION 4   /* 4: + gs_mesh_set_destination (round 5); every version-3 entry point is unchanged */
+#define GS_ABI_VERSION 5   /* 5: + gs_mesh_set_draw_mode (round 6); 4: + gs_mesh_set_destination (round 5); earlier entry points unchanged */
 
 /* status codes (negative = error, positive = warning, result still defined) */
 #define GS_OK 0
@@ -421,6 +421,22 @@ int gs_mesh_debug_read(gs_mesh* m, int what, void* dst, uint32_t count);
  * splat, farthest first.  (x0, y0) in GL window coordinates (row 0 = bottom), inside the rows the last draw covered;
  * rgba_out_host: uint8[4*width*height], row-major from y0 upwards.  A thread per pixel walks its whole list: not a draw mode. */
 int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uint32_t height, uint8_t* rgba_out_host);
+
+/* DRAW MODE of the draws that follow.
+ *   GS_DRAW_FP32 (default)  the front-to-back fp32 composite, rounded to RGBA8 once (early termination, chunks, the deep pass):
+ *                           <= 0.52 / 255 from the exact composite, 3-4 / 255 from what a browser's RGBA8 target shows on
+ *                           translucent content (tests/test_gpu_crops.py gates both).
+ *   GS_DRAW_ROP8            the reference's own blend state as it executes on a GPU (SplatMaterial3D.js:65-75: NormalBlending into
+ *                           an RGBA8 target; src/Viewer.js:358-359: cleared to (0,0,0,0), or the destination's colour): back to
+ *                           front, rgb = a*src + (1-a)*rgb, alpha = a + (1-a)*alpha, every channel rounded to 8 bits after EVERY
+ *                           splat - gs_mesh_debug_rop8's semantics for the whole frame: >= 99.85 % of the channel values equal to
+ *                           the ROP-emulating oracle, never more than 1 apart.  Every list is walked whole (no early
+ *                           termination is possible back to front): the blend of a 1080p garden frame takes 4.0 ms instead of 0.06 - for hosts that need
+ *                           the browser's pixels.  Strips, destinations (depth test and colour) and device-resident outputs work
+ *                           as in the fp32 mode; the statistics count the pairs this mode walked. */
+#define GS_DRAW_FP32 0u
+#define GS_DRAW_ROP8 1u
+int gs_mesh_set_draw_mode(gs_mesh* m, uint32_t mode);
 
 /* Scheduling switch, 1 by default (0 also via $GSPLAT_NO_DEEP at gs_mesh_create): whether the draws that follow may composite
  * very deep bins through the deep pass.  The frame is the same either way (see the composite above). */

@@ -542,6 +542,17 @@ static napi_value GroupWait(napi_env env, napi_callback_info info) {
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
+/* meshSetDrawMode(mesh, mode): 0 = the fp32 composite rounded once, 1 = the reference's RGBA8 target, rounded after every splat
+ * (gs_mesh_set_draw_mode) */
+static napi_value MeshSetDrawMode(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    int st;
+    LOCKED(st = gs_mesh_set_draw_mode((gs_mesh*)get_external(env, argv[0]), get_u32(env, argv[1])));
+    if (st < 0) return throw_gs(env, st);
+    return NULL;
+}
+
 /* meshSetDeepPass(mesh, enabled): scheduling only, the pixels do not change (gs_mesh_set_deep_pass) */
 static napi_value MeshSetDeepPass(napi_env env, napi_callback_info info) {
     ARGS(2)
@@ -798,7 +809,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"meshProject", MeshProject},       {"sorterSetVisibilityCull", SorterSetVisibilityCull},
         {"groupUniqueId", GroupUniqueId},   {"groupCreate", GroupCreate},     {"groupDestroy", GroupDestroy},
         {"groupRenderGather", GroupRenderGather}, {"groupSetOverlap", GroupSetOverlap}, {"groupWait", GroupWait},
-        {"meshSetDeepPass", MeshSetDeepPass}, {"meshSetDestination", MeshSetDestination},
+        {"meshSetDeepPass", MeshSetDeepPass}, {"meshSetDestination", MeshSetDestination}, {"meshSetDrawMode", MeshSetDrawMode},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

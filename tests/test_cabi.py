@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsplat_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes table and header disagree"
-    assert lib.gs_abi_version() == 4
+    assert lib.gs_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header():

@@ -152,6 +152,23 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
             f"{tag} {name}: engine vs the RGBA8-ROP-emulating oracle: {excess.max():+.2f} beyond the per-pixel bound (max diff {ours.max():.2f}, mean {ours.mean():.3f}; mean limit 1.0 of 1/255)"
         assert ours.max() <= ROP8_RECORDED_MAX[tag] + 1.0, \
             f"{tag} {name}: engine vs the RGBA8-ROP-emulating oracle: worst pixel {ours.max():.1f} / 255, recorded {ROP8_RECORDED_MAX[tag]:.0f} (tripwire: recorded + 1)"
+    # GS_DRAW_ROP8 (round 6): the same frame drawn in the reference's RGBA8-per-splat mode, on the windows the
+    # ROP-emulating oracle rasterised: >= 99.5 % of the channel values equal, never more than 1 apart - the verification kernel's gate
+    if tag in ROP8_MODE_CONFIGS:
+        mesh.set_draw_mode(rop8=True)
+        worker.sort_on_device(mvp, n)
+        frame8, st8 = mesh.render()
+        mesh.set_draw_mode(rop8=False)
+        eq, worst = [], 0.0
+        for (name, x0, y0, w, h), (fb8, _) in zip(wins, crops8):
+            d = np.abs(frame8[y0:y0 + h, x0:x0 + w].astype(np.float32) - np.round(np.clip(fb8, 0, 1) * 255.0))
+            eq.append(float((d == 0).mean()))
+            worst = max(worst, float(d.max()))
+            assert d.max() <= ROP8_MAX and (d == 0).mean() >= ROP8_EQUAL, \
+                f"{tag} {name}: GS_DRAW_ROP8 vs the ROP-emulating oracle: {(d == 0).mean():.4f} equal, max {d.max():.0f}"
+        report["rop8_mode"] = {"equal_frac_min": round(min(eq), 5), "equal_frac_mean": round(float(np.mean(eq)), 5), "max_diff": worst,
+                               "splats_walked": int(st8.splats_walked), "blend_ms": round(float(st8.blend_ms), 4)}
+        print(f"{tag} GS_DRAW_ROP8: equal >= {min(eq):.4f}, max {worst:.0f}, walked {int(st8.splats_walked)}, blend {float(st8.blend_ms):.3f} ms")
     report["ambiguous_pixels_total"] = amb_pixels
     report["entries_scanned"] = int(stats.entries_scanned)
     report["splats_walked"] = int(stats.splats_walked)
@@ -162,6 +179,7 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
     return report
 
 
+ROP8_MODE_CONFIGS = ("C3", "C3T", "C2")   # configurations whose crops are also drawn in GS_DRAW_ROP8
 ENGINE_SLACK = 1.05        # the engine's own final rounding (0.5) + its strict-gated distance to the fp32 oracle (<= 0.5) + fp32 noise
 # Tripwire beside the derived bound: the bound reaches 18.5 / 255 on translucent content while the engine
 # sits at <= 4, so a regression that doubled the distance to the ROP result would pass it.  The worst pixel of every

@@ -27,11 +27,11 @@ def test_addon_loads_and_exports_the_seams():
           "w:typeof g.createSortWorker,m:typeof g.SplatMeshHIP,args:g.createSortWorker.length}))")
     out = subprocess.check_output(["node", "-e", js], cwd=NODE_DIR, text=True)
     info = json.loads(out.strip().splitlines()[-1])
-    assert info["abi"] == 4 and info["w"] == "function" and info["m"] == "function"
+    assert info["abi"] == 5 and info["w"] == "function" and info["m"] == "function"
     for name in ("contextCreate", "sorterCreate", "sorterUploadCenters", "sorterSort", "meshCreate", "meshUpload",
                  "meshRender", "sorterDestroy", "meshDestroy", "contextDestroy", "deviceCount", "sorterBindMesh",
                  "sorterSetFrustumCull", "sorterSortGathered", "treeCreate", "treeGather", "assetLoad", "meshSetScenes",
-                 "meshUploadSceneIndexes", "meshUploadShU8"):
+                 "meshUploadSceneIndexes", "meshUploadShU8", "meshSetDestination", "meshSetDrawMode"):
         assert name in info["k"]
     assert info["args"] == 5          # five positional parameters before the defaulted precision, like the reference
 

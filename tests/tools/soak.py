@@ -6,7 +6,9 @@
   * three strips of tile rows == the full frame, byte for byte; the same frame from a context with streams of its own;
   * a visibility-culled sort draws the same frame;
   * every other scene: a random destination (depth planes with per-pixel noise or holes, fp32 or 24-bit, with or without colour)
-    against the oracle with the same destination (same tolerance), strips included.
+    against the oracle with the same destination (same tolerance), strips included;
+  * every third scene: the same frame in GS_DRAW_ROP8 (the reference's RGBA8 target, rounded after every splat) against the
+    ROP-emulating oracle (>= 99.5 % of the channel values equal, never more than 1 apart), over the destination when there is one.
 The oracle is the checker here, as in tests/ (this tool is test infrastructure, not product).
 
 usage: python tests/tools/soak.py [iterations=24] [first_seed=1000] [max_splats=60000]   -> one line per iteration, "soak: N iterations, 0 failures" """
@@ -27,6 +29,22 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 60000
 failures = 0
+def rop8_check(mesh, ocam, inputs, order, W, H, cuts, depth=None, unorm24=False, dst=None):
+    """GS_DRAW_ROP8 (gs_mesh_set_draw_mode): the frame against the ROP-emulating oracle - >= 99.5 % of the channel values equal,
+    never more than 1 apart (gs_mesh_debug_rop8's gate) - and strips that tile it byte for byte."""
+    mesh.set_draw_mode(rop8=True)
+    try:
+        got, _ = mesh.render()
+        (fb8, _), = oracle.render_windows(ocam, *inputs, order, windows=[(0, 0, W, H)], rop8=True, depth=depth, depth_unorm24=unorm24, dst_rgba=dst)[0]
+        d = np.abs(got.astype(np.int32) - np.floor(np.clip(fb8, 0, 1) * 255.0 + 0.5).astype(np.int32))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.995, f"ROP8 mode vs the ROP-emulating oracle: {(d == 0).mean():.4f} equal, max {d.max()}"
+        parts = [mesh.render(tile_rows=(a, b))[0] for a, b in zip(cuts[:-1], cuts[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=0), got), "strips do not tile the ROP8 frame"
+    finally:
+        mesh.set_draw_mode(rop8=False)
+    return f"rop8 {(d == 0).mean():.4f} equal max {int(d.max())}"
+
+
 t_start = time.perf_counter()
 ctx1 = Context(0, single_stream=True)
 ctx2 = Context(0)
@@ -108,9 +126,16 @@ for it in range(iters):
                     msg += " | " + helpers.compare_frames(got_d, fb_d, amb_d, f"destination kind {kind}{' unorm24' if unorm24 else ''}")
                     parts = [mesh.render(tile_rows=(a, b))[0] for a, b in zip(cuts[:-1], cuts[1:])]
                     assert np.array_equal(np.concatenate(parts, axis=0), got_d), "strips do not tile the depth-tested frame"
+                    if it % 3 == 0:                            # ... and in the reference's RGBA8-per-splat mode over the same destination
+                        msg += " | " + rop8_check(mesh, ocam, (c, cov, rgba, sh), expect, W, H, cuts, depth, unorm24, dst)
                     mesh.set_destination()
                     again, _ = mesh.render()
                     assert np.array_equal(again, full), "clearing the destination does not restore the plain frame"
+                elif it % 3 == 0:
+                    w.sort_on_device(cam.sort_mvp(), n)
+                    msg += " | " + rop8_check(mesh, ocam, (c, cov, rgba, sh), expect, W, H, cuts)
+                    again, _ = mesh.render()
+                    assert np.array_equal(again, full), "leaving the ROP8 mode does not restore the plain frame"
             w.terminate(); mesh.dispose()
         assert np.array_equal(frames["one stream"], frames["streams"]), "the default context's frame differs from the one-stream context's"
         print(f"ok   {label} | entries {st.tile_entries} visible {st.visible_splats} | {msg}", flush=True)

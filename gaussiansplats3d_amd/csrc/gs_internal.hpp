@@ -462,7 +462,7 @@ struct gs_mesh {
     struct ProjSet {
         DevBuf recs, zrec, rects, vis_mask, block_any, vis32, prect, vis_orig;
         hipEvent_t ev_done = nullptr;
-        bool drawn = false, vis_orig_dirty = true;
+        bool drawn = false, vis_orig_dirty = true, vis_orig_lazy = false;
         uint32_t vis_orig_count = 0;
     } alt;
     bool two_sets = false;                         // alt is allocated and in use
@@ -477,6 +477,9 @@ struct gs_mesh {
     uint32_t full_serial[8] = {0, 0, 0, 0, 0, 0, 0, 0}, full_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last full-frame draws: serial (slot = serial & 7) and splats projected
     uint32_t project_serial = 0;
     uint32_t last_project_mode = 1;       // gs_launch_project: 1 = k_block_test + k_project, 0 = the test in every workgroup, 2 = no test
+    bool derive_orig_mask = false;        // a bound sorter builds vis_orig itself from vis_mask + its position map (sorter.hip,
+                                          // k_mask_derive_count): full-frame gs_mesh_project calls skip the per-survivor atomics
+    bool vis_orig_lazy = false;           // ... and the pending projection did: vis_orig holds nothing yet
     bool vis_orig_dirty = true;           // vis_orig may hold bits (cleared by the sort that consumes it, see k_mask_compact)
     uint32_t vis_orig_count = 0;          // splats the last gs_mesh_project looked at
     bool timed_project = false;           // the last vertex stage was bracketed with ev_p0 / ev_p1

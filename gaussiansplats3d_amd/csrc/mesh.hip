@@ -647,7 +647,7 @@ static void mesh_swap_sets(gs_mesh* m) {
     swap_buf(m->recs, o.recs); swap_buf(m->zrec, o.zrec); swap_buf(m->rects, o.rects); swap_buf(m->vis_mask, o.vis_mask); swap_buf(m->block_any, o.block_any);
     swap_buf(m->vis32, o.vis32); swap_buf(m->prect, o.prect); swap_buf(m->vis_orig, o.vis_orig);
     std::swap(m->ev_done, o.ev_done); std::swap(m->set_drawn, o.drawn);
-    std::swap(m->vis_orig_dirty, o.vis_orig_dirty); std::swap(m->vis_orig_count, o.vis_orig_count);
+    std::swap(m->vis_orig_dirty, o.vis_orig_dirty); std::swap(m->vis_orig_count, o.vis_orig_count); std::swap(m->vis_orig_lazy, o.vis_orig_lazy);
 }
 
 static int mesh_project(gs_mesh* m, const ProjectParams& pp, bool orig_mask, bool timed) {
@@ -817,7 +817,17 @@ int gs_mesh_project(gs_mesh* m, const gs_camera* cam) {
     ProjectParams pp;
     GS_TRY(mesh_params(m, cam, pp));
     ScopedDevice sd(m->ctx->device);
-    GS_TRY(mesh_project(m, pp, true, m->ctx->stage_events));   // + the per-splat mask a visibility-culled sort reads
+    // + the per-splat mask a visibility-culled sort reads: written here by one atomic per survivor - or, for a full frame whose
+    // consumer is a bound sorter that holds the mesh's position map, left to that sorter (k_mask_derive_count: 25 us of a C3 frame)
+    static const bool no_lazy = getenv("GSPLAT_NO_LAZY_MASK") != nullptr;      // (A/B and tests)
+    const bool lazy = m->derive_orig_mask && m->reorder && !no_lazy && pp.row_begin == 0u && pp.row_end >= pp.tiles_y && pp.count == m->uploaded;
+    GS_TRY(mesh_project(m, pp, !lazy, m->ctx->stage_events));
+    m->vis_orig_lazy = lazy;
+    if (lazy) {
+        GS_TRY(m->vis_orig.ensure(((size_t)m->max_count + 63) / 64 * 8 + 64));
+        m->vis_orig_dirty = true;                              // (whatever it holds beyond the words the sorter will write)
+        m->vis_orig_count = pp.count;
+    }
     m->projection_pending = true;
     m->projected_cam = *cam;
     m->projected_depth_mode = pp.depth_mode;

@@ -691,24 +691,114 @@ __global__ __launch_bounds__(VC_THREADS) void k_mask_count(KeyParams p, const ui
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// k_mask_count for a projection whose by-original-index mask was NOT written by the vertex stage (round 6).  gs_mesh_project used
+// to set one bit per survivor with an atomicOr at inv_perm[position]: 1.44 M atomics scattered over a 0.7 MB table cost k_project
+// 25 us of a full C3 frame (47 -> 72 us in the kernel table of the visibility-culled frame, profiles/r06n_vis_n1_kstats.txt).
+// The sorter can build the same mask from what it streams anyway: position i of the identity list is the splat at storage
+// position map[i], whose bit is in the vertex stage's own storage-order mask (vis_mask, 1 bit per position, 0.7 MB: it stays in
+// L2) - and three of four splats sit in a storage block with no survivor at all (block_any, kept as bits in LDS as the binner
+// does), so only a quarter of the positions gather anything.  64 positions per wave and step (ballot -> one 8-byte word), four
+// steps in flight.  Writes the mask words of its chunk (so k_cull_front / k_mask_compact find what they always found) and the
+// chunk's survivor count; full-frame projections only - a strip keeps a few per cent and pays few atomics.
+constexpr uint32_t VC_ANY_WORDS = 2048;                    // block_any as bits in LDS: 65536 storage blocks = 16.7 M splats
+__global__ __launch_bounds__(VC_THREADS) void k_mask_derive_count(KeyParams p, const uint32_t* __restrict__ map,
+                                                                  const unsigned long long* __restrict__ vis_mask,
+                                                                  const uint8_t* __restrict__ block_any, uint32_t blocks, uint32_t chunk_len,
+                                                                  uint32_t subs, unsigned long long* __restrict__ mask64,
+                                                                  uint32_t* __restrict__ chunk_counts) {
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_any[VC_ANY_WORDS];
+    const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) p.digit_total[w] = 0u;      // (the sort's housekeeping: k_mask_count's)
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;
+        p.next_frame->key_max[t] = -2147483640;
+    }
+    if (t == 0) {
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+    }
+    const bool coarse = blocks <= VC_ANY_WORDS * 32u;
+    if (coarse) {
+        for (uint32_t w = threadIdx.x; w < (blocks + 31u) / 32u; w += VC_THREADS) {
+            const uint4* src = reinterpret_cast<const uint4*>(block_any + 32u * w);               // (the buffer is padded to 64 bytes)
+            const uint4 a = src[0], b = src[1];
+            const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t bits = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                bits |= (((v[k] & 0xFFu) ? 1u : 0u) | ((v[k] & 0xFF00u) ? 2u : 0u) | ((v[k] & 0xFF0000u) ? 4u : 0u) |
+                         ((v[k] & 0xFF000000u) ? 8u : 0u)) << (4 * k);
+            s_any[w] = bits;
+        }
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t N = p.render_count;
+    // `subs` workgroups share a chunk of the front end (which runs two workgroups per CU; this kernel is a chain of two dependent
+    // round trips per round - the map, then the gather - and wants every SIMD full of waves): piece blockIdx.x % subs of chunk
+    // blockIdx.x / subs, counts per piece.  A wave takes DERIVE_STEPS x 64 consecutive positions per round, and the NEXT round's
+    // map words are fetched before this round's gathers are used.  (One workgroup per chunk, 4 steps, no prefetch: 25 us for the
+    // C3 frame's 5.8 M positions; 8 steps + prefetch: 20.9 us; r06p kernel tables.)
+    const uint32_t chunk = blockIdx.x / subs, piece = blockIdx.x % subs, piece_len = chunk_len / subs;     // chunk_len % (4096 * subs) == 0
+    const uint32_t cend = min(min(chunk * chunk_len, N) + chunk_len, N);
+    const uint32_t begin = min(chunk * chunk_len + piece * piece_len, cend), end = min(begin + piece_len, cend);
+    uint32_t cnt = 0;
+    constexpr uint32_t DERIVE_STEPS = 8, DERIVE_ROUND = DERIVE_STEPS * 64u * (VC_THREADS / 64u);
+    static_assert(VC_TURN % DERIVE_ROUND == 0, "a chunk is a whole number of rounds");
+    uint32_t nxt[DERIVE_STEPS];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (uint32_t k = 0; k < DERIVE_STEPS; k++) nxt[k] = map[min(base + 64u * k + lane, N - 1u)];     // (unconditional, clamped)
+    };
+    if (begin < end) fetch(begin + DERIVE_STEPS * 64u * wave);
+    for (uint32_t base = begin + DERIVE_STEPS * 64u * wave; base < end; base += DERIVE_ROUND) {
+        uint32_t pos[DERIVE_STEPS];
+        bool live[DERIVE_STEPS];
+#pragma unroll
+        for (uint32_t k = 0; k < DERIVE_STEPS; k++) {
+            pos[k] = nxt[k];
+            live[k] = base + 64u * k + lane < end;
+        }
+        fetch(min(base + DERIVE_ROUND, N - 1u));
+#pragma unroll
+        for (uint32_t k = 0; k < DERIVE_STEPS; k++)
+            live[k] = live[k] && (coarse ? ((s_any[pos[k] >> 13] >> ((pos[k] >> 8) & 31u)) & 1u) != 0u : block_any[pos[k] >> 8] != 0);
+        unsigned long long w[DERIVE_STEPS];
+#pragma unroll
+        for (uint32_t k = 0; k < DERIVE_STEPS; k++) w[k] = vis_mask[live[k] ? pos[k] >> 6 : 0u];         // (unconditional: no wait at a join)
+#pragma unroll
+        for (uint32_t k = 0; k < DERIVE_STEPS; k++) {
+            const unsigned long long word = __ballot(live[k] && ((w[k] >> (pos[k] & 63u)) & 1ull));
+            cnt += (uint32_t)__popcll(word);                                                      // (the same value in every lane)
+            if (lane == 0u && base + 64u * k < end) mask64[(base + 64u * k) >> 6] = word;
+        }
+    }
+    if (lane == 0u) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
 // MAP: payloads come from the bound mesh's position table (a compile-time switch, see above)
 template <bool MAP>
 __global__ __launch_bounds__(VC_THREADS) void k_cull_front(KeyParams p, uint32_t* __restrict__ mask, uint32_t* __restrict__ mask_copy,
                                                            const uint32_t* __restrict__ chunk_counts, uint32_t chunk_len,
-                                                           const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out) {
+                                                           const uint32_t* __restrict__ map, uint32_t* __restrict__ pay_out, uint32_t subs) {
     __shared__ uint32_t s_before[4], s_all[4], s_turn[2][4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     static_assert(VC_THREADS == 256, "four waves per workgroup");
     uint32_t before = 0, all = 0;                                   // survivors of the chunks before this one / of all chunks
-    for (uint32_t c0 = 0; c0 < gridDim.x; c0 += 4u * VC_THREADS) {  // (four loads in flight per lane)
+    // (the counts arrive in `subs` consecutive pieces per chunk: k_mask_count writes one, k_mask_derive_count one per sub-workgroup)
+    const uint32_t pieces = gridDim.x * subs, mine = blockIdx.x * subs;
+    for (uint32_t c0 = 0; c0 < pieces; c0 += 4u * VC_THREADS) {     // (four loads in flight per lane)
         uint32_t x[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) x[k] = chunk_counts[min(c0 + VC_THREADS * k + threadIdx.x, gridDim.x - 1u)];
+        for (uint32_t k = 0; k < 4u; k++) x[k] = chunk_counts[min(c0 + VC_THREADS * k + threadIdx.x, pieces - 1u)];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) {
             const uint32_t c = c0 + VC_THREADS * k + threadIdx.x;
-            all += c < gridDim.x ? x[k] : 0u;
-            before += c < blockIdx.x ? x[k] : 0u;
+            all += c < pieces ? x[k] : 0u;
+            before += c < mine ? x[k] : 0u;
         }
     }
 #pragma unroll
@@ -1282,6 +1372,17 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             GS_TRY(s->idx_in.ensure((size_t)s->max_count * 4));
             GS_TRY(s->mask_copy.ensure(((size_t)s->max_count + 31) / 32 * 4 + 64));
             uint32_t* mask = s->bound_mesh->vis_orig.as<uint32_t>();
+            // The projection left the by-original-index mask to us (gs_mesh_project of a full frame for a mesh whose bound sorter
+            // culls by visibility): k_mask_derive_count builds it from the storage-order mask through the payload map.
+            const bool lazy = s->bound_mesh->vis_orig_lazy;
+            GS_REQUIRE(!lazy || map, "the pending projection expects the sorter to derive its visibility mask, but the sorter has no position map of the mesh");
+            const uint32_t mblocks = (s->bound_mesh->uploaded + 255u) >> 8;
+            constexpr uint32_t DERIVE_SUBS = 4;
+            auto derive = [&](uint32_t dgrid, uint32_t dlen) {
+                hipLaunchKernelGGL(k_mask_derive_count, dim3(dgrid * DERIVE_SUBS), dim3(VC_THREADS), 0, st, kp, map,
+                                   s->bound_mesh->vis_mask.as<unsigned long long>(), s->bound_mesh->block_any.as<uint8_t>(), mblocks, dlen,
+                                   DERIVE_SUBS, reinterpret_cast<unsigned long long*>(mask), s->chunk_counts.as<uint32_t>());
+            };
             // Two front ends, chosen by what the vertex stage drew.  A full frame keeps a large part of the scene (C3: a quarter):
             // the streaming front end keys the survivors on the way (N = 1 frame 0.285 -> 0.270 ms, r05k).  A rank's strip keeps
             // a few per cent: round 4's chain - a 12-byte-per-splat min / max pass, a compaction of the mask, and centre gathers
@@ -1297,18 +1398,27 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             vis_front = force ? force[0] == 's' : !strip;
             if (vis_front) {
                 // one contiguous run of positions per workgroup, walked in turns of 4096 (two workgroups per CU)
-                const uint32_t turns = (R + VC_TURN - 1u) / VC_TURN;
+                // (a chunk is a whole number of turns; with the mask derived here, of DERIVE_SUBS x turns: one piece per sub-workgroup)
+                const uint32_t tlen = lazy ? VC_TURN * DERIVE_SUBS : VC_TURN;
+                const uint32_t turns = (R + tlen - 1u) / tlen;
                 const uint32_t wgrid = turns < (uint32_t)ctx->cu_count * 2u ? turns : (uint32_t)ctx->cu_count * 2u;
-                const uint32_t wlen = ((turns + wgrid - 1u) / wgrid) * VC_TURN;
-                GS_TRY(s->chunk_counts.ensure((size_t)wgrid * 4));
+                const uint32_t wlen = ((turns + wgrid - 1u) / wgrid) * tlen;
+                GS_TRY(s->chunk_counts.ensure((size_t)wgrid * DERIVE_SUBS * 4));
                 GS_TRY(s->pay_in.ensure((size_t)s->max_count * 4));
-                hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wlen, s->chunk_counts.as<uint32_t>());
+                if (lazy) derive(wgrid, wlen);
+                else hipLaunchKernelGGL(k_mask_count, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, wlen, s->chunk_counts.as<uint32_t>());
                 if (map) hipLaunchKernelGGL(k_cull_front<true>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                            s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>());
+                                            s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>(), lazy ? DERIVE_SUBS : 1u);
                 else hipLaunchKernelGGL(k_cull_front<false>, dim3(wgrid), dim3(VC_THREADS), 0, st, kp, mask, s->mask_copy.as<uint32_t>(),
-                                        s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>());
+                                        s->chunk_counts.as<uint32_t>(), wlen, map, s->pay_in.as<uint32_t>(), 1u);
             } else {
                 if (!s->pending_tree) s->has_gathered = false;     // k_mask_compact overwrites a gathered list that was already copied into idx_in
+                if (lazy) {                                        // (a forced compact front end: the mask first, its counts are redone below)
+                    const uint32_t tlen = VC_TURN * DERIVE_SUBS, turns = (R + tlen - 1u) / tlen;
+                    const uint32_t dgrid = turns < (uint32_t)ctx->cu_count * 2u ? turns : (uint32_t)ctx->cu_count * 2u;
+                    GS_TRY(s->chunk_counts.ensure((size_t)std::max(dgrid * DERIVE_SUBS, grid) * 4));
+                    derive(dgrid, ((turns + dgrid - 1u) / dgrid) * tlen);
+                }
                 hipLaunchKernelGGL(k_minmax_count, dim3(grid), dim3(VC_THREADS), 0, st, kp, mask, chunk_len, s->chunk_counts.as<uint32_t>());
                 hipLaunchKernelGGL(k_mask_compact, dim3(grid), dim3(VC_THREADS), 0, st, mask, s->mask_copy.as<uint32_t>(),
                                    s->chunk_counts.as<uint32_t>(), R, chunk_len, s->idx_in.as<uint32_t>(), kp.frame);
@@ -1464,10 +1574,24 @@ int gs_sorter_sort_gathered(gs_sorter* s, const float* mvp, uint32_t sort_count,
     return sorter_sort_impl(s, mvp, nullptr, true, sort_count, s->gathered, precomputed, transforms, sorted_out, stats);
 }
 
+// A bound sorter that culls by visibility and holds the mesh's position map derives the by-original-index mask itself
+// (k_mask_derive_count): the mesh's next full-frame gs_mesh_project may then skip its per-survivor atomics.
+static void sorter_tell_mesh(gs_sorter* s) {
+    gs_mesh* m = s->bound_mesh;
+    if (!m) return;
+    bool alive = false;
+    for (gs_mesh* l : s->ctx->live_meshes) alive = alive || l == m;
+    if (alive) m->derive_orig_mask = s->visibility_cull && gs_mesh_payload_map(m, s->uploaded) != nullptr;
+}
+
 int gs_sorter_bind_mesh(gs_sorter* s, gs_mesh* m) {
     GS_REQUIRE(s != nullptr, "sorter == NULL");
     GS_REQUIRE(!m || m->ctx == s->ctx, "mesh lives on another context");
+    if (s->bound_mesh && s->bound_mesh != m) {
+        for (gs_mesh* l : s->ctx->live_meshes) if (l == s->bound_mesh) l->derive_orig_mask = false;
+    }
     s->bound_mesh = m;
+    sorter_tell_mesh(s);
     return GS_OK;
 }
 
@@ -1482,6 +1606,7 @@ int gs_sorter_set_visibility_cull(gs_sorter* s, int enable) {
     GS_REQUIRE(s != nullptr, "sorter == NULL");
     GS_REQUIRE(!enable || !(s->flags & GS_SORT_DYNAMIC), "the visibility cull is not available to a dynamic-mode sorter");
     s->visibility_cull = enable != 0;
+    sorter_tell_mesh(s);
     return GS_OK;
 }
 

@@ -189,3 +189,44 @@ def test_visibility_mask_lifecycle(ctx):
     worker.set_visibility_cull(False)
     worker.terminate()
     mesh.dispose()
+
+
+def test_full_frame_projection_leaves_the_original_order_mask_to_the_sorter(ctx):
+    """Round 6: a full-frame gs_mesh_project for a mesh whose bound sorter culls by visibility no longer sets one bit per survivor
+    with an atomicOr at inv_perm[position] (25 us of a C3 frame); the sorter derives the mask from the vertex stage's storage-order
+    mask through its position map (k_mask_derive_count).  The list is the reference's restricted to what the frame draws, the keep
+    bits are the vertex stage's survivors, the frame is the full sort's - also for a list shorter than the mesh, and beside strips
+    (which keep the atomics).  $GSPLAT_NO_LAZY_MASK=1 and both front ends: tests/tools/soak_paths.sh."""
+    scene, cam, ci, worker, mesh = _setup(ctx, n=90000, sh=1, seed=33)
+    n, mvp = scene.count, cam.sort_mvp()
+    worker.sort_on_device(mvp, n)
+    mesh.use_sorter_result(worker, n)
+    worker.sort_on_device(mvp, n)
+    full, _ = mesh.render()
+    _, _, vis = mesh.debug_records()
+    order = oracle.sort_indexes(np.arange(n, dtype=np.uint32), ci, mvp)
+    worker.set_visibility_cull(True)
+
+    def culled(strip=None):
+        mesh.project(strip)
+        reply = worker.post_message({"sort": {"modelViewProj": mvp, "splatRenderCount": n, "splatSortCount": n}})
+        bits = worker.keep_bits(n).copy()
+        img, st = mesh.render(tile_rows=strip)
+        return reply["sortedIndexes"].copy(), bits, img, int(st.visible_splats)
+
+    lazy = culled()
+    np.testing.assert_array_equal(lazy[0], order[vis[order]])
+    np.testing.assert_array_equal(lazy[1], vis)
+    np.testing.assert_array_equal(lazy[2], full)
+    strip = (4, 11)
+    lazy_strip = culled(strip)
+    # fewer splats sorted than the mesh holds: the mask covers the list's positions only
+    m = n // 2
+    order_m = oracle.sort_indexes(np.arange(m, dtype=np.uint32), ci, mvp)
+    mesh.project()
+    reply = worker.post_message({"sort": {"modelViewProj": mvp, "splatRenderCount": m, "splatSortCount": m}})
+    np.testing.assert_array_equal(reply["sortedIndexes"], order_m[vis[order_m]])
+    assert lazy_strip[3] < lazy[3]                           # a strip draws (and sorts) less than the frame
+    worker.set_visibility_cull(False)
+    worker.terminate()
+    mesh.dispose()

@@ -47,6 +47,10 @@ bash tools/sort_prof.sh ${TAG}_sort_k4 C4 gpurun_ab/lib_this_tree.so 15 > gpurun
 bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_out/$TAG/sort_pmc_C3.txt 2>&1
 [ -z "$GS_EVIDENCE_LIGHT" ] && (tools/probes/gather_rate.bin 2>&1 | grep -v "^start") > gpurun_out/$TAG/gather_rate.txt
 (python tools/cull_prof.py 2>&1 | grep cull-on) > gpurun_out/$TAG/cull_on_frame.txt
+# round 6: the blend's schedule under camera motion (this tree against the previous round's library, one process), and the kernel
+# table of the N = 1 visibility-culled frame (the mask derived by the sorter)
+[ -f $PREV ] && (timeout 500 python tools/orbit_ab.py "C3 C2 C3S" $PREV gpurun_ab/lib_this_tree.so --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/orbit_ab.txt
+bash tools/rank_prof.sh $TAG C3 1:0 > gpurun_out/$TAG/vis_cull_n1_kstats.txt 2>&1
 [ -n "$GS_EVIDENCE_SORT_MIDDLE" ] && (timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 # the same rank frames on the default context (streams of its own + two sets of vertex-stage outputs: what bench.py --gpus N runs)

@@ -23,12 +23,12 @@ def measure(label, cam, strip):
     mesh.update_render_indexes(order, N)
     for _ in range(3):
         mesh.render(tile_rows=strip, to_host=False, want_stats=True)
-    mesh.kernel_time(0, reset=True)
+    mesh.kernel_time(1, reset=True)            # (timed draws: the whole vertex stage - block test + mask reset + k_project - is clock 1)
     vis = 0
     for _ in range(20):
         _, st = mesh.render(tile_rows=strip, to_host=False, want_stats=True)
         vis = st.visible_splats
-    ms, n = mesh.kernel_time(0, reset=True)
+    ms, n = mesh.kernel_time(1, reset=True)
     print(f"{name} k_project, {label:28s} strip={strip}: {ms / n * 1e3:7.1f} us  visible {vis}")
 
 

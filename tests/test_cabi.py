@@ -58,3 +58,15 @@ def test_product_never_imports_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".js", ".mjs", ".c", ".sh")):
                     src = open(os.path.join(dirpath, f), errors="replace").read()
                     assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, os.path.join(top, f)
+
+
+def test_graft_entry_checks_the_header_abi_version():
+    """The driver's build() asserts the ABI version: it must follow include/gsplat_hip.h (round 6: the header went to 5 and the
+    entry point still said 4 until the smoke run on a GPU box found it)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "gsplat_hip.h")).read()
+    version = int(re.search(r"#define GS_ABI_VERSION (\d+)", header).group(1))
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert f"gs_abi_version() == {version}" in entry
+    assert g.load().gs_abi_version() == version

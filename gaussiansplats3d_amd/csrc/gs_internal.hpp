@@ -438,6 +438,7 @@ struct gs_mesh {
     DevBuf deep_partial;       // float4 [GS_DEEP_UNITS][256]: {C, T} of every (deep bin, quadrant, chunk)
     DevBuf deep_work;          // uint32 [GS_DEEP_UNITS]: the (bin, quadrant, chunk) units that exist, packed (k_deep_plan)
     uint32_t draw_mode = 0;    // GS_DRAW_FP32 | GS_DRAW_ROP8 (gs_mesh_set_draw_mode)
+    bool blend_stats_rop8 = false;   // blend_stats were written by a GS_DRAW_ROP8 draw (every list walked whole: useless as a schedule)
     bool no_deep = false;      // GSPLAT_NO_DEEP: never launch the deep pass (the per-bin kernel draws everything)
     bool deep_pass = false;    // this draw runs the deep pass (decided in gs_launch_binning)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)

@@ -602,6 +602,8 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
         GS_HIP(hipMemcpyAsync(&fail, (const char*)m->bin_scan.p + ((size_t)3 * 2048 + 3 * 64) * 8, 4, hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));
         if (fail) {
+            // (reported once: the word is cleared so that the draws that follow are judged on their own)
+            GS_HIP(hipMemsetAsync((char*)m->bin_scan.p + ((size_t)3 * 2048 + 3 * 64) * 8, 0, 4, st));
             gs_set_error("the binner's cross-workgroup scan timed out (k_bin_fused): the frame is incomplete");
             return GS_ERR_HIP;
         }

@@ -1160,6 +1160,7 @@ void gs_sorter_destroy(gs_sorter* s) {
     delete s;
 }
 
+static void sorter_tell_mesh(gs_sorter* s);   // (defined with gs_sorter_bind_mesh)
 int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const void* centers_aos4,
                              const uint32_t* scene_indexes) {
     GS_REQUIRE(s && centers_aos4, "sorter / centers == NULL");
@@ -1179,6 +1180,7 @@ int gs_sorter_upload_centers(gs_sorter* s, uint32_t from, uint32_t count, const 
     GS_HIP(hipStreamSynchronize(st));   // staging and the caller's buffers are reusable on return
     if (from + count > s->uploaded) s->uploaded = from + count;   // uploadedSplatCount, SortWorker.js:97
     s->centers_version++;
+    sorter_tell_mesh(s);                                   // (more centres than the bound mesh holds: no position map, no derived mask)
     return GS_OK;
 }
 

@@ -715,7 +715,8 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 4u * GS_CHUNK;
     static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 3u;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
-                          m->blend_width == (uint32_t)pp.width && !getenv("GSPLAT_NO_BLEND_ORDER");
+                          m->blend_width == (uint32_t)pp.width && !m->blend_stats_rop8 && !getenv("GSPLAT_NO_BLEND_ORDER");
+    // (!blend_stats_rop8: a GS_DRAW_ROP8 draw walks every list whole - its per-bin counters say nothing about what an fp32 draw costs)
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
     // ... and they ORDER this draw's blend workgroups only when that draw had THIS draw's view.  Heaviest-first from statistics of
     // the same view is worth 5-8 % of a frame (C3 demo pose 0.261 -> 0.248 ms, the orbit's poses held fixed 0.350 -> 0.322); from

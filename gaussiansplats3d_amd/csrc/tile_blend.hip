@@ -1199,6 +1199,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     if (m->draw_mode == GS_DRAW_ROP8) {                    // the reference's RGBA8 target, splat by splat (no deep pass: nothing to schedule)
         if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend_rop8<true>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
         else hipLaunchKernelGGL(k_tile_blend_rop8<false>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        m->blend_stats_rop8 = true;                        // (the next fp32 draw neither orders its bins nor picks deep bins from these)
         m->blend_row_begin = pp.bin_row_begin;
         m->blend_width = (uint32_t)pp.width;
         GS_HIP(hipGetLastError());
@@ -1211,6 +1212,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend<true>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     else hipLaunchKernelGGL(k_tile_blend<false>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     if (m->deep_pass) hipLaunchKernelGGL(k_deep_fold, dim3(GS_DEEP_MAX_BINS), dim3(BLEND_THREADS), 0, st, fa, da);
+    m->blend_stats_rop8 = false;
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;
     GS_HIP(hipGetLastError());

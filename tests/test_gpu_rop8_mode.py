@@ -115,3 +115,26 @@ def test_rop8_draw_from_a_device_resident_sort_and_on_one_stream():
         mesh.dispose()
         c.close()
     np.testing.assert_array_equal(frames[0], frames[1])
+
+
+def test_rop8_statistics_do_not_schedule_the_next_fp32_draw(ctx):
+    """A GS_DRAW_ROP8 draw walks every list whole: its per-bin counters would order the next fp32 draw's bins - and send hundreds of
+    them to the deep pass - from numbers that say nothing about an fp32 draw.  The draw after a mode switch is scheduled as a first
+    draw is (no order, no deep bins), its pixels are the fp32 frame's, and the draws after it use their own statistics again."""
+    scene = helpers.small_scene(120000, 0, seed=17, scale=0.03)
+    cam = camera.demo_camera("garden", 640, 360)
+    mesh = SplatMesh(ctx, scene.count, 0).build(scene.centers, scene.cov, scene.rgba, None)
+    mesh.set_camera(cam)
+    mesh.update_render_indexes(_order(scene, cam), scene.count)
+    for _ in range(3):
+        fp32, st = mesh.render()
+    mesh.set_draw_mode(rop8=True)
+    _, st8 = mesh.render()
+    assert st8.splats_walked > st.splats_walked
+    mesh.set_draw_mode(rop8=False)
+    for _ in range(3):
+        again, st2 = mesh.render()
+        np.testing.assert_array_equal(again, fp32)
+        assert mesh.deep_pass_info()["bins"].size == 0          # nothing of this small frame belongs in the deep pass
+    assert st2.splats_walked == st.splats_walked
+    mesh.dispose()

@@ -688,6 +688,7 @@ def main():
                 second_solo = measure(env, second_cfg, min(args.steps, 20), 3, 1, 0, stages=True, median_frames=min(args.median_frames, 50))
         dist.barrier()
     pipelined, orbit, cull, fused, vis_fused, translucent, capture, lanes = None, None, None, None, None, None, None, None
+    rop8 = None
     if world == 1:
         with torch.cuda.stream(stream):
             worker.set_visibility_cull(False)
@@ -767,6 +768,25 @@ def main():
                                  "moving_camera_*: 120 frames, a new pose each, enqueued back to back like the headline's (the orbit's "
                                  "poses see 1.8 M splats at the median, the demo pose 1.44 M)"}
 
+                # GS_DRAW_ROP8 (round 6): the headline frame in the reference's own blend state - RGBA8, rounded after every splat,
+                # back to front (SplatMaterial3D.js:65-75) - over the splats in front of each quadrant's saturation depth, and
+                # GS_DRAW_ROP8_FULL over every list to its end; same sort, same vertex stage, same lists
+                rop8 = {}
+                for label, full_walk in (("bounded", False), ("full", True)):
+                    mesh.set_draw_mode(rop8=True, full=full_walk)
+                    for _ in range(2):
+                        rig.frame(strip.data_ptr())
+                    r_steps = min(args.steps, 20 if not full_walk else 8)
+                    r_el, _ = rig.timed(r_steps, strip.data_ptr())
+                    _, r_st = mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=True)
+                    rop8[label] = {"ms_per_frame": round(r_el / r_steps * 1e3, 4), "Msplats_per_s": round(N / (r_el / r_steps) / 1e6, 1),
+                                   "blend_ms": round(float(r_st.blend_ms), 4), "splats_walked": int(r_st.splats_walked)}
+                mesh.set_draw_mode(rop8=False)
+                for _ in range(2):                              # (the fp32 statistics back in place for whatever follows)
+                    rig.frame(strip.data_ptr())
+                rop8["note"] = ("gs_mesh_set_draw_mode: GS_DRAW_ROP8 = colour to the ROP-emulating oracle's gate (>= 99.5 % of channel values "
+                                "equal, <= 1 apart; alpha <= 2 where it stalls below 255), GS_DRAW_ROP8_FULL = all four channels "
+                                "(tests/test_gpu_crops.py); the fp32 draw is the headline")
                 rig.frame(strip.data_ptr())                       # the frame every culled variant must reproduce bit for bit
                 torch.cuda.synchronize()
                 ref_img = strip.clone()
@@ -1110,6 +1130,7 @@ def main():
             "visibility_cull_fused": vis_fused,
             "translucent": translucent,
             "capture_like": capture,
+            "rop8_draw_mode": rop8,
             "cpu_baseline": None,
             "frames_drawn_before_timing_ended": frames_headline,
             "scene_gen_s": round(t_gen, 1),

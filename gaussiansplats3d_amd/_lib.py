@@ -67,7 +67,7 @@ class Destination(C.Structure):
 
 
 GS_DEST_DEPTH_UNORM24 = 1
-GS_DRAW_FP32, GS_DRAW_ROP8 = 0, 1
+GS_DRAW_FP32, GS_DRAW_ROP8, GS_DRAW_ROP8_FULL = 0, 1, 2
 
 
 class TreeInfo(C.Structure):

@@ -963,7 +963,7 @@ int gs_mesh_kernel_time(gs_mesh* m, int which, int reset, double* sum_ms, uint32
 
 int gs_mesh_set_draw_mode(gs_mesh* m, uint32_t mode) {
     GS_REQUIRE(m, "mesh == NULL");
-    GS_REQUIRE(mode == GS_DRAW_FP32 || mode == GS_DRAW_ROP8, "unknown draw mode");
+    GS_REQUIRE(mode == GS_DRAW_FP32 || mode == GS_DRAW_ROP8 || mode == GS_DRAW_ROP8_FULL, "unknown draw mode");
     m->draw_mode = mode;
     return GS_OK;
 }

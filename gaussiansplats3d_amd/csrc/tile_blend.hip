@@ -1030,10 +1030,10 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
 // 32-px bin, a wave per quadrant, the list walked from its END in batches of 256 entries that are staged exactly like the fp32
 // draw's (same rect and exact reach tests, same expansion into LDS, same alpha arithmetic and depth test), each wave taking its
 // survivors of a batch in DESCENDING order.  A splat that cannot reach a quadrant would blend alpha = 0 there: q8(0 src + 1 c) =
-// c for an already rounded c, so skipping it changes nothing.  No early termination (a far splat may be fully hidden, but the
-// rounding of every splat in front of it is what the browser shows) and no chunks: every list is walked whole - C3: 11.4 M (splat,
-// quadrant) pairs instead of 0.49 M, blend 3.98 ms instead of 0.058 (C2 2.68 ms, C3T 3.99 ms; tests/test_gpu_crops.py prints them) -
-// for hosts that need the browser's pixels, not for frame rate.
+// c for an already rounded c, so skipping it changes nothing.  Back to front there is no early termination and there are no
+// chunks: GS_DRAW_ROP8_FULL walks every list whole - C3: 11.4 M (splat, quadrant) pairs instead of 0.49 M, blend 4.0 ms instead of
+// 0.058 (C2 2.6 ms, C3T 4.0 ms) - and GS_DRAW_ROP8 (below) first finds, front to back, how far into its list a quadrant can be seen
+// at all: C3 0.78 M pairs, blend 0.32 ms (C2 1.02, C3T 3.4: translucent content is walked almost whole).
 struct Rop8Px {                                  // a lane's 4 pixels, channel values k / 255 held as floats (packed pairs as in Px)
     v2f r[2], g[2], b[2], a[2];
 };
@@ -1060,7 +1060,34 @@ __device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, con
         px.a[h] = q8_pair(a + om * px.a[h]);
     }
 }
-template <bool DEPTH>
+// GS_DRAW_ROP8 is BOUNDED (the default of the mode): back to front over the splats IN FRONT OF THE QUADRANT'S SATURATION DEPTH only.
+// Pass 1 walks the list front to back like the fp32 draw, carrying nothing but the transmittance, until every pixel of the quadrant
+// has T <= 1e-6 (tested after every 8th survivor: a function of the quadrant's own survivor sequence, so strips reproduce it); pass 2
+// walks exactly those survivors back to front with the per-splat rounding.  What lies behind that depth reaches the frame scaled by
+// <= 1e-6 - 0.0003 of an 8-bit step before the roundings in front of it, which pass a difference on with probability (1 - alpha)
+// each - so the frame stays within the gate of the full walk (tests/test_gpu_crops.py: >= 99.5 % of the channel values equal to the
+// ROP-emulating oracle, never more than 1 apart).  A quadrant that never saturates is walked whole, as before.
+// Measured against the ROP-emulating oracle on the BASELINE crops (tests/test_gpu_crops.py, `rop8_mode`): colour - C3 >= 99.79 % of
+// the r, g, b values equal (full walk 99.85 %), C2 99.99 %, C3T 99.85 % (identical to the full walk's colour on every pixel of the
+// frame), never more than 1 apart.  ALPHA is the exception: alpha' = q8(a + (1 - a) alpha) only ever rises and STALLS once
+// a (255 - alpha) < 0.5; where it stalls below 255 the value depends on every splat of the list, the ones behind the saturation depth
+// included, and the bounded walk may end 1-2 steps off (14 % of C3T's pixels); where it reaches 255 it is exact (the update is
+// monotone in its start value).  Hosts that need that channel to the step take GS_DRAW_ROP8_FULL.
+// GS_DRAW_ROP8_FULL (BOUNDED = false) is the full walk: every list to its end.
+// What "hidden" means for an 8-bit target: blending a fragment of alpha a over an 8-bit value c gives q8(c + a (s - c)) - for
+// a |s - c| < 0.5 / 255 that is c again, whatever lies behind shines through UNATTENUATED, where exact arithmetic would have dimmed it
+// by (1 - a).  A pile of faint fragments therefore hides nothing (the first version of this bound took the exact transmittance:
+// 95.4 % of C3T's channel values equal, two steps apart at worst; C3 and C2 passed).  Pass 1 counts a fragment only from alpha >=
+// 1 / 64 on - where a (s - c) spans several steps and a difference between two backgrounds survives the rounding with probability
+// ~(1 - a) - so translucent content is simply walked whole.
+#ifndef GS_ROP8_T_EPS_CFG
+#define GS_ROP8_T_EPS_CFG 1e-6f
+#endif
+#ifndef GS_ROP8_A_MIN_CFG
+#define GS_ROP8_A_MIN_CFG (1.0f / 64.0f)
+#endif
+constexpr float GS_ROP8_T_EPS = GS_ROP8_T_EPS_CFG, GS_ROP8_A_MIN = GS_ROP8_A_MIN_CFG;
+template <bool DEPTH, bool BOUNDED>
 __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa, uint32_t bins) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
@@ -1080,22 +1107,10 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
     v2f dz[2] = {{GS_HUGE, GS_HUGE}, {GS_HUGE, GS_HUGE}};
     if (DEPTH) load_dst_depth(fa, px, py0, dz);
     const bool live_wave = bg.live(fa, wave);
-    Rop8Px acc;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {                              // the target starts as the destination's colour, or cleared
-        const uint32_t py = py0 + 4u * g;
-        uint32_t d = 0u;
-        if (fa.dst_rgba && px < fa.width && py < fa.height) d = fa.dst_rgba[(size_t)py * fa.width + px];
-        acc.r[g >> 1][g & 1] = (float)(d & 255u) * (1.0f / 255.0f);
-        acc.g[g >> 1][g & 1] = (float)((d >> 8) & 255u) * (1.0f / 255.0f);
-        acc.b[g >> 1][g & 1] = (float)((d >> 16) & 255u) * (1.0f / 255.0f);
-        acc.a[g >> 1][g & 1] = (float)(d >> 24) * (1.0f / 255.0f);
-    }
-    uint32_t walked = 0;
     const uint32_t batches = (n + BLEND_THREADS - 1u) / BLEND_THREADS;
-    for (uint32_t bi = batches; bi-- > 0u;) {                  // the farthest batch first
+    // one batch of <= 256 entries -> LDS, exactly as the fp32 draw stages it (between two barriers of the caller)
+    auto stage = [&](uint32_t bi) {
         const uint32_t base = bi * BLEND_THREADS, cnt = min((uint32_t)BLEND_THREADS, n - base);
-        __syncthreads();                                       // the previous batch is consumed
         uint32_t qm = 0;
         if (tid < cnt) {
             const uint32_t slot = fa.vals[begin + base + tid];
@@ -1108,17 +1123,101 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
             }
         }
         s_qmask[tid] = qm;
-        __syncthreads();
-        if (live_wave) {
-            for (uint32_t g0 = ((cnt - 1u) / 64u) * 64u + 64u; g0 > 0u;) {
-                g0 -= 64u;
-                unsigned long long m = __ballot((s_qmask[g0 + lane] >> wave) & 1u);
-                while (m) {
-                    const uint32_t jl = 63u - (uint32_t)__builtin_clzll(m);          // the farthest survivor left
-                    m &= ~(1ull << jl);
-                    walked++;
-                    composite_rop8<DEPTH>(&s_batch[g0 + jl], fx, fy, dz, acc);
+        return cnt;
+    };
+    // where this quadrant's walk ends: batch b_stop (-1: nothing to walk), its first c_stop survivors (ascending)
+    int32_t b_stop = live_wave && batches ? (int32_t)batches - 1 : -1;
+    uint32_t c_stop = 0xFFFFFFFFu;
+    uint32_t last = batches ? batches - 1u : 0u;               // the last batch a walk has to look at (uniform)
+    if (BOUNDED && batches) {
+        // pass 1: transmittance only, front to back, the fp32 draw's cadence of saturation tests
+        v2f T[2] = {{1.0f, 1.0f}, {1.0f, 1.0f}};
+        bool active = live_wave;
+        uint32_t since = 0;
+        uint32_t bi = 0;
+        for (;; bi++) {
+            __syncthreads();
+            const uint32_t cnt = stage(bi);
+            __syncthreads();
+            if (active) {
+                uint32_t taken = 0;
+                for (uint32_t g0 = 0; g0 < cnt && active; g0 += 64u) {
+                    unsigned long long m = __ballot((s_qmask[g0 + lane] >> wave) & 1u);
+                    while (m) {
+                        const uint32_t jl = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1ull;
+                        taken++;
+                        Alpha al;
+                        uint32_t d0 = 0, d1 = 0;
+                        Px unused;
+                        unused.reset();
+                        alpha_of<DEPTH>(&s_batch[g0 + jl], fx, fy, dz, unused, al, d0, d1);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {                      // (a faint fragment hides nothing from an 8-bit target: see above)
+                            const v2f a = {al.a[h].x >= GS_ROP8_A_MIN ? al.a[h].x : 0.0f, al.a[h].y >= GS_ROP8_A_MIN ? al.a[h].y : 0.0f};
+                            T[h] = fma2(-T[h], a, T[h]);
+                        }
+                        if (++since == GS_BLEND_CHECK) {
+                            since = 0;
+                            const float tmax = fmaxf(fmaxf(T[0].x, T[0].y), fmaxf(T[1].x, T[1].y));
+                            if (__ballot(tmax > GS_ROP8_T_EPS) == 0ull) {
+                                active = false;
+                                b_stop = (int32_t)bi;
+                                c_stop = taken;
+                                break;
+                            }
+                        }
+                    }
                 }
+            }
+            // (the barrier doubles as "the batch is consumed"; nobody walks on: the last batch staged is still in LDS)
+            if (!__syncthreads_or(active ? 1 : 0) || bi + 1u == batches) break;
+        }
+        last = bi;
+    }
+    Rop8Px acc;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {                              // the target starts as the destination's colour, or cleared
+        const uint32_t py = py0 + 4u * g;
+        uint32_t d = 0u;
+        if (fa.dst_rgba && px < fa.width && py < fa.height) d = fa.dst_rgba[(size_t)py * fa.width + px];
+        acc.r[g >> 1][g & 1] = (float)(d & 255u) * (1.0f / 255.0f);
+        acc.g[g >> 1][g & 1] = (float)((d >> 8) & 255u) * (1.0f / 255.0f);
+        acc.b[g >> 1][g & 1] = (float)((d >> 16) & 255u) * (1.0f / 255.0f);
+        acc.a[g >> 1][g & 1] = (float)(d >> 24) * (1.0f / 255.0f);
+    }
+    uint32_t walked = 0;
+    // pass 2 (the only pass of the full walk): back to front, every channel rounded after every splat
+    for (uint32_t bi = batches ? last + 1u : 0u; bi-- > 0u;) {
+        uint32_t cnt = min((uint32_t)BLEND_THREADS, n - bi * BLEND_THREADS);
+        if (!(BOUNDED && bi == last)) {                        // (the bounded walk's last batch is still staged)
+            __syncthreads();
+            cnt = stage(bi);
+            __syncthreads();
+        }
+        if ((int32_t)bi > b_stop) continue;
+        const uint32_t groups = (cnt + 63u) / 64u;
+        unsigned long long gm[4] = {0ull, 0ull, 0ull, 0ull};
+        uint32_t before[4] = {0u, 0u, 0u, 0u}, run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            if (k < groups) gm[k] = __ballot((s_qmask[64u * k + lane] >> wave) & 1u);
+            before[k] = run;
+            run += (uint32_t)__popcll(gm[k]);
+        }
+#pragma unroll
+        for (uint32_t kk = 0; kk < 4u; kk++) {
+            const uint32_t k = 3u - kk;
+            unsigned long long m = gm[k];
+            if ((int32_t)bi == b_stop && c_stop != 0xFFFFFFFFu) {     // only the first c_stop survivors of this batch
+                const uint32_t have = (uint32_t)__popcll(m), take = c_stop > before[k] ? min(c_stop - before[k], have) : 0u;
+                for (uint32_t drop = have - take; drop; drop--) m &= ~(1ull << (63u - (uint32_t)__builtin_clzll(m)));
+            }
+            while (m) {
+                const uint32_t jl = 63u - (uint32_t)__builtin_clzll(m);           // the farthest survivor left
+                m &= ~(1ull << jl);
+                walked++;
+                composite_rop8<DEPTH>(&s_batch[64u * k + jl], fx, fy, dz, acc);
             }
         }
     }
@@ -1126,7 +1225,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
     __syncthreads();
     if (tid == 0u) {                                            // the blend's per-bin statistics, as the fp32 draw leaves them
         const uint32_t pairs = s_walked[0] + s_walked[1] + s_walked[2] + s_walked[3];
-        fa.bin_stats[bin] = make_uint2(n, 2u * pairs);
+        fa.bin_stats[bin] = make_uint2(min((last + 1u) * BLEND_THREADS, n), 2u * pairs);
         fa.bin_pairs[bin] = pairs;
     }
 #pragma unroll
@@ -1196,9 +1295,12 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     da.work = m->deep_work.as<uint32_t>();
     // (as many workgroups as the device holds at BLEND_OCC per CU: their waves loop over the unit list)
     da.unit_wgs = m->deep_pass ? (uint32_t)m->ctx->cu_count * BLEND_OCC : 0u;
-    if (m->draw_mode == GS_DRAW_ROP8) {                    // the reference's RGBA8 target, splat by splat (no deep pass: nothing to schedule)
-        if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend_rop8<true>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
-        else hipLaunchKernelGGL(k_tile_blend_rop8<false>, dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+    if (m->draw_mode != GS_DRAW_FP32) {                    // the reference's RGBA8 target, splat by splat (no deep pass: nothing to schedule)
+        const bool full = m->draw_mode == GS_DRAW_ROP8_FULL;
+        if (fa.depth_mode && full) hipLaunchKernelGGL((k_tile_blend_rop8<true, false>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        else if (fa.depth_mode) hipLaunchKernelGGL((k_tile_blend_rop8<true, true>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        else if (full) hipLaunchKernelGGL((k_tile_blend_rop8<false, false>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
+        else hipLaunchKernelGGL((k_tile_blend_rop8<false, true>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
         m->blend_stats_rop8 = true;                        // (the next fp32 draw neither orders its bins nor picks deep bins from these)
         m->blend_row_begin = pp.bin_row_begin;
         m->blend_width = (uint32_t)pp.width;

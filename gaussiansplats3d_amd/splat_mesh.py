@@ -298,12 +298,13 @@ class SplatMesh:
         L.check(self.lib.gs_mesh_debug_read(self.handle, 4, out.ctypes.data, by * bx))
         return out.reshape(by, bx, 2)
 
-    def set_draw_mode(self, rop8=False):
+    def set_draw_mode(self, rop8=False, full=False):
         """How the following draws composite: the fp32 front-to-back composite rounded once (default), or - rop8=True - the
         reference's RGBA8 render target as a GPU executes it: back to front, every channel rounded to 8 bits after every splat
-        (SplatMaterial3D.js:65-75; gs_mesh_set_draw_mode GS_DRAW_ROP8).  Every list is walked whole (C3 blend 4.0 ms instead of 0.06):
-        for hosts that need the browser's pixels."""
-        L.check(self.lib.gs_mesh_set_draw_mode(self.handle, L.GS_DRAW_ROP8 if rop8 else L.GS_DRAW_FP32))
+        (SplatMaterial3D.js:65-75; gs_mesh_set_draw_mode).  GS_DRAW_ROP8 walks the splats in front of each quadrant's saturation depth
+        (T <= 1e-6) - ~4x the fp32 blend; full=True (GS_DRAW_ROP8_FULL) walks every list to its end (~70x)."""
+        mode = L.GS_DRAW_FP32 if not rop8 else (L.GS_DRAW_ROP8_FULL if full else L.GS_DRAW_ROP8)
+        L.check(self.lib.gs_mesh_set_draw_mode(self.handle, mode))
         return self
 
     def set_deep_pass(self, enabled):

@@ -426,16 +426,27 @@ int gs_mesh_debug_rop8(gs_mesh* m, uint32_t x0, uint32_t y0, uint32_t width, uin
  *   GS_DRAW_FP32 (default)  the front-to-back fp32 composite, rounded to RGBA8 once (early termination, chunks, the deep pass):
  *                           <= 0.52 / 255 from the exact composite, 3-4 / 255 from what a browser's RGBA8 target shows on
  *                           translucent content (tests/test_gpu_crops.py gates both).
- *   GS_DRAW_ROP8            the reference's own blend state as it executes on a GPU (SplatMaterial3D.js:65-75: NormalBlending into
+ *   GS_DRAW_ROP8_FULL       the reference's own blend state as it executes on a GPU (SplatMaterial3D.js:65-75: NormalBlending into
  *                           an RGBA8 target; src/Viewer.js:358-359: cleared to (0,0,0,0), or the destination's colour): back to
  *                           front, rgb = a*src + (1-a)*rgb, alpha = a + (1-a)*alpha, every channel rounded to 8 bits after EVERY
  *                           splat - gs_mesh_debug_rop8's semantics for the whole frame: >= 99.85 % of the channel values equal to
- *                           the ROP-emulating oracle, never more than 1 apart.  Every list is walked whole (no early
- *                           termination is possible back to front): the blend of a 1080p garden frame takes 4.0 ms instead of 0.06 - for hosts that need
- *                           the browser's pixels.  Strips, destinations (depth test and colour) and device-resident outputs work
- *                           as in the fp32 mode; the statistics count the pairs this mode walked. */
+ *                           the ROP-emulating oracle, never more than 1 apart.  Every list is walked whole (no early termination
+ *                           is possible back to front): the blend of a 1080p garden frame takes 4.0 ms instead of 0.06.
+ *   GS_DRAW_ROP8            the same composite over the splats IN FRONT OF each 16x16 quadrant's saturation depth only: a first
+ *                           pass walks the list front to back until every pixel of the quadrant has let <= 1e-6 through (counting
+ *                           fragments of alpha >= 1/64: fainter ones hide nothing from an 8-bit target), a second pass blends
+ *                           exactly those splats back to front with the per-splat rounding.  Colour: the full walk's gate
+ *                           (>= 99.5 % of the r, g, b values equal to the ROP-emulating oracle, never more than 1 apart; on the
+ *                           C3T crops colour is identical to the full walk).  Alpha: exact wherever it reaches 255; where it
+ *                           stalls below 255 - alpha = q8(a + (1-a) alpha) stops moving once a (255 - alpha) < 0.5 - the value
+ *                           it stalls at depends on the whole list and may differ by <= 2 steps.  Garden stand-in at 1080p:
+ *                           blend 0.32 ms, i.e. a 0.50 ms frame = 11.6 Gsplats/s with the browser's colours; translucent content
+ *                           (nothing saturates) costs what the full walk costs.
+ * Strips, destinations (depth test and colour) and device-resident outputs work as in the fp32 mode; the statistics count the pairs
+ * the mode walked, and they never schedule a later fp32 draw. */
 #define GS_DRAW_FP32 0u
 #define GS_DRAW_ROP8 1u
+#define GS_DRAW_ROP8_FULL 2u
 int gs_mesh_set_draw_mode(gs_mesh* m, uint32_t mode);
 
 /* Scheduling switch, 1 by default (0 also via $GSPLAT_NO_DEEP at gs_mesh_create): whether the draws that follow may composite

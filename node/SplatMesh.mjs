@@ -172,7 +172,7 @@ export class SplatMesh {
       this.core.setSplatScale(this.splatScale);
       this.core.setPointCloudModeEnabled(this.pointCloudModeEnabled);
       if (this._destination) this.setDestination(this._destination);      // a rebuilt mesh keeps the host's destination
-      if (this._rop8) this.core.setRop8(true);                            // ... and its draw mode
+      if (this._rop8) this.core.setRop8(true, this._rop8 === 2);          // ... and its draw mode
       this.splatDataTextures = { baseData: {}, maxSplatCount,
         covariances: { compressionLevel: this.getTargetCovarianceCompressionLevel(), size: new THREE.Vector2(maxSplatCount, 1) },
         centerColors: { size: new THREE.Vector2(maxSplatCount, 1) } };       // sizes: Viewer.js:1289-1296 only logs them
@@ -348,11 +348,11 @@ export class SplatMesh {
     else this.core.setDestination(dest.depth || null, dest.colour || null, dest.width, dest.height, dest.depthBits || 32);
   }
   // HIP-engine extra: draw as the browser's RGBA8 render target does (every channel rounded to 8 bits after every splat, back to
-  // front: SplatMaterial3D.js:65-75 as a ROP executes it) instead of in fp32 rounded once.  Every list is walked whole: ~4 ms per
-  // 1080p frame instead of 0.25.
-  setRop8(enabled) {
-    this._rop8 = !!enabled;
-    if (this.core) this.core.setRop8(this._rop8);
+  // front: SplatMaterial3D.js:65-75 as a ROP executes it) instead of in fp32 rounded once: ~0.45 ms per 1080p frame of the garden
+  // stand-in instead of 0.25; full = true walks every list to its end (~4 ms: verification).
+  setRop8(enabled, full = false) {
+    this._rop8 = enabled ? (full ? 2 : 1) : 0;
+    if (this.core) this.core.setRop8(!!enabled, !!full);
   }
   renderFrame(camera, out) {
     if (!this.core || this.getSplatCount() <= 0) return null;

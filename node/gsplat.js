@@ -239,9 +239,9 @@ class SplatMeshHIP {
   // HIP-engine extra: whether very deep bins may be composited by many waves at once (same pixels either way)
   setDeepPass(enabled) { addon.meshSetDeepPass(this.handle, enabled ? 1 : 0); }
   // HIP-engine extra: composite as the browser's RGBA8 render target does - back to front, every channel rounded to 8 bits after
-  // every splat (SplatMaterial3D.js:65-75 as a ROP executes it) - instead of in fp32 rounded once; every list is walked whole
-  // (a 1080p garden frame: blend 4.0 ms instead of 0.06)
-  setRop8(enabled) { addon.meshSetDrawMode(this.handle, enabled ? 1 : 0); }
+  // every splat (SplatMaterial3D.js:65-75 as a ROP executes it) - instead of in fp32 rounded once.  The mode walks the splats in
+  // front of each quadrant's saturation depth (~4x the fp32 blend); full = true walks every list to its end (~70x: verification)
+  setRop8(enabled, full = false) { addon.meshSetDrawMode(this.handle, enabled ? (full ? 2 : 1) : 0); }
   // The destination of the following draws: `depthTest: true, depthWrite: false` against `depth` (Float32Array W*H, window depth in
   // [0, 1], row 0 = bottom: what the host's opaque geometry left) and NormalBlending over `rgba` (Uint8Array 4*W*H) - the reference's
   // material state (SplatMaterial3D.js:72-73) when the splat mesh shares a scene with other objects (DropInViewer.js:34-42,

@@ -542,8 +542,8 @@ static napi_value GroupWait(napi_env env, napi_callback_info info) {
     if (st < 0) return throw_gs(env, st);
     return NULL;
 }
-/* meshSetDrawMode(mesh, mode): 0 = the fp32 composite rounded once, 1 = the reference's RGBA8 target, rounded after every splat
- * (gs_mesh_set_draw_mode) */
+/* meshSetDrawMode(mesh, mode): 0 = the fp32 composite rounded once, 1 = the reference's RGBA8 target, rounded after every splat,
+ * over the splats in front of the saturation depth, 2 = the same over every list to its end (gs_mesh_set_draw_mode) */
 static napi_value MeshSetDrawMode(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
     napi_get_cb_info(env, info, &argc, argv, NULL, NULL);

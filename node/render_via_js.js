@@ -2,7 +2,8 @@
 // in.bin: uint32 header {n, shDegree, width, height, flags(1 ortho | 2 fade | 4 effects), sceneCount, 0, 0}, then
 // centers F32[3n], cov F32[6n], rgba U8[4n], sh U16[ncoef*n], order U32[n], sceneIdx U32[n], modelView F32[16], proj F32[16],
 // camPos F32[3], focal F32[2], orthoZoom F32[1], sceneCenter F32[3], fadeStart F32[1], opacity F32[sceneCount], visible U32[sceneCount]
-// and, with flag 8 (a destination: drop-in mode's depth test and colour), depth F32[width*height], colour U8[4*width*height]
+// and, with flag 8 (a destination: drop-in mode's depth test and colour), depth F32[width*height], colour U8[4*width*height];
+// flag 16: draw in GS_DRAW_ROP8 (the reference's RGBA8 target, rounded after every splat), flag 32: GS_DRAW_ROP8_FULL
 'use strict';
 const fs = require('fs');
 const gs = require('./gsplat.js');
@@ -28,6 +29,7 @@ mesh.updateRenderIndexes(order, n);
 mesh.updateUniforms({ x: width, y: height }, focal[0], focal[1], !!(flags & 1), orthoZoom, 1.0);
 mesh.setCameraMatrices(modelView, proj, camPos);
 if (flags & 8) mesh.setDestination(dstDepth, dstColour, width, height, 24);
+if (flags & 48) mesh.setRop8(true, !!(flags & 32));
 const { pixels, stats } = mesh.render();
 fs.writeFileSync(outPath, Buffer.from(pixels.buffer, pixels.byteOffset, pixels.byteLength));
 // the multi-GPU entry points with a group of one: the same frame through gs_group_render_gather

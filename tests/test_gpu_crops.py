@@ -155,20 +155,31 @@ def _crop_parity(ctx, cfg_name, n_windows, cam=None, tag=None):
     # GS_DRAW_ROP8 (round 6): the same frame drawn in the reference's RGBA8-per-splat mode, on the windows the
     # ROP-emulating oracle rasterised: >= 99.5 % of the channel values equal, never more than 1 apart - the verification kernel's gate
     if tag in ROP8_MODE_CONFIGS:
-        mesh.set_draw_mode(rop8=True)
-        worker.sort_on_device(mvp, n)
-        frame8, st8 = mesh.render()
-        mesh.set_draw_mode(rop8=False)
-        eq, worst = [], 0.0
-        for (name, x0, y0, w, h), (fb8, _) in zip(wins, crops8):
-            d = np.abs(frame8[y0:y0 + h, x0:x0 + w].astype(np.float32) - np.round(np.clip(fb8, 0, 1) * 255.0))
-            eq.append(float((d == 0).mean()))
-            worst = max(worst, float(d.max()))
-            assert d.max() <= ROP8_MAX and (d == 0).mean() >= ROP8_EQUAL, \
-                f"{tag} {name}: GS_DRAW_ROP8 vs the ROP-emulating oracle: {(d == 0).mean():.4f} equal, max {d.max():.0f}"
-        report["rop8_mode"] = {"equal_frac_min": round(min(eq), 5), "equal_frac_mean": round(float(np.mean(eq)), 5), "max_diff": worst,
-                               "splats_walked": int(st8.splats_walked), "blend_ms": round(float(st8.blend_ms), 4)}
-        print(f"{tag} GS_DRAW_ROP8: equal >= {min(eq):.4f}, max {worst:.0f}, walked {int(st8.splats_walked)}, blend {float(st8.blend_ms):.3f} ms")
+        report["rop8_mode"] = {}
+        for label, full in (("bounded", False), ("full", True)):
+            mesh.set_draw_mode(rop8=True, full=full)
+            worker.sort_on_device(mvp, n)
+            frame8, st8 = mesh.render()
+            mesh.set_draw_mode(rop8=False)
+            eq, alpha_eq, worst = [], [], 0.0
+            for (name, x0, y0, w, h), (fb8, _) in zip(wins, crops8):
+                d = np.abs(frame8[y0:y0 + h, x0:x0 + w].astype(np.float32) - np.round(np.clip(fb8, 0, 1) * 255.0))
+                if not full:
+                    # the bounded walk: colour to the full walk's gate; the ALPHA channel may sit up to 2 steps off where it stalls
+                    # below 255 (alpha = q8(a + (1 - a) alpha) stops moving once a (255 - alpha) < 0.5, at a value that depends on
+                    # the whole list - the far splats the bounded walk leaves out included; tile_blend.hip)
+                    assert d[..., 3].max() <= 2.0, f"{tag} {name}: GS_DRAW_ROP8 (bounded) alpha channel {d[..., 3].max():.0f} steps from the oracle"
+                    alpha_eq.append(float((d[..., 3] == 0).mean()))
+                    d = d[..., :3]
+                eq.append(float((d == 0).mean()))
+                worst = max(worst, float(d.max()))
+                assert d.max() <= ROP8_MAX and (d == 0).mean() >= ROP8_EQUAL, \
+                    f"{tag} {name}: GS_DRAW_ROP8 ({label}) vs the ROP-emulating oracle: {(d == 0).mean():.4f} equal, max {d.max():.0f}"
+            report["rop8_mode"][label] = {"equal_frac_min": round(min(eq), 5), "equal_frac_mean": round(float(np.mean(eq)), 5), "max_diff": worst,
+                                          "channels": "rgba" if full else "rgb (alpha: <= 2 steps)",
+                                          "alpha_equal_frac_min": round(min(alpha_eq), 5) if alpha_eq else None,
+                                          "splats_walked": int(st8.splats_walked), "blend_ms": round(float(st8.blend_ms), 4)}
+            print(f"{tag} GS_DRAW_ROP8 {label}: equal >= {min(eq):.4f}, max {worst:.0f}, walked {int(st8.splats_walked)}, blend {float(st8.blend_ms):.3f} ms")
     report["ambiguous_pixels_total"] = amb_pixels
     report["entries_scanned"] = int(stats.entries_scanned)
     report["splats_walked"] = int(stats.splats_walked)

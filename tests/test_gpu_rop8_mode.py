@@ -24,8 +24,11 @@ def _ref8(fb):
     return np.floor(np.clip(fb, 0, 1) * 255.0 + 0.5).astype(np.int32)
 
 
+@pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("sh_degree,cov_half,w,h,n", [(0, False, 256, 144, 4000), (2, False, 320, 200, 20000), (1, True, 200, 120, 3000)])
-def test_rop8_draw_matches_the_rop_emulating_oracle_on_every_pixel(ctx, sh_degree, cov_half, w, h, n):
+def test_rop8_draw_matches_the_rop_emulating_oracle_on_every_pixel(ctx, sh_degree, cov_half, w, h, n, full):
+    """Both shapes of the mode: GS_DRAW_ROP8 (the splats in front of each quadrant's saturation depth) and GS_DRAW_ROP8_FULL (every list
+    to its end)."""
     scene = helpers.small_scene(n, sh_degree, seed=500 + sh_degree, cov_half=cov_half)
     cam = camera.demo_camera("garden", w, h)
     order = _order(scene, cam)
@@ -34,13 +37,16 @@ def test_rop8_draw_matches_the_rop_emulating_oracle_on_every_pixel(ctx, sh_degre
     mesh.set_camera(cam)
     mesh.update_render_indexes(order, scene.count)
     fp32, st32 = mesh.render()
-    mesh.set_draw_mode(rop8=True)
+    mesh.set_draw_mode(rop8=True, full=full)
     got, st = mesh.render()
     c, cov, rgba, sh = helpers.oracle_inputs(scene)
     ocam = oracle.make_camera(cam.model_view(), cam.projection, cam.position, w, h, scene.sh_degree, scene.sh_degree)
     (fb8, _), = oracle.render_windows(ocam, c, cov, rgba, sh, order, windows=[(0, 0, w, h)], rop8=True)[0]
     d = np.abs(got.astype(np.int32) - _ref8(fb8))
     assert got[..., 3].any()
+    if not full:                                   # the bounded walk: colour to the gate, alpha within 2 steps (tile_blend.hip)
+        assert d[..., 3].max() <= 2
+        d = d[..., :3]
     assert d.max() <= MAXDIFF and (d == 0).mean() >= EQUAL, (int(d.max()), float((d == 0).mean()))
     # ... and the verification kernel, which walks the same lists with its own formulation of the fragment rule, agrees with the mode
     win = (w // 4, h // 4, 96, 64)
@@ -73,13 +79,16 @@ def test_rop8_draw_over_a_destination_tests_depth_and_blends_over_its_colour(ctx
     mesh.build(scene.centers, scene.cov, scene.rgba, scene.sh)
     mesh.set_camera(cam)
     mesh.update_render_indexes(order, scene.count)
-    mesh.set_draw_mode(rop8=True)
-    for unorm24 in (False, True):
+    for unorm24, full in ((False, False), (True, False), (False, True)):
+        mesh.set_draw_mode(rop8=True, full=full)
         mesh.set_destination(depth=depth, rgba=dst, depth_unorm24=unorm24)
         got, _ = mesh.render()
         (fb8, _), = oracle.render_windows(ocam, *s, order, windows=[(0, 0, w, h)], rop8=True, depth=depth, depth_unorm24=unorm24, dst_rgba=dst)[0]
         d = np.abs(got.astype(np.int32) - _ref8(fb8))
-        assert d.max() <= MAXDIFF and (d == 0).mean() >= EQUAL, (unorm24, int(d.max()), float((d == 0).mean()))
+        if not full:
+            assert d[..., 3].max() <= 2
+            d = d[..., :3]
+        assert d.max() <= MAXDIFF and (d == 0).mean() >= EQUAL, (unorm24, full, int(d.max()), float((d == 0).mean()))
         corner = got[-h // 6:, -w // 5:]                            # in front of everything: the destination untouched
         np.testing.assert_array_equal(corner, dst[-h // 6:, -w // 5:])
     mesh.set_destination()
@@ -128,7 +137,7 @@ def test_rop8_statistics_do_not_schedule_the_next_fp32_draw(ctx):
     mesh.update_render_indexes(_order(scene, cam), scene.count)
     for _ in range(3):
         fp32, st = mesh.render()
-    mesh.set_draw_mode(rop8=True)
+    mesh.set_draw_mode(rop8=True, full=True)
     _, st8 = mesh.render()
     assert st8.splats_walked > st.splats_walked
     mesh.set_draw_mode(rop8=False)

@@ -172,12 +172,12 @@ def test_tree_gather_through_node_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ortho,fade,effects,dest", [(False, False, False, False), (True, False, False, False), (False, True, True, False),
-                                                     (False, False, False, True)])
-def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho, fade, effects, dest):
+@pytest.mark.parametrize("ortho,fade,effects,dest,rop8", [(False, False, False, False, 0), (True, False, False, False, 0), (False, True, True, False, 0),
+                                                          (False, False, False, True, 0), (False, False, False, True, 1), (False, False, False, False, 2)])
+def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho, fade, effects, dest, rop8):
     """SplatMeshHIP (node/gsplat.js -> N-API -> C ABI) and SplatMesh (ctypes -> C ABI) must draw the same pixels,
     including the orthographic, fade-in and per-scene opacity / visibility uniforms, and a destination (drop-in mode's depth test
-    against the host's geometry + its colour, gs_mesh_set_destination)."""
+    against the host's geometry + its colour, gs_mesh_set_destination) and the RGBA8-per-splat draw modes (setRop8: gs_mesh_set_draw_mode)."""
     import helpers
     import oracle
     from gaussiansplats3d_amd import Context, SplatMesh, camera, util
@@ -206,12 +206,14 @@ def test_mesh_draw_through_the_js_shim_matches_the_python_mirror(tmp_path, ortho
     dst_colour = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
     if dest:
         mesh.set_destination(depth=dst_depth, rgba=dst_colour, depth_unorm24=True)
+    if rop8:
+        mesh.set_draw_mode(rop8=True, full=rop8 == 2)
     expect, _ = mesh.render()
     mesh.dispose()
     ctx.close()
     # the same draw through Node
     fx, fy = cam.focal()
-    flags = (1 if ortho else 0) | (2 if fade else 0) | (4 if effects else 0) | (8 if dest else 0)
+    flags = (1 if ortho else 0) | (2 if fade else 0) | (4 if effects else 0) | (8 if dest else 0) | (16 if rop8 == 1 else 0) | (32 if rop8 == 2 else 0)
     nsc = 3 if effects else 1
     hdr = np.array([n, 1, W, H, flags, nsc, 0, 0], np.uint32)
     parts = [hdr, scene.centers.astype(np.float32), scene.cov.astype(np.float32), scene.rgba, scene.sh.view(np.uint16), order, sidx,

@@ -375,6 +375,8 @@ struct gs_mesh {
     ProjectParams last_pp = {};                    // the last draw's geometry (gs_mesh_debug_rop8 walks its lists)
     ProjectParams stats_pp = {};                   // ... of the draw that wrote blend_stats (set once that draw is enqueued)
     bool stats_pp_valid = false;
+    double centre_sum[3] = {0.0, 0.0, 0.0}, centre_sq = 0.0;   // over every finite centre ever uploaded: where the scene is and how large
+    uint64_t centre_n = 0;                          // (tile_bin.hip: how far a camera moved, in screen heights)
     int forced_list_shift = -1;                    // GSPLAT_LIST_SHIFT (A/B and tests)
     uint32_t max_count = 0, sh_degree = 0, flags = 0, uploaded = 0;
     // SoA planes
@@ -438,7 +440,7 @@ struct gs_mesh {
     DevBuf deep_partial;       // float4 [GS_DEEP_UNITS][256]: {C, T} of every (deep bin, quadrant, chunk)
     DevBuf deep_work;          // uint32 [GS_DEEP_UNITS]: the (bin, quadrant, chunk) units that exist, packed (k_deep_plan)
     uint32_t draw_mode = 0;    // GS_DRAW_FP32 | GS_DRAW_ROP8 (gs_mesh_set_draw_mode)
-    bool blend_stats_rop8 = false;   // blend_stats were written by a GS_DRAW_ROP8 draw (every list walked whole: useless as a schedule)
+    int32_t blend_stats_mode = 0;    // the draw mode (GS_DRAW_*) that wrote blend_stats: they schedule a later draw of the SAME mode only
     bool no_deep = false;      // GSPLAT_NO_DEEP: never launch the deep pass (the per-bin kernel draws everything)
     bool deep_pass = false;    // this draw runs the deep pass (decided in gs_launch_binning)
     DevBuf blend_order;        // uint32 [blend bins]: this draw's bins by descending cost in the previous draw (k_bin_emit)
@@ -472,9 +474,9 @@ struct gs_mesh {
     bool has_draw = false;
     uint32_t last_count = 0;
     uint32_t* mirror_host = nullptr;   // mapped pinned words written by every draw's k_bin_emit: [0..3] {serial, overflow, entries lo, hi},
-                                       // [4] bins over the deep pass's threshold, [6..7] {serial, visible splats}
+                                       // [4] bins over the deep pass's threshold, [8..11] {serial, visible splats, 16-px tiles lo, hi}
     uint32_t* mirror_dev = nullptr;
-    uint32_t draw_serial = 0, healed_serial = 0;
+    uint32_t draw_serial = 0, healed_serial = 0, adapted_serial = 0;
     uint32_t full_serial[8] = {0, 0, 0, 0, 0, 0, 0, 0}, full_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last full-frame draws: serial (slot = serial & 7) and splats projected
     uint32_t project_serial = 0;
     uint32_t last_project_mode = 1;       // gs_launch_project: 1 = k_block_test + k_project, 0 = the test in every workgroup, 2 = no test

@@ -474,6 +474,17 @@ int gs_mesh_upload(gs_mesh* m, uint32_t from, uint32_t count, const float* cente
     if (m->ctx->aux != m->ctx->stream) GS_HIP(hipStreamSynchronize(m->ctx->aux));
     const uint32_t ncoef = (m->sh_degree == 0 || sh_u8) ? 0 : (m->sh_degree == 1 ? 9 : 24);
     const uint32_t end = from + count;
+    {   // where the scene is and how large (mean and RMS radius of the centres; a heuristic's inputs: re-uploads count twice)
+        double sx = 0.0, sy = 0.0, sz = 0.0, sq = 0.0;
+        uint64_t n = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            const float x = centers[3 * (size_t)i], y = centers[3 * (size_t)i + 1], z = centers[3 * (size_t)i + 2];
+            const float r2 = x * x + y * y + z * z;
+            if (!(r2 < 1e30f)) continue;                      // NaN / infinite centres draw nothing
+            sx += x; sy += y; sz += z; sq += r2; n++;
+        }
+        m->centre_sum[0] += sx; m->centre_sum[1] += sy; m->centre_sum[2] += sz; m->centre_sq += sq; m->centre_n += n;
+    }
     // cut [from, end) at the borders of the ranges that already own storage slots (disjoint, sorted by begin)
     std::vector<std::pair<uint32_t, bool>> cuts;          // (segment begin, fresh)
     uint32_t pos = from;
@@ -563,6 +574,25 @@ int gs_mesh_set_scenes(gs_mesh* m, const gs_scene_params* params) {
     return GS_OK;
 }
 
+// List-bin size of the following draws, from what a draw saw: the 16-px tiles its visible splats touch.  Large lists only pay when
+// splats are large enough to share them (a scene of tiny splats under 128-px lists makes every 32-px bin scan 16 bins' worth of
+// entries: the capture-like C3S stand-in draws in 4.5 ms instead of 1.2).  Fed by gs_mesh_last_stats / a draw with statistics AND by
+// the words every draw leaves in mapped host memory (mesh_read_view_share), so that a host that never asks for statistics - a
+// viewer's render loop - gets the same bins a few frames later (profiles/r06w_motion_ab.txt: the flaw this closed).
+// (with 8 % of hysteresis around each threshold: a camera that sits on one does not flip the size - and with it the entry
+// statistics and the frame time - from draw to draw)
+static void mesh_adapt_list_bins(gs_mesh* m, uint64_t tiles16, uint32_t visible) {
+    if (visible == 0u) return;
+    const float tiles = (float)tiles16, vis = (float)visible;
+    static const uint32_t shifts[4] = {GS_LIST_SHIFT_SMALL, GS_LIST_SHIFT_LARGE, GS_LIST_SHIFT_BIG, GS_LIST_SHIFT_HUGE};
+    static const float thr[3] = {GS_LIST_TILES_PER_SPLAT, GS_LIST_TILES_PER_SPLAT_BIG, GS_LIST_TILES_PER_SPLAT_HUGE};
+    uint32_t level = 0;
+    while (level < 3u && shifts[level] != m->list_shift) level++;
+    while (level < 3u && tiles >= 1.08f * thr[level] * vis) level++;
+    while (level > 0u && tiles < 0.92f * thr[level - 1u] * vis) level--;
+    m->list_shift = shifts[level];
+}
+
 static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
     hipStream_t st = m->ctx->stream;
     RenderFrame f;
@@ -622,20 +652,7 @@ static int mesh_collect_stats(gs_mesh* m, gs_render_stats* stats) {
             m->last.splats_walked += bs[2 * nb + b];
         }
     }
-    // list-bin size of the following draws: large lists only pay when splats are large enough to share them
-    if (m->last.visible_splats > 0)
-    {
-        // (with 8 % of hysteresis around each threshold: a camera that sits on one does not flip the size - and with it the
-        // entry statistics and the frame time - from draw to draw)
-        const float tiles = (float)m->last.tiles16, vis = (float)m->last.visible_splats;
-        static const uint32_t shifts[4] = {GS_LIST_SHIFT_SMALL, GS_LIST_SHIFT_LARGE, GS_LIST_SHIFT_BIG, GS_LIST_SHIFT_HUGE};
-        static const float thr[3] = {GS_LIST_TILES_PER_SPLAT, GS_LIST_TILES_PER_SPLAT_BIG, GS_LIST_TILES_PER_SPLAT_HUGE};
-        uint32_t level = 0;
-        while (level < 3u && shifts[level] != m->list_shift) level++;
-        while (level < 3u && tiles >= 1.08f * thr[level] * vis) level++;
-        while (level > 0u && tiles < 0.92f * thr[level - 1u] * vis) level--;
-        m->list_shift = shifts[level];
-    }
+    mesh_adapt_list_bins(m, m->last.tiles16, m->last.visible_splats);
     if (stats) *stats = m->last;
     return f.overflow ? 1 : 0;
 }
@@ -784,14 +801,20 @@ static int mesh_params(gs_mesh* m, const gs_camera* cam, ProjectParams& pp) {
 // then missing its farthest list entries.  Every draw leaves its verdict in mapped host memory (k_bin_emit), and the next
 // draw reads it here - no synchronisation when everything fitted.  After an overflow the buffers are grown to what that
 // draw needed (this waits for the stream once) and the caller is told with GS_WARN_FRAME_TRUNCATED.
-// The share of the scene in view, from the last FULL-frame draw whose verdict has arrived (an 8-byte store of k_bin_emit's into the
-// mapped words: {serial, visible}); only a hint for the vertex stage's launch shape (project.hip), frames do not depend on it.
+// The share of the scene in view, from the last FULL-frame draw whose verdict has arrived (a 16-byte store of k_bin_emit's into the
+// mapped words: {serial, visible, 16-px tiles}), and the size of the list bins from the last draw of any kind; hints for the vertex
+// stage's launch shape (project.hip) and the binner's geometry: frames do not depend on either.
 static void mesh_read_view_share(gs_mesh* m) {
     volatile uint32_t* mir = m->mirror_host;
-    const uint32_t vs = mir[6], vv = mir[7];
-    if (vs != 0u && vs == m->full_serial[vs & 7u] && mir[6] == vs) {
+    const uint32_t vs = mir[8], vv = mir[9], t_lo = mir[10], t_hi = mir[11];
+    if (vs == 0u || mir[8] != vs) return;                   // nothing yet / a newer draw is writing: look again next time
+    if (vs == m->full_serial[vs & 7u]) {
         m->measured_visible = vv;
         m->measured_count = m->full_count[vs & 7u];
+    }
+    if (vs != m->adapted_serial) {                          // (any draw, strips included: tiles per visible splat is a ratio)
+        m->adapted_serial = vs;
+        if (!getenv("GSPLAT_NO_ASYNC_LIST_BINS")) mesh_adapt_list_bins(m, ((uint64_t)t_hi << 32) | t_lo, vv);
     }
 }
 

@@ -502,11 +502,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = {serial, D64 > capacity ? 1u : 0u, (uint32_t)D64, (uint32_t)(D64 >> 32)};
                 *reinterpret_cast<volatile u32x4*>(mirror) = v;
-                // ... and, as a second 8-byte store, {serial, visible splats}: what tells the vertex stage of the following draws how
-                // much of the scene is in view (project.hip: where the block test runs) without anybody asking for statistics
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 sv = {serial, s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]};
-                *reinterpret_cast<volatile u32x2*>(mirror + 6) = sv;
+                // ... and, as a second 16-byte store, {serial, visible splats, 16-px tiles they touch}: what tells the following draws how
+                // much of the scene is in view (project.hip: where the block test runs) and how large its splats are on screen (the size
+                // of the list bins, mesh.hip: mesh_adapt_list_bins) without anybody asking for statistics
+                const u32x4 sv = {serial, s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3], (uint32_t)tsum, (uint32_t)(tsum >> 32)};
+                *reinterpret_cast<volatile u32x4*>(mirror + 8) = sv;
             }
         }
     }
@@ -666,13 +666,12 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                     frame->overflow = D64 > capacity ? 1u : 0u;
                     frame->entry_count = D64 > capacity ? capacity : (uint32_t)D64;
                     frame->pad = 0;
-                    if (mirror) {                                           // (see k_bin_emit: one 16-byte and one 8-byte store to mapped host memory)
+                    if (mirror) {                                           // (see k_bin_emit: two 16-byte stores to mapped host memory)
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 v = {serial, D64 > capacity ? 1u : 0u, (uint32_t)D64, (uint32_t)(D64 >> 32)};
                         *reinterpret_cast<volatile u32x4*>(mirror) = v;
-                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                        const u32x2 sv = {serial, vis};
-                        *reinterpret_cast<volatile u32x2*>(mirror + 6) = sv;
+                        const u32x4 sv = {serial, vis, (uint32_t)tsum, (uint32_t)(tsum >> 32)};
+                        *reinterpret_cast<volatile u32x4*>(mirror + 8) = sv;
                     }
                 }
             }
@@ -712,11 +711,14 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // deep pass: a bin qualifies when its previous draw walked >= deep_min (splat, quadrant) pairs and >= deep_factor x the mean bin
     // (4096 pairs.  C3S frame ms at 2048 / 3072 / 4096 / 6144 / 8192: 1.336 / 1.338 / 1.309 / 1.296 / 1.500 - k_deep_scan costs
     // 0.17 ms for 512 bins and is bound by its gathers, so: fewer, deeper bins; profiles/r03zz_kstats_C3S.txt)
-    static const uint32_t deep_min = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 4u * GS_CHUNK;
+    static const uint32_t deep_min_cfg = getenv("GSPLAT_DEEP_MIN") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_MIN")) : 4u * GS_CHUNK;
     static const uint32_t deep_factor = getenv("GSPLAT_DEEP_FACTOR") ? (uint32_t)atoi(getenv("GSPLAT_DEEP_FACTOR")) : 3u;
+    // (a GS_DRAW_ROP8 draw has no deep pass - rounding after every splat does not split into chunks - and must not raise its trigger)
+    const uint32_t deep_min = m->draw_mode == GS_DRAW_FP32 ? deep_min_cfg : 0x7FFFFFFFu;
     const bool order_ok = blend_bins > 0 && blend_bins <= 8192u && m->blend_bins == blend_bins && m->blend_row_begin == pp.bin_row_begin &&
-                          m->blend_width == (uint32_t)pp.width && !m->blend_stats_rop8 && !getenv("GSPLAT_NO_BLEND_ORDER");
-    // (!blend_stats_rop8: a GS_DRAW_ROP8 draw walks every list whole - its per-bin counters say nothing about what an fp32 draw costs)
+                          m->blend_width == (uint32_t)pp.width && m->blend_stats_mode == m->draw_mode && !getenv("GSPLAT_NO_BLEND_ORDER");
+    // (the same draw mode: a GS_DRAW_ROP8 draw walks its lists to the saturation depth twice or to their ends - its per-bin counters
+    // say nothing about what an fp32 draw costs, and the other way round)
     if (order_ok) GS_TRY(m->blend_order.ensure((size_t)blend_bins * 4));
     // ... and they ORDER this draw's blend workgroups only when that draw had THIS draw's view.  Heaviest-first from statistics of
     // the same view is worth 5-8 % of a frame (C3 demo pose 0.261 -> 0.248 ms, the orbit's poses held fixed 0.350 -> 0.322); from
@@ -727,12 +729,43 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // permutation that makes the late starters a uniform sample of the screen (r06e: 0.3624 vs 0.3625).  The deep pass's
     // membership (which executor composites a bin, not when) keeps using the statistics of whatever view came before.
     const ProjectParams& lp = m->stats_pp;
-    const bool same_view = m->stats_pp_valid && memcmp(lp.view, pp.view, sizeof(pp.view)) == 0 && memcmp(lp.proj, pp.proj, sizeof(pp.proj)) == 0 &&
-                           lp.width == pp.width && lp.height == pp.height && lp.count == pp.count && lp.list_shift == pp.list_shift;
+    const bool same_frame = m->stats_pp_valid && memcmp(lp.proj, pp.proj, sizeof(pp.proj)) == 0 && lp.width == pp.width && lp.height == pp.height &&
+                            lp.count == pp.count && lp.list_shift == pp.list_shift;
+    bool same_view = same_frame && memcmp(lp.view, pp.view, sizeof(pp.view)) == 0;
+    // ... or a view close to it.  How far the picture moved, in screen heights: (the camera's rotation + its translation over its
+    // distance to the scene) x focal / height.  Measured on the 60-pose orbit at 0.25 ... 6 degrees per frame (tools/motion_ab.py,
+    // profiles/r06w_motion_ab.txt): the previous frame's order beats row-major up to 2 degrees per frame (C2 7-11 %, C3 1-2 % of the
+    // frame) = 0.06-0.10 screen heights on these scenes, is level at 3 and loses 2.5-3 % at 6; for a camera turning about its own
+    // position it wins 2-10 % up to 2 degrees per frame (0.037), and loses 4 % at 4 (0.075: C2).  The limit is 0.06 screen heights
+    // ($GSPLAT_ORDER_MOTION; 0 = the same view only: the first half of round 6).
+    if (same_frame && !same_view && pp.block_cull && m->centre_n > 0) {
+        static const float limit = getenv("GSPLAT_ORDER_MOTION") ? (float)atof(getenv("GSPLAT_ORDER_MOTION")) : 0.06f;
+        float rot = 0.0f;                                  // largest angle between corresponding axes of the two view rotations
+        for (int k = 0; k < 3; k++) {
+            const float* a = lp.view + 4 * k;
+            const float* b = pp.view + 4 * k;
+            const float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            const float na = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], nb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+            const float c = d / sqrtf(fmaxf(na * nb, 1e-30f));
+            rot = fmaxf(rot, acosf(fminf(fmaxf(c, -1.0f), 1.0f)));
+        }
+        const double inv_n = 1.0 / (double)m->centre_n;
+        const double mean[3] = {m->centre_sum[0] * inv_n, m->centre_sum[1] * inv_n, m->centre_sum[2] * inv_n};
+        const double var = m->centre_sq * inv_n - (mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
+        const float rms = (float)sqrt(var > 0.0 ? var : 0.0);
+        float t2 = 0.0f, d2 = 0.0f;
+        for (int k = 0; k < 3; k++) {
+            const float dt = pp.cam_pos[k] - lp.cam_pos[k], dc = pp.cam_pos[k] - (float)mean[k];
+            t2 += dt * dt; d2 += dc * dc;
+        }
+        const float z_ref = fmaxf(sqrtf(d2), 0.5f * rms);
+        const float moved = (rot + (z_ref > 0.0f ? sqrtf(t2) / z_ref : 1e9f)) * pp.focal_y / fmaxf(pp.height, 1.0f);
+        same_view = moved <= limit;                        // (NaN compares false)
+    }
     const bool stale_order = getenv("GSPLAT_BLEND_ORDER_STALE") != nullptr;   // (A/B: rounds 2-5 - order from whatever draw came before)
     // The deep pass runs when the last draw whose verdict has arrived (mapped host word, no synchronisation) left bins over the
     // threshold - the decision only moves work between executors, the pixels do not depend on it (tile_blend.hip)
-    m->deep_pass = order_ok && !m->no_deep && m->mirror_host && ((volatile uint32_t*)m->mirror_host)[4] > 0u;
+    m->deep_pass = order_ok && m->draw_mode == GS_DRAW_FP32 && !m->no_deep && m->mirror_host && ((volatile uint32_t*)m->mirror_host)[4] > 0u;
     if (m->deep_pass) {
         GS_TRY(m->deep_ent.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_LIST_CAP * 4));
         GS_TRY(m->deep_cnt.ensure((size_t)GS_DEEP_MAX_BINS * GS_DEEP_RANGES * 4 * 4));

@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(256) void k_rop8_window(FrameArgs fa, uint32_t wx0,
 // c for an already rounded c, so skipping it changes nothing.  Back to front there is no early termination and there are no
 // chunks: GS_DRAW_ROP8_FULL walks every list whole - C3: 11.4 M (splat, quadrant) pairs instead of 0.49 M, blend 4.0 ms instead of
 // 0.058 (C2 2.6 ms, C3T 4.0 ms) - and GS_DRAW_ROP8 (below) first finds, front to back, how far into its list a quadrant can be seen
-// at all: C3 0.78 M pairs, blend 0.32 ms (C2 1.02, C3T 3.4: translucent content is walked almost whole).
+// at all: C3 0.78 M pairs, blend 0.26 ms (C2 0.70, C3T 3.4: translucent content is walked almost whole).  Both shapes take their
+// bins costliest-first from the previous draw of the same mode and view (k_bin_emit's schedule workgroup; worth 10-23 % of the frame:
+// C3 0.473 -> 0.427 ms, C2 1.035 -> 0.801, full walk C3 3.97 -> 3.52, profiles/r06w_rop8_order_ab.txt).
 struct Rop8Px {                                  // a lane's 4 pixels, channel values k / 255 held as floats (packed pairs as in Px)
     v2f r[2], g[2], b[2], a[2];
 };
@@ -1072,7 +1074,9 @@ __device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, con
 // frame), never more than 1 apart.  ALPHA is the exception: alpha' = q8(a + (1 - a) alpha) only ever rises and STALLS once
 // a (255 - alpha) < 0.5; where it stalls below 255 the value depends on every splat of the list, the ones behind the saturation depth
 // included, and the bounded walk may end 1-2 steps off (14 % of C3T's pixels); where it reaches 255 it is exact (the update is
-// monotone in its start value).  Hosts that need that channel to the step take GS_DRAW_ROP8_FULL.
+// monotone in its start value).  (The reference's own renderer is created without an alpha channel - src/Viewer.js:353-356, three's
+// default `alpha: false` - and NormalBlending's colour never reads destination alpha: the browser shows r, g, b only.)  Hosts that
+// composite the frame themselves and need that channel to the step take GS_DRAW_ROP8_FULL.
 // GS_DRAW_ROP8_FULL (BOUNDED = false) is the full walk: every list to its end.
 // What "hidden" means for an 8-bit target: blending a fragment of alpha a over an 8-bit value c gives q8(c + a (s - c)) - for
 // a |s - c| < 0.5 / 255 that is c again, whatever lies behind shines through UNATTENUATED, where exact arithmetic would have dimmed it
@@ -1092,8 +1096,8 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
     __shared__ LdsSplat s_batch[BLEND_THREADS];
     __shared__ uint32_t s_qmask[BLEND_THREADS];
     __shared__ uint32_t s_walked[4];
-    const uint32_t bin = blockIdx.x;
-    if (bin >= bins) return;
+    if (blockIdx.x >= bins) return;
+    const uint32_t bin = fa.bin_order ? fa.bin_order[blockIdx.x] : blockIdx.x;   // costliest bins of the previous draw of this mode and view first
     const BinGeom bg(fa, bin);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -1301,7 +1305,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
         else if (fa.depth_mode) hipLaunchKernelGGL((k_tile_blend_rop8<true, true>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
         else if (full) hipLaunchKernelGGL((k_tile_blend_rop8<false, false>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
         else hipLaunchKernelGGL((k_tile_blend_rop8<false, true>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);
-        m->blend_stats_rop8 = true;                        // (the next fp32 draw neither orders its bins nor picks deep bins from these)
+        m->blend_stats_mode = m->draw_mode;                // (a later fp32 draw neither orders its bins nor picks deep bins from these)
         m->blend_row_begin = pp.bin_row_begin;
         m->blend_width = (uint32_t)pp.width;
         GS_HIP(hipGetLastError());
@@ -1314,7 +1318,7 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     if (fa.depth_mode) hipLaunchKernelGGL(k_tile_blend<true>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     else hipLaunchKernelGGL(k_tile_blend<false>, dim3(bins + da.unit_wgs), dim3(BLEND_THREADS), 0, st, fa, da, bins);
     if (m->deep_pass) hipLaunchKernelGGL(k_deep_fold, dim3(GS_DEEP_MAX_BINS), dim3(BLEND_THREADS), 0, st, fa, da);
-    m->blend_stats_rop8 = false;
+    m->blend_stats_mode = GS_DRAW_FP32;
     m->blend_row_begin = pp.bin_row_begin;
     m->blend_width = (uint32_t)pp.width;
     GS_HIP(hipGetLastError());

@@ -313,6 +313,44 @@ def test_every_list_bin_size_gives_the_same_pixels(ctx, monkeypatch):
     print(helpers.compare_frames(frames[3], fb, amb, "list bins"))
 
 
+def test_asynchronous_draws_choose_their_list_bins_without_statistics(ctx, monkeypatch):
+    """The size of the list bins follows what the last draws saw (16-px tiles per visible splat).  That used to happen only when
+    somebody asked for statistics: a render loop that never does stayed on the first guess for ever - 128-px lists under a scene of
+    tiny splats, every 32-px bin scanning 16 bins' worth of entries (the capture-like stand-in drew in 4.5 ms instead of 1.2).  Every
+    draw now leaves {visible, tiles} in mapped host words and the next draws read them."""
+    scene = helpers.small_scene(6000, 0, seed=23, scale=0.2)    # large splats: lists larger than the first guess (128 px) pay
+    cam = camera.demo_camera("garden", 960, 540)
+    order = sorted_order(scene, cam)
+
+    def fresh():
+        m = build_mesh(ctx, scene)
+        m.set_camera(cam)
+        m.update_render_indexes(order, scene.count)
+        return m
+
+    a = fresh()                                             # with statistics: the first guess, then what the rule settles on
+    frame, first = a.render()
+    for _ in range(3):
+        _, settled = a.render()
+    a.dispose()
+    assert settled.list_bin_px != first.list_bin_px, (first.list_bin_px, settled.list_bin_px)  # (else this scene proves nothing)
+    b = fresh()                                             # never asks: draws that return nothing to the host
+    for _ in range(6):
+        b.render(to_host=False, want_stats=False)
+        ctx.synchronize()                                   # (a frame boundary: the words of that draw have arrived)
+    got, st = b.render()
+    assert st.list_bin_px == settled.list_bin_px
+    np.testing.assert_array_equal(got, frame)
+    b.dispose()
+    monkeypatch.setenv("GSPLAT_NO_ASYNC_LIST_BINS", "1")    # the A/B switch: rounds 1-5
+    c = fresh()
+    for _ in range(6):
+        c.render(to_host=False, want_stats=False)
+        ctx.synchronize()
+    assert c.last_stats().list_bin_px == first.list_bin_px
+    c.dispose()
+
+
 def test_asynchronous_draws_heal_an_overflowing_entry_buffer(ctx):
     """A draw that returns nothing to the host cannot re-run itself when its entry buffer overflows; the next draw notices
     (mapped host mirror, no synchronisation), grows the buffer and says so once.  Moving camera: every pose needs a

@@ -756,8 +756,28 @@ def main():
                 moving_enq_ms = (time.perf_counter() - t1) / (2 * len(o_cams)) * 1e3      # the host's share: all 120 frames enqueued
                 torch.cuda.synchronize()
                 moving_ms = (time.perf_counter() - t1) / (2 * len(o_cams)) * 1e3
+                # ... and at a viewer's pace: the first 120 poses of a 360-pose orbit (1 degree per frame - still 60 degrees per second at
+                # 60 fps), then of a 1440-pose one.  Below ~0.06 screen heights of motion per frame the blend takes the previous frame's
+                # bin order (tile_bin.hip); at the 60-pose orbit's 6 degrees it takes none
+                slow = {}
+                for label, poses in (("1_deg_per_frame", 360), ("quarter_deg_per_frame", 1440)):
+                    s_cams = camera.orbit_cameras(cfg["pose"], W, H, poses)[:120]
+                    s_mvps = [oc.sort_mvp() for oc in s_cams]
+                    for oc, o_mvp in list(zip(s_cams, s_mvps))[:4]:
+                        mesh.set_camera(oc)
+                        worker.sort_on_device(o_mvp, N)
+                        mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for oc, o_mvp in zip(s_cams, s_mvps):
+                        mesh.set_camera(oc)
+                        worker.sort_on_device(o_mvp, N)
+                        mesh.render(out_device_ptr=strip.data_ptr(), to_host=False, want_stats=False)
+                    torch.cuda.synchronize()
+                    slow[label] = round((time.perf_counter() - t1) / len(s_cams) * 1e3, 4)
                 mesh.set_camera(cam)
                 orbit = {"poses": 60, "frame_latency_ms_median": round(float(np.median(ms)), 4),
+                         "moving_camera_ms_per_frame_slow_orbit": slow,
                          "frame_latency_ms_min": round(float(np.min(ms)), 4), "frame_latency_ms_max": round(float(np.max(ms)), 4),
                          "visible_splats_median": int(np.median(vis)), "visible_splats_max": int(np.max(vis)),
                          "frame_latency_ms_mean": round(float(np.mean(ms)), 4),
@@ -969,8 +989,53 @@ def main():
                                 if lap:
                                     o_ms.append((time.perf_counter() - t1) * 1e3)
                                     o_bins.append(int(len(rg.mesh.deep_pass_info()["bins"])))
+                        torch.cuda.synchronize()                     # ... and as a MOVING camera: a new pose every frame, nothing synchronised
+                        t1 = time.perf_counter()
+                        for lap in range(2):
+                            for oc in camera.orbit_cameras(cfg["pose"], W, H, 60):
+                                rg.set_view(oc)
+                                rg.frame(out_ptr)
+                        torch.cuda.synchronize()
+                        o_moving = (time.perf_counter() - t1) / 120 * 1e3
                         rg.set_view(cam)
-                        obj["orbit"] = {"poses": 60, "frame_latency_ms_median": round(float(np.median(o_ms)), 4),
+
+                        def cold_loop():
+                            """A render loop that never asks for statistics, from a cold start: fresh worker and mesh, one frame per
+                            pose, the first lap synchronised at every frame boundary (a viewer presents its frames), the second free."""
+                            rc = Rig(ctx, sc, cam, device, torch)
+                            rc.worker.sort_on_device(rc.mvp, rc.N)
+                            rc.mesh.use_sorter_result(rc.worker, rc.N)
+                            lat = []
+                            cams60 = camera.orbit_cameras(cfg["pose"], W, H, 60)
+                            for oc in cams60:
+                                rc.set_view(oc)
+                                torch.cuda.synchronize()
+                                t2 = time.perf_counter()
+                                rc.frame(out_ptr)
+                                torch.cuda.synchronize()
+                                lat.append((time.perf_counter() - t2) * 1e3)
+                            t2 = time.perf_counter()
+                            for oc in cams60:
+                                rc.set_view(oc)
+                                rc.frame(out_ptr)
+                            torch.cuda.synchronize()
+                            mv = (time.perf_counter() - t2) / 60 * 1e3
+                            px = int(rc.mesh.last_stats().list_bin_px)
+                            rc.close()
+                            return {"first_lap_frame_latency_ms_median": round(float(np.median(lat)), 4),
+                                    "first_lap_frame_latency_ms_max": round(float(np.max(lat)), 4),
+                                    "second_lap_moving_camera_ms_per_frame": round(mv, 4), "list_bin_px": px}
+
+                        loop = cold_loop()
+                        os.environ["GSPLAT_NO_ASYNC_LIST_BINS"] = "1"    # rounds 1-5: the list-bin size only followed gs_mesh_last_stats
+                        loop["with_GSPLAT_NO_ASYNC_LIST_BINS"] = cold_loop()
+                        del os.environ["GSPLAT_NO_ASYNC_LIST_BINS"]
+                        loop["note"] = ("every draw leaves {visible splats, 16-px tiles} in mapped host words and the following draws size their "
+                                        "list bins from them (mesh.hip, mesh_adapt_list_bins); before round 6 a loop that never called "
+                                        "gs_mesh_last_stats kept the first guess (128-px lists) for ever")
+                        obj["render_loop_without_statistics"] = loop
+                        obj["orbit"] = {"poses": 60, "moving_camera_ms_per_frame": round(o_moving, 4),
+                                        "frame_latency_ms_median": round(float(np.median(o_ms)), 4),
                                         "frame_latency_ms_min": round(float(np.min(o_ms)), 4),
                                         "frame_latency_ms_max": round(float(np.max(o_ms)), 4),
                                         "frame_latency_ms_p90": round(float(np.percentile(o_ms, 90)), 4),

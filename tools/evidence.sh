@@ -51,6 +51,10 @@ bash tools/sort_pmc.sh ${TAG}_sort_pmc C3 gpurun_ab/lib_this_tree.so > gpurun_ou
 # table of the N = 1 visibility-culled frame (the mask derived by the sorter)
 [ -f $PREV ] && (timeout 500 python tools/orbit_ab.py "C3 C2 C3S" $PREV gpurun_ab/lib_this_tree.so --rounds 2 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/orbit_ab.txt
 bash tools/rank_prof.sh $TAG C3 1:0 > gpurun_out/$TAG/vis_cull_n1_kstats.txt 2>&1
+# second half of round 6: how far the camera may move before the previous frame's bin order stops paying (orbit and turning in place:
+# the gate / always the previous order / never an order), and the ROP8 draw modes with and without their own bin order
+(timeout 400 python tools/motion_ab.py "C3 C2" --rounds 1 --steps "0.5 1 2 3 6"; timeout 400 python tools/motion_ab.py "C3 C2" --pan --rounds 1 --steps "0.5 1 2 4 8"; timeout 300 python tools/motion_ab.py C3S --rounds 1 --steps "1 6") 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/motion_ab.txt
+(timeout 300 python tools/rop8_ab.py "C3 C2" 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/rop8_order_ab.txt
 [ -n "$GS_EVIDENCE_SORT_MIDDLE" ] && (timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 # the same rank frames on the default context (streams of its own + two sets of vertex-stage outputs: what bench.py --gpus N runs)

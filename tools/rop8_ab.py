@@ -1,5 +1,13 @@
-import os, sys, time, zlib
-sys.path.insert(0, "/root/repo")
+"""The ROP8 draw modes (GS_DRAW_ROP8 = bounded walk, GS_DRAW_ROP8_FULL) with their bins ordered by the previous draw of the same mode
+and view, and in row-major order ($GSPLAT_NO_BLEND_ORDER, read per draw): ms per frame, the blend's share, the frame's CRC.
+
+usage: python tools/rop8_ab.py "C3 C2" """
+import os
+import sys
+import time
+import zlib
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gaussiansplats3d_amd import Context, SplatMesh, create_sort_worker, camera, scenes, util
 for name in sys.argv[1].split():

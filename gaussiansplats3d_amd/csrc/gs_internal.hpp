@@ -477,6 +477,7 @@ struct gs_mesh {
                                        // [4] bins over the deep pass's threshold, [8..11] {serial, visible splats, 16-px tiles lo, hi}
     uint32_t* mirror_dev = nullptr;
     uint32_t draw_serial = 0, healed_serial = 0, adapted_serial = 0;
+    uint32_t grow_entries_to = 0;         // entry capacity wanted before the next draw (the list bins became smaller: mesh.hip)
     uint32_t full_serial[8] = {0, 0, 0, 0, 0, 0, 0, 0}, full_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last full-frame draws: serial (slot = serial & 7) and splats projected
     uint32_t project_serial = 0;
     uint32_t last_project_mode = 1;       // gs_launch_project: 1 = k_block_test + k_project, 0 = the test in every workgroup, 2 = no test

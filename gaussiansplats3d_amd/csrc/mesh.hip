@@ -814,7 +814,17 @@ static void mesh_read_view_share(gs_mesh* m) {
     }
     if (vs != m->adapted_serial) {                          // (any draw, strips included: tiles per visible splat is a ratio)
         m->adapted_serial = vs;
-        if (!getenv("GSPLAT_NO_ASYNC_LIST_BINS")) mesh_adapt_list_bins(m, ((uint64_t)t_hi << 32) | t_lo, vv);
+        if (!getenv("GSPLAT_NO_ASYNC_LIST_BINS")) {
+            const uint32_t before = m->list_shift;
+            const uint64_t tiles16 = ((uint64_t)t_hi << 32) | t_lo;
+            mesh_adapt_list_bins(m, tiles16, vv);
+            // smaller list bins mean more entries - at most one per 16-px tile touched: room for them before the first draw that
+            // uses the new size, instead of one truncated frame and a heal after it (mesh_heal_overflow grows the buffers)
+            if (m->list_shift < before) {
+                const uint64_t want = tiles16 + tiles16 / 8 + 1024;
+                m->grow_entries_to = (uint32_t)(want > 0x7FFFFFFFull ? 0x7FFFFFFFull : want);
+            }
+        }
     }
 }
 
@@ -822,6 +832,11 @@ static int mesh_heal_overflow(gs_mesh* m, bool* healed) {
     *healed = false;
     volatile uint32_t* mir = m->mirror_host;
     mesh_read_view_share(m);
+    if (m->grow_entries_to > m->entry_capacity) {           // the list bins just became smaller (mesh_read_view_share)
+        GS_HIP(hipStreamSynchronize(m->ctx->stream));       // draws in flight still use the old buffers
+        GS_TRY(mesh_alloc_entries(m, m->grow_entries_to));
+    }
+    m->grow_entries_to = 0;
     const uint32_t serial = mir[0];
     if (serial == m->healed_serial || !mir[1]) return GS_OK;
     const uint64_t need = ((uint64_t)mir[3] << 32) | mir[2];

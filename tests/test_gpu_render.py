@@ -351,6 +351,40 @@ def test_asynchronous_draws_choose_their_list_bins_without_statistics(ctx, monke
     c.dispose()
 
 
+def test_smaller_list_bins_chosen_asynchronously_come_with_room_for_their_entries(ctx):
+    """Smaller list bins mean more entries.  When the words a draw left say "smaller bins", the entry buffers grow to the bound those
+    words imply (one entry per 16-px tile touched) BEFORE the first draw that uses the new size - not one truncated frame later."""
+    from gaussiansplats3d_amd import _lib as L
+    scene = helpers.small_scene(60000, 0, seed=29, scale=0.002)   # splats of a pixel or two: one tile each
+    cam = camera.demo_camera("garden", 960, 540)
+    order = sorted_order(scene, cam)
+
+    def fresh():
+        m = build_mesh(ctx, scene)
+        m.set_camera(cam)
+        m.update_render_indexes(order, scene.count)
+        return m
+
+    a = fresh()
+    frame, first = a.render()
+    for _ in range(3):
+        _, settled = a.render()
+    a.dispose()
+    assert settled.list_bin_px < first.list_bin_px and settled.tile_entries > first.tile_entries, \
+        (first.list_bin_px, settled.list_bin_px, int(first.tile_entries), int(settled.tile_entries))
+    b = fresh()
+    b.debug_set_entry_capacity(max(1024, (int(first.tile_entries) + int(settled.tile_entries)) // 2))   # fits the first guess only
+    warnings = 0
+    for _ in range(6):
+        b.render(to_host=False, want_stats=False)
+        warnings += b.last_status == L.GS_WARN_FRAME_TRUNCATED
+        ctx.synchronize()
+    got, st = b.render()
+    assert warnings == 0 and st.list_bin_px == settled.list_bin_px and not st.overflowed
+    np.testing.assert_array_equal(got, frame)
+    b.dispose()
+
+
 def test_asynchronous_draws_heal_an_overflowing_entry_buffer(ctx):
     """A draw that returns nothing to the host cannot re-run itself when its entry buffer overflows; the next draw notices
     (mapped host mirror, no synchronisation), grows the buffer and says so once.  Moving camera: every pose needs a

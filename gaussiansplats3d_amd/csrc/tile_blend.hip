@@ -1091,6 +1091,7 @@ __device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, con
 #define GS_ROP8_A_MIN_CFG (1.0f / 64.0f)
 #endif
 constexpr float GS_ROP8_T_EPS = GS_ROP8_T_EPS_CFG, GS_ROP8_A_MIN = GS_ROP8_A_MIN_CFG;
+// (7 / 8 workgroups per CU instead of 6 - 72 / 64 VGPRs, a handful of spilled dwords - were measured: C2 bounded 0.80 -> 0.81 / 0.82 ms)
 template <bool DEPTH, bool BOUNDED>
 __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa, uint32_t bins) {
     __shared__ LdsSplat s_batch[BLEND_THREADS];

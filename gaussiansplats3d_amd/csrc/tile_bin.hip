@@ -739,7 +739,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     // position it wins 2-10 % up to 2 degrees per frame (0.037), and loses 4 % at 4 (0.075: C2).  The limit is 0.06 screen heights
     // ($GSPLAT_ORDER_MOTION; 0 = the same view only: the first half of round 6).
     if (same_frame && !same_view && pp.block_cull && m->centre_n > 0) {
-        static const float limit = getenv("GSPLAT_ORDER_MOTION") ? (float)atof(getenv("GSPLAT_ORDER_MOTION")) : 0.06f;
+        const float limit = getenv("GSPLAT_ORDER_MOTION") ? (float)atof(getenv("GSPLAT_ORDER_MOTION")) : 0.06f;
         float rot = 0.0f;                                  // largest angle between corresponding axes of the two view rotations
         for (int k = 0; k < 3; k++) {
             const float* a = lp.view + 4 * k;

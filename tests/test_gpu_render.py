@@ -385,6 +385,40 @@ def test_smaller_list_bins_chosen_asynchronously_come_with_room_for_their_entrie
     b.dispose()
 
 
+def test_a_slowly_moving_camera_keeps_the_bin_order_and_the_pixels(ctx, monkeypatch):
+    """The blend takes its bins costliest-first from the previous frame while the camera moved less than 0.06 screen heights since
+    (tile_bin.hip), and in row-major order otherwise; the deep pass's members always come from the previous frame.  Scheduling only:
+    every frame of a slow and of a fast camera path equals the frame of a fresh mesh, under the gate, with the gate shut
+    ($GSPLAT_ORDER_MOTION=0: the same view only) and wide open (100)."""
+    scene = helpers.small_scene(90000, 1, seed=31, scale=0.03)          # tiny splats: deep bins, long lists
+    w, h = 640, 360
+    slow = camera.orbit_cameras("garden", w, h, 1440)[:6]                # a quarter of a degree per frame
+    fast = camera.orbit_cameras("garden", w, h, 30)[:4]                  # twelve degrees per frame
+    path = slow + fast + slow[::-1]
+    orders = [sorted_order(scene, c) for c in path]
+    want = []
+    for c, o in zip(path, orders):
+        m = build_mesh(ctx, scene)
+        m.set_camera(c)
+        m.update_render_indexes(o, scene.count)
+        want.append(m.render()[0])
+        m.dispose()
+    assert any(f.any() for f in want)
+    for limit in (None, "0", "100"):
+        if limit is None:
+            monkeypatch.delenv("GSPLAT_ORDER_MOTION", raising=False)
+        else:
+            monkeypatch.setenv("GSPLAT_ORDER_MOTION", limit)
+        m = build_mesh(ctx, scene)                                       # (the limit is read per draw)
+        for lap in range(2):
+            for k, (c, o) in enumerate(zip(path, orders)):
+                m.set_camera(c)
+                m.update_render_indexes(o, scene.count)
+                got, _ = m.render()
+                np.testing.assert_array_equal(got, want[k], err_msg=f"limit {limit} lap {lap} frame {k}")
+        m.dispose()
+
+
 def test_asynchronous_draws_heal_an_overflowing_entry_buffer(ctx):
     """A draw that returns nothing to the host cannot re-run itself when its entry buffer overflows; the next draw notices
     (mapped host mirror, no synchronisation), grows the buffer and says so once.  Moving camera: every pose needs a

@@ -1045,6 +1045,28 @@ __device__ __forceinline__ v2f q8_pair(v2f v) {
     const v2f t = c * v2f{255.0f, 255.0f} + v2f{0.5f, 0.5f};
     return v2f{floorf(t.x), floorf(t.y)} * v2f{1.0f / 255.0f, 1.0f / 255.0f};
 }
+// How the update is evaluated (GS_ROP8_FUSED; same box, tests/test_gpu_crops.py's `rop8_mode` numbers, profiles/r06z_rop8_arith_ab.txt):
+//   0  the oracle's operation order, no contraction: mul, mul, add, max, min, mul, add, 2 x floor, mul = 10 VALU slots per channel
+//      and pixel pair;
+//   1  (default) fused multiply-adds: (1 - a) c + (a src) rounded once with the clamp as the instruction's modifier, x 255 + 0.5 as
+//      one more fma = 6 slots.  Equal to the ROP-emulating oracle exactly as often as 0 (C3 full walk 0.99847 of the channel values
+//      at the worst window / 0.99920 in the mean, both ways; C2 0.99994, C3T 0.99890 / 0.99936 vs 0.99937), never more than 1 apart
+//      - the differences to the oracle come from the alphas (v_exp_f32 against expf), not from this rounding - and C3 bounded
+//      0.422 -> 0.375 ms per frame, the full walk 3.50 -> 2.62, C2 0.80 -> 0.69 / 2.14 -> 1.60;
+//   2  channel values held as 0 .. 255 (no clamp, no final scaling: 5 slots): another 2 % (bounded) / 6 % (full), equality 0.99854 /
+//      0.99982 / 0.99878 at C3 / C2 / C3T - not the same population of differing values, so not taken.
+#ifndef GS_ROP8_FUSED
+#define GS_ROP8_FUSED 1
+#endif
+__device__ __forceinline__ v2f q8_pair_fused(v2f c01) {
+    const v2f t = fma2(c01, v2f{255.0f, 255.0f}, v2f{0.5f, 0.5f});
+    return v2f{floorf(t.x), floorf(t.y)} * v2f{1.0f / 255.0f, 1.0f / 255.0f};
+}
+__device__ __forceinline__ v2f pk_fma_sat_vvv(v2f a, v2f b, v2f c) {
+    v2f d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 template <bool DEPTH>
 __device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, const v2f (&fy)[2], const v2f (&dz)[2], Rop8Px& px) {
 #pragma clang fp contract(off)
@@ -1056,10 +1078,29 @@ __device__ __forceinline__ void composite_rop8(const LdsSplat* sp, float fx, con
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const v2f a = al.a[h], om = v2f{1.0f, 1.0f} - a;
+#if GS_ROP8_FUSED == 2
+        // channel values held as k (0 .. 255), the splat's colour x 255: k' = floor((1 - a) k + a s255 + 0.5); a convex combination
+        // of values in [0, 255] needs no clamp
+        const v2f half = {0.5f, 0.5f};
+        auto q = [&](v2f c, float s255) {
+            const v2f t = fma2(om, c, a * v2f{s255, s255}) + half;
+            return v2f{floorf(t.x), floorf(t.y)};
+        };
+        px.r[h] = q(px.r[h], al.r * 255.0f);
+        px.g[h] = q(px.g[h], al.g * 255.0f);
+        px.b[h] = q(px.b[h], al.b * 255.0f);
+        px.a[h] = q(px.a[h], 255.0f);
+#elif GS_ROP8_FUSED
+        px.r[h] = q8_pair_fused(pk_fma_sat_vvv(om, px.r[h], a * v2f{al.r, al.r}));
+        px.g[h] = q8_pair_fused(pk_fma_sat_vvv(om, px.g[h], a * v2f{al.g, al.g}));
+        px.b[h] = q8_pair_fused(pk_fma_sat_vvv(om, px.b[h], a * v2f{al.b, al.b}));
+        px.a[h] = q8_pair_fused(pk_fma_sat_vvv(om, px.a[h], a));
+#else
         px.r[h] = q8_pair(a * v2f{al.r, al.r} + om * px.r[h]);
         px.g[h] = q8_pair(a * v2f{al.g, al.g} + om * px.g[h]);
         px.b[h] = q8_pair(a * v2f{al.b, al.b} + om * px.b[h]);
         px.a[h] = q8_pair(a + om * px.a[h]);
+#endif
     }
 }
 // GS_DRAW_ROP8 is BOUNDED (the default of the mode): back to front over the splats IN FRONT OF THE QUADRANT'S SATURATION DEPTH only.
@@ -1186,10 +1227,11 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
         const uint32_t py = py0 + 4u * g;
         uint32_t d = 0u;
         if (fa.dst_rgba && px < fa.width && py < fa.height) d = fa.dst_rgba[(size_t)py * fa.width + px];
-        acc.r[g >> 1][g & 1] = (float)(d & 255u) * (1.0f / 255.0f);
-        acc.g[g >> 1][g & 1] = (float)((d >> 8) & 255u) * (1.0f / 255.0f);
-        acc.b[g >> 1][g & 1] = (float)((d >> 16) & 255u) * (1.0f / 255.0f);
-        acc.a[g >> 1][g & 1] = (float)(d >> 24) * (1.0f / 255.0f);
+        constexpr float unit = GS_ROP8_FUSED == 2 ? 1.0f : 1.0f / 255.0f;
+        acc.r[g >> 1][g & 1] = (float)(d & 255u) * unit;
+        acc.g[g >> 1][g & 1] = (float)((d >> 8) & 255u) * unit;
+        acc.b[g >> 1][g & 1] = (float)((d >> 16) & 255u) * unit;
+        acc.a[g >> 1][g & 1] = (float)(d >> 24) * unit;
     }
     uint32_t walked = 0;
     // pass 2 (the only pass of the full walk): back to front, every channel rounded after every splat
@@ -1237,7 +1279,7 @@ __global__ __launch_bounds__(BLEND_THREADS) void k_tile_blend_rop8(FrameArgs fa,
     for (int g = 0; g < 4; g++) {
         const uint32_t py = py0 + 4u * g;
         if (px < fa.width && py >= fa.y0 && py < fa.y1) {
-            auto u8 = [](float v) { return (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
+            auto u8 = [](float v) { return GS_ROP8_FUSED == 2 ? (uint32_t)fminf(fmaxf(v, 0.0f), 255.0f) : (uint32_t)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f + 0.5f); };
             fa.out[(size_t)(py - fa.y0) * fa.width + px] = u8(acc.r[g >> 1][g & 1]) | (u8(acc.g[g >> 1][g & 1]) << 8) |
                                                            (u8(acc.b[g >> 1][g & 1]) << 16) | (u8(acc.a[g >> 1][g & 1]) << 24);
         }

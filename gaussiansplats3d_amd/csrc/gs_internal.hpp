@@ -474,7 +474,7 @@ struct gs_mesh {
     bool has_draw = false;
     uint32_t last_count = 0;
     uint32_t* mirror_host = nullptr;   // mapped pinned words written by every draw's k_bin_emit: [0..3] {serial, overflow, entries lo, hi},
-                                       // [4] bins over the deep pass's threshold, [8..11] {serial, visible splats, 16-px tiles lo, hi}
+                                       // [4] bins over the deep pass's threshold, [5] their share of the last walk in 1 / 1024, [8..11] {serial, visible splats, 16-px tiles lo, hi}
     uint32_t* mirror_dev = nullptr;
     uint32_t draw_serial = 0, healed_serial = 0, adapted_serial = 0;
     uint32_t grow_entries_to = 0;         // entry capacity wanted before the next draw (the list bins became smaller: mesh.hip)

@@ -351,8 +351,8 @@ __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ pre
     const uint32_t deep_trigger = max(2u * deep_min, deep_factor * mean_halves), deep_thr = max(2u * deep_min, mean_halves - mean_halves / 4u);
     __shared__ uint32_t s_trigger;
     if (threadIdx.x == 0) s_trigger = 0u;
-    __shared__ uint32_t s_deep_n;
-    if (threadIdx.x == 0) s_deep_n = 0u;
+    __shared__ uint32_t s_deep_n, s_deep_cost;
+    if (threadIdx.x == 0) { s_deep_n = 0u; s_deep_cost = 0u; }
     __threadfence_block();
     __syncthreads();                                   // blend_order complete (and visible to this workgroup)
     for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
@@ -361,6 +361,7 @@ __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ pre
         if (cost >= deep_trigger) s_trigger = 1u;
         if (cost >= deep_thr) {
             const uint32_t k = atomicAdd(&s_deep_n, 1u);
+            atomicAdd(&s_deep_cost, cost >> 4);            // (the members' share of the frame's walk: sixteenths, < 2^32 for any frame)
             if (deep) {
                 deep_flags[GS_FLAG_LIST + k] = i;
                 deep_flags[GS_FLAG_OF + i] = k;
@@ -374,7 +375,12 @@ __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ pre
         // membership rule - and tells the next one to stop)
         deep_flags[GS_FLAG_CAND] = s_trigger ? s_deep_n : 0u;
         if (deep) deep_flags[GS_FLAG_COUNT] = s_deep_n;
-        if (mirror) mirror[4] = s_trigger ? s_deep_n : 0u;
+        if (mirror) {
+            mirror[4] = s_trigger ? s_deep_n : 0u;
+            // ... and what share of the previous draw's walk those bins were, in 1 / 1024: how many of the blend's workgroups the pass
+            // should get (tile_blend.hip, gs_launch_blend)
+            mirror[5] = (uint32_t)(((unsigned long long)s_deep_cost << 14) / (unsigned long long)max(total_walked, 1u));
+        }
     }
 }
 

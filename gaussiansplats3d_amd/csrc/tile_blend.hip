@@ -346,6 +346,7 @@ struct DeepArgs {
     float4* pool;               // [pool_slots][256]
     uint32_t pool_slots;        // GS_POOL_SLOTS (tests shrink it: $GSPLAT_POOL_SLOTS)
     uint32_t unit_wgs;          // workgroups of (bin, quadrant, chunk) units behind the per-bin workgroups (0: no deep pass)
+    uint32_t unit_at;           // ... sit at blockIdx [unit_at, unit_at + unit_wgs): behind the unit_at costliest bins' workgroups
 };
 
 struct FrameArgs {
@@ -932,8 +933,12 @@ __global__ __launch_bounds__(BLEND_THREADS, BLEND_OCC) void k_tile_blend(FrameAr
     if (blockIdx.x < bins) bin_body<DEPTH>(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
     (void)s_queue;
 #else
-    if (blockIdx.x < bins) bin_body<DEPTH>(fa, da, blockIdx.x, s_batch, s_qmask, &s_live, s_walked);
-    else deep_unit<DEPTH>(fa, da, s_batch, s_queue);
+    const uint32_t b = blockIdx.x, at = min(da.unit_at, bins);
+    if (b >= at && b < at + da.unit_wgs) {
+        deep_unit<DEPTH>(fa, da, s_batch, s_queue);
+    } else {
+        bin_body<DEPTH>(fa, da, b < at ? b : b - da.unit_wgs, s_batch, s_qmask, &s_live, s_walked);
+    }
 #endif
 }
 
@@ -1342,6 +1347,30 @@ int gs_launch_blend(gs_mesh* m, const ProjectParams& pp, uint8_t* out_dev) {
     da.work = m->deep_work.as<uint32_t>();
     // (as many workgroups as the device holds at BLEND_OCC per CU: their waves loop over the unit list)
     da.unit_wgs = m->deep_pass ? (uint32_t)m->ctx->cu_count * BLEND_OCC : 0u;
+    // Where the deep pass's workgroups sit in the launch, and how many.  Their waves take (bin, quadrant, chunk) units from a list
+    // until it is empty, so any number of them finishes the pass; what matters is WHEN they run against the per-bin workgroups
+    // (tools/probes: GSPLAT_DEEP_UNIT_AT / _WGS; capture-like C3S, profiles/r06z_deep_unit_ab.txt):
+    //  * bins in costliest-first order (this view's statistics): the units used to come last, started 340 us into a 985 us launch and
+    //    ended it alone; all 1536 of them in front (AT = 0) crowd the costliest bins out.  Two workgroups per CU behind the deep bins'
+    //    own (empty) workgroups and the ~1.5 costliest bins per CU: frame 1.300 -> 1.13 ms at the demo pose, 1.300 -> 1.105 in the mean
+    //    of the orbit's poses held fixed;
+    //  * bins in row-major order (the camera moved on: no order): units are the fine-grained work that fills the end of the launch -
+    //    in the middle they cost 13 % (moving camera 1.35 -> 1.52 ms) - so they stay last, all of them.
+    da.unit_at = bins;
+    if (m->deep_pass && m->blend_order_valid && !getenv("GSPLAT_DEEP_UNITS_LAST")) {
+        const uint32_t cus = (uint32_t)m->ctx->cu_count;
+        const uint32_t deep_hint = m->mirror_host ? ((volatile uint32_t*)m->mirror_host)[4] : 0u;      // bins the last verdict put in the pass
+        // two per CU - or, when the pass's bins were most of the previous draw's walk, 0.6 of their share of the resident workgroups
+        // (C3S: share 0.55, best at a third of the workgroups whatever AT is: 256 / 512 / 768 / 1536 -> 1.30 / 1.125 / 1.15 / 1.20 ms;
+        // with exactly the share, 1.17)
+        const float share = (float)std::min(m->mirror_host ? ((volatile uint32_t*)m->mirror_host)[5] : 0u, 1024u) * (1.0f / 1024.0f);
+        const float k = getenv("GSPLAT_DEEP_SHARE_K") ? (float)atof(getenv("GSPLAT_DEEP_SHARE_K")) : 0.6f;
+        da.unit_wgs = std::min(da.unit_wgs, std::max(2u * cus, (uint32_t)(k * share * (float)da.unit_wgs + 0.5f)));
+        da.unit_at = std::min(bins, std::min(deep_hint, (uint32_t)GS_DEEP_MAX_BINS) + cus + cus / 2u);
+    }
+    if (getenv("GSPLAT_DEEP_UNIT_AT") && m->deep_pass) da.unit_at = (uint32_t)atoi(getenv("GSPLAT_DEEP_UNIT_AT"));
+    if (getenv("GSPLAT_DEEP_UNIT_WGS") && m->deep_pass)
+        da.unit_wgs = std::max(1u, std::min<uint32_t>((uint32_t)atoi(getenv("GSPLAT_DEEP_UNIT_WGS")), (uint32_t)m->ctx->cu_count * BLEND_OCC));
     if (m->draw_mode != GS_DRAW_FP32) {                    // the reference's RGBA8 target, splat by splat (no deep pass: nothing to schedule)
         const bool full = m->draw_mode == GS_DRAW_ROP8_FULL;
         if (fa.depth_mode && full) hipLaunchKernelGGL((k_tile_blend_rop8<true, false>), dim3(bins), dim3(BLEND_THREADS), 0, st, fa, bins);

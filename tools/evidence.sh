@@ -7,6 +7,7 @@
 TAG=${1:-rXX}
 cd /root/repo; mkdir -p gpurun_out/$TAG
 (timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -6) > gpurun_out/$TAG/pytest_gpu.txt
+cp gpurun_out/crops_C*.json gpurun_out/whole_frame_*.json gpurun_out/$TAG/ 2>/dev/null    # (before tools/probes/rop8_arith_ab.sh redraws three of them with variant builds)
 bash tools/pmc.sh $TAG hbm > /dev/null 2>&1
 bash tools/pmc.sh $TAG valu > /dev/null 2>&1
 python tools/pmc_traffic.py gpurun_out/pmc_$TAG gpurun_out/$TAG/pmc_traffic.json > gpurun_out/$TAG/pmc_traffic.txt 2>&1
@@ -55,6 +56,13 @@ bash tools/rank_prof.sh $TAG C3 1:0 > gpurun_out/$TAG/vis_cull_n1_kstats.txt 2>&
 # the gate / always the previous order / never an order), and the ROP8 draw modes with and without their own bin order
 (timeout 400 python tools/motion_ab.py "C3 C2" --rounds 1 --steps "0.5 1 2 3 6"; timeout 400 python tools/motion_ab.py "C3 C2" --pan --rounds 1 --steps "0.5 1 2 4 8"; timeout 300 python tools/motion_ab.py C3S --rounds 1 --steps "1 6") 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/motion_ab.txt
 (timeout 300 python tools/rop8_ab.py "C3 C2" 2>&1 | grep -v amdgpu.ids) > gpurun_out/$TAG/rop8_order_ab.txt
+# end of round 6: the rounding arithmetic of the ROP8 modes (three builds: tools/probes/rop8_arith_ab.sh needs gpurun_ab/lib_rop8f{0,1,2}.so,
+# built by tools/build_variant.sh rop8f<k> -DGS_ROP8_FUSED=<k>), the kernel tables of the bounded ROP8 frame and of the capture-like frame, and
+# where the deep pass's workgroups sit in the blend's launch (the adopted rule against GSPLAT_DEEP_UNITS_LAST=1)
+[ -f gpurun_ab/lib_rop8f0.so ] && bash tools/probes/rop8_arith_ab.sh > gpurun_out/$TAG/rop8_arith_ab.txt 2>&1
+(bash tools/prof_script.sh ${TAG}_rop8 44 /root/repo/tools/rop8_prof.py C3 bounded 40; grep frame gpurun_out/${TAG}_rop8/log.txt) > gpurun_out/$TAG/kstats_rop8_bounded.txt 2>&1
+(bash tools/prof_script.sh ${TAG}_c3s 47 /root/repo/tools/rop8_prof.py C3S fp32 40; grep frame gpurun_out/${TAG}_c3s/log.txt) > gpurun_out/$TAG/kstats_C3S.txt 2>&1
+(L=gpurun_ab/lib_this_tree.so; timeout 500 python tools/orbit_ab.py "C3S" "GSPLAT_DEEP_UNITS_LAST=1|$L" $L --rounds 2; for e in GSPLAT_DEEP_UNITS_LAST=1 GS_NOTHING=1; do echo "== $e"; env $e timeout 300 python tools/motion_ab.py C3S --rounds 1 --steps "0.25 1 6"; done; timeout 500 python tools/ab_libs.py "C3 C3T C2 C4" "GSPLAT_DEEP_UNITS_LAST=1|$L" $L --frames 30 --rounds 2) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/deep_unit_ab.txt
 [ -n "$GS_EVIDENCE_SORT_MIDDLE" ] && (timeout 600 python tools/strip_scaling.py C5 15 sm; timeout 600 python tools/strip_scaling.py C3 20 sm) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/sort_middle_parts.txt
 (python tools/strip_scaling.py C3 20; python tools/strip_scaling.py C5 15) 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/strip_scaling.txt
 # the same rank frames on the default context (streams of its own + two sets of vertex-stage outputs: what bench.py --gpus N runs)
@@ -65,5 +73,4 @@ bash tools/rank_prof.sh $TAG C3 1:0 > gpurun_out/$TAG/vis_cull_n1_kstats.txt 2>&
 # FILE -> native reader -> sort -> draw at BASELINE size: a 5.8 M-splat INRIA .ply staged on the box (synthetic content, real format)
 [ -z "$GS_EVIDENCE_LIGHT" ] && (timeout 600 python tools/stage_ply.py C3 /tmp/gsdata 2>&1 | grep -v amdgpu.ids; GS_DATA_DIR=/tmp/gsdata timeout 500 python bench.py --only-headline --no-cpu 2>/dev/null | tail -1; rm -rf /tmp/gsdata) > gpurun_out/$TAG/bench_from_file.txt
 (timeout 60 tools/probes/lookback_probe.bin 5800000 20; timeout 60 tools/probes/lookback_probe.bin 270000 20) > gpurun_out/$TAG/lookback_probe.txt 2>&1
-cp gpurun_out/crops_C*.json gpurun_out/whole_frame_*.json gpurun_out/$TAG/ 2>/dev/null
 cat gpurun_out/$TAG/pytest_gpu.txt; head -c 700 gpurun_out/$TAG/bench.json; echo; head -14 gpurun_out/$TAG/kstats.txt; cat gpurun_out/$TAG/pmc_traffic.txt | tail -3; cat gpurun_out/$TAG/strip_scaling.txt

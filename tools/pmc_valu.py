@@ -15,6 +15,7 @@ import csv
 import glob
 import json
 import re
+import statistics
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
@@ -35,7 +36,9 @@ for name, cs in sorted(acc.items()):
         continue
     if "SQ_ACTIVE_INST_VALU" not in cs:
         continue
-    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    # the MEDIAN over the dispatches: a launch or two of a pass carry the module load / a clock ramp (r06zz: one k_project dispatch of 56
+    # with GRBM_GUI_ACTIVE = 41 M cycles against 1.0 M, the mean said 0.36 busy where every other dispatch says 0.63)
+    m = {c: statistics.median(v) for c, v in cs.items()}
     clocks = (m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) or (m.get("SQ_BUSY_CYCLES", 0.0) / 32.0)
     k = {c: round(v, 1) for c, v in sorted(m.items())}
     k["dispatches"] = len(cs["SQ_ACTIVE_INST_VALU"])

@@ -307,6 +307,9 @@ struct gs_sorter {
     const SortFrame* result_frame = nullptr;
     DevBuf keep_mask;                  // 1 bit per list position (frustum-cull variant)
     DevBuf chunk_counts;               // survivors per chunk of the identity list (visibility-cull variant)
+    DevBuf key_sync;                   // uint32 [2]: {arrivals, time-outs} of k_depth_key_hist's barrier across the grid ($GSPLAT_KEY_HIST_FUSED)
+    uint32_t key_sync_base = 0;        // arrivals before the next launch
+    bool key_sync_used = false;
     DevBuf mask_copy;                  // the bound mesh's visibility mask as the last visibility-culled sort consumed it
     bool last_vis_culled = false;
 };

@@ -831,11 +831,12 @@ int radix_pass_ex(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift
 // A pass of the depth sort between / after packing passes (see k_radix_scatter_chunk); the caller checked radix_chunk_grid_for.
 template <class HistLoader, class Loader, bool PACK_OUT>
 int radix_pass_chunk(const RadixExec& ex, const HistLoader& ld_hist, int hist_shift, const Loader& ld, uint32_t n_upper, int shift,
-                     int pass_slot, uint32_t* out, uint32_t val_bits, uint32_t* count_out = nullptr) {
+                     int pass_slot, uint32_t* out, uint32_t val_bits, uint32_t* count_out = nullptr, bool skip_hist = false) {
     const uint32_t grid = radix_chunk_grid_for(n_upper);
     uint32_t* bh = ex.scratch->block_hist.as<uint32_t>();
     uint32_t* dt = ex.scratch->digit_total.as<uint32_t>() + pass_slot * RADIX_MAX_GROUPS * RADIX_BINS;
-    hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
+    // (skip_hist: the rows were left by the kernel in front of this pass - sorter.hip, k_depth_key_hist)
+    if (!skip_hist) hipLaunchKernelGGL((k_radix_hist<HistLoader>), dim3(grid), dim3(HIST_THREADS), 0, ex.stream, ld_hist, hist_shift, bh, dt);
     if (ex.atomic_rank)
         hipLaunchKernelGGL((k_radix_scatter_chunk<Loader, PACK_OUT, true>), dim3(grid), dim3(CHUNK_THREADS), 0, ex.stream, ld, shift, bh, dt, out, val_bits, count_out);
     else

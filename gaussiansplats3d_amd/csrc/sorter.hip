@@ -1043,6 +1043,139 @@ __global__ void k_unmap(const uint32_t* __restrict__ in, const uint32_t* __restr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = unmap[min(in[i], last)];
 }
 
+// Phase A + the histogram of pass 0 in ONE launch ($GSPLAT_KEY_HIST_FUSED=1, opt-in).  A key's bucket needs the
+// exact min / max over ALL keys (sorter.cpp:142-146), which exist only when the last workgroup has keyed its splats - so the launch
+// is two phases around a barrier ACROSS THE GRID: one workgroup per chunk of the pass-0 scatter (radix.hpp: <= CHUNK_TILES tiles),
+// every thread keeps its <= 12 keys in registers, the grid meets on one counter (no reset: it only ever grows, every launch waits for
+// `base + gridDim.x`), then each workgroup reads the final min / max and histograms its own keys - the 24 MB re-read of the keys and
+// the kernel boundary of k_radix_hist are what this saves, the barrier is what it costs.  Needs the whole grid resident at once (the
+// host launches it only for <= 2 workgroups of 1024 threads per CU); the wait is bounded all the same: a workgroup that runs out of
+// patience raises `fail` (the sort reports GS_ERR_HIP at the next statistics read) instead of hanging the device.
+// Identity list, static integer mode, sort_start = 0, render_count a multiple of 4 (the 16-byte plane loads).
+#ifndef KEY_HIST_SLEEP
+#define KEY_HIST_SLEEP 4
+#endif
+struct KeyHistSync {
+    uint32_t* arrive;          // grows by gridDim.x per launch
+    uint32_t* fail;
+    uint32_t base;             // *arrive before this launch
+};
+__global__ __launch_bounds__(HIST_THREADS) void k_depth_key_hist(KeyParams p, DepthLoader ld, int shift, uint32_t* __restrict__ block_hist,
+                                                                  uint32_t* __restrict__ digit_total, KeyHistSync sync) {
+    __shared__ uint32_t s_hist[4][RADIX_BINS];
+    __shared__ int32_t s_lo[HIST_THREADS / 64], s_hi[HIST_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + tid;
+    // (k_depth_key's housekeeping.  The group rows are added to BEHIND the barrier by workgroups of other XCDs: zeroed with
+    // agent-scope stores, which go through to the memory side - a plain store would sit dirty in this XCD's L2 until a release
+    // wrote the whole L2 back, and 472 such releases made this kernel 80 us long)
+    // (only pass 0's rows - the first RADIX_MAX_GROUPS x RADIX_BINS words - are touched inside this launch; the later passes' rows are
+    // read by later kernels and take plain stores)
+    for (uint32_t w = t; w < (uint32_t)RADIX_TOTAL_WORDS; w += stride) {
+        if (w < (uint32_t)(RADIX_MAX_GROUPS * RADIX_BINS)) __hip_atomic_store(&p.digit_total[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else p.digit_total[w] = 0u;
+    }
+    if (t < SORT_SHARDS) {
+        p.next_frame->key_min[t] = 2147483640;
+        p.next_frame->key_max[t] = -2147483640;
+    }
+    if (t == 0) {
+        p.next_frame->clamped = 0;
+        p.next_frame->kept = 0;
+    }
+    for (uint32_t k = tid; k < 4u * RADIX_BINS; k += HIST_THREADS) (&s_hist[0][0])[k] = 0;
+    const uint32_t R = p.render_count;
+    const RadixChunk ch = radix_chunk(R);
+    // logical element j of the radix passes is list position R - 1 - j: this chunk's elements [j0, j1) are positions (R - j1, R - j0]
+    const uint32_t j0 = min(ch.tile_begin * (uint32_t)RADIX_TILE, R), j1 = min(ch.tile_end * (uint32_t)RADIX_TILE, R);
+    const uint32_t v0 = (R - j1) / 4u, v1 = (R - j0) / 4u;                  // vectors of four positions (R, j0, j1 are multiples of 4)
+    constexpr uint32_t KV = (uint32_t)CHUNK_TILES * RADIX_TILE / (HIST_THREADS * 4u);
+    static_assert(KV * HIST_THREADS * 4u == (uint32_t)CHUNK_TILES * RADIX_TILE, "whole vectors per thread");
+    const uint4* x4 = reinterpret_cast<const uint4*>(p.cx);
+    const uint4* y4 = reinterpret_cast<const uint4*>(p.cy);
+    const uint4* z4 = reinterpret_cast<const uint4*>(p.cz);
+    int4* o4 = reinterpret_cast<int4*>(p.keys_out);
+    const uint32_t m0 = (uint32_t)p.im0, m1 = (uint32_t)p.im1, m2 = (uint32_t)p.im2;
+    int4 key[KV];
+    int32_t lo = 2147483640, hi = -2147483640;
+    uint4 x[KV], y[KV], z[KV];
+#pragma unroll
+    for (uint32_t k = 0; k < KV; k++) {
+        const uint32_t v = min(v0 + k * HIST_THREADS + tid, v1 ? v1 - 1u : 0u);     // (unconditional loads, clamped)
+        x[k] = x4[v]; y[k] = y4[v]; z[k] = z4[v];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KV; k++) {
+        const uint32_t v = v0 + k * HIST_THREADS + tid;
+        key[k].x = (int32_t)(x[k].x * m0 + y[k].x * m1 + z[k].x * m2);
+        key[k].y = (int32_t)(x[k].y * m0 + y[k].y * m1 + z[k].y * m2);
+        key[k].z = (int32_t)(x[k].z * m0 + y[k].z * m1 + z[k].z * m2);
+        key[k].w = (int32_t)(x[k].w * m0 + y[k].w * m1 + z[k].w * m2);
+        if (v < v1) {
+            o4[v] = key[k];
+            lo = min(min(lo, key[k].x), min(min(key[k].y, key[k].z), key[k].w));
+            hi = max(max(hi, key[k].x), max(max(key[k].y, key[k].z), key[k].w));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (uint32_t w = 1; w < HIST_THREADS / 64; w++) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+        if (v1 > v0) {
+            atomicMin(&p.frame->key_min[blockIdx.x % SORT_SHARDS], lo);
+            atomicMax(&p.frame->key_max[blockIdx.x % SORT_SHARDS], hi);
+        }
+        // The barrier across the grid.  What the other workgroups need from this one are agent-scope atomics and stores (min / max,
+        // the zeroed group rows): performed at the memory side, so "complete" is "visible" - the arrival only has to be issued after
+        // they are complete (a workgroup-scope release = s_waitcnt), not after an L2 write-back.  The keys and the histogram rows are
+        // for the NEXT kernel.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_fetch_add(sync.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t spins = 0;
+        // (relaxed polls: an acquiring load per poll invalidates the caches the workgroups that are still keying read through)
+        while (__hip_atomic_load(sync.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sync.base < gridDim.x) {
+            __builtin_amdgcn_s_sleep(KEY_HIST_SLEEP);
+            if (++spins > 4000000u) { atomicAdd(sync.fail, 1u); break; }            // (seconds: the grid was not resident at once)
+        }
+        // (what is read behind the barrier is read with agent-scope atomic loads and updated with agent-scope atomics: no acquire)
+    }
+    __syncthreads();
+    // phase 2: the final range (fresh loads: the words were written by other workgroups' atomics)
+    {
+        const uint32_t l = tid & (SORT_SHARDS - 1u);
+        int32_t glo = __hip_atomic_load(&ld.frame->key_min[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int32_t ghi = __hip_atomic_load(&ld.frame->key_max[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = SORT_SHARDS / 2; o > 0; o >>= 1) {
+            glo = min(glo, __shfl_xor(glo, o, 64));
+            ghi = max(ghi, __shfl_xor(ghi, o, 64));
+        }
+        ld.range_map = __fdiv_rn((float)(ld.range - 1), __fsub_rn((float)ghi, (float)glo));
+        ld.lo = __builtin_amdgcn_readfirstlane(glo);
+        ld.range_map = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ld.range_map)));
+    }
+    uint32_t* hist = s_hist[wave & 3u];
+#pragma unroll
+    for (uint32_t k = 0; k < KV; k++) {
+        if (v0 + k * HIST_THREADS + tid < v1) {
+            atomicAdd(&hist[(ld.hist_key(key[k].x) >> shift) & 255u], 1u);
+            atomicAdd(&hist[(ld.hist_key(key[k].y) >> shift) & 255u], 1u);
+            atomicAdd(&hist[(ld.hist_key(key[k].z) >> shift) & 255u], 1u);
+            atomicAdd(&hist[(ld.hist_key(key[k].w) >> shift) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid >= RADIX_BINS || ch.tile_begin >= ch.tile_end) return;
+    const uint32_t total = s_hist[0][tid] + s_hist[1][tid] + s_hist[2][tid] + s_hist[3][tid];
+    block_hist[ch.id * RADIX_BINS + tid] = total;
+    if (total) atomicAdd(&digit_total[(ch.id / RADIX_GROUP) * RADIX_BINS + tid], total);
+}
+
 __global__ void k_debug_buckets(DepthLoader ld, int32_t* out) {
     ld.prepare();
     for (uint32_t i = ld.sort_start + blockIdx.x * blockDim.x + threadIdx.x; i < ld.render_count;
@@ -1060,6 +1193,7 @@ struct Pass0Args {
     void* kbuf0;
     uint32_t* vo;
     uint32_t* kept_out;
+    bool skip_hist;                     // k_depth_key_hist already left pass 0's histogram rows
 };
 template <bool CULL, bool IDX>
 static int depth_pass0(const RadixExec& ex, const Pass0Args& a) {
@@ -1069,7 +1203,7 @@ static int depth_pass0(const RadixExec& ex, const Pass0Args& a) {
     d.sort_start = a.base.sort_start; d.render_count = a.base.render_count; d.range = a.base.range; d.last_splat = a.base.last_splat;
     L h = d;                            // only the histogram launch counts clamped buckets (once per element)
     h.count_clamps = 1;
-    if (a.pack && a.chunked) return radix_pass_chunk<L, L, true>(ex, h, a.shift, d, a.Rs, a.shift, 0, a.vo, a.val_bits, a.kept_out);
+    if (a.pack && a.chunked) return radix_pass_chunk<L, L, true>(ex, h, a.shift, d, a.Rs, a.shift, 0, a.vo, a.val_bits, a.kept_out, a.skip_hist);
     if (a.pack) return radix_pass_ex<L, L, uint8_t, false, false, true>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint8_t*)nullptr, a.vo, nullptr, 0u, a.val_bits, a.kept_out);
     if (a.wide) return radix_pass_ex<L, L, uint32_t, true, false, false>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint32_t*)a.kbuf0, a.vo, nullptr, 0u, 0u, a.kept_out);
     return radix_pass_ex<L, L, uint16_t, true, false, false>(ex, h, a.shift, d, a.Rs, a.shift, 0, (uint16_t*)a.kbuf0, a.vo, nullptr, 0u, 0u, a.kept_out);
@@ -1188,6 +1322,16 @@ static int sorter_collect_stats(gs_sorter* s, gs_sort_stats* stats) {
     SortFrame f;
     GS_HIP(hipMemcpyAsync(&f, s->frame.as<SortFrame>() + s->frame_index, sizeof(f), hipMemcpyDeviceToHost, s->stream));
     GS_HIP(hipStreamSynchronize(s->stream));
+    if (s->key_sync_used) {                        // k_depth_key_hist: a workgroup gave up waiting for the rest of its grid
+        uint32_t w[2] = {0u, 0u};
+        GS_HIP(hipMemcpyAsync(w, s->key_sync.p, sizeof(w), hipMemcpyDeviceToHost, s->stream));
+        GS_HIP(hipStreamSynchronize(s->stream));
+        if (w[1]) {
+            GS_HIP(hipMemsetAsync((char*)s->key_sync.p + 4, 0, 4, s->stream));       // (reported once)
+            gs_set_error("the key kernel's barrier across its grid timed out (k_depth_key_hist): the sorted list is not valid");
+            return GS_ERR_HIP;
+        }
+    }
     float ms = 0.f;
     if (s->timed_sort) GS_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     int32_t key_lo = f.lo(), key_hi = f.hi();
@@ -1336,6 +1480,27 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
     uint32_t passes = 0;
     if (Rs > 0) {
         const bool vec4 = (kp.mode == MODE_INT) && !idx_dev;
+        // $GSPLAT_KEY_HIST_FUSED=1: keys + pass 0's histogram in one launch behind a barrier across the grid (k_depth_key_hist) - only for
+        // the plain full sort of the identity list whose pass 0 is the packed, chunk-staged one, and only when the whole grid is
+        // resident at once (<= 2 workgroups of 1024 threads per CU)
+        uint32_t kh_grid = 0;
+        bool key_hist_fused = false;
+        if (getenv("GSPLAT_KEY_HIST_FUSED") && vec4 && !fused_tree && !vis_cull && !cull && sort_start == 0u && Rs == R && (R & 3u) == 0u &&
+            !list_count_dev && !getenv("GSPLAT_NO_SORT_PACK") && !getenv("GSPLAT_NO_SORT_CHUNK") && s->precision > 8u) {
+            uint32_t mp = kp.last_splat;
+            if (map && s->bound_mesh->uploaded && s->bound_mesh->uploaded - 1u > mp) mp = s->bound_mesh->uploaded - 1u;
+            uint32_t vb = 1;
+            while (vb < 32u && (mp >> vb)) vb++;
+            kh_grid = radix_chunk_grid_for(Rs);
+            key_hist_fused = vb <= 24u && (s->precision - 8u) + vb <= 32u && kh_grid != 0u && kh_grid <= 2u * (uint32_t)ctx->cu_count;
+            if (key_hist_fused) {
+                if (!s->key_sync.p) {
+                    GS_TRY(s->key_sync.alloc(64));
+                    GS_HIP(hipMemsetAsync(s->key_sync.p, 0, 64, st));
+                    s->key_sync_base = 0u;
+                }
+            }
+        }
         if (fused_tree) {
             // copy + keys (+ keep bits) of the planned gather in one kernel over leaf-major copies of the centres and payloads
             TreeCopyParams cp;
@@ -1436,7 +1601,16 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
             hipLaunchKernelGGL(k_depth_key_cull<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
         else if (cull)
             hipLaunchKernelGGL(k_depth_key_cull<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 4)), dim3(256), 0, st, kp);
-        else if (vec4)
+        else if (vec4 && key_hist_fused) {
+            DepthLoader hl = {};
+            hl.keys = s->keys.as<int32_t>(); hl.frame = kp.frame; hl.sort_start = 0u; hl.render_count = R; hl.range = 1u << s->precision;
+            hl.last_splat = kp.last_splat; hl.count_clamps = 1u;
+            KeyHistSync sync = {s->key_sync.as<uint32_t>(), s->key_sync.as<uint32_t>() + 1, s->key_sync_base};
+            s->key_sync_base += kh_grid;
+            s->key_sync_used = true;
+            hipLaunchKernelGGL(k_depth_key_hist, dim3(kh_grid), dim3(HIST_THREADS), 0, st, kp, hl, 0, s->radix.block_hist.as<uint32_t>(),
+                               s->radix.digit_total.as<uint32_t>(), sync);
+        } else if (vec4)
             hipLaunchKernelGGL(k_depth_key<true>, dim3(grid_for(Rs, 256 * 16, (uint32_t)ctx->cu_count * GS_KEY_GRID_MULT)), dim3(256), 0, st, kp);
         else
             hipLaunchKernelGGL(k_depth_key<false>, dim3(grid_for(Rs, 256 * 4, (uint32_t)ctx->cu_count * 2)), dim3(256), 0, st, kp);
@@ -1487,6 +1661,7 @@ static int sorter_sort_impl(gs_sorter* s, const float* mvp, const uint32_t* inde
                 a.base = dl; a.keep = cull ? kp.keep : nullptr; a.Rs = Rs; a.val_bits = val_bits; a.shift = shift;
                 a.pack = pack; a.chunked = chunked; a.wide = wide; a.kbuf0 = kbuf[0]; a.vo = vo;
                 a.kept_out = cull ? &kp.frame->kept : nullptr;         // a culling pass 0 compacts: it publishes the result's length
+                a.skip_hist = key_hist_fused;
                 const bool has_idx = dl.idx != nullptr;
                 if (cull && has_idx) GS_TRY((depth_pass0<true, true>(ex, a)));
                 else if (cull) GS_TRY((depth_pass0<true, false>(ex, a)));

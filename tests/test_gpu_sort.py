@@ -128,3 +128,32 @@ def test_ballot_ranking_fallback_is_bit_exact(monkeypatch):
         assert kat_cases.digest(reply["sortedIndexes"]) == meta[name]["output"]
         w.terminate()
     c.close()
+
+
+def test_keys_and_pass_0_histogram_in_one_launch_is_bit_exact(monkeypatch):
+    """$GSPLAT_KEY_HIST_FUSED=1 (built as an opt-in): k_depth_key_hist keys the splats, meets its whole grid on one
+    counter for the exact min / max and histograms pass 0 from registers.  Same list as the two kernels at sizes that give one
+    chunk, several, ragged last tiles; sizes it does not take (not a multiple of 4) and partial sorts fall back silently."""
+    c = Context(0)
+    rng = np.random.default_rng(99)
+    cam = camera.demo_camera("garden", 640, 360)
+    for n in (4, 4096, 12288, 12292, 100000, 1200000, 999999):
+        centers = (rng.normal(size=(n, 3)) * 3.0).astype(np.float32)
+        ci = util.integer_centers(centers)
+        w = create_sort_worker(c, n)
+        w.post_message({"centers": ci, "range": {"from": 0, "to": n - 1, "count": n}})
+
+        def sort(count):
+            return w.post_message({"sort": {"modelViewProj": cam.sort_mvp(), "splatRenderCount": n, "splatSortCount": count,
+                                            "usePrecomputedDistances": False, "indexesToSort": None, "transforms": None,
+                                            "precomputedDistances": None}})["sortedIndexes"].copy()
+        monkeypatch.setenv("GSPLAT_KEY_HIST_FUSED", "1")
+        full = sort(n)
+        np.testing.assert_array_equal(full, oracle.sort_indexes(np.arange(n, dtype=np.uint32), ci, cam.sort_mvp()), err_msg=f"n {n}")
+        assert w.last_stats()[0].result_count == n
+        part = sort(max(n // 2, 1))
+        monkeypatch.delenv("GSPLAT_KEY_HIST_FUSED")
+        np.testing.assert_array_equal(sort(n), full)
+        np.testing.assert_array_equal(sort(max(n // 2, 1)), part)
+        w.terminate()
+    c.close()

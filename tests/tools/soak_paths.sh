@@ -16,7 +16,7 @@ for E in - GSPLAT_NO_LDS_ATOMIC_RANK=1 GSPLAT_NO_SORT_PACK=1 GSPLAT_NO_SORT_CHUN
   run "$E" soak.py 30 41000 120000
   run "$E" soak_stateful.py 3 42000 16 40000
 done
-for E in - GSPLAT_NO_LDS_ATOMIC_RANK=1 GSPLAT_NO_SORT_PACK=1 GSPLAT_NO_SORT_CHUNK=1; do
+for E in - GSPLAT_NO_LDS_ATOMIC_RANK=1 GSPLAT_NO_SORT_PACK=1 GSPLAT_NO_SORT_CHUNK=1 GSPLAT_KEY_HIST_FUSED=1; do
   run "$E" soak_sort.py 150 43000 300000
   run "$E" soak_sort.py sizes 4095,4096,4097,12287,12288,12289,24577,6291457,16777215,16777217
 done

@@ -107,8 +107,17 @@ def main():
         res = {}
         for rnd in range(a.rounds):
             for lib in a.libs:
-                use_library(lib)
+                env, path = lib.split("|") if "|" in lib else ("", lib)      # `ENV=V,ENV=V|lib.so`: that library under those switches
+                sets = dict(kv.split("=", 1) for kv in env.split(",") if kv)
+                old_env = {k: os.environ.get(k) for k in sets}
+                os.environ.update(sets)
+                use_library(path)
                 med, mn, crc, _ = measure(centers, cfg, a.sorts, bound=not a.unbound)
+                for k, v in old_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
                 res.setdefault(lib, []).append((med, mn, crc))
                 if mark:
                     print(f"MARK {name} {os.path.basename(lib)} sorts={a.sorts + 3}", flush=True)
@@ -117,7 +126,7 @@ def main():
             r = res[lib]
             ok = "" if want is None else ("  == oracle" if r[0][2] == want else "  != ORACLE")
             bad += (want is not None and r[0][2] != want)
-            print(f"{name:4s} {os.path.basename(lib):28s} sort median " + " / ".join(f"{x[0]:.4f}" for x in r) + " ms   min " +
+            print(f"{name:4s} {lib.replace(os.path.dirname(lib.split(chr(124))[-1]) + os.sep, ''):40s} sort median " + " / ".join(f"{x[0]:.4f}" for x in r) + " ms   min " +
                   " / ".join(f"{x[1]:.4f}" for x in r) + f"   crc {r[0][2]:08x}{ok}", flush=True)
         if len(crcs) != 1:
             print(f"{name}: THE LIBRARIES DISAGREE ({len(crcs)} different sorted lists)", flush=True)

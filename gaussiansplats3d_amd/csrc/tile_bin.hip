@@ -822,7 +822,11 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                            order_wg ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
                            m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
     }
-    m->blend_order_valid = order_ok && (same_view || stale_order);
+    // ... and whenever the deep pass runs: its frames have the long tail that an order - even one from a view several degrees away -
+    // and the pass's workgroups behind the costliest bins (tile_blend.hip) shorten.  Capture-like C3S, orbit at 3 / 6 / 12 degrees per
+    // frame: 1.24 / 1.356 / 1.54 -> 1.18 / 1.31 / 1.51 ms, turning 4 degrees per frame 2.84 -> 2.77, never slower
+    // (profiles/r06zz_deep_keeps_order_ab.txt; $GSPLAT_DEEP_ROW_MAJOR_ON_MOTION=1 is the earlier rule).
+    m->blend_order_valid = order_ok && (same_view || stale_order || (m->deep_pass && !getenv("GSPLAT_DEEP_ROW_MAJOR_ON_MOTION")));
     GS_HIP(hipGetLastError());
     if (pp.row_begin == 0u && pp.row_end >= pp.tiles_y) {     // (a strip's visible count says nothing about the scene: mesh_heal_overflow)
         m->full_serial[m->draw_serial & 7u] = m->draw_serial;

@@ -292,10 +292,17 @@ __device__ __forceinline__ uint32_t bin_emit_batch(const uint32_t* __restrict__ 
     return n;
 }
 
+// The previous draw's per-bin statistics describe ITS view.  When the camera has moved since, the host says how far the scene's centre
+// of mass moved on screen, in bins (binning_typed): the schedule reads the statistics of the bin a bin's content came FROM - a camera
+// that turns about its own position shifts the whole picture, and with it the costly bins and the deep pass's members, by that much.
+struct StatShift {
+    int32_t sx, sy;            // this draw's bin (bx, by) shows what the previous draw's bin (bx - sx, by - sy) showed
+    uint32_t bins_x;
+};
 // The blend's schedule and the deep pass's members, one workgroup of BIN_THREADS (see where it is called: k_bin_emit / k_bin_fused)
 __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins, uint32_t* __restrict__ blend_order,
                                                    uint32_t deep, uint32_t* __restrict__ deep_flags, uint32_t* __restrict__ blend_stats_w,
-                                                   uint32_t deep_min, uint32_t deep_factor, volatile uint32_t* __restrict__ mirror) {
+                                                   uint32_t deep_min, uint32_t deep_factor, volatile uint32_t* __restrict__ mirror, StatShift sh) {
     __shared__ uint32_t s_cost[RADIX_BINS], s_tmp2[4];
     // the chunked composite's per-draw words: no deep bins yet, an empty partial pool (k_bin_count resets them as well; in the fused
     // launch this workgroup runs BESIDE the counting workgroups, so the reset has to be its own)
@@ -306,13 +313,20 @@ __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ pre
     // three sweeps over the statistics, 8 loads in flight per lane (registers for all 8192 / 256 values would set the
     // whole kernel's VGPR allocation and cost every emitting workgroup its occupancy)
     constexpr uint32_t SWEEP = 8;
+    auto cost_of = [&](uint32_t i) -> uint32_t {
+        if (sh.sx == 0 && sh.sy == 0) return prev_blend_stats[i].y;
+        const uint32_t by = i / sh.bins_x, bx = i - by * sh.bins_x;
+        const int32_t fx = (int32_t)bx - sh.sx, fy = (int32_t)by - sh.sy;
+        const uint32_t from = (uint32_t)fy * sh.bins_x + (uint32_t)fx;
+        return (fx >= 0 && fy >= 0 && (uint32_t)fx < sh.bins_x && from < blend_bins) ? prev_blend_stats[from].y : 0u;
+    };
     auto sweep = [&](auto&& use) {
         for (uint32_t base = 0; base < blend_bins; base += SWEEP * BIN_THREADS) {
             uint32_t c[SWEEP];
 #pragma unroll
             for (uint32_t k = 0; k < SWEEP; k++) {
                 const uint32_t i = base + threadIdx.x + k * BIN_THREADS;
-                c[k] = i < blend_bins ? prev_blend_stats[i].y : 0u;
+                c[k] = i < blend_bins ? cost_of(i) : 0u;
             }
 #pragma unroll
             for (uint32_t k = 0; k < SWEEP; k++) {
@@ -357,7 +371,7 @@ __device__ __forceinline__ void blend_schedule_job(const uint2* __restrict__ pre
     __syncthreads();                                   // blend_order complete (and visible to this workgroup)
     for (uint32_t p = threadIdx.x; p < min(blend_bins, GS_DEEP_MAX_BINS); p += BIN_THREADS) {
         const uint32_t i = __hip_atomic_load(&blend_order[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t cost = i < blend_bins ? prev_blend_stats[i].y : 0u;
+        const uint32_t cost = i < blend_bins ? cost_of(i) : 0u;
         if (cost >= deep_trigger) s_trigger = 1u;
         if (cost >= deep_thr) {
             const uint32_t k = atomicAdd(&s_deep_n, 1u);
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
                                                           const uint2* __restrict__ prev_blend_stats, uint32_t blend_bins,
                                                           uint32_t* __restrict__ blend_order, uint32_t deep,
                                                           uint32_t* __restrict__ deep_flags, uint32_t* __restrict__ blend_stats_w,
-                                                          uint32_t deep_min, uint32_t deep_factor) {
+                                                          uint32_t deep_min, uint32_t deep_factor, StatShift sh) {
     __shared__ __attribute__((aligned(16))) uint32_t s_eoff[BIN_MAX_BLOCKS];   // entries of the binning workgroups before b (saturating)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BIN_MAX_BLOCKS];    // compacted splats of binning workgroup b
     __shared__ unsigned long long s_wsum[4], s_t16[4];
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(RenderFrame* __restric
     // keys is irrelevant (pixels do not depend on which workgroup draws a bin).
     const uint32_t first_wg = blend_order ? 1u : 0u;
     if (blend_order && blockIdx.x == 0) {
-        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror);
+        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror, sh);
         BIN_PROF(1, 1, wall_clock64());
         BIN_PROF(1, 2, wall_clock64());
         return;
@@ -589,14 +603,14 @@ __global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     RenderFrame* __restrict__ frame, uint32_t capacity, uint32_t tiles_x /* list bins per row */, uint32_t row_begin /* first list-bin row */,
     KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, volatile uint32_t* __restrict__ mirror, uint32_t serial,
     const uint2* __restrict__ prev_blend_stats, uint32_t* __restrict__ blend_order, uint32_t deep, uint32_t* __restrict__ blend_stats_w,
-    uint32_t deep_min, uint32_t deep_factor, BinScan scan) {
+    uint32_t deep_min, uint32_t deep_factor, BinScan scan, StatShift sh) {
     __shared__ unsigned long long s_w[4];
     __shared__ uint32_t s_any[ANY_WORDS];
     __shared__ uint32_t s_base;
     // (+ one workgroup, the first to be dispatched, for the blend's schedule and the deep pass's members: k_bin_emit's)
     const uint32_t first_wg = blend_order ? 1u : 0u;
     if (blend_order && blockIdx.x == 0) {
-        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror);
+        blend_schedule_job(prev_blend_stats, blend_bins, blend_order, deep, deep_flags, blend_stats_w, deep_min, deep_factor, mirror, sh);
         return;
     }
     const uint32_t wg = blockIdx.x - first_wg, G = gridDim.x - first_wg;
@@ -738,35 +752,61 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
     const bool same_frame = m->stats_pp_valid && memcmp(lp.proj, pp.proj, sizeof(pp.proj)) == 0 && lp.width == pp.width && lp.height == pp.height &&
                             lp.count == pp.count && lp.list_shift == pp.list_shift;
     bool same_view = same_frame && memcmp(lp.view, pp.view, sizeof(pp.view)) == 0;
-    // ... or a view close to it.  How far the picture moved, in screen heights: (the camera's rotation + its translation over its
-    // distance to the scene) x focal / height.  Measured on the 60-pose orbit at 0.25 ... 6 degrees per frame (tools/motion_ab.py,
-    // profiles/r06w_motion_ab.txt): the previous frame's order beats row-major up to 2 degrees per frame (C2 7-11 %, C3 1-2 % of the
-    // frame) = 0.06-0.10 screen heights on these scenes, is level at 3 and loses 2.5-3 % at 6; for a camera turning about its own
-    // position it wins 2-10 % up to 2 degrees per frame (0.037), and loses 4 % at 4 (0.075: C2).  The limit is 0.06 screen heights
-    // ($GSPLAT_ORDER_MOTION; 0 = the same view only: the first half of round 6).
+    // ... or a view close to it.  Two things are taken from the two cameras (second half of round 6; tools/motion_ab.py):
+    //  * how far the scene's centre of mass moved on screen, in whole bins: the schedule reads the statistics of the bin a bin's
+    //    content came FROM (StatShift).  A camera turning about its own position shifts the whole picture - and the costly bins, and
+    //    the deep pass's members - by that much: capture-like C3S turning 2 / 4 / 8 degrees per frame 2.14 / 2.77 / 3.78 -> 1.16 / 1.39 /
+    //    2.06 ms per frame, C2 with the previous order at 4 / 8 degrees 0.3175 / 0.3139 -> 0.2913 / 0.3001 (row-major: 0.303)
+    //    (profiles/r06zz_stat_shift_ab.txt; $GSPLAT_NO_STAT_SHIFT);
+    //  * what that shift does NOT describe - parallax: how far points at half and at twice the centre's distance, on the previous
+    //    camera's ray through the centre, end up from the centre in the new picture, in screen heights.  Orbiting the scene at 0.25 ...
+    //    6 degrees per frame the previous frame's order beats row-major up to 2 degrees (C2 7-11 %, C3 1-2 % of the frame), is level
+    //    at 3 and loses 2.5-3 % at 6 (profiles/r06w_motion_ab.txt): the order is taken below a parallax of 0.045 screen heights
+    //    ($GSPLAT_ORDER_MOTION; 0 = the same view only).  Turning in place has none, at any speed.
+    StatShift stat_shift = {0, 0, pp.bins_x};
     if (same_frame && !same_view && pp.block_cull && m->centre_n > 0) {
-        const float limit = getenv("GSPLAT_ORDER_MOTION") ? (float)atof(getenv("GSPLAT_ORDER_MOTION")) : 0.06f;
-        float rot = 0.0f;                                  // largest angle between corresponding axes of the two view rotations
-        for (int k = 0; k < 3; k++) {
-            const float* a = lp.view + 4 * k;
-            const float* b = pp.view + 4 * k;
-            const float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-            const float na = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], nb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
-            const float c = d / sqrtf(fmaxf(na * nb, 1e-30f));
-            rot = fmaxf(rot, acosf(fminf(fmaxf(c, -1.0f), 1.0f)));
-        }
+        const float limit = getenv("GSPLAT_ORDER_MOTION") ? (float)atof(getenv("GSPLAT_ORDER_MOTION")) : 0.045f;
         const double inv_n = 1.0 / (double)m->centre_n;
-        const double mean[3] = {m->centre_sum[0] * inv_n, m->centre_sum[1] * inv_n, m->centre_sum[2] * inv_n};
-        const double var = m->centre_sq * inv_n - (mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2]);
-        const float rms = (float)sqrt(var > 0.0 ? var : 0.0);
-        float t2 = 0.0f, d2 = 0.0f;
-        for (int k = 0; k < 3; k++) {
-            const float dt = pp.cam_pos[k] - lp.cam_pos[k], dc = pp.cam_pos[k] - (float)mean[k];
-            t2 += dt * dt; d2 += dc * dc;
+        const float c[3] = {(float)(m->centre_sum[0] * inv_n), (float)(m->centre_sum[1] * inv_n), (float)(m->centre_sum[2] * inv_n)};
+        auto window = [&](const ProjectParams& q, const float* p, float* xy) {       // (column-major matrices, window y up: project.hip)
+            float v[4], o[4];
+            for (int r = 0; r < 4; r++) v[r] = q.view[r] * p[0] + q.view[4 + r] * p[1] + q.view[8 + r] * p[2] + q.view[12 + r];
+            for (int r = 0; r < 4; r++) o[r] = q.proj[r] * v[0] + q.proj[4 + r] * v[1] + q.proj[8 + r] * v[2] + q.proj[12 + r] * v[3];
+            if (!(o[3] > 1e-6f)) return false;
+            xy[0] = (o[0] / o[3] * 0.5f + 0.5f) * q.width;
+            xy[1] = (o[1] / o[3] * 0.5f + 0.5f) * q.height;
+            return true;
+        };
+        float was[2], is[2];
+        if (window(lp, c, was) && window(pp, c, is)) {
+            const float dx = (is[0] - was[0]) / (float)GS_BIN, dy = (is[1] - was[1]) / (float)GS_BIN;
+            const bool shift_ok = fabsf(dx) < 4096.0f && fabsf(dy) < 4096.0f && !getenv("GSPLAT_NO_STAT_SHIFT");   // (false for NaN)
+            if (shift_ok) {
+                stat_shift.sx = (int32_t)lrintf(dx);
+                stat_shift.sy = (int32_t)lrintf(dy);
+            }
+            // the previous camera's position in the splats' own space: -A^-1 b of its modelView = [A | b]
+            const float* V = lp.view;
+            const float a00 = V[0], a10 = V[1], a20 = V[2], a01 = V[4], a11 = V[5], a21 = V[6], a02 = V[8], a12 = V[9], a22 = V[10];
+            const float c00 = a11 * a22 - a12 * a21, c01 = a02 * a21 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+            const float det = a00 * c00 + a10 * c01 + a20 * c02;
+            const float b0 = V[12], b1 = V[13], b2 = V[14], id = 1.0f / det;
+            const float eye[3] = {-(c00 * b0 + c01 * b1 + c02 * b2) * id,
+                                  -((a12 * a20 - a10 * a22) * b0 + (a00 * a22 - a02 * a20) * b1 + (a02 * a10 - a00 * a12) * b2) * id,
+                                  -((a10 * a21 - a11 * a20) * b0 + (a01 * a20 - a00 * a21) * b1 + (a00 * a11 - a01 * a10) * b2) * id};
+            float parallax = 0.0f;
+            bool seen = fabsf(det) > 1e-20f;
+            for (int k = 0; k < 2 && seen; k++) {
+                const float t = k ? 2.0f : 0.5f;
+                const float p[3] = {eye[0] + t * (c[0] - eye[0]), eye[1] + t * (c[1] - eye[1]), eye[2] + t * (c[2] - eye[2])};
+                float at[2];
+                seen = window(pp, p, at);
+                if (seen) parallax = fmaxf(parallax, sqrtf((at[0] - is[0]) * (at[0] - is[0]) + (at[1] - is[1]) * (at[1] - is[1])));
+            }
+            // (without the shift the whole motion counts, not only the parallax)
+            const float moved = (parallax + (shift_ok ? 0.0f : sqrtf(dx * dx + dy * dy) * (float)GS_BIN)) / fmaxf(pp.height, 1.0f);
+            same_view = seen && moved <= limit;            // (NaN compares false)
         }
-        const float z_ref = fmaxf(sqrtf(d2), 0.5f * rms);
-        const float moved = (rot + (z_ref > 0.0f ? sqrtf(t2) / z_ref : 1e9f)) * pp.focal_y / fmaxf(pp.height, 1.0f);
-        same_view = moved <= limit;                        // (NaN compares false)
     }
     const bool stale_order = getenv("GSPLAT_BLEND_ORDER_STALE") != nullptr;   // (A/B: rounds 2-5 - order from whatever draw came before)
     // The deep pass runs when the last draw whose verdict has arrived (mapped host word, no synchronisation) left bins over the
@@ -809,7 +849,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                            m->block_any.as<uint8_t>(), m->deep_flags.as<uint32_t>(), blend_bins, frame, cap, pp.lists_x, pp.list_row_begin,
                            m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), m->mirror_dev, m->draw_serial,
                            order_wg ? m->blend_stats.as<uint2>() : nullptr, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
-                           m->deep_pass ? 1u : 0u, m->blend_stats.as<uint32_t>(), deep_min, deep_factor, scan);
+                           m->deep_pass ? 1u : 0u, m->blend_stats.as<uint32_t>(), deep_min, deep_factor, scan, stat_shift);
     } else {
         hipLaunchKernelGGL(k_bin_count, dim3(grid), dim3(BIN_THREADS), 0, st, order_dev, R, R_dev,
                            m->translate ? m->perm.as<uint32_t>() : nullptr, m->prect.as<uint2>(), m->cidx.as<uint32_t>(), m->rect_q.as<uint2>(), m->coff.as<uint32_t>(),
@@ -820,7 +860,7 @@ static int binning_typed(gs_mesh* m, const ProjectParams& pp, const uint32_t* or
                            m->rect_q.as<uint2>(), m->coff.as<uint32_t>(), m->bin_sums.as<uint32_t>(), grid, pp.lists_x, pp.list_row_begin,
                            m->ekeyA.as<KeyT>(), m->evalA.as<uint32_t>(), pp.list_shift, m->mirror_dev, m->draw_serial,
                            order_wg ? m->blend_stats.as<uint2>() : nullptr, blend_bins, order_wg ? m->blend_order.as<uint32_t>() : nullptr,
-                           m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor);
+                           m->deep_pass ? 1u : 0u, m->deep_flags.as<uint32_t>(), m->blend_stats.as<uint32_t>(), deep_min, deep_factor, stat_shift);
     }
     // ... and whenever the deep pass runs: its frames have the long tail that an order - even one from a view several degrees away -
     // and the pass's workgroups behind the costliest bins (tile_blend.hip) shorten.  Capture-like C3S, orbit at 3 / 6 / 12 degrees per

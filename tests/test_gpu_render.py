@@ -386,8 +386,8 @@ def test_smaller_list_bins_chosen_asynchronously_come_with_room_for_their_entrie
 
 
 def test_a_slowly_moving_camera_keeps_the_bin_order_and_the_pixels(ctx, monkeypatch):
-    """The blend takes its bins costliest-first from the previous frame while the camera moved less than 0.06 screen heights since
-    (tile_bin.hip), and in row-major order otherwise; the deep pass's members always come from the previous frame.  Scheduling only:
+    """The blend takes its bins costliest-first from the previous frame while the picture moved with little parallax since (tile_bin.hip:
+    a whole-picture shift is followed bin by bin), and in row-major order otherwise; the deep pass's members always come from the previous frame.  Scheduling only:
     every frame of a slow and of a fast camera path equals the frame of a fresh mesh, under the gate, with the gate shut
     ($GSPLAT_ORDER_MOTION=0: the same view only) and wide open (100)."""
     scene = helpers.small_scene(90000, 1, seed=31, scale=0.03)          # tiny splats: deep bins, long lists

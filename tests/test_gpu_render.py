@@ -394,7 +394,15 @@ def test_a_slowly_moving_camera_keeps_the_bin_order_and_the_pixels(ctx, monkeypa
     w, h = 640, 360
     slow = camera.orbit_cameras("garden", w, h, 1440)[:6]                # a quarter of a degree per frame
     fast = camera.orbit_cameras("garden", w, h, 30)[:4]                  # twelve degrees per frame
-    path = slow + fast + slow[::-1]
+    up, pos, look = (np.asarray(v, dtype=np.float64) for v in camera.DEMO_POSES["garden"])
+    axis, rel = up / np.linalg.norm(up), look - pos
+
+    def turned(deg):                                                     # the camera turning about its own position
+        a = np.radians(deg)
+        r = rel * np.cos(a) + np.cross(axis, rel) * np.sin(a) + axis * np.dot(axis, rel) * (1.0 - np.cos(a))
+        return camera.PerspectiveCamera(w, h, tuple(pos), tuple(pos + r), tuple(up))
+    turning = [turned(d) for d in (0.0, 3.0, 6.0, 9.0, 4.0, -7.0)]        # (the statistics are read shifted by whole bins)
+    path = slow + fast + slow[::-1] + turning
     orders = [sorted_order(scene, c) for c in path]
     want = []
     for c, o in zip(path, orders):

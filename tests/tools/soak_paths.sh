@@ -12,7 +12,7 @@ run() {  # <env assignments or -> <soak script> <args...>
 for E in - GSPLAT_NO_LDS_ATOMIC_RANK=1 GSPLAT_NO_SORT_PACK=1 GSPLAT_NO_SORT_CHUNK=1 GSPLAT_ONE_RECORD_SET=1 GSPLAT_SERIAL=1 \
          GSPLAT_NO_BLOCK_CULL=1 GSPLAT_NO_REORDER=1 GSPLAT_NO_DEEP=1 GSPLAT_NO_COARSE_VIS=1 GSPLAT_NO_BLEND_ORDER=1 GSPLAT_WIDE_ENTRY_KEYS=1 \
          GSPLAT_LIST_SHIFT=1 GSPLAT_LIST_SHIFT=5 GSPLAT_VIS_FRONT=stream GSPLAT_VIS_FRONT=compact GSPLAT_NO_BLOCK_LIST=1 GSPLAT_BLOCK_TEST_ALWAYS=1 \
-         GSPLAT_BIN_FUSED=1 GSPLAT_BLEND_ORDER_STALE=1 GSPLAT_NO_LAZY_MASK=1 GSPLAT_NO_ASYNC_LIST_BINS=1 GSPLAT_ORDER_MOTION=0 GSPLAT_ORDER_MOTION=100; do
+         GSPLAT_BIN_FUSED=1 GSPLAT_BLEND_ORDER_STALE=1 GSPLAT_NO_LAZY_MASK=1 GSPLAT_NO_ASYNC_LIST_BINS=1 GSPLAT_ORDER_MOTION=0 GSPLAT_ORDER_MOTION=100 GSPLAT_NO_STAT_SHIFT=1 GSPLAT_DEEP_UNITS_LAST=1 GSPLAT_DEEP_ROW_MAJOR_ON_MOTION=1 GSPLAT_KEY_HIST_FUSED=1; do
   run "$E" soak.py 30 41000 120000
   run "$E" soak_stateful.py 3 42000 16 40000
 done
